@@ -1,0 +1,161 @@
+"""Pin the CPU oracle to golden vectors captured from the real reference (tools/gen_golden.py).
+
+Tolerance: <= 1e-5 max-abs relative to the output scale (fp32 summation-order noise only).
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_names, load_golden
+from oracle import aten_ops as ops
+from oracle import direct_np as dnp
+from oracle import generator as ogen
+
+TOL = 1e-5
+
+
+def _t(a, grad=False):
+    if a is None:
+        return None
+    t = torch.from_numpy(np.array(a))
+    return t.requires_grad_(True) if grad else t
+
+
+def _close(a, b, tol=TOL, what=''):
+    a = a.detach().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    b = np.asarray(b)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    scale = max(1.0, float(np.abs(b).max()))
+    err = float(np.abs(a - b).max())
+    assert err <= tol * scale, f'{what}: max-abs err {err:.3e} (scale {scale:.3g})'
+
+
+@pytest.mark.parametrize('name', golden_names('F'))
+def test_filtered_lrelu(name):
+    g = load_golden(name)
+    up, down, *pad = [int(v) for v in g['meta']]
+    gain, slope, clamp, flip = g['fmeta']
+    clamp = None if clamp < 0 else float(clamp)
+    x = _t(g['x'], True)
+    b = _t(g.get('b'), True)
+    y = ops.filtered_lrelu(x, fu=_t(g.get('fu')), fd=_t(g.get('fd')), b=b, up=up, down=down, padding=pad, gain=float(gain),
+                           slope=float(slope), clamp=clamp, flip_filter=bool(flip))
+    _close(y, g['y'], what=name + ' y')
+    grads = torch.autograd.grad((y * _t(g['r'])).sum(), [x] + ([b] if b is not None else []))
+    _close(grads[0], g['dx'], what=name + ' dx')
+    if b is not None:
+        _close(grads[1], g['db'], what=name + ' db', tol=1e-4)
+    # independent definition-level restatement (float64)
+    y2 = dnp.filtered_lrelu(g['x'], g.get('fu'), g.get('fd'), g.get('b'), up, down, pad, float(gain), float(slope), clamp, bool(flip))
+    _close(y2, g['y'], what=name + ' y(direct)', tol=2e-5)
+
+
+@pytest.mark.parametrize('name', golden_names('U'))
+def test_upfirdn2d(name):
+    g = load_golden(name)
+    up, down, px0, px1, py0, py1, flip = [int(v) for v in g['meta']]
+    gain = float(g['fmeta'][0])
+    fn = str(g['fn'])
+    x = _t(g['x'], True)
+    f = _t(g['f'])
+    if fn == 'upfirdn2d':
+        y = ops.upfirdn2d(x, f, up=up, down=down, padding=[px0, px1, py0, py1], flip_filter=bool(flip), gain=gain)
+        y2 = dnp.upfirdn2d(g['x'], g['f'], up, down, [px0, px1, py0, py1], bool(flip), gain)
+        _close(y2, g['y'], what=name + ' y(direct)', tol=2e-5)
+    elif fn == 'filter2d':
+        y = ops.filter2d(x, f, padding=[px0, px1, py0, py1], flip_filter=bool(flip), gain=gain)
+    elif fn == 'upsample2d':
+        y = ops.upsample2d(x, f, up=up, padding=[px0, px1, py0, py1], flip_filter=bool(flip), gain=gain)
+    else:
+        y = ops.downsample2d(x, f, down=down, padding=[px0, px1, py0, py1], flip_filter=bool(flip), gain=gain)
+    _close(y, g['y'], what=name + ' y')
+    dx, = torch.autograd.grad((y * _t(g['r'])).sum(), [x])
+    _close(dx, g['dx'], what=name + ' dx')
+
+
+@pytest.mark.parametrize('name', golden_names('B'))
+def test_bias_act(name):
+    g = load_golden(name)
+    alpha, gain, clamp = [None if np.isnan(v) else float(v) for v in g['fmeta']]
+    x = _t(g['x'], True)
+    b = _t(g.get('b'), True)
+    y = ops.bias_act(x, b, dim=int(g['dim']), act=str(g['act']), alpha=alpha, gain=gain, clamp=clamp)
+    _close(y, g['y'], what=name)
+    grads = torch.autograd.grad((y * _t(g['r'])).sum(), [x, b])
+    _close(grads[0], g['dx'], what=name + ' dx')
+    _close(grads[1], g['db'], what=name + ' db')
+
+
+@pytest.mark.parametrize('name', golden_names('M'))
+def test_modulated_conv2d(name):
+    g = load_golden(name)
+    demod, padding = [int(v) for v in g['meta']]
+    ig = None if np.isnan(g['fmeta'][0]) else torch.tensor(float(g['fmeta'][0]))
+    x, w, s = _t(g['x'], True), _t(g['w'], True), _t(g['s'], True)
+    y = ops.modulated_conv2d(x, w, s, demodulate=bool(demod), padding=padding, input_gain=ig)
+    _close(y, g['y'], what=name)
+    dx, dw, ds = torch.autograd.grad((y * _t(g['r'])).sum(), [x, w, s])
+    _close(dx, g['dx'], what=name + ' dx')
+    _close(dw, g['dw'], what=name + ' dw', tol=1e-4)
+    _close(ds, g['ds'], what=name + ' ds', tol=1e-4)
+
+
+TINY = dict(channel_base=256, channel_max=8)
+
+
+@pytest.mark.parametrize('name,res', [('G1_tiny128', 128), ('G2_tiny256', 256)])
+def test_generator(name, res):
+    g = load_golden(name)
+    sd = {k[3:]: _t(v) for k, v in g.items() if k.startswith('sd/')}
+    pl = ogen.plan(res, 4, 1, TINY)
+    # the plan must reproduce the reference's layer names and the filters stored in its state dict
+    names = [L['name'] for L in pl['enc'] + pl['dec']]
+    assert names == [str(n) for n in g['layer_names']]
+    for L in pl['enc'] + pl['dec']:
+        for key, f in (('up_filter', L['fu']), ('down_filter', L['fd'])):
+            k = f'synthesis.{L["name"]}.{key}'
+            assert (k in sd) == (f is not None)
+            if f is not None:
+                _close(f, sd[k].numpy(), tol=1e-7, what=k)
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and not k.endswith(('_filter', 'magnitude_ema', 'w_avg'))}
+    full = dict(sd)
+    full.update(params)
+    taps = {}
+    y = ogen.generator(full, pl, _t(g['z']), _t(g['c']), _t(g['x']), mapping_layers=2, taps=taps)
+    _close(y, g['y'], what=name + ' y', tol=2e-5)
+    for lname, t in taps.items():
+        st = g['stat/' + lname]
+        got = np.array([t.mean().item(), t.std().item(), t.abs().max().item()])
+        assert np.allclose(got, st, rtol=1e-3, atol=1e-5), (lname, got, st)
+    want = {k[5:]: v for k, v in g.items() if k.startswith('grad/')}
+    names = list(want.keys())
+    grads = torch.autograd.grad((y * _t(g['r'])).sum(), [params[k] for k in names])
+    for k, gr in zip(names, grads):
+        _close(gr, want[k], tol=1e-4, what=name + ' grad ' + k)
+
+
+def test_layer_table_full_width():
+    """Geometry of the shipped 256^2 configuration (SURVEY.md section 8 layer table)."""
+    g = load_golden('T256_layer_table')
+    pl = ogen.plan(256, 4, 1, {})
+    layers = pl['enc'] + pl['dec']
+    assert [L['name'] for L in layers] == [str(n) for n in g['names']]
+    for L, row in zip(layers, g['table']):
+        cin, cout, insz, outsz, up, down, ut, dt, p0, p1, p2, p3, k = [int(v) for v in row]
+        assert (L['cin'], L['cout'], L['in_size'], L['out_size'], L['up'], L['down'], L['k']) == (cin, cout, insz, outsz, up, down, k)
+        assert L['padding'] == [p0, p1, p2, p3]
+        assert (1 if L['fu'] is None else len(L['fu'])) == ut
+        assert (1 if L['fd'] is None else len(L['fd'])) == dt
+        for key, f in (('fu/', L['fu']), ('fd/', L['fd'])):
+            if f is not None:
+                _close(f, g[key + L['name']], tol=1e-7, what=key + L['name'])
+    sd = ogen.random_state_dict(pl, 512, 1, 512, 8)
+    assert sum(v.numel() for k, v in sd.items() if not k.endswith(('magnitude_ema', 'w_avg'))) == int(g['nparams'])
+
+
+def test_sign_code_packing():
+    codes = np.random.RandomState(0).randint(0, 3, size=(1, 2, 5, 37)).astype(np.uint8)
+    packed = dnp.pack_codes_rowmajor(codes)
+    assert packed.shape == (1, 2, 5, 12)
+    for x in range(37):
+        assert np.array_equal((packed[..., x >> 2] >> (2 * (x & 3))) & 3, codes[..., x])
