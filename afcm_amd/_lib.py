@@ -1,0 +1,99 @@
+"""ctypes binding of libafcm_hip.so (C ABI declared in include/afcm_hip.h)."""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libafcm_hip.so')
+
+F32, F16, BF16 = 0, 1, 2
+E_NOKERNEL, E_INVALID = -1, -2
+SIGNS_NONE, SIGNS_WRITE, SIGNS_READ = 0, 1, 2
+
+_DTYPES = {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16}
+
+
+class FilteredLReluArgs(C.Structure):
+    """Mirror of `afcm_filtered_lrelu_args` (include/afcm_hip.h)."""
+    _fields_ = [
+        ('x', C.c_void_p), ('y', C.c_void_p), ('b', C.c_void_p), ('signs', C.c_void_p),
+        ('fu', C.c_void_p), ('fd', C.c_void_p),
+        ('dtype', C.c_int32),
+        ('n', C.c_int32), ('c', C.c_int32), ('xh', C.c_int32), ('xw', C.c_int32), ('yh', C.c_int32), ('yw', C.c_int32),
+        ('fuw', C.c_int32), ('fuh', C.c_int32), ('fdw', C.c_int32), ('fdh', C.c_int32),
+        ('up', C.c_int32), ('down', C.c_int32),
+        ('px0', C.c_int32), ('px1', C.c_int32), ('py0', C.c_int32), ('py1', C.c_int32),
+        ('sx', C.c_int32), ('sy', C.c_int32), ('sh', C.c_int32), ('swb', C.c_int32),
+        ('gain', C.c_float), ('slope', C.c_float), ('clamp', C.c_float),
+        ('flip_filter', C.c_int32), ('sign_mode', C.c_int32),
+    ]
+
+
+_lib = None
+
+# name -> (restype, argtypes); every symbol include/afcm_hip.h declares must be listed here
+# (tests/test_abi.py cross-checks this table against the header).
+_i32, _i64, _f32, _vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
+SIGNATURES = {
+    'afcm_abi_version': (C.c_int, []),
+    'afcm_last_error': (C.c_char_p, []),
+    'afcm_filtered_lrelu_shapes': (C.c_int, [C.POINTER(FilteredLReluArgs)]),
+    'afcm_filtered_lrelu': (C.c_int, [C.POINTER(FilteredLReluArgs), _vp]),
+    'afcm_filtered_lrelu_act': (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _f32, _i32, _vp]),
+    'afcm_upfirdn2d': (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32,
+                                 _i32, _i32, _i32, _f32, _vp]),
+    'afcm_bias_act': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i64, _i32, _i32, _i32, _f32, _f32, _f32, _vp]),
+}
+
+
+def load():
+    """Load the HIP library.  Raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f'{LIB_PATH} is missing: the HIP kernels are not built.  Run `python -c "import __graft_entry__ as g; g.build()"` '
+                f'or `make -C afcm_amd/csrc`.  afcm_amd has no CPU fallback.')
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        if lib.afcm_abi_version() != 1:
+            raise RuntimeError(f'libafcm_hip.so ABI version {lib.afcm_abi_version()} does not match this package (1); rebuild it')
+        _lib = lib
+    return _lib
+
+
+def dtype_code(t):
+    try:
+        return _DTYPES[t.dtype]
+    except KeyError:
+        raise RuntimeError(f'afcm_amd kernels support float32/float16/bfloat16, got {t.dtype}') from None
+
+
+def require_gpu(*tensors):
+    """Every afcm_amd op runs on the GPU only: fail loudly otherwise."""
+    for t in tensors:
+        if t is not None and t.device.type != 'cuda':
+            raise RuntimeError(
+                f'afcm_amd ops need ROCm device tensors (got a tensor on {t.device}); there is no CPU path in this package '
+                f'-- the aten reference lives in oracle/ and is test-only')
+
+
+def stream_ptr(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def check(rc, what):
+    """Translate a C-ABI status into the reference's error convention (RuntimeError <- TORCH_CHECK)."""
+    if rc == 0 or rc == E_NOKERNEL:
+        return rc
+    if rc == E_INVALID:
+        raise RuntimeError(f'{what}: {load().afcm_last_error().decode()}')
+    raise RuntimeError(f'{what}: HIP error {rc - 1000} at kernel launch')

@@ -1,0 +1,517 @@
+// filtered_lrelu for gfx950 (MI355X): bias -> zero-insert upsample -> pad/crop -> separable FIR(fu)
+// -> * up^2 * gain -> leaky ReLU -> clamp (+ 2-bit sign codes) -> separable FIR(fd) -> decimate, fused in
+// one kernel so the up^2-times-larger intermediate never leaves the CU.
+//
+// Semantics follow the reference op (SG3OPS/filtered_lrelu.py:121-153; edge rules of
+// SG3OPS/filtered_lrelu.cu:264-297, 484-505, 564-571).  The kernel structure is new: wave64
+// workgroups, one output tile per workgroup staged through LDS in five register-blocked passes
+// (load+bias, up-FIR along x, up-FIR along y + activation + sign codes, down-FIR along x,
+// down-FIR along y + store).  Filter taps are expanded into per-phase polyphase tables in LDS by the
+// kernel itself -- no global filter buffer, so launches on different streams never interfere.
+//
+// Polyphase indexing (derivation in DESIGN.md): for a tile whose upsampled origin is U0,
+//   d = U0 - px0,  I0 = ceil(d / up),  ph = up*I0 - d  in [0, up)
+//   u[U0 + up*m + a] = sum_j F[kmin(a) + up*j] * x[I0 + m + o(a) + j]
+//   o(a) = (a > ph),  kmin(a) = o(a) ? up - (a - ph) : ph - a,   F = flip ? fu : reversed(fu)
+#include "common.h"
+
+namespace afcm {
+
+struct FlreluParams {
+    const void* x;
+    void* y;
+    const void* b;
+    unsigned char* s;
+    int xw, xh, yw, yh, C;
+    int px0, py0;
+    int tilesX, tilesY;
+    float gain;  // up^2 * gain, formed in fp32 like filtered_lrelu.cu:484
+    float slope, clamp;
+    int flip;
+    int sx, sy, sh, swb;
+    float fscale;  // pointwise kernel only: product of the 1x1 filters
+};
+
+// ---------------------------------------------------------------------------------------------
+// Activation on one element of the upsampled grid.  Returns the 2-bit code in WRITE mode.
+template <int SIGN>
+__device__ __forceinline__ unsigned act_elem(float& v, float gain, float slope, float clamp, unsigned code_in) {
+    v *= gain;
+    if (SIGN == AFCM_SIGNS_READ) {
+        if (code_in & 1u) v *= slope;
+        if (code_in & 2u) v = 0.f;
+        return 0u;
+    }
+    unsigned code = __float_as_uint(v) >> 31;
+    if (code) v *= slope;
+    if (fabsf(v) > clamp) {
+        code = 2u;
+        v = (v < 0.f) ? -clamp : clamp;
+    }
+    return code;
+}
+
+// Fetch the packed codes of 4 consecutive elements starting at sign coordinate (X, Y); elements
+// outside the tensor read as code 0 (value passes through unchanged).
+__device__ __forceinline__ unsigned fetch_codes4(const unsigned char* __restrict__ srow_base, int X, int Y, int sh, int swb) {
+    if ((unsigned)Y >= (unsigned)sh) return 0u;
+    const unsigned char* row = srow_base + (size_t)Y * swb;
+    int b0 = X >> 2;  // arithmetic shift: floor for negative X
+    unsigned lo = ((unsigned)b0 < (unsigned)swb) ? row[b0] : 0u;
+    unsigned hi = ((unsigned)(b0 + 1) < (unsigned)swb) ? row[b0 + 1] : 0u;
+    return ((lo | (hi << 8)) >> ((X & 3) << 1)) & 0xffu;
+}
+
+__device__ __forceinline__ int quad_or(int v) {
+    // OR-reduce over the 4 lanes of a quad with two DPP quad_perm moves ([1,0,3,2] then [2,3,0,1]).
+    v |= __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true);
+    v |= __builtin_amdgcn_mov_dpp(v, 0x4E, 0xF, 0xF, true);
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+template <typename T, int UP, int DOWN, int FUT, int FD, int TOW, int TOH, int RO, int NT, int SIGN>
+struct FlreluTile {
+    static constexpr int FU = UP * FUT;
+    static constexpr int TUW = (TOW - 1) * DOWN + FD;      // upsampled columns the tile's outputs need
+    static constexpr int TUH = (TOH - 1) * DOWN + FD;
+    static constexpr int TUWP = round_up(TUW, 16);         // computed/pitched width (16 = one sign dword)
+    static constexpr int ROWS_C = 8;                       // upsampled rows per stage-C item
+    static constexpr int TUHP = round_up(TUH, ROWS_C);
+    static constexpr int MB = ROWS_C / UP;                 // input-row steps per stage-C item
+    static constexpr int TIW = TUWP / UP + FUT;
+    static constexpr int TIWP = round_up(TIW, 4);
+    static constexpr int TIH = TUHP / UP + FUT;
+    static constexpr int SZ_A = cmax(TIH * TIWP, TUHP * TUWP);  // sIn, later upXY
+    static constexpr int SZ_B = cmax(TIH * TUWP, TUH * TOW);    // upX, later downX
+    static constexpr int NCOEF = 2 * FU + FD;
+    static constexpr int LDS_FLOATS = SZ_A + SZ_B + round_up(NCOEF, 4);
+    static_assert(ROWS_C % UP == 0 && FUT % 2 == 0 && TOW % 4 == 0 && TOH % RO == 0, "tile shape");
+    static_assert((TOW * DOWN) % 16 == 0, "sign ownership must fall on dword boundaries");
+    static_assert(DOWN * (TOW - 4) + round_up(DOWN * 3 + FD, 4) <= TUWP, "stage D over-read must stay inside the row");
+    static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS overflow");
+
+    // ---- stage B: up-FIR along x.  One item = one input row x 4 input columns -> 4*UP outputs.
+    template <int PH>
+    static __device__ __forceinline__ void up_x(const float* __restrict__ sIn, float* __restrict__ upX,
+                                                const float* __restrict__ cu, int tid) {
+        float c[UP][FUT];
+#pragma unroll
+        for (int a = 0; a < UP; a++)
+#pragma unroll
+            for (int j = 0; j < FUT; j++) c[a][j] = cu[a * FUT + j];
+        constexpr int NCH = TUWP / (4 * UP);
+        constexpr int NIN = 4 + FUT;
+        for (int item = tid; item < TIH * NCH; item += NT) {
+            const int r = item / NCH, ch = item - r * NCH;
+            const float* src = sIn + r * TIWP + 4 * ch;
+            float in[NIN];
+#pragma unroll
+            for (int i = 0; i < NIN / 2; i++) {
+                float2 t = *(const float2*)(src + 2 * i);
+                in[2 * i] = t.x;
+                in[2 * i + 1] = t.y;
+            }
+            float out[4 * UP];
+#pragma unroll
+            for (int mm = 0; mm < 4; mm++)
+#pragma unroll
+                for (int a = 0; a < UP; a++) {
+                    constexpr int dummy = 0;
+                    (void)dummy;
+                    const int o = (a > PH) ? 1 : 0;
+                    float acc = 0.f;
+#pragma unroll
+                    for (int j = 0; j < FUT; j++) acc = fmaf(c[a][j], in[mm + o + j], acc);
+                    out[mm * UP + a] = acc;
+                }
+            float* dst = upX + r * TUWP + 4 * UP * ch;
+#pragma unroll
+            for (int q = 0; q < UP; q++) *(float4*)(dst + 4 * q) = make_float4(out[4 * q], out[4 * q + 1], out[4 * q + 2], out[4 * q + 3]);
+        }
+    }
+
+    // ---- stage C: up-FIR along y + gain + leaky ReLU + clamp + sign codes.  One item = 4 columns x 8 rows.
+    template <int PH>
+    static __device__ __forceinline__ void up_y_act(const float* __restrict__ upX, float* __restrict__ upXY,
+                                                    const float* __restrict__ cu, int tid, const FlreluParams& p,
+                                                    int plane, int U0x, int U0y, bool lastX, bool lastY) {
+        float c[UP][FUT];
+#pragma unroll
+        for (int a = 0; a < UP; a++)
+#pragma unroll
+            for (int j = 0; j < FUT; j++) c[a][j] = cu[a * FUT + j];
+        constexpr int NG = TUWP / 4;
+        constexpr int NRB = TUHP / ROWS_C;
+        constexpr int NIN = MB + FUT;
+        unsigned char* splane = p.s + (size_t)plane * p.sh * p.swb;
+        for (int item = tid; item < NG * NRB; item += NT) {
+            const int rb = item / NG, g = item - rb * NG;
+            float4 in[NIN];
+#pragma unroll
+            for (int i = 0; i < NIN; i++) in[i] = *(const float4*)(upX + (rb * MB + i) * TUWP + 4 * g);
+            const int X = U0x + 4 * g;
+#pragma unroll
+            for (int mm = 0; mm < MB; mm++)
+#pragma unroll
+                for (int a = 0; a < UP; a++) {
+                    const int o = (a > PH) ? 1 : 0;
+                    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                    for (int j = 0; j < FUT; j++) {
+                        const float w = c[a][j];
+                        const float4 v = in[mm + o + j];
+                        acc.x = fmaf(w, v.x, acc.x);
+                        acc.y = fmaf(w, v.y, acc.y);
+                        acc.z = fmaf(w, v.z, acc.z);
+                        acc.w = fmaf(w, v.w, acc.w);
+                    }
+                    const int row = rb * ROWS_C + mm * UP + a;
+                    const int Y = U0y + row;
+                    unsigned codes = 0;
+                    if (SIGN == AFCM_SIGNS_READ) codes = fetch_codes4(splane, X + p.sx, Y + p.sy, p.sh, p.swb);
+                    unsigned c0 = act_elem<SIGN>(acc.x, p.gain, p.slope, p.clamp, codes);
+                    unsigned c1 = act_elem<SIGN>(acc.y, p.gain, p.slope, p.clamp, codes >> 2);
+                    unsigned c2 = act_elem<SIGN>(acc.z, p.gain, p.slope, p.clamp, codes >> 4);
+                    unsigned c3 = act_elem<SIGN>(acc.w, p.gain, p.slope, p.clamp, codes >> 6);
+                    *(float4*)(upXY + row * TUWP + 4 * g) = acc;
+                    if (SIGN == AFCM_SIGNS_WRITE) {
+                        // 4 lanes of a quad hold 16 consecutive columns: assemble one dword.
+                        int byte = (int)(c0 | (c1 << 2) | (c2 << 4) | (c3 << 6));
+                        int word = quad_or(byte << ((g & 3) << 3));
+                        const bool ownX = (4 * g < TOW * DOWN) || lastX;
+                        const bool ownY = (row < TOH * DOWN) || lastY;
+                        if ((g & 3) == 0 && ownX && ownY && (X >> 2) < p.swb && Y < p.sh)
+                            *(int*)(splane + (size_t)Y * p.swb + (X >> 2)) = word;
+                    }
+                }
+        }
+    }
+
+    // ---- stage D: down-FIR along x.  One item = one upsampled row x 4 outputs.
+    static __device__ __forceinline__ void down_x(const float* __restrict__ upXY, float* __restrict__ downX,
+                                                  const float* __restrict__ cdl, int tid) {
+        float cd[FD];
+#pragma unroll
+        for (int k = 0; k < FD; k++) cd[k] = cdl[k];
+        constexpr int NCD = TOW / 4;
+        constexpr int NIN4 = cdiv(DOWN * 3 + FD, 4);
+        for (int item = tid; item < TUH * NCD; item += NT) {
+            const int r = item / NCD, ch = item - r * NCD;
+            const float* src = upXY + r * TUWP + DOWN * 4 * ch;
+            float in[NIN4 * 4];
+#pragma unroll
+            for (int i = 0; i < NIN4; i++) {
+                float4 t = *(const float4*)(src + 4 * i);
+                in[4 * i] = t.x; in[4 * i + 1] = t.y; in[4 * i + 2] = t.z; in[4 * i + 3] = t.w;
+            }
+            float out[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                float acc = 0.f;
+#pragma unroll
+                for (int k = 0; k < FD; k++) acc = fmaf(cd[k], in[DOWN * t + k], acc);
+                out[t] = acc;
+            }
+            *(float4*)(downX + r * TOW + 4 * ch) = make_float4(out[0], out[1], out[2], out[3]);
+        }
+    }
+
+    // ---- stage E: down-FIR along y + store.  One item = 2 output columns x RO output rows.
+    static __device__ __forceinline__ void down_y_store(const float* __restrict__ downX, const float* __restrict__ cdl,
+                                                        int tid, const FlreluParams& p, int plane, int O0x, int O0y) {
+        float cd[FD];
+#pragma unroll
+        for (int k = 0; k < FD; k++) cd[k] = cdl[k];
+        constexpr int NCP = TOW / 2;
+        constexpr int NROW = DOWN * (RO - 1) + FD;
+        T* yp = (T*)p.y + (size_t)plane * p.yh * p.yw;
+        for (int item = tid; item < NCP * (TOH / RO); item += NT) {
+            const int rbk = item / NCP, cp = item - rbk * NCP;
+            const int p0 = rbk * RO;
+            float2 acc[RO];
+#pragma unroll
+            for (int t = 0; t < RO; t++) acc[t] = make_float2(0.f, 0.f);
+#pragma unroll
+            for (int i = 0; i < NROW; i++) {
+                const float2 v = *(const float2*)(downX + (DOWN * p0 + i) * TOW + 2 * cp);
+#pragma unroll
+                for (int t = 0; t < RO; t++) {
+                    const int k = i - DOWN * t;
+                    if (k >= 0 && k < FD) {
+                        acc[t].x = fmaf(cd[k], v.x, acc[t].x);
+                        acc[t].y = fmaf(cd[k], v.y, acc[t].y);
+                    }
+                }
+            }
+            const int ox = O0x + 2 * cp;
+#pragma unroll
+            for (int t = 0; t < RO; t++) {
+                const int oy = O0y + p0 + t;
+                if (oy < p.yh) {
+                    T* dst = yp + (size_t)oy * p.yw + ox;
+                    if (ox < p.yw) dst[0] = from_f32<T>(acc[t].x);
+                    if (ox + 1 < p.yw) dst[1] = from_f32<T>(acc[t].y);
+                }
+            }
+        }
+    }
+};
+
+template <typename T, int UP, int DOWN, int FUT, int FD, int TOW, int TOH, int RO, int NT, int SIGN>
+__global__ __launch_bounds__(NT) void flrelu_sep_kernel(FlreluParams p, const float* __restrict__ fu,
+                                                        const float* __restrict__ fd) {
+    typedef FlreluTile<T, UP, DOWN, FUT, FD, TOW, TOH, RO, NT, SIGN> K;
+    __shared__ __attribute__((aligned(16))) float lds[K::LDS_FLOATS];
+    float* bufA = lds;
+    float* bufB = lds + K::SZ_A;
+    float* cuX = lds + K::SZ_A + K::SZ_B;
+    float* cuY = cuX + K::FU;
+    float* cdl = cuY + K::FU;
+
+    const int tid = threadIdx.x;
+    int bid = blockIdx.x;
+    const int tx = bid % p.tilesX;
+    bid /= p.tilesX;
+    const int ty = bid % p.tilesY;
+    const int plane = bid / p.tilesY;
+
+    const int O0x = tx * TOW, O0y = ty * TOH;
+    const int U0x = O0x * DOWN, U0y = O0y * DOWN;
+    const int I0x = -floor_div(p.px0 - U0x, UP), phx = pos_mod(p.px0 - U0x, UP);
+    const int I0y = -floor_div(p.py0 - U0y, UP), phy = pos_mod(p.py0 - U0y, UP);
+
+    // polyphase coefficient tables
+    if (tid < K::FU) {
+        const int a = tid / FUT, j = tid - a * FUT;
+        {
+            const int kmin = (a > phx) ? UP - (a - phx) : phx - a;
+            const int k = kmin + UP * j;
+            cuX[tid] = p.flip ? fu[k] : fu[K::FU - 1 - k];
+        }
+        {
+            const int kmin = (a > phy) ? UP - (a - phy) : phy - a;
+            const int k = kmin + UP * j;
+            cuY[tid] = p.flip ? fu[k] : fu[K::FU - 1 - k];
+        }
+    }
+    if (tid < FD) cdl[tid] = p.flip ? fd[tid] : fd[FD - 1 - tid];
+
+    // stage A: input tile + bias (zero outside the image, without bias: the bias is added before padding)
+    {
+        const T* xp = (const T*)p.x + (size_t)plane * p.xh * p.xw;
+        const float bias = p.b ? to_f32(((const T*)p.b)[plane % p.C]) : 0.f;
+        for (int idx = tid; idx < K::TIH * K::TIWP; idx += NT) {
+            const int r = idx / K::TIWP, c = idx - r * K::TIWP;
+            const int iy = I0y + r, ix = I0x + c;
+            float v = 0.f;
+            if ((unsigned)ix < (unsigned)p.xw && (unsigned)iy < (unsigned)p.xh) v = to_f32(xp[(size_t)iy * p.xw + ix]) + bias;
+            bufA[idx] = v;
+        }
+    }
+    __syncthreads();
+    switch (phx) {
+        case 0: K::template up_x<0>(bufA, bufB, cuX, tid); break;
+        case 1: K::template up_x<1>(bufA, bufB, cuX, tid); break;
+        case 2: if (UP > 2) K::template up_x<(UP > 2 ? 2 : 0)>(bufA, bufB, cuX, tid); break;
+        default: if (UP > 2) K::template up_x<(UP > 2 ? 3 : 0)>(bufA, bufB, cuX, tid); break;
+    }
+    __syncthreads();
+    const bool lastX = (tx == p.tilesX - 1), lastY = (ty == p.tilesY - 1);
+    switch (phy) {
+        case 0: K::template up_y_act<0>(bufB, bufA, cuY, tid, p, plane, U0x, U0y, lastX, lastY); break;
+        case 1: K::template up_y_act<1>(bufB, bufA, cuY, tid, p, plane, U0x, U0y, lastX, lastY); break;
+        case 2: if (UP > 2) K::template up_y_act<(UP > 2 ? 2 : 0)>(bufB, bufA, cuY, tid, p, plane, U0x, U0y, lastX, lastY); break;
+        default: if (UP > 2) K::template up_y_act<(UP > 2 ? 3 : 0)>(bufB, bufA, cuY, tid, p, plane, U0x, U0y, lastX, lastY); break;
+    }
+    __syncthreads();
+    K::down_x(bufA, bufB, cdl, tid);
+    __syncthreads();
+    K::down_y_store(bufB, cdl, tid, p, plane, O0x, O0y);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Pointwise form: up = down = 1 with 1x1 filters (the ToRGB layer, NET:369-372) and the in-place
+// activation of the generic fallback (filtered_lrelu_act_, filtered_lrelu.cu:1105-1211).
+// One thread = 16 consecutive columns of one row = one sign dword.
+template <typename T, int SIGN>
+__global__ __launch_bounds__(256) void flrelu_pointwise_kernel(FlreluParams p) {
+    const int chunks = (p.yw + 15) >> 4;
+    const long long total = (long long)p.tilesY * p.yh * chunks;  // tilesY = planes here
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int ch = (int)(idx % chunks);
+        const long long t = idx / chunks;
+        const int oy = (int)(t % p.yh);
+        const int plane = (int)(t / p.yh);
+        const T* xp = (const T*)p.x + (size_t)plane * p.xh * p.xw;
+        T* yp = (T*)p.y + (size_t)plane * p.yh * p.yw;
+        const float bias = p.b ? to_f32(((const T*)p.b)[plane % p.C]) : 0.f;
+        const int iy = oy - p.py0;
+        const bool rowIn = (unsigned)iy < (unsigned)p.xh;
+        unsigned char* splane = (SIGN != AFCM_SIGNS_NONE) ? p.s + (size_t)plane * p.sh * p.swb : nullptr;
+        unsigned word = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int ox0 = ch * 16 + q * 4;
+            unsigned codes = 0;
+            if (SIGN == AFCM_SIGNS_READ) codes = fetch_codes4(splane, ox0 + p.sx, oy + p.sy, p.sh, p.swb);
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int ox = ox0 + e;
+                const int ix = ox - p.px0;
+                float v = 0.f;
+                if (ox < p.yw && rowIn && (unsigned)ix < (unsigned)p.xw) v = (to_f32(xp[(size_t)iy * p.xw + ix]) + bias) * p.fscale;
+                unsigned code = act_elem<SIGN>(v, p.gain, p.slope, p.clamp, codes >> (2 * e));
+                word |= code << (2 * (q * 4 + e));
+                if (ox < p.yw) yp[(size_t)oy * p.yw + ox] = from_f32<T>(v);
+            }
+        }
+        if (SIGN == AFCM_SIGNS_WRITE && oy < p.sh && ch * 4 < p.swb) *(unsigned*)(splane + (size_t)oy * p.swb + ch * 4) = word;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+template <typename T, int UP, int DOWN, int FUT, int FD, int TOW, int TOH, int RO, int NT>
+static int launch_sep(const afcm_filtered_lrelu_args* a, FlreluParams p, hipStream_t st) {
+    p.tilesX = cdiv(a->yw, TOW);
+    p.tilesY = cdiv(a->yh, TOH);
+    const long long blocks = (long long)p.tilesX * p.tilesY * a->n * a->c;
+    AFCM_REQUIRE(blocks > 0 && blocks < (1ll << 31), "filtered_lrelu: grid of %lld blocks is out of range", blocks);
+    dim3 grid((unsigned)blocks), block(NT);
+    switch (a->sign_mode) {
+        case AFCM_SIGNS_NONE:
+            hipLaunchKernelGGL((flrelu_sep_kernel<T, UP, DOWN, FUT, FD, TOW, TOH, RO, NT, AFCM_SIGNS_NONE>), grid, block, 0, st, p, a->fu, a->fd);
+            break;
+        case AFCM_SIGNS_WRITE:
+            hipLaunchKernelGGL((flrelu_sep_kernel<T, UP, DOWN, FUT, FD, TOW, TOH, RO, NT, AFCM_SIGNS_WRITE>), grid, block, 0, st, p, a->fu, a->fd);
+            break;
+        default:
+            hipLaunchKernelGGL((flrelu_sep_kernel<T, UP, DOWN, FUT, FD, TOW, TOH, RO, NT, AFCM_SIGNS_READ>), grid, block, 0, st, p, a->fu, a->fd);
+            break;
+    }
+    return hip_status(hipGetLastError());
+}
+
+template <typename T>
+static int launch_pointwise(FlreluParams p, int planes, int sign_mode, hipStream_t st) {
+    p.tilesY = planes;
+    const long long items = (long long)planes * p.yh * ((p.yw + 15) >> 4);
+    long long blocks = (items + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    if (blocks < 1) blocks = 1;
+    dim3 grid((unsigned)blocks), block(256);
+    switch (sign_mode) {
+        case AFCM_SIGNS_NONE: hipLaunchKernelGGL((flrelu_pointwise_kernel<T, AFCM_SIGNS_NONE>), grid, block, 0, st, p); break;
+        case AFCM_SIGNS_WRITE: hipLaunchKernelGGL((flrelu_pointwise_kernel<T, AFCM_SIGNS_WRITE>), grid, block, 0, st, p); break;
+        default: hipLaunchKernelGGL((flrelu_pointwise_kernel<T, AFCM_SIGNS_READ>), grid, block, 0, st, p); break;
+    }
+    return hip_status(hipGetLastError());
+}
+
+template <typename T>
+static int dispatch(const afcm_filtered_lrelu_args* a, const FlreluParams& p, hipStream_t st) {
+    const bool sep = (a->fuh == 0 && a->fdh == 0);
+    if (sep && a->up == 2 && a->down == 2 && a->fuw == 12 && a->fdw == 12)
+        return launch_sep<T, 2, 2, 6, 12, 64, 35, 5, 384>(a, p, st);
+    if (sep && a->up == 2 && a->down == 4 && a->fuw == 12 && a->fdw == 24)
+        return launch_sep<T, 2, 4, 6, 24, 32, 12, 4, 384>(a, p, st);
+    if (sep && a->up == 4 && a->down == 2 && a->fuw == 24 && a->fdw == 12)
+        return launch_sep<T, 4, 2, 6, 12, 64, 35, 5, 384>(a, p, st);
+    return AFCM_E_NOKERNEL;
+}
+
+}  // namespace afcm
+
+using namespace afcm;
+
+extern "C" int afcm_filtered_lrelu_shapes(afcm_filtered_lrelu_args* a) {
+    AFCM_REQUIRE(a != nullptr, "filtered_lrelu: null args");
+    AFCM_REQUIRE(a->up >= 1 && a->down >= 1, "up and down must be at least 1");
+    AFCM_REQUIRE(a->fuw >= 1 && a->fdw >= 1 && a->fuh >= 0 && a->fdh >= 0, "fu and fd must not be empty");
+    const long long fut_w = a->fuw - 1, fut_h = (a->fuh ? a->fuh : a->fuw) - 1;
+    const long long fdt_w = a->fdw - 1, fdt_h = (a->fdh ? a->fdh : a->fdw) - 1;
+    const long long cw = (long long)a->xw * a->up + (a->px0 + a->px1) - fut_w;
+    const long long ch = (long long)a->xh * a->up + (a->py0 + a->py1) - fut_h;
+    AFCM_REQUIRE(cw > fdt_w && ch > fdt_h, "upsampled buffer must be at least the size of downsampling filter");
+    const long long yw = (cw - fdt_w + (a->down - 1)) / a->down;
+    const long long yh = (ch - fdt_h + (a->down - 1)) / a->down;
+    AFCM_REQUIRE(yw > 0 && yh > 0 && yw < (1ll << 31) && yh < (1ll << 31), "output must be at least 1x1");
+    a->yw = (int)yw;
+    a->yh = (int)yh;
+    if (a->sign_mode == AFCM_SIGNS_WRITE) {
+        const long long sw_active = yw * a->down - (a->down - 1) + fdt_w;
+        a->sh = (int)(yh * a->down - (a->down - 1) + fdt_h);
+        a->swb = (int)(((sw_active + 15) & ~15ll) >> 2);
+    }
+    return AFCM_OK;
+}
+
+extern "C" int afcm_filtered_lrelu(const afcm_filtered_lrelu_args* a, void* stream) {
+    AFCM_REQUIRE(a != nullptr && a->x && a->y, "filtered_lrelu: x and y must be non-null");
+    AFCM_REQUIRE(a->dtype == AFCM_F32 || a->dtype == AFCM_F16 || a->dtype == AFCM_BF16, "x must be float32, float16 or bfloat16");
+    AFCM_REQUIRE(a->n > 0 && a->c > 0 && a->xh > 0 && a->xw > 0, "x is empty");
+    AFCM_REQUIRE((long long)a->n * a->c < (1ll << 31), "x is too large");
+    afcm_filtered_lrelu_args chk = *a;
+    int rc = afcm_filtered_lrelu_shapes(&chk);
+    if (rc != AFCM_OK) return rc;
+    AFCM_REQUIRE(chk.yh == a->yh && chk.yw == a->yw, "y has shape [%d, %d], expected [%d, %d]", a->yh, a->yw, chk.yh, chk.yw);
+    if (a->sign_mode != AFCM_SIGNS_NONE) {
+        AFCM_REQUIRE(a->signs != nullptr && a->sh > 0 && a->swb > 0 && (a->swb & 3) == 0, "signs must be a [N,C,sh,4k] uint8 tensor");
+        if (a->sign_mode == AFCM_SIGNS_WRITE) {
+            AFCM_REQUIRE(a->sx == 0 && a->sy == 0, "sign offsets must be zero when writing signs");
+            AFCM_REQUIRE(chk.sh == a->sh && chk.swb == a->swb, "signs has shape [%d, %d], expected [%d, %d]", a->sh, a->swb, chk.sh, chk.swb);
+        }
+    }
+    hipStream_t st = (hipStream_t)stream;
+
+    FlreluParams p;
+    p.x = a->x; p.y = a->y; p.b = a->b; p.s = a->signs;
+    p.xw = a->xw; p.xh = a->xh; p.yw = a->yw; p.yh = a->yh; p.C = a->c;
+    p.px0 = a->px0; p.py0 = a->py0;
+    p.tilesX = p.tilesY = 0;
+    p.gain = (float)a->up * (float)a->up * a->gain;
+    p.slope = a->slope; p.clamp = a->clamp; p.flip = a->flip_filter;
+    p.sx = a->sx; p.sy = a->sy; p.sh = a->sh; p.swb = a->swb;
+    p.fscale = 1.f;
+
+    // 1x1 filters, no resampling: pointwise kernel.  The two taps are folded into the launch: they are
+    // read back on the host only when the caller did not pass NULL (= identity).
+    if (a->up == 1 && a->down == 1 && a->fuw == 1 && a->fdw == 1 && a->fuh <= 1 && a->fdh <= 1) {
+        if (a->fu != nullptr || a->fd != nullptr) return AFCM_E_NOKERNEL;  // non-identity 1x1 taps: generic path
+        switch (a->dtype) {
+            case AFCM_F32: return launch_pointwise<float>(p, a->n * a->c, a->sign_mode, st);
+            case AFCM_F16: return launch_pointwise<f16_t>(p, a->n * a->c, a->sign_mode, st);
+            default: return launch_pointwise<bf16_t>(p, a->n * a->c, a->sign_mode, st);
+        }
+    }
+    AFCM_REQUIRE(a->fu != nullptr && a->fd != nullptr, "fu and fd must be non-null for resampling filters");
+    switch (a->dtype) {
+        case AFCM_F32: return dispatch<float>(a, p, st);
+        case AFCM_F16: return dispatch<f16_t>(a, p, st);
+        default: return dispatch<bf16_t>(a, p, st);
+    }
+}
+
+extern "C" int afcm_filtered_lrelu_act(void* x, uint8_t* signs, int32_t dtype, int32_t n, int32_t c, int32_t h, int32_t w,
+                                       int32_t sh, int32_t swb, int32_t sx, int32_t sy, float gain, float slope, float clamp,
+                                       int32_t sign_mode, void* stream) {
+    AFCM_REQUIRE(x != nullptr && n > 0 && c > 0 && h > 0 && w > 0, "x is empty");
+    AFCM_REQUIRE(dtype == AFCM_F32 || dtype == AFCM_F16 || dtype == AFCM_BF16, "x must be float32, float16 or bfloat16");
+    if (sign_mode != AFCM_SIGNS_NONE) {
+        AFCM_REQUIRE(signs != nullptr && sh > 0 && swb > 0 && (swb & 3) == 0, "signs must be a [N,C,sh,4k] uint8 tensor");
+        if (sign_mode == AFCM_SIGNS_WRITE)
+            AFCM_REQUIRE(sx == 0 && sy == 0 && sh == h && swb == (((w + 15) & ~15) >> 2), "signs must be [N,C,%d,%d] with zero offsets when writing", h, ((w + 15) & ~15) >> 2);
+    }
+    FlreluParams p;
+    p.x = x; p.y = x; p.b = nullptr; p.s = signs;
+    p.xw = w; p.xh = h; p.yw = w; p.yh = h; p.C = c;
+    p.px0 = p.py0 = 0; p.tilesX = p.tilesY = 0;
+    p.gain = gain; p.slope = slope; p.clamp = clamp; p.flip = 0;
+    p.sx = sx; p.sy = sy; p.sh = sh; p.swb = swb; p.fscale = 1.f;
+    hipStream_t st = (hipStream_t)stream;
+    switch (dtype) {
+        case AFCM_F32: return launch_pointwise<float>(p, n * c, sign_mode, st);
+        case AFCM_F16: return launch_pointwise<f16_t>(p, n * c, sign_mode, st);
+        default: return launch_pointwise<bf16_t>(p, n * c, sign_mode, st);
+    }
+}

@@ -1,0 +1,122 @@
+/*
+ * afcm_hip.h -- C ABI of libafcm_hip.so: the MI355X (gfx950) kernels behind the
+ * `--model stylegan3` generator hot path of zhiyuns/AFCM.
+ *
+ * This is the drop-in boundary.  Every entry point replaces one function of the reference's
+ * native plugins (pybind modules JIT-built by torch_utils/custom_ops.py:59-155); the reference
+ * interface each one stands in for is cited above it.  Shorthand:
+ *   SG3OPS = models/networks/stylegan3/torch_utils/ops   (in the reference tree)
+ *   NET    = models/networks/stylegan3/networks_stylegan3.py
+ *
+ * Conventions
+ *   - plain C: device pointers + sizes; no torch / ATen types.  All tensor pointers are DEVICE
+ *     pointers into contiguous NCHW storage; filters are DEVICE float32 arrays as in the
+ *     reference (filtered_lrelu.cpp:26).
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  Launches are
+ *     asynchronous; no call allocates, synchronises or keeps global mutable state, so all
+ *     of them are re-entrant across streams and capturable into a hipGraph.  (The reference
+ *     is not: global filter buffers g_fbuf/c_fbuf, filtered_lrelu.cu:77-78.)
+ *   - return value: 0 = launched; AFCM_E_NOKERNEL (-1) = no specialised kernel for these
+ *     parameters (the reference's `return_code = -1`, filtered_lrelu.cpp:52-56 -- the host
+ *     falls back to the generic upfirdn2d + act path); AFCM_E_INVALID (-2) = argument check
+ *     failed (the reference's TORCH_CHECK); >= 1000 = 1000 + hipError_t of the launch.
+ *   - dtype codes: AFCM_F32, AFCM_F16, AFCM_BF16 (bf16 is new capability; the reference
+ *     plugin accepts half/float only).  Arithmetic is always fp32 inside the kernels.
+ */
+#ifndef AFCM_HIP_H
+#define AFCM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AFCM_ABI_VERSION 1
+
+enum { AFCM_F32 = 0, AFCM_F16 = 1, AFCM_BF16 = 2 };
+enum { AFCM_OK = 0, AFCM_E_NOKERNEL = -1, AFCM_E_INVALID = -2 };
+enum { AFCM_SIGNS_NONE = 0, AFCM_SIGNS_WRITE = 1, AFCM_SIGNS_READ = 2 };
+
+/* Library / device introspection. */
+int afcm_abi_version(void);
+/* Human-readable description of the last AFCM_E_INVALID on this thread. */
+const char* afcm_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * filtered_lrelu -- fused bias -> zero-insert upsample -> pad/crop -> FIR(fu) * up^2 ->
+ *                   * gain -> leaky ReLU -> clamp -> FIR(fd) -> decimate.
+ *
+ * Replaces plugin `filtered_lrelu(x, fu, fd, b, si, up, down, px0, px1, py0, py1, sx, sy, gain,
+ * slope, clamp, flip_filter, writeSigns) -> (y, so, return_code)`
+ *   SG3OPS/filtered_lrelu.cpp:16-209, kernels SG3OPS/filtered_lrelu.cu:139-1099.
+ *
+ * Sign tensor (2 bits per element of the upsampled grid, bit0 = value was negative, value 2 =
+ * clamped): uint8 [N, C, sh, swb] with element x of a row in byte x>>2 at bits 2*(x&3) -- the
+ * reference's shape and packing (filtered_lrelu.cpp:87-94).  In WRITE mode sx = sy = 0 is
+ * required (the reference never writes with an offset: filtered_lrelu.py:115,263).
+ * In READ mode element (X, Y) of this call's upsampled grid uses code (X + sx, Y + sy); codes
+ * outside the tensor leave the value unchanged (filtered_lrelu.cu:564-571).
+ * Separable filters: fuh == 0 / fdh == 0 and fu/fd hold fuw / fdw taps (the reference's
+ * "shape [n, 0] indicates separable", filtered_lrelu.cpp:49-50).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct afcm_filtered_lrelu_args {
+    const void* x;          /* [N, C, xh, xw]                                  */
+    void*       y;          /* [N, C, yh, yw]   (allocated by the caller)      */
+    const void* b;          /* [C] same dtype as x, or NULL                    */
+    uint8_t*    signs;      /* [N, C, sh, swb] or NULL                         */
+    const float* fu;        /* device, fuw taps (separable) or fuh*fuw         */
+    const float* fd;        /* device, fdw taps (separable) or fdh*fdw         */
+    int32_t dtype;          /* AFCM_F32 / AFCM_F16 / AFCM_BF16                 */
+    int32_t n, c, xh, xw, yh, yw;
+    int32_t fuw, fuh, fdw, fdh;     /* fuh/fdh == 0: separable                 */
+    int32_t up, down;
+    int32_t px0, px1, py0, py1;
+    int32_t sx, sy;         /* sign offsets                                    */
+    int32_t sh, swb;        /* sign tensor rows / bytes per row                */
+    float   gain, slope, clamp;     /* clamp = +inf to disable                 */
+    int32_t flip_filter;
+    int32_t sign_mode;      /* AFCM_SIGNS_*                                    */
+} afcm_filtered_lrelu_args;
+
+/* Output / sign-tensor geometry for the arguments above (filtered_lrelu.cpp:61-94). Fills yh, yw
+ * and, for WRITE mode, sh, swb.  Pure host arithmetic. */
+int afcm_filtered_lrelu_shapes(afcm_filtered_lrelu_args* a);
+int afcm_filtered_lrelu(const afcm_filtered_lrelu_args* a, void* stream);
+
+/* In-place gain -> leaky ReLU -> clamp with sign write/read, used by the generic fallback.
+ * Replaces plugin `filtered_lrelu_act_(x, si, sx, sy, gain, slope, clamp, writeSigns) -> so`
+ *   SG3OPS/filtered_lrelu.cpp:213-290, kernel SG3OPS/filtered_lrelu.cu:1105-1211.
+ * signs: uint8 [N, C, h, swb] with swb = ceil16(w)/4 in WRITE mode. */
+int afcm_filtered_lrelu_act(void* x, uint8_t* signs, int32_t dtype, int32_t n, int32_t c, int32_t h, int32_t w,
+                            int32_t sh, int32_t swb, int32_t sx, int32_t sy, float gain, float slope, float clamp,
+                            int32_t sign_mode, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * upfirdn2d -- zero-insert upsample, pad/crop, 2-D FIR, decimate.
+ * Replaces plugin `upfirdn2d(x, f, upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip, gain) -> y`
+ *   SG3OPS/upfirdn2d.cpp:16-98, kernels SG3OPS/upfirdn2d.cu:29-375.
+ * f is a device float32 [fh, fw] array (a separable filter is two calls, as in
+ * SG3OPS/upfirdn2d.py:244-245).  y: [N, C, yh, yw] with yw = (xw*upx + padx0 + padx1 - fw + downx) / downx.
+ * ---------------------------------------------------------------------------------------- */
+int afcm_upfirdn2d(void* y, const void* x, const float* f, int32_t dtype, int32_t n, int32_t c, int32_t xh, int32_t xw,
+                   int32_t yh, int32_t yw, int32_t fh, int32_t fw, int32_t upx, int32_t upy, int32_t downx, int32_t downy,
+                   int32_t padx0, int32_t pady0, int32_t flip, float gain, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * bias_act -- y = clamp(act(x + b) * gain); grad = 1: first-order backward from saved x/y;
+ * grad = 2: second-order.  act: 1 linear, 2 relu, 3 lrelu, 4 tanh, 5 sigmoid, 6 elu, 7 selu,
+ * 8 softplus, 9 swish (the reference's cuda_idx, SG3OPS/bias_act.py:21-31).
+ * Replaces plugin `bias_act(x, b, xref, yref, dy, grad, dim, act, alpha, gain, clamp) -> y`
+ *   SG3OPS/bias_act.cpp:32-90, kernel SG3OPS/bias_act.cu:23-147.
+ * x is viewed as [outer, nb, inner] with the bias indexed by the middle dimension
+ * (nb = 0 / b = NULL: no bias).  xref / yref / dy may be NULL when the mode does not need them.
+ * ---------------------------------------------------------------------------------------- */
+int afcm_bias_act(void* y, const void* x, const void* b, const void* xref, const void* yref, const void* dy,
+                  int32_t dtype, int64_t numel, int64_t inner, int32_t nb, int32_t grad, int32_t act, float alpha,
+                  float gain, float clamp, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AFCM_HIP_H */

@@ -1,0 +1,88 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds for gfx950, loads without a GPU,
+and exports exactly the symbols include/afcm_hip.h declares (no compute calls here)."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, 'include', 'afcm_hip.h')
+
+
+def _declared_symbols():
+    src = open(HEADER).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(afcm_[a-z0-9_]+)\s*\(', src)))
+
+
+@pytest.fixture(scope='module')
+def lib():
+    from afcm_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__ as ge
+        ge.build()
+    return _lib.load()
+
+
+def test_header_symbols_are_exported(lib):
+    names = _declared_symbols()
+    assert len(names) >= 7
+    for n in names:
+        assert hasattr(lib, n), f'{n} declared in include/afcm_hip.h but not exported by libafcm_hip.so'
+
+
+def test_binding_table_matches_header(lib):
+    from afcm_amd import _lib
+    assert sorted(_lib.SIGNATURES.keys()) == _declared_symbols()
+
+
+def test_abi_version(lib):
+    assert lib.afcm_abi_version() == 1
+
+
+def test_shapes_helper_is_pure_host(lib):
+    """afcm_filtered_lrelu_shapes is host arithmetic (filtered_lrelu.cpp:61-94): enc0 of the 256^2 model."""
+    from afcm_amd import _lib
+    a = _lib.FilteredLReluArgs()
+    a.n, a.c, a.xh, a.xw = 2, 3, 278, 278
+    a.fuw, a.fuh, a.fdw, a.fdh = 12, 0, 12, 0
+    a.up, a.down = 2, 2
+    a.px0, a.px1, a.py0, a.py1 = 9, 8, 9, 8
+    a.sign_mode = _lib.SIGNS_WRITE
+    assert lib.afcm_filtered_lrelu_shapes(a) == 0
+    assert (a.yh, a.yw) == (276, 276)
+    assert (a.sh, a.swb) == (276 * 2 - 1 + 11, ((276 * 2 - 1 + 11 + 15) & ~15) // 4)
+    a.px0 = -600                                         # upsampled buffer smaller than the down filter
+    assert lib.afcm_filtered_lrelu_shapes(a) == _lib.E_INVALID
+    assert b'upsampled buffer' in lib.afcm_last_error()
+
+
+def test_struct_layout_matches_c():
+    """sizeof/offsetof of the ctypes mirror vs the C compiler's view of the header."""
+    from afcm_amd import _lib
+    prog = r'''
+#include <stdio.h>
+#include <stddef.h>
+#include "afcm_hip.h"
+int main(void){ printf("%zu %zu %zu %zu %zu\n", sizeof(afcm_filtered_lrelu_args), offsetof(afcm_filtered_lrelu_args, dtype),
+  offsetof(afcm_filtered_lrelu_args, up), offsetof(afcm_filtered_lrelu_args, gain), offsetof(afcm_filtered_lrelu_args, sign_mode)); return 0; }
+'''
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, 't.c'), 'w').write(prog)
+        subprocess.check_call(['gcc', '-I', os.path.join(ROOT, 'include'), '-o', os.path.join(d, 't'), os.path.join(d, 't.c')])
+        out = subprocess.check_output([os.path.join(d, 't')]).decode().split()
+    S = _lib.FilteredLReluArgs
+    assert [int(v) for v in out] == [ctypes.sizeof(S), S.dtype.offset, S.up.offset, S.gain.offset, S.sign_mode.offset]
+
+
+def test_ops_refuse_cpu_tensors():
+    import torch
+    from afcm_amd.torch_utils.ops import bias_act, filtered_lrelu, upfirdn2d
+    x = torch.zeros(1, 1, 4, 4)
+    for fn in (lambda: filtered_lrelu.filtered_lrelu(x), lambda: bias_act.bias_act(x, act='lrelu'),
+               lambda: upfirdn2d.upfirdn2d(x, None)):
+        with pytest.raises(RuntimeError, match='no CPU'):
+            fn()

@@ -1,0 +1,235 @@
+"""GPU parity tests (run with `-m gpu` on an MI355X): HIP kernels behind the C ABI vs the CPU oracle
+and vs golden vectors captured from the reference.
+
+Tolerance: the north-star bar is <= 1e-3 max-abs in fp32; these tests assert the tighter 2e-5 x scale
+(fp32 summation-order noise).  16-bit I/O is compared against the fp32 oracle with a stated looser bound.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_names, load_golden
+
+pytestmark = pytest.mark.gpu
+
+TOL = 2e-5
+
+
+def _dev(a, grad=False, dtype=None):
+    if a is None:
+        return None
+    t = torch.from_numpy(np.array(a)).cuda()
+    if dtype is not None and t.dtype.is_floating_point:
+        t = t.to(dtype)
+    return t.requires_grad_(True) if grad else t
+
+
+def _close(a, b, tol=TOL, what=''):
+    a = a.detach().float().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    b = b.detach().float().cpu().numpy() if isinstance(b, torch.Tensor) else np.asarray(b)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    scale = max(1.0, float(np.abs(b).max()))
+    err = float(np.abs(a - b).max())
+    assert err <= tol * scale, f'{what}: max-abs err {err:.3e} (scale {scale:.3g}, tol {tol:g})'
+    return err
+
+
+def _flrelu_args(g):
+    up, down, *pad = [int(v) for v in g['meta']]
+    gain, slope, clamp, flip = g['fmeta']
+    return dict(up=up, down=down, padding=pad, gain=float(gain), slope=float(slope),
+                clamp=None if clamp < 0 else float(clamp), flip_filter=bool(flip))
+
+
+@pytest.mark.parametrize('name', golden_names('F'))
+def test_filtered_lrelu_golden(name):
+    import warnings
+    from afcm_amd.torch_utils.ops import filtered_lrelu as flr
+    g = load_golden(name)
+    kw = _flrelu_args(g)
+    x = _dev(g['x'], True)
+    b = _dev(g.get('b'), True)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore', RuntimeWarning)   # F8 (2-D filter) legitimately takes the generic GPU path
+        y = flr.filtered_lrelu(x, fu=_dev(g.get('fu')), fd=_dev(g.get('fd')), b=b, **kw)
+        _close(y, g['y'], what=name + ' y')
+        grads = torch.autograd.grad((y * _dev(g['r'])).sum(), [x] + ([b] if b is not None else []))
+    _close(grads[0], g['dx'], what=name + ' dx')
+    if b is not None:
+        _close(grads[1], g['db'], what=name + ' db', tol=1e-4)
+
+
+@pytest.mark.parametrize('name', ['F1_up2_down2', 'F2_up2_down4', 'F3_up4_down2', 'F6_clamp', 'F10_multitile'])
+def test_filtered_lrelu_sign_codes_bit_exact(name):
+    """The 2-bit codes written by the kernel equal the definition-level restatement, bit for bit,
+    wherever the pre-activation value is not within rounding distance of 0 or of the clamp."""
+    from afcm_amd import _lib
+    from afcm_amd.torch_utils.ops.filtered_lrelu import _FilteredLRelu
+    from oracle import direct_np as dnp
+    g = load_golden(name)
+    kw = _flrelu_args(g)
+    up, down, pad = kw['up'], kw['down'], kw['padding']
+    x = _dev(g['x'], True)
+    b = _dev(g.get('b'))
+    cfg = (up, down, *pad, kw['gain'], kw['slope'], float('inf') if kw['clamp'] is None else kw['clamp'], kw['flip_filter'], 0, 0)
+    y = _FilteredLRelu.apply(x, _dev(g['fu']), _dev(g['fd']), b, None, cfg)
+    signs = y.grad_fn.saved_tensors[2].cpu().numpy()
+    xb = g['x'].astype(np.float64) + (g['b'].astype(np.float64).reshape(1, -1, 1, 1) if 'b' in g else 0)
+    u = dnp.upfirdn2d(xb, g['fu'], up=up, padding=pad, gain=float(up * up), flip_filter=kw['flip_filter'])
+    v, codes = dnp.lrelu_codes(u, kw['gain'], kw['slope'], kw['clamp'])
+    sh, sw = signs.shape[2], signs.shape[3] * 4
+    assert sh <= codes.shape[2] and codes.shape[3] <= sw
+    got = np.stack([(signs >> (2 * k)) & 3 for k in range(4)], axis=-1).reshape(*signs.shape[:3], sw)
+    w = codes.shape[3]
+    want = codes[:, :, :sh, :]
+    margin = 1e-4 * max(1.0, np.abs(u).max())
+    safe = np.abs(u[:, :, :sh]) > margin
+    if kw['clamp'] is not None:
+        safe &= np.abs(np.abs(u[:, :, :sh] * kw['gain'] * np.where(u[:, :, :sh] < 0, kw['slope'], 1.0)) - kw['clamp']) > 1e-3
+    assert safe.mean() > 0.95
+    assert np.array_equal(got[..., :w][safe], want[safe])
+
+
+@pytest.mark.parametrize('dtype,tol', [(torch.float16, 4e-3), (torch.bfloat16, 3e-2)])
+@pytest.mark.parametrize('name', ['F1_up2_down2', 'F2_up2_down4', 'F3_up4_down2', 'F5_identity'])
+def test_filtered_lrelu_16bit_io(name, dtype, tol):
+    """16-bit storage, fp32 arithmetic: the error is the input/output rounding only."""
+    from afcm_amd.torch_utils.ops import filtered_lrelu as flr
+    from oracle import aten_ops as ops
+    g = load_golden(name)
+    kw = _flrelu_args(g)
+    x16 = _dev(g['x'], dtype=dtype)
+    b16 = _dev(g.get('b'), dtype=dtype)
+    y = flr.filtered_lrelu(x16, fu=_dev(g.get('fu')), fd=_dev(g.get('fd')), b=b16, **kw)
+    assert y.dtype == dtype
+    fu = None if 'fu' not in g else torch.from_numpy(g['fu'])
+    fd = None if 'fd' not in g else torch.from_numpy(g['fd'])
+    ref = ops.filtered_lrelu(x16.float().cpu(), fu=fu, fd=fd, b=None if b16 is None else b16.float().cpu(), **kw)
+    _close(y, ref, tol=tol, what=f'{name} {dtype}')
+
+
+def test_filtered_lrelu_full_size_properties():
+    """Full BASELINE size (batch 16 x 64 ch x 278^2, the enc1 shape): properties that need no CPU oracle run --
+    linearity of the backward op in dy, and agreement of the fused kernel with the generic GPU path
+    (upfirdn2d -> act -> upfirdn2d) on a random subset of planes checked against the CPU oracle."""
+    from afcm_amd.torch_utils.ops import filtered_lrelu as flr
+    from oracle import aten_ops as ops
+    from oracle import generator as ogen
+    pl = ogen.plan(256, 4, 1, {})
+    L = pl['enc'][1]
+    torch.manual_seed(0)
+    x = torch.randn(16, 64, 278, 278, device='cuda', requires_grad=True)
+    b = torch.randn(64, device='cuda') * 0.1
+    kw = dict(up=L['up'], down=L['down'], padding=L['padding'], gain=float(np.sqrt(2)), slope=0.2, clamp=256.0)
+    fu, fd = L['fu'].cuda(), L['fd'].cuda()
+    y = flr.filtered_lrelu(x, fu=fu, fd=fd, b=b, **kw)
+    assert y.shape == (16, 64, 276, 276)
+    r1, r2 = torch.randn_like(y), torch.randn_like(y)
+    g1, = torch.autograd.grad(y, x, r1, retain_graph=True)
+    g2, = torch.autograd.grad(y, x, r2, retain_graph=True)
+    g12, = torch.autograd.grad(y, x, r1 + 2 * r2)
+    assert (g12 - (g1 + 2 * g2)).abs().max().item() <= 1e-4 * g12.abs().max().item()
+    # spot-check 3 planes against the CPU oracle
+    for (n, c) in [(0, 0), (7, 33), (15, 63)]:
+        xs = x[n:n + 1, c:c + 1].detach().cpu().requires_grad_(True)
+        ref = ops.filtered_lrelu(xs, fu=L['fu'], fd=L['fd'], b=b[c:c + 1].cpu(), **kw)
+        _close(y[n:n + 1, c:c + 1], ref, what=f'plane {n},{c}')
+        gref, = torch.autograd.grad(ref, xs, r1[n:n + 1, c:c + 1].cpu())
+        _close(g1[n:n + 1, c:c + 1], gref, what=f'plane {n},{c} dx')
+
+
+def test_filtered_lrelu_errors():
+    from afcm_amd.torch_utils.ops import filtered_lrelu as flr
+    x = torch.randn(1, 2, 8, 8, device='cuda')
+    with pytest.raises(RuntimeError):
+        flr.filtered_lrelu(x.cpu())                                   # no CPU path
+    with pytest.raises(RuntimeError):
+        flr.filtered_lrelu(x, b=torch.zeros(3, device='cuda'))        # bias length
+    with pytest.raises(RuntimeError):
+        flr.filtered_lrelu(x, fu=torch.ones(12, device='cuda'), up=2, padding=-20)   # upsampled buffer smaller than fd
+    with pytest.raises(NotImplementedError):
+        flr.filtered_lrelu(x, impl='ref')
+
+
+def test_filtered_lrelu_second_order():
+    """Backward is the op itself, so grad-of-grad exists; check against autograd on the oracle."""
+    from afcm_amd.torch_utils.ops import filtered_lrelu as flr
+    from oracle import aten_ops as ops
+    g = load_golden('F1_up2_down2')
+    kw = _flrelu_args(g)
+    x = _dev(g['x'], True)
+    y = flr.filtered_lrelu(x, fu=_dev(g['fu']), fd=_dev(g['fd']), b=_dev(g['b']), **kw)
+    q = torch.randn(x.shape, device='cuda')
+    # d/dr of <dx, q> : use r as a differentiable input
+    r2 = _dev(g['r'], True)
+    dx2, = torch.autograd.grad((y * r2).sum(), x, create_graph=True)
+    gr, = torch.autograd.grad((dx2 * q).sum(), r2)
+    xc = torch.from_numpy(g['x']).requires_grad_(True)
+    rc = torch.from_numpy(g['r']).requires_grad_(True)
+    yc = ops.filtered_lrelu(xc, fu=torch.from_numpy(g['fu']), fd=torch.from_numpy(g['fd']), b=torch.from_numpy(g['b']), **kw)
+    dxc, = torch.autograd.grad((yc * rc).sum(), xc, create_graph=True)
+    grc, = torch.autograd.grad((dxc * q.cpu()).sum(), rc)
+    _close(gr, grc, what='d<dx,q>/dr')
+
+
+@pytest.mark.parametrize('name', golden_names('U'))
+def test_upfirdn2d_golden(name):
+    from afcm_amd.torch_utils.ops import upfirdn2d as ufd
+    g = load_golden(name)
+    up, down, px0, px1, py0, py1, flip = [int(v) for v in g['meta']]
+    gain = float(g['fmeta'][0])
+    fn = str(g['fn'])
+    x = _dev(g['x'], True)
+    f = _dev(g['f'])
+    pad = [px0, px1, py0, py1]
+    if fn == 'upfirdn2d':
+        y = ufd.upfirdn2d(x, f, up=up, down=down, padding=pad, flip_filter=bool(flip), gain=gain)
+    elif fn == 'filter2d':
+        y = ufd.filter2d(x, f, padding=pad, flip_filter=bool(flip), gain=gain)
+    elif fn == 'upsample2d':
+        y = ufd.upsample2d(x, f, up=up, padding=pad, flip_filter=bool(flip), gain=gain)
+    else:
+        y = ufd.downsample2d(x, f, down=down, padding=pad, flip_filter=bool(flip), gain=gain)
+    _close(y, g['y'], what=name + ' y')
+    dx, = torch.autograd.grad((y * _dev(g['r'])).sum(), [x])
+    _close(dx, g['dx'], what=name + ' dx')
+
+
+@pytest.mark.parametrize('name', golden_names('B'))
+def test_bias_act_golden(name):
+    from afcm_amd.torch_utils.ops import bias_act as ba
+    g = load_golden(name)
+    alpha, gain, clamp = [None if np.isnan(v) else float(v) for v in g['fmeta']]
+    x = _dev(g['x'], True)
+    b = _dev(g.get('b'), True)
+    y = ba.bias_act(x, b, dim=int(g['dim']), act=str(g['act']), alpha=alpha, gain=gain, clamp=clamp)
+    _close(y, g['y'], what=name)
+    dx, db = torch.autograd.grad((y * _dev(g['r'])).sum(), [x, b])
+    _close(dx, g['dx'], what=name + ' dx')
+    _close(db, g['db'], what=name + ' db')
+
+
+@pytest.mark.parametrize('act', ['lrelu', 'tanh', 'sigmoid', 'elu', 'selu', 'softplus', 'swish'])
+def test_bias_act_second_order(act):
+    """grad=2 mode of the kernel vs double-backward of the oracle."""
+    from afcm_amd.torch_utils.ops import bias_act as ba
+    from oracle import aten_ops as ops
+    torch.manual_seed(3)
+    xc = torch.randn(2, 3, 5, 6).requires_grad_(True)
+    bc = torch.randn(3).requires_grad_(True)
+    rc = torch.randn(2, 3, 5, 6)
+    qc = torch.randn(2, 3, 5, 6)
+
+    def run(x, b, r, q, fn):
+        y = fn(x, b, dim=1, act=act)
+        dx, = torch.autograd.grad((y * r).sum(), x, create_graph=True)
+        return torch.autograd.grad((dx * q).sum(), [x, b], allow_unused=True)
+    want = run(xc, bc, rc, qc, ops.bias_act)
+    xg = xc.detach().cuda().requires_grad_(True)
+    bg = bc.detach().cuda().requires_grad_(True)
+    got = run(xg, bg, rc.cuda(), qc.cuda(), ba.bias_act)
+    for a, b_, nm in zip(got, want, ['d2x', 'd2b']):
+        if b_ is None:
+            assert a is None or a.abs().max().item() == 0
+        else:
+            _close(a, b_, tol=1e-4, what=f'{act} {nm}')
