@@ -40,6 +40,8 @@ static inline int hip_status(hipError_t e) { return e == hipSuccess ? AFCM_OK : 
 constexpr int cdiv(int a, int b) { return (a + b - 1) / b; }
 constexpr int round_up(int a, int b) { return cdiv(a, b) * b; }
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
+// smallest odd multiple of 4 that is >= a (a itself a multiple of 4)
+constexpr int odd4(int a) { return ((a / 4) % 2 == 1) ? a : a + 4; }
 
 // floor division / modulo for possibly negative numerators (b > 0)
 __host__ __device__ __forceinline__ int floor_div(int a, int b) {

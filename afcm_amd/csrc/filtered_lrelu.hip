@@ -80,16 +80,47 @@ struct FlreluTile {
     static constexpr int TUHP = round_up(TUH, ROWS_C);
     static constexpr int MB = ROWS_C / UP;                 // input-row steps per stage-C item
     static constexpr int TIW = TUWP / UP + FUT;
-    static constexpr int TIWP = round_up(TIW, 4);
+    // LDS row pitches are odd multiples of 4 floats (16 B): lanes that walk down consecutive rows at a fixed
+    // column then hit 16 distinct 16-byte slots per ds_read_b128 / ds_write_b128 lane group (conflict-free).
+    static constexpr int TIWP = odd4(round_up(TIW + 2, 4));     // sIn pitch (+2: stage B reads 12 floats per item)
+    static constexpr int PU = odd4(TUWP);                       // upX / upXY pitch
+    static constexpr int PD = odd4(TOW);                        // downX pitch
     static constexpr int TIH = TUHP / UP + FUT;
-    static constexpr int SZ_A = cmax(TIH * TIWP, TUHP * TUWP);  // sIn, later upXY
-    static constexpr int SZ_B = cmax(TIH * TUWP, TUH * TOW);    // upX, later downX
+    static constexpr int SZ_A = cmax(TIH * TIWP, TUHP * PU);    // sIn, later upXY
+    static constexpr int SZ_B = cmax(TIH * PU, TUH * PD);       // upX, later downX
     static constexpr int NCOEF = 2 * FU + FD;
-    static constexpr int LDS_FLOATS = SZ_A + SZ_B + round_up(NCOEF, 4);
+    // READ mode: the tile's window of the sign tensor, staged as dwords (16 codes each): per row the
+    // dwords covering columns [U0x + sx, U0x + sx + TUWP) -- TUWP/16 + 1 of them because sx is arbitrary.
+    static constexpr int SGN_W = TUWP / 16 + 1;
+    static constexpr int SGN_WORDS = (SIGN == AFCM_SIGNS_READ) ? TUHP * SGN_W : 0;
+    static constexpr int LDS_FLOATS = SZ_A + SZ_B + round_up(NCOEF, 4) + SGN_WORDS;
     static_assert(ROWS_C % UP == 0 && FUT % 2 == 0 && TOW % 4 == 0 && TOH % RO == 0, "tile shape");
     static_assert((TOW * DOWN) % 16 == 0, "sign ownership must fall on dword boundaries");
-    static_assert(DOWN * (TOW - 4) + round_up(DOWN * 3 + FD, 4) <= TUWP, "stage D over-read must stay inside the row");
+    static_assert(DOWN * (TOW - 4) + round_up(DOWN * 3 + FD, 4) <= PU, "stage D over-read must stay inside the row");
     static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS overflow");
+
+    // Stage the sign window into LDS.  Dwords outside the tensor read as 0 (= values pass unchanged).
+    static __device__ __forceinline__ void stage_signs(unsigned* __restrict__ sgn, const FlreluParams& p, int plane,
+                                                       int U0x, int U0y, int tid) {
+        const unsigned* splane = (const unsigned*)(p.s + (size_t)plane * p.sh * p.swb);
+        const int wpr = p.swb >> 2;                         // dwords per sign row
+        const int w0 = (U0x + p.sx) >> 4;                   // floor: arithmetic shift
+        constexpr int NW = cdiv(TUHP * SGN_W, NT);
+        unsigned v[NW];
+#pragma unroll
+        for (int i = 0; i < NW; i++) {
+            const int idx = tid + i * NT;
+            const int r = idx / SGN_W, c = idx - r * SGN_W;
+            const int Y = U0y + p.sy + r, wi = w0 + c;
+            const bool ok = idx < TUHP * SGN_W && (unsigned)Y < (unsigned)p.sh && (unsigned)wi < (unsigned)wpr;
+            v[i] = ok ? splane[(size_t)Y * wpr + wi] : 0u;
+        }
+#pragma unroll
+        for (int i = 0; i < NW; i++) {
+            const int idx = tid + i * NT;
+            if (idx < TUHP * SGN_W) sgn[idx] = v[i];
+        }
+    }
 
     // ---- stage B: up-FIR along x.  One item = one input row x 4 input columns -> 4*UP outputs.
     template <int PH>
@@ -101,31 +132,28 @@ struct FlreluTile {
 #pragma unroll
             for (int j = 0; j < FUT; j++) c[a][j] = cu[a * FUT + j];
         constexpr int NCH = TUWP / (4 * UP);
-        constexpr int NIN = 4 + FUT;
+        constexpr int NIN4 = cdiv(4 + FUT, 4);
         for (int item = tid; item < TIH * NCH; item += NT) {
-            const int r = item / NCH, ch = item - r * NCH;
+            const int ch = item / TIH, r = item - ch * TIH;     // consecutive lanes -> consecutive rows
             const float* src = sIn + r * TIWP + 4 * ch;
-            float in[NIN];
+            float in[NIN4 * 4];
 #pragma unroll
-            for (int i = 0; i < NIN / 2; i++) {
-                float2 t = *(const float2*)(src + 2 * i);
-                in[2 * i] = t.x;
-                in[2 * i + 1] = t.y;
+            for (int i = 0; i < NIN4; i++) {
+                float4 t = *(const float4*)(src + 4 * i);
+                in[4 * i] = t.x; in[4 * i + 1] = t.y; in[4 * i + 2] = t.z; in[4 * i + 3] = t.w;
             }
             float out[4 * UP];
 #pragma unroll
             for (int mm = 0; mm < 4; mm++)
 #pragma unroll
                 for (int a = 0; a < UP; a++) {
-                    constexpr int dummy = 0;
-                    (void)dummy;
                     const int o = (a > PH) ? 1 : 0;
                     float acc = 0.f;
 #pragma unroll
                     for (int j = 0; j < FUT; j++) acc = fmaf(c[a][j], in[mm + o + j], acc);
                     out[mm * UP + a] = acc;
                 }
-            float* dst = upX + r * TUWP + 4 * UP * ch;
+            float* dst = upX + r * PU + 4 * UP * ch;
 #pragma unroll
             for (int q = 0; q < UP; q++) *(float4*)(dst + 4 * q) = make_float4(out[4 * q], out[4 * q + 1], out[4 * q + 2], out[4 * q + 3]);
         }
@@ -134,8 +162,8 @@ struct FlreluTile {
     // ---- stage C: up-FIR along y + gain + leaky ReLU + clamp + sign codes.  One item = 4 columns x 8 rows.
     template <int PH>
     static __device__ __forceinline__ void up_y_act(const float* __restrict__ upX, float* __restrict__ upXY,
-                                                    const float* __restrict__ cu, int tid, const FlreluParams& p,
-                                                    int plane, int U0x, int U0y, bool lastX, bool lastY) {
+                                                    const float* __restrict__ cu, const unsigned* __restrict__ sgn, int tid,
+                                                    const FlreluParams& p, int plane, int U0x, int U0y, bool lastX, bool lastY) {
         float c[UP][FUT];
 #pragma unroll
         for (int a = 0; a < UP; a++)
@@ -149,8 +177,11 @@ struct FlreluTile {
             const int rb = item / NG, g = item - rb * NG;
             float4 in[NIN];
 #pragma unroll
-            for (int i = 0; i < NIN; i++) in[i] = *(const float4*)(upX + (rb * MB + i) * TUWP + 4 * g);
+            for (int i = 0; i < NIN; i++) in[i] = *(const float4*)(upX + (rb * MB + i) * PU + 4 * g);
             const int X = U0x + 4 * g;
+            // READ mode: bit offset of this item's 4 codes inside the staged dword pair
+            const int sbit = (((U0x + p.sx) & 15) + 4 * g) * 2;
+            const int sw0 = sbit >> 5, sshift = sbit & 31;
 #pragma unroll
             for (int mm = 0; mm < MB; mm++)
 #pragma unroll
@@ -169,12 +200,16 @@ struct FlreluTile {
                     const int row = rb * ROWS_C + mm * UP + a;
                     const int Y = U0y + row;
                     unsigned codes = 0;
-                    if (SIGN == AFCM_SIGNS_READ) codes = fetch_codes4(splane, X + p.sx, Y + p.sy, p.sh, p.swb);
+                    if (SIGN == AFCM_SIGNS_READ) {
+                        const unsigned lo = sgn[row * SGN_W + sw0];
+                        const unsigned hi = (sw0 + 1 < SGN_W) ? sgn[row * SGN_W + sw0 + 1] : 0u;
+                        codes = __builtin_amdgcn_alignbit(hi, lo, sshift) & 0xffu;
+                    }
                     unsigned c0 = act_elem<SIGN>(acc.x, p.gain, p.slope, p.clamp, codes);
                     unsigned c1 = act_elem<SIGN>(acc.y, p.gain, p.slope, p.clamp, codes >> 2);
                     unsigned c2 = act_elem<SIGN>(acc.z, p.gain, p.slope, p.clamp, codes >> 4);
                     unsigned c3 = act_elem<SIGN>(acc.w, p.gain, p.slope, p.clamp, codes >> 6);
-                    *(float4*)(upXY + row * TUWP + 4 * g) = acc;
+                    *(float4*)(upXY + row * PU + 4 * g) = acc;
                     if (SIGN == AFCM_SIGNS_WRITE) {
                         // 4 lanes of a quad hold 16 consecutive columns: assemble one dword.
                         int byte = (int)(c0 | (c1 << 2) | (c2 << 4) | (c3 << 6));
@@ -197,8 +232,8 @@ struct FlreluTile {
         constexpr int NCD = TOW / 4;
         constexpr int NIN4 = cdiv(DOWN * 3 + FD, 4);
         for (int item = tid; item < TUH * NCD; item += NT) {
-            const int r = item / NCD, ch = item - r * NCD;
-            const float* src = upXY + r * TUWP + DOWN * 4 * ch;
+            const int ch = item / TUH, r = item - ch * TUH;     // consecutive lanes -> consecutive rows
+            const float* src = upXY + r * PU + DOWN * 4 * ch;
             float in[NIN4 * 4];
 #pragma unroll
             for (int i = 0; i < NIN4; i++) {
@@ -213,7 +248,7 @@ struct FlreluTile {
                 for (int k = 0; k < FD; k++) acc = fmaf(cd[k], in[DOWN * t + k], acc);
                 out[t] = acc;
             }
-            *(float4*)(downX + r * TOW + 4 * ch) = make_float4(out[0], out[1], out[2], out[3]);
+            *(float4*)(downX + r * PD + 4 * ch) = make_float4(out[0], out[1], out[2], out[3]);
         }
     }
 
@@ -234,7 +269,7 @@ struct FlreluTile {
             for (int t = 0; t < RO; t++) acc[t] = make_float2(0.f, 0.f);
 #pragma unroll
             for (int i = 0; i < NROW; i++) {
-                const float2 v = *(const float2*)(downX + (DOWN * p0 + i) * TOW + 2 * cp);
+                const float2 v = *(const float2*)(downX + (DOWN * p0 + i) * PD + 2 * cp);
 #pragma unroll
                 for (int t = 0; t < RO; t++) {
                     const int k = i - DOWN * t;
@@ -268,6 +303,7 @@ __global__ __launch_bounds__(NT) void flrelu_sep_kernel(FlreluParams p, const fl
     float* cuX = lds + K::SZ_A + K::SZ_B;
     float* cuY = cuX + K::FU;
     float* cdl = cuY + K::FU;
+    unsigned* sgn = (unsigned*)(lds + K::SZ_A + K::SZ_B + round_up(K::NCOEF, 4));
 
     const int tid = threadIdx.x;
     int bid = blockIdx.x;
@@ -297,16 +333,28 @@ __global__ __launch_bounds__(NT) void flrelu_sep_kernel(FlreluParams p, const fl
     }
     if (tid < FD) cdl[tid] = p.flip ? fd[tid] : fd[FD - 1 - tid];
 
-    // stage A: input tile + bias (zero outside the image, without bias: the bias is added before padding)
+    // stage A: input tile + bias (zero outside the image, without bias: the bias is added before padding).
+    // All global loads of the tile are issued back to back before the first LDS write, so the tile
+    // pays one HBM round trip, not one per element.
     {
         const T* xp = (const T*)p.x + (size_t)plane * p.xh * p.xw;
         const float bias = p.b ? to_f32(((const T*)p.b)[plane % p.C]) : 0.f;
-        for (int idx = tid; idx < K::TIH * K::TIWP; idx += NT) {
+        constexpr int NLD = cdiv(K::TIH * K::TIWP, NT);
+        T raw[NLD];
+        bool ok[NLD];
+#pragma unroll
+        for (int i = 0; i < NLD; i++) {
+            const int idx = tid + i * NT;
             const int r = idx / K::TIWP, c = idx - r * K::TIWP;
             const int iy = I0y + r, ix = I0x + c;
-            float v = 0.f;
-            if ((unsigned)ix < (unsigned)p.xw && (unsigned)iy < (unsigned)p.xh) v = to_f32(xp[(size_t)iy * p.xw + ix]) + bias;
-            bufA[idx] = v;
+            ok[i] = (idx < K::TIH * K::TIWP) && (unsigned)ix < (unsigned)p.xw && (unsigned)iy < (unsigned)p.xh;
+            raw[i] = ok[i] ? xp[(size_t)iy * p.xw + ix] : from_f32<T>(0.f);
+        }
+        if (SIGN == AFCM_SIGNS_READ) K::stage_signs(sgn, p, plane, U0x, U0y, tid);
+#pragma unroll
+        for (int i = 0; i < NLD; i++) {
+            const int idx = tid + i * NT;
+            if (idx < K::TIH * K::TIWP) bufA[idx] = ok[i] ? to_f32(raw[i]) + bias : 0.f;
         }
     }
     __syncthreads();
@@ -319,10 +367,10 @@ __global__ __launch_bounds__(NT) void flrelu_sep_kernel(FlreluParams p, const fl
     __syncthreads();
     const bool lastX = (tx == p.tilesX - 1), lastY = (ty == p.tilesY - 1);
     switch (phy) {
-        case 0: K::template up_y_act<0>(bufB, bufA, cuY, tid, p, plane, U0x, U0y, lastX, lastY); break;
-        case 1: K::template up_y_act<1>(bufB, bufA, cuY, tid, p, plane, U0x, U0y, lastX, lastY); break;
-        case 2: if (UP > 2) K::template up_y_act<(UP > 2 ? 2 : 0)>(bufB, bufA, cuY, tid, p, plane, U0x, U0y, lastX, lastY); break;
-        default: if (UP > 2) K::template up_y_act<(UP > 2 ? 3 : 0)>(bufB, bufA, cuY, tid, p, plane, U0x, U0y, lastX, lastY); break;
+        case 0: K::template up_y_act<0>(bufB, bufA, cuY, sgn, tid, p, plane, U0x, U0y, lastX, lastY); break;
+        case 1: K::template up_y_act<1>(bufB, bufA, cuY, sgn, tid, p, plane, U0x, U0y, lastX, lastY); break;
+        case 2: if (UP > 2) K::template up_y_act<(UP > 2 ? 2 : 0)>(bufB, bufA, cuY, sgn, tid, p, plane, U0x, U0y, lastX, lastY); break;
+        default: if (UP > 2) K::template up_y_act<(UP > 2 ? 3 : 0)>(bufB, bufA, cuY, sgn, tid, p, plane, U0x, U0y, lastX, lastY); break;
     }
     __syncthreads();
     K::down_x(bufA, bufB, cdl, tid);

@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Per-layer filtered_lrelu micro-benchmark (GPU): forward (sign write) and backward (sign read) of every
+resampling layer of the 256^2 generator at batch B, reported as algorithmic GB/s (SURVEY.md 8d:
+read x + write y + 2 bits/elem of signs)."""
+import argparse
+import math
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from afcm_amd import layer_schedule as sched  # noqa: E402
+from afcm_amd.torch_utils.ops import filtered_lrelu as flr  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--batch', type=int, default=16)
+    ap.add_argument('--res', type=int, default=256)
+    ap.add_argument('--dtype', default='fp32')
+    ap.add_argument('--iters', type=int, default=10)
+    args = ap.parse_args()
+    dt = {'fp32': torch.float32, 'bf16': torch.bfloat16, 'fp16': torch.float16}[args.dtype]
+    pl = sched.plan(args.res, 4, 1, {})
+    tot_b = tot_t = tot_bb = tot_tb = 0.0
+    seen = {}
+    for L in pl['enc'] + pl['dec']:
+        h = L['in_size'] + L['k'] - 1
+        key = (L['cout'], h, L['up'], L['down'], tuple(L['padding']))
+        x = torch.randn(args.batch, L['cout'], h, h, device='cuda', dtype=dt).requires_grad_(True)
+        b = torch.zeros(L['cout'], device='cuda', dtype=dt)
+        fu = None if L['fu'] is None else L['fu'].cuda()
+        fd = None if L['fd'] is None else L['fd'].cuda()
+        kw = dict(up=L['up'], down=L['down'], padding=L['padding'], gain=1.0 if L.get('torgb') else math.sqrt(2),
+                  slope=1.0 if L.get('torgb') else 0.2, clamp=256.0)
+        y = flr.filtered_lrelu(x, fu=fu, fd=fd, b=b, **kw)
+        signs = y.grad_fn.saved_tensors[2]
+        r = torch.randn_like(y)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        for _ in range(2):
+            y = flr.filtered_lrelu(x, fu=fu, fd=fd, b=b, **kw)
+        ev[0].record()
+        for _ in range(args.iters):
+            y = flr.filtered_lrelu(x, fu=fu, fd=fd, b=b, **kw)
+        ev[1].record()
+        for _ in range(2):
+            torch.autograd.grad(y, x, r, retain_graph=True)
+        ev[2].record()
+        for _ in range(args.iters):
+            torch.autograd.grad(y, x, r, retain_graph=True)
+        ev[3].record()
+        torch.cuda.synchronize()
+        tf = ev[0].elapsed_time(ev[1]) / args.iters
+        tb = ev[2].elapsed_time(ev[3]) / args.iters
+        nbytes = (x.numel() + y.numel()) * x.element_size() + signs.numel()
+        tot_b += nbytes; tot_t += tf; tot_bb += nbytes; tot_tb += tb
+        if key not in seen:
+            seen[key] = 1
+            print(f'{L["name"]:14s} C={L["cout"]:3d} {h:3d}->{L["out_size"]:3d} up{L["up"]} down{L["down"]}  fwd {tf:7.3f} ms {nbytes/tf/1e6:7.1f} GB/s   bwd {tb:7.3f} ms {nbytes/tb/1e6:7.1f} GB/s')
+        del x, y, r, signs
+    print(f'TOTAL fwd {tot_t:.2f} ms = {tot_b/tot_t/1e6:.1f} GB/s ({tot_t/args.batch:.3f} ms/img); bwd {tot_tb:.2f} ms = {tot_bb/tot_tb/1e6:.1f} GB/s; bytes/img {tot_b/args.batch/1e6:.1f} MB')
+
+
+if __name__ == '__main__':
+    main()
