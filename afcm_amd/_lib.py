@@ -44,6 +44,13 @@ SIGNATURES = {
     'afcm_upfirdn2d': (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32,
                                  _i32, _i32, _i32, _f32, _vp]),
     'afcm_bias_act': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i64, _i32, _i32, _i32, _f32, _f32, _f32, _vp]),
+    'afcm_conv2d_block_k': (C.c_int, [_i32]),
+    'afcm_conv2d_pack_weights': (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    'afcm_conv2d': (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    'afcm_conv2d_wgrad_splits': (C.c_int, [_i32, _i32, _i32, _i32]),
+    'afcm_conv2d_wgrad': (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    'afcm_scale_planes': (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i64, _i32, _vp]),
+    'afcm_plane_dot': (C.c_int, [_vp, _vp, _vp, _i32, _i64, _i32, _vp]),
 }
 
 

@@ -1,0 +1,622 @@
+// Dense KxK convolution for the modulated / encoder convs of the generator (NET:25-64, NET:505) on gfx950 MFMA.
+//
+// The reference materialises per-sample weights [N,O,I,k,k] and runs a grouped cuDNN conv (NET:46-63).
+// Here the mathematically identical factorisation is used (the non-fused branch of CoModGAN/layers.py:56-65):
+//     y[n,o] = d[n,o] * conv(W^, s[n,i] * x[n,i])          W^ shared by the whole batch
+// so the contraction is one implicit GEMM  D[o][pixel] = sum_{tap,i} W^[tap][o][i] * xs[n][i][pixel+tap]  with
+//   A = weights  (MFMA rows  = output channels), pre-packed K-contiguous by conv2d_pack_weights
+//   B = activations (MFMA cols = output pixels), NCHW in HBM, transposed to [pixel][channel] while staging
+//       into LDS so that every tap is a pure address offset of the same LDS patch (im2col never exists)
+//   D = fp32 accumulators in registers; the per-(n,o) scale is applied in the epilogue.
+// bf16/f16 use v_mfma_f32_32x32x16_{bf16,f16}; fp32 uses v_mfma_f32_32x32x2_f32 (exact fp32, for the <=1e-3 parity path).
+// The same kernel computes the data gradient (weights packed transposed + flipped, pad' = k-1-pad).
+#include <type_traits>
+
+#include "common.h"
+
+namespace afcm {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+
+template <typename T> struct ConvCfg;
+template <> struct ConvCfg<bf16_t> { static constexpr int BK = 16, PITCH = 24; };   // elements; 48-byte rows: conflict-free b128
+template <> struct ConvCfg<f16_t>  { static constexpr int BK = 16, PITCH = 24; };
+template <> struct ConvCfg<float>  { static constexpr int BK = 8,  PITCH = 9;  };   // 36-byte rows: conflict-free b32
+
+constexpr int kPatchMax = 416;   // LDS patch capacity in pixels
+constexpr int kSlots = 256;      // output pixels per workgroup
+
+struct ConvParams {
+    const void* x;        // [N, Cin, H, W]
+    void* y;              // [N, Cout, P, Q]
+    const void* wp;       // packed weights [nkc][KK][Opad][BK]
+    const float* oscale;  // [N * Cout] or null
+    int N, Cin, Cout, H, W, P, Q;
+    int pad;
+    int TH, TW, PWL, tilesX, tilesY;
+    int Opad, nkc;
+};
+
+template <typename T, int BM_O, int KS>
+__global__ __launch_bounds__(256, 2) void conv2d_fwd_kernel(ConvParams p) {
+    typedef ConvCfg<T> C;
+    constexpr int BK = C::BK, PITCH = C::PITCH, MI = BM_O / 64, KK = KS * KS;
+    constexpr bool F32 = sizeof(T) == 4;
+    constexpr int EPV = 16 / sizeof(T);              // elements per 16-byte piece
+    constexpr int PPR = BK / EPV;                    // pieces per weight row (2)
+    constexpr int NPIECES = KK * BM_O * PPR;
+    constexpr int NWP = cdiv(NPIECES, 256);
+    constexpr int NCG = F32 ? 1 : BK / 8;            // 8-channel groups per chunk in the patch staging
+    __shared__ __attribute__((aligned(16))) T lds[(KK * BM_O + kPatchMax) * PITCH];
+    T* lds_w = lds;
+    T* lds_p = lds + KK * BM_O * PITCH;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wo = wave & 1, wpx = wave >> 1;
+    const int r32 = lane & 31, h = lane >> 5;
+
+    int bid = blockIdx.x;
+    const int tx = bid % p.tilesX; bid /= p.tilesX;
+    const int ty = bid % p.tilesY; bid /= p.tilesY;
+    const int n = bid % p.N;
+    const int ob = bid / p.N;
+    const int y0 = ty * p.TH, x0 = tx * p.TW;
+    const int o0 = ob * BM_O;
+    const int PH = p.TH + KS - 1, PWL = p.PWL;
+    const int xorg = (x0 - p.pad) & ~1;
+    const int xoff = (x0 - p.pad) - xorg;
+
+    // fragment bases (element offsets into LDS)
+    int bbase[4], pyv[4], pxv[4];
+#pragma unroll
+    for (int ti = 0; ti < 4; ti++) {
+        const int j = wpx * 128 + ti * 32 + r32;
+        int py = j / p.TW, px = j - py * p.TW;
+        const bool valid = j < p.TH * p.TW;
+        if (!valid) { py = 0; px = 0; }
+        pyv[ti] = valid ? y0 + py : p.P;             // invalid slots fall outside the image -> never stored
+        pxv[ti] = x0 + px;
+        bbase[ti] = (py * PWL + px + xoff) * PITCH + h * (F32 ? 1 : 8);
+    }
+    int abase[MI];
+#pragma unroll
+    for (int mi = 0; mi < MI; mi++) abase[mi] = (wo * (BM_O / 2) + mi * 32 + r32) * PITCH + h * (F32 ? 1 : 8);
+
+    f32x16 acc[MI][4];
+#pragma unroll
+    for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+        for (int ti = 0; ti < 4; ti++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[mi][ti][e] = 0.f;
+
+    // ---- staging descriptors -------------------------------------------------------------------------------
+    // weights: 16-byte pieces, straight copies
+    int wsrc[NWP], wdst[NWP];
+#pragma unroll
+    for (int i = 0; i < NWP; i++) {
+        const int j = tid + i * 256;
+        const int tap = j / (BM_O * PPR), q = j - tap * (BM_O * PPR);
+        const int o = q / PPR, pc = q - o * PPR;
+        wsrc[i] = ((tap * p.Opad) + o0 + o) * BK + pc * EPV;
+        wdst[i] = (tap * BM_O + o) * PITCH + pc * EPV;
+    }
+    const size_t wchunk = (size_t)KK * p.Opad * BK;
+    // patch: one item = 4 pixels x 8 channels
+    const int cg = tid % NCG, pg = tid / NCG;
+    const int pcols = PWL >> 2;
+    const int prow = pg / pcols, pcol4 = pg - prow * pcols;
+    const bool pvalid = prow < PH;
+    const int iy = y0 - p.pad + prow, ix = xorg + 4 * pcol4;
+    const bool rowok = pvalid && (unsigned)iy < (unsigned)p.H;
+    const T* xn = (const T*)p.x + (size_t)n * p.Cin * p.H * p.W;
+    const long long pix_off = (long long)(rowok ? iy : 0) * p.W + ix;
+    const int pdst = (prow * PWL + 4 * pcol4) * PITCH + cg * 8;
+
+    uint4 wreg[NWP];
+    unsigned preg[8][F32 ? 4 : 2];
+
+    auto issue_loads = [&](int kc) {
+        const T* wsrcp = (const T*)p.wp + (size_t)kc * wchunk;
+#pragma unroll
+        for (int i = 0; i < NWP; i++)
+            if (tid + i * 256 < NPIECES) wreg[i] = *(const uint4*)(wsrcp + wsrc[i]);
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            const int ch = kc * BK + cg * 8 + c;
+            const bool chok = rowok && ch < p.Cin;
+            const T* src = xn + ((long long)ch * p.H * p.W + pix_off);
+            if (F32) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) preg[c][e] = (chok && (unsigned)(ix + e) < (unsigned)p.W) ? *(const unsigned*)(src + e) : 0u;
+            } else {
+                preg[c][0] = (chok && (unsigned)ix < (unsigned)p.W) ? *(const unsigned*)(src) : 0u;
+                preg[c][1] = (chok && (unsigned)(ix + 2) < (unsigned)p.W) ? *(const unsigned*)(src + 2) : 0u;
+            }
+        }
+    };
+    auto write_lds = [&]() {
+#pragma unroll
+        for (int i = 0; i < NWP; i++)
+            if (tid + i * 256 < NPIECES) {
+                if (F32) {
+                    unsigned* d = (unsigned*)(lds_w + wdst[i]);
+                    d[0] = wreg[i].x; d[1] = wreg[i].y; d[2] = wreg[i].z; d[3] = wreg[i].w;
+                } else {
+                    *(uint4*)(lds_w + wdst[i]) = wreg[i];
+                }
+            }
+        if (pvalid) {
+            if (F32) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    unsigned* d = (unsigned*)(lds_p + pdst + e * PITCH);
+#pragma unroll
+                    for (int c = 0; c < 8; c++) d[c] = preg[c][e];
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const unsigned sel = (e & 1) ? 0x07060302u : 0x05040100u;
+                    uint4 v;
+                    v.x = __builtin_amdgcn_perm(preg[1][e >> 1], preg[0][e >> 1], sel);
+                    v.y = __builtin_amdgcn_perm(preg[3][e >> 1], preg[2][e >> 1], sel);
+                    v.z = __builtin_amdgcn_perm(preg[5][e >> 1], preg[4][e >> 1], sel);
+                    v.w = __builtin_amdgcn_perm(preg[7][e >> 1], preg[6][e >> 1], sel);
+                    *(uint4*)(lds_p + pdst + e * PITCH) = v;
+                }
+            }
+        }
+    };
+
+    issue_loads(0);
+    write_lds();
+    __syncthreads();
+    for (int kc = 0; kc < p.nkc; kc++) {
+        if (kc + 1 < p.nkc) issue_loads(kc + 1);
+#pragma unroll
+        for (int r = 0; r < KS; r++)
+#pragma unroll
+            for (int s = 0; s < KS; s++) {
+                const int tap = r * KS + s;
+                const int tapoff = (r * PWL + s) * PITCH;
+                if constexpr (F32) {
+#pragma unroll
+                    for (int k2 = 0; k2 < BK / 2; k2++) {
+                        float a[MI], b[4];
+#pragma unroll
+                        for (int mi = 0; mi < MI; mi++) a[mi] = lds_w[tap * BM_O * PITCH + abase[mi] + 2 * k2];
+#pragma unroll
+                        for (int ti = 0; ti < 4; ti++) b[ti] = lds_p[bbase[ti] + tapoff + 2 * k2];
+#pragma unroll
+                        for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+                            for (int ti = 0; ti < 4; ti++)
+                                acc[mi][ti] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], b[ti], acc[mi][ti], 0, 0, 0);
+                    }
+                } else {
+                    typedef typename std::conditional<std::is_same<T, bf16_t>::value, bf16x8, f16x8>::type frag_t;
+                    frag_t a[MI], b[4];
+#pragma unroll
+                    for (int mi = 0; mi < MI; mi++) a[mi] = *(const frag_t*)(lds_w + tap * BM_O * PITCH + abase[mi]);
+#pragma unroll
+                    for (int ti = 0; ti < 4; ti++) b[ti] = *(const frag_t*)(lds_p + bbase[ti] + tapoff);
+#pragma unroll
+                    for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+                        for (int ti = 0; ti < 4; ti++) {
+                            if constexpr (std::is_same<T, bf16_t>::value)
+                                acc[mi][ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ti], acc[mi][ti], 0, 0, 0);
+                            else
+                                acc[mi][ti] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mi], b[ti], acc[mi][ti], 0, 0, 0);
+                        }
+                }
+            }
+        __syncthreads();
+        if (kc + 1 < p.nkc) {
+            write_lds();
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: D[row = channel][col = pixel]; row = (reg&3) + 8*(reg>>2) + 4*h within the 32x32 tile.
+    T* yn = (T*)p.y + (size_t)n * p.Cout * p.P * p.Q;
+#pragma unroll
+    for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+        for (int reg = 0; reg < 16; reg++) {
+            const int o = o0 + wo * (BM_O / 2) + mi * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+            if (o < p.Cout) {
+                const float sc = p.oscale ? p.oscale[(size_t)n * p.Cout + o] : 1.f;
+                T* yo = yn + (size_t)o * p.P * p.Q;
+#pragma unroll
+                for (int ti = 0; ti < 4; ti++)
+                    if (pyv[ti] < p.P && pxv[ti] < p.Q) yo[(size_t)pyv[ti] * p.Q + pxv[ti]] = from_f32<T>(acc[mi][ti][reg] * sc);
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Weight packing: w[O][I][KS][KS] (fp32) -> [nkc][KK][Opad][BK] of T, zero padded.
+//   mode 0 (forward):        dst[kc][r*KS+s][o][kk]  = w[o][kc*BK+kk][r][s]
+//   mode 1 (data gradient):  roles of O and I swap and taps flip:
+//                            dst[kc][r*KS+s][i][kk]  = w[kc*BK+kk][i][KS-1-r][KS-1-s]
+template <typename T>
+__global__ __launch_bounds__(256) void conv2d_pack_kernel(T* __restrict__ dst, const float* __restrict__ w, int O, int I, int KS,
+                                                          int rows, int cols, int rows_pad, int BK, int nkc, int mode) {
+    const int KK = KS * KS;
+    const long long total = (long long)nkc * KK * rows_pad * BK;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int kk = (int)(idx % BK);
+        long long t = idx / BK;
+        const int row = (int)(t % rows_pad); t /= rows_pad;
+        const int tap = (int)(t % KK);
+        const int kc = (int)(t / KK);
+        const int col = kc * BK + kk;
+        float v = 0.f;
+        if (row < rows && col < cols) {
+            const int r = tap / KS, s = tap - r * KS;
+            if (mode == 0) v = w[(((size_t)row * I + col) * KS + r) * KS + s];
+            else v = w[(((size_t)col * I + row) * KS + (KS - 1 - r)) * KS + (KS - 1 - s)];
+        }
+        dst[idx] = from_f32<T>(v);
+    }
+}
+
+// y[plane, :] = x[plane, :] * scale[plane]  (dtype conversion fused).  HBM-bound elementwise pass.
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void scale_planes_kernel(TO* __restrict__ y, const TI* __restrict__ x, const float* __restrict__ scale,
+                                                           long long planes, int hw) {
+    const int per = (hw + 3) >> 2;
+    const long long total = planes * per;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const long long plane = idx / per;
+        const int i0 = (int)(idx - plane * per) << 2;
+        const float sc = scale ? scale[plane] : 1.f;
+        const TI* xp = x + plane * hw + i0;
+        TO* yp = y + plane * hw + i0;
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+            if (i0 + e < hw) yp[e] = from_f32<TO>(to_f32(xp[e]) * sc);
+    }
+}
+
+// Per-plane reductions: out0[plane] = sum a*b (or sum a when b == null).  One wave per plane chunk, fp32 accumulate.
+template <typename T>
+__global__ __launch_bounds__(256) void plane_dot_kernel(float* __restrict__ out, const T* __restrict__ a, const T* __restrict__ b,
+                                                        long long planes, int hw) {
+    __shared__ float part[4];
+    const long long plane = blockIdx.x;
+    if (plane >= planes) return;
+    const T* ap = a + plane * hw;
+    const T* bp = b ? b + plane * hw : nullptr;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < hw; i += 256) s += to_f32(ap[i]) * (bp ? to_f32(bp[i]) : 1.f);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[plane] = part[0] + part[1] + part[2] + part[3];
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Weight gradient: dW[o][i][r][s] = sum_n sum_{p,q} dy[n,o,p,q] * x[n,i,p+r-pad,q+s-pad]   (inputs already scaled per plane)
+// GEMM with K = pixels: both operands are K-contiguous in NCHW, so the LDS images are plain row copies and the
+// 3 column shifts of a tap row come from ONE 5-dword read per row (shift 0: dwords 0-3, shift 2: dwords 1-4,
+// shift 1: v_alignbyte of neighbours).  One workgroup = 64 o x 64 i x all taps; 4 waves as 2(o) x 2(i), each
+// wave holds KK accumulator tiles of 32x32.  K is split over workgroups by output row; partial sums go to
+// a workspace [split][O][I][KK] and are summed by wgrad_reduce_kernel.
+constexpr int kWgKQ = 64;        // pixels of one output row per K macro-step
+
+struct WgradParams {
+    const void* dy;   // [N, O, P, Q]
+    const void* x;    // [N, I, H, W]
+    float* part;      // [splits][O][I][KK]
+    int N, O, I, H, W, P, Q, pad;
+    int splits, rows_per_split;   // K rows = N * P
+    int qchunks;                  // ceil(Q / kWgKQ)
+};
+
+template <typename T, int KS>
+__global__ __launch_bounds__(256, 2) void conv2d_wgrad_kernel(WgradParams p) {
+    constexpr bool F32 = sizeof(T) == 4;
+    constexpr int KK = KS * KS;
+    constexpr int PDY = kWgKQ + 8;                 // 72 elements: 16-bit rows of 144 B (odd x 16 B)
+    constexpr int PX = kWgKQ + 24;                 // 88 elements: 176 B rows; 3 rows per channel -> 528 B (odd x 16 B)
+    constexpr int XW = kWgKQ + 8;                  // staged x columns per row (covers shifts 0..KS-1, +1 alignment, rounded)
+    __shared__ __attribute__((aligned(16))) T lds[64 * PDY + 64 * KS * PX];
+    T* lds_dy = lds;
+    T* lds_x = lds + 64 * PDY;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wo = wave & 1, wi = wave >> 1;
+    const int r32 = lane & 31, h = lane >> 5;
+
+    int bid = blockIdx.x;
+    const int split = bid % p.splits; bid /= p.splits;
+    const int ib = bid % cdiv(p.I, 64);
+    const int obk = bid / cdiv(p.I, 64);
+    const int o0 = obk * 64, i0 = ib * 64;
+
+    f32x16 acc[KK];
+#pragma unroll
+    for (int t = 0; t < KK; t++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) acc[t][e] = 0.f;
+
+    const int krow0 = split * p.rows_per_split;
+    const int krow1 = min(krow0 + p.rows_per_split, p.N * p.P);
+    const int EPD = F32 ? 1 : 2;                   // elements per staged dword
+    for (int krow = krow0; krow < krow1; krow++) {
+        const int n = krow / p.P, prow = krow - n * p.P;
+        for (int qc = 0; qc < p.qchunks; qc++) {
+            const int q0 = qc * kWgKQ;
+            const int xorg = (q0 - p.pad) & ~1;    // even origin: dword-aligned 16-bit loads
+            const int xoff = (q0 - p.pad) - xorg;
+            __syncthreads();                        // previous macro-step's reads are done
+            // ---- stage dy: 64 rows x kWgKQ pixels (zero beyond Q / beyond O)
+            {
+                const T* dyn = (const T*)p.dy + (size_t)n * p.O * p.P * p.Q;
+                constexpr int DPR = kWgKQ / (F32 ? 1 : 2);          // dwords per row
+                for (int j = tid; j < 64 * DPR; j += 256) {
+                    const int o = j / DPR, d = j - o * DPR;
+                    const int q = q0 + d * EPD;
+                    unsigned v = 0u;
+                    if (o0 + o < p.O && q < p.Q) v = *(const unsigned*)(dyn + ((size_t)(o0 + o) * p.P + prow) * p.Q + q);
+                    *(unsigned*)(lds_dy + o * PDY + d * EPD) = v;
+                }
+            }
+            // ---- stage x: 64 channels x KS rows x XW pixels starting at column xorg (zero outside the image)
+            {
+                const T* xn = (const T*)p.x + (size_t)n * p.I * p.H * p.W;
+                constexpr int DPR = XW / (F32 ? 1 : 2);
+                for (int j = tid; j < 64 * KS * DPR; j += 256) {
+                    const int rowi = j / DPR, d = j - rowi * DPR;
+                    const int ic = rowi / KS, r = rowi - ic * KS;
+                    const int iy = prow + r - p.pad, ixx = xorg + d * EPD;
+                    unsigned v = 0u;
+                    if (i0 + ic < p.I && (unsigned)iy < (unsigned)p.H && (unsigned)ixx < (unsigned)p.W)
+                        v = *(const unsigned*)(xn + ((size_t)(i0 + ic) * p.H + iy) * p.W + ixx);
+                    *(unsigned*)(lds_x + (ic * KS + r) * PX + d * EPD) = v;
+                }
+            }
+            __syncthreads();
+            // ---- MFMA over the chunk
+            if constexpr (F32) {
+#pragma unroll 4
+                for (int k2 = 0; k2 < kWgKQ / 2; k2++) {
+                    const float a = lds_dy[(wo * 32 + r32) * PDY + 2 * k2 + h];
+#pragma unroll
+                    for (int r = 0; r < KS; r++)
+#pragma unroll
+                        for (int s = 0; s < KS; s++) {
+                            const float b = lds_x[((wi * 32 + r32) * KS + r) * PX + 2 * k2 + h + s + xoff];
+                            acc[r * KS + s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[r * KS + s], 0, 0, 0);
+                        }
+                }
+            } else {
+                typedef typename std::conditional<std::is_same<T, bf16_t>::value, bf16x8, f16x8>::type frag_t;
+#pragma unroll
+                for (int k16 = 0; k16 < kWgKQ / 16; k16++) {
+                    const frag_t a = *(const frag_t*)(lds_dy + (wo * 32 + r32) * PDY + k16 * 16 + 8 * h);
+#pragma unroll
+                    for (int r = 0; r < KS; r++) {
+                        // 6 dwords = 12 elements starting at element k16*16 + 8h of the staged row
+                        const unsigned* src = (const unsigned*)(lds_x + ((wi * 32 + r32) * KS + r) * PX + k16 * 16 + 8 * h);
+                        const uint4 lo = *(const uint4*)src;
+                        const uint2 hi = *(const uint2*)(src + 4);
+                        const unsigned d[6] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y};
+#pragma unroll
+                        for (int s = 0; s < KS; s++) {
+                            // element shift s + xoff in [0, 3]
+                            union { unsigned u[4]; frag_t f; } b;
+                            const int sh = s + xoff;                          // runtime xoff in {0,1}: resolved by selects
+#pragma unroll
+                            for (int w = 0; w < 4; w++) {
+                                const unsigned e0 = d[w], e1 = d[w + 1], e2 = d[w + 2];
+                                const unsigned odd_lo = __builtin_amdgcn_alignbyte(e1, e0, 2);   // shift 1
+                                const unsigned odd_hi = __builtin_amdgcn_alignbyte(e2, e1, 2);   // shift 3
+                                b.u[w] = (sh == 0) ? e0 : (sh == 1) ? odd_lo : (sh == 2) ? e1 : odd_hi;
+                            }
+                            if constexpr (std::is_same<T, bf16_t>::value)
+                                acc[r * KS + s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b.f, acc[r * KS + s], 0, 0, 0);
+                            else
+                                acc[r * KS + s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b.f, acc[r * KS + s], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    // ---- write the partial tile: D[row = o][col = i]
+    float* out = p.part + (size_t)split * p.O * p.I * KK;
+#pragma unroll
+    for (int reg = 0; reg < 16; reg++) {
+        const int o = o0 + wo * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+        const int i = i0 + wi * 32 + r32;
+        if (o < p.O && i < p.I) {
+            float* dst = out + ((size_t)o * p.I + i) * KK;
+#pragma unroll
+            for (int t = 0; t < KK; t++) dst[t] = acc[t][reg];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(float* __restrict__ dw, const float* __restrict__ part, long long numel, int splits) {
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < numel; idx += (long long)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int k = 0; k < splits; k++) s += part[(size_t)k * numel + idx];
+        dw[idx] = s;
+    }
+}
+
+static void choose_tile(int P, int Q, int KS, int* TH, int* TW, int* PWL) {
+    // Tile of TH x TW output pixels with TH*TW <= 256 slots and an LDS patch (TH+KS-1) x round4(TW+KS) <= kPatchMax,
+    // chosen to maximise the fraction of useful slots.
+    double best = -1;
+    for (int tw = 2; tw <= 128; tw += 2) {
+        int th = kSlots / tw;
+        if (th > P) th = P;
+        for (; th >= 1; th--) {
+            const int pwl = round_up(tw + KS, 4);
+            if ((th + KS - 1) * pwl > kPatchMax) continue;
+            const double tiles = (double)cdiv(P, th) * cdiv(Q, tw);
+            const double util = (double)P * Q / (tiles * kSlots);
+            // small preference for wide tiles (longer contiguous runs for loads/stores)
+            const double score = util + 1e-4 * tw;
+            if (score > best) { best = score; *TH = th; *TW = tw; *PWL = pwl; }
+            break;
+        }
+    }
+}
+
+template <typename T, int BM_O>
+static int launch_conv(ConvParams p, int ks, hipStream_t st) {
+    const long long blocks = (long long)p.tilesX * p.tilesY * p.N * cdiv(p.Cout, BM_O);
+    AFCM_REQUIRE(blocks > 0 && blocks < (1ll << 31), "conv2d: grid of %lld blocks is out of range", blocks);
+    dim3 grid((unsigned)blocks), block(256);
+    if (ks == 3) hipLaunchKernelGGL((conv2d_fwd_kernel<T, BM_O, 3>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((conv2d_fwd_kernel<T, BM_O, 1>), grid, block, 0, st, p);
+    return hip_status(hipGetLastError());
+}
+
+}  // namespace afcm
+
+using namespace afcm;
+
+extern "C" int afcm_conv2d_block_k(int32_t dtype) { return dtype == AFCM_F32 ? ConvCfg<float>::BK : ConvCfg<bf16_t>::BK; }
+
+extern "C" int afcm_conv2d_pack_weights(void* dst, const float* w, int32_t dtype, int32_t cout, int32_t cin, int32_t ks,
+                                        int32_t mode, int32_t rows_pad, void* stream) {
+    AFCM_REQUIRE(dst != nullptr && w != nullptr, "conv2d_pack_weights: null pointer");
+    AFCM_REQUIRE(dtype == AFCM_F32 || dtype == AFCM_F16 || dtype == AFCM_BF16, "dtype must be float32, float16 or bfloat16");
+    AFCM_REQUIRE(ks == 1 || ks == 3, "only 1x1 and 3x3 kernels are supported");
+    AFCM_REQUIRE(mode == 0 || mode == 1, "mode must be 0 (forward) or 1 (data gradient)");
+    const int rows = mode == 0 ? cout : cin, cols = mode == 0 ? cin : cout;
+    AFCM_REQUIRE(rows_pad >= rows && rows_pad % 64 == 0, "rows_pad must be a multiple of 64 covering the rows");
+    const int BK = afcm_conv2d_block_k(dtype);
+    const int nkc = cdiv(cols, BK);
+    const long long total = (long long)nkc * ks * ks * rows_pad * BK;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    dim3 grid((unsigned)blocks), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    switch (dtype) {
+        case AFCM_F32: hipLaunchKernelGGL((conv2d_pack_kernel<float>), grid, block, 0, st, (float*)dst, w, cout, cin, ks, rows, cols, rows_pad, BK, nkc, mode); break;
+        case AFCM_F16: hipLaunchKernelGGL((conv2d_pack_kernel<f16_t>), grid, block, 0, st, (f16_t*)dst, w, cout, cin, ks, rows, cols, rows_pad, BK, nkc, mode); break;
+        default: hipLaunchKernelGGL((conv2d_pack_kernel<bf16_t>), grid, block, 0, st, (bf16_t*)dst, w, cout, cin, ks, rows, cols, rows_pad, BK, nkc, mode); break;
+    }
+    return hip_status(hipGetLastError());
+}
+
+extern "C" int afcm_conv2d(void* y, const void* x, const void* wpacked, const float* oscale, int32_t dtype, int32_t n, int32_t cin,
+                           int32_t cout, int32_t h, int32_t w, int32_t ks, int32_t pad, int32_t rows_pad, void* stream) {
+    AFCM_REQUIRE(y != nullptr && x != nullptr && wpacked != nullptr, "conv2d: null pointer");
+    AFCM_REQUIRE(dtype == AFCM_F32 || dtype == AFCM_F16 || dtype == AFCM_BF16, "x must be float32, float16 or bfloat16");
+    AFCM_REQUIRE(n > 0 && cin > 0 && cout > 0 && h > 0 && w > 0, "x is empty");
+    AFCM_REQUIRE(ks == 1 || ks == 3, "only 1x1 and 3x3 kernels are supported");
+    AFCM_REQUIRE(pad >= 0 && pad <= ks - 1, "padding must be in [0, k-1]");
+    AFCM_REQUIRE(dtype == AFCM_F32 || (w % 2 == 0), "16-bit conv2d needs an even input width (got %d)", w);
+    AFCM_REQUIRE(rows_pad >= cout && rows_pad % 64 == 0, "rows_pad must be a multiple of 64 covering cout");
+    ConvParams p;
+    p.x = x; p.y = y; p.wp = wpacked; p.oscale = oscale;
+    p.N = n; p.Cin = cin; p.Cout = cout; p.H = h; p.W = w;
+    p.P = h + 2 * pad - ks + 1; p.Q = w + 2 * pad - ks + 1;
+    AFCM_REQUIRE(p.P >= 1 && p.Q >= 1, "output must be at least 1x1");
+    p.pad = pad;
+    choose_tile(p.P, p.Q, ks, &p.TH, &p.TW, &p.PWL);
+    p.tilesX = cdiv(p.Q, p.TW); p.tilesY = cdiv(p.P, p.TH);
+    p.Opad = rows_pad;
+    p.nkc = cdiv(cin, afcm_conv2d_block_k(dtype));
+    hipStream_t st = (hipStream_t)stream;
+    // 64-row blocks when they waste fewer padded rows than 128-row blocks
+    const bool small = (rows_pad % 128 != 0) || cout <= 64;
+    switch (dtype) {
+        case AFCM_F32: return small ? launch_conv<float, 64>(p, ks, st) : launch_conv<float, 128>(p, ks, st);
+        case AFCM_F16: return small ? launch_conv<f16_t, 64>(p, ks, st) : launch_conv<f16_t, 128>(p, ks, st);
+        default: return small ? launch_conv<bf16_t, 64>(p, ks, st) : launch_conv<bf16_t, 128>(p, ks, st);
+    }
+}
+
+
+// Split count for the weight gradient: enough workgroups to fill the chip, bounded by the K rows.
+extern "C" int afcm_conv2d_wgrad_splits(int32_t n, int32_t cout, int32_t cin, int32_t p_rows) {
+    const int tiles = cdiv(cout, 64) * cdiv(cin, 64);
+    int splits = cdiv(768, tiles);
+    const long long krows = (long long)n * p_rows;
+    if (splits > krows) splits = (int)krows;
+    if (splits < 1) splits = 1;
+    return splits;
+}
+
+extern "C" int afcm_conv2d_wgrad(float* dw, float* workspace, const void* dy, const void* x, int32_t dtype, int32_t n, int32_t cin,
+                                 int32_t cout, int32_t h, int32_t w, int32_t ks, int32_t pad, void* stream) {
+    AFCM_REQUIRE(dw != nullptr && workspace != nullptr && dy != nullptr && x != nullptr, "conv2d_wgrad: null pointer");
+    AFCM_REQUIRE(dtype == AFCM_F32 || dtype == AFCM_F16 || dtype == AFCM_BF16, "x must be float32, float16 or bfloat16");
+    AFCM_REQUIRE(ks == 1 || ks == 3, "only 1x1 and 3x3 kernels are supported");
+    AFCM_REQUIRE(pad >= 0 && pad <= ks - 1, "padding must be in [0, k-1]");
+    WgradParams p;
+    p.dy = dy; p.x = x; p.part = workspace;
+    p.N = n; p.O = cout; p.I = cin; p.H = h; p.W = w; p.pad = pad;
+    p.P = h + 2 * pad - ks + 1; p.Q = w + 2 * pad - ks + 1;
+    AFCM_REQUIRE(p.P >= 1 && p.Q >= 1, "output must be at least 1x1");
+    AFCM_REQUIRE(dtype == AFCM_F32 || (w % 2 == 0 && p.Q % 2 == 0), "16-bit conv2d_wgrad needs even widths (got %d, %d)", w, p.Q);
+    p.splits = afcm_conv2d_wgrad_splits(n, cout, cin, p.P);
+    p.rows_per_split = cdiv(n * p.P, p.splits);
+    p.qchunks = cdiv(p.Q, kWgKQ);
+    const long long blocks = (long long)cdiv(cout, 64) * cdiv(cin, 64) * p.splits;
+    dim3 grid((unsigned)blocks), block(256);
+    hipStream_t st = (hipStream_t)stream;
+#define AFCM_WG(T) do { if (ks == 3) hipLaunchKernelGGL((conv2d_wgrad_kernel<T, 3>), grid, block, 0, st, p); \
+                        else hipLaunchKernelGGL((conv2d_wgrad_kernel<T, 1>), grid, block, 0, st, p); } while (0)
+    switch (dtype) {
+        case AFCM_F32: AFCM_WG(float); break;
+        case AFCM_F16: AFCM_WG(f16_t); break;
+        default: AFCM_WG(bf16_t); break;
+    }
+#undef AFCM_WG
+    int rc = hip_status(hipGetLastError());
+    if (rc != AFCM_OK) return rc;
+    const long long numel = (long long)cout * cin * ks * ks;
+    long long rb = (numel + 255) / 256;
+    if (rb > 2048) rb = 2048;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)rb), dim3(256), 0, st, dw, (const float*)workspace, numel, p.splits);
+    return hip_status(hipGetLastError());
+}
+
+extern "C" int afcm_scale_planes(void* y, const void* x, const float* scale, int32_t dtype_in, int32_t dtype_out, int64_t planes,
+                                 int32_t hw, void* stream) {
+    AFCM_REQUIRE(y != nullptr && x != nullptr && planes > 0 && hw > 0, "scale_planes: empty input");
+    long long blocks = (planes * ((hw + 3) >> 2) + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    dim3 grid((unsigned)blocks), block(256);
+    hipStream_t st = (hipStream_t)stream;
+#define AFCM_SP(TI, TO) hipLaunchKernelGGL((scale_planes_kernel<TI, TO>), grid, block, 0, st, (TO*)y, (const TI*)x, scale, (long long)planes, hw)
+    if (dtype_in == AFCM_F32 && dtype_out == AFCM_F32) AFCM_SP(float, float);
+    else if (dtype_in == AFCM_F32 && dtype_out == AFCM_BF16) AFCM_SP(float, bf16_t);
+    else if (dtype_in == AFCM_F32 && dtype_out == AFCM_F16) AFCM_SP(float, f16_t);
+    else if (dtype_in == AFCM_BF16 && dtype_out == AFCM_BF16) AFCM_SP(bf16_t, bf16_t);
+    else if (dtype_in == AFCM_F16 && dtype_out == AFCM_F16) AFCM_SP(f16_t, f16_t);
+    else if (dtype_in == AFCM_BF16 && dtype_out == AFCM_F32) AFCM_SP(bf16_t, float);
+    else if (dtype_in == AFCM_F16 && dtype_out == AFCM_F32) AFCM_SP(f16_t, float);
+    else { set_error("scale_planes: unsupported dtype pair %d -> %d", dtype_in, dtype_out); return AFCM_E_INVALID; }
+#undef AFCM_SP
+    return hip_status(hipGetLastError());
+}
+
+extern "C" int afcm_plane_dot(float* out, const void* a, const void* b, int32_t dtype, int64_t planes, int32_t hw, void* stream) {
+    AFCM_REQUIRE(out != nullptr && a != nullptr && planes > 0 && hw > 0, "plane_dot: empty input");
+    AFCM_REQUIRE(planes < (1ll << 31), "plane_dot: too many planes");
+    dim3 grid((unsigned)planes), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    switch (dtype) {
+        case AFCM_F32: hipLaunchKernelGGL((plane_dot_kernel<float>), grid, block, 0, st, out, (const float*)a, (const float*)b, (long long)planes, hw); break;
+        case AFCM_F16: hipLaunchKernelGGL((plane_dot_kernel<f16_t>), grid, block, 0, st, out, (const f16_t*)a, (const f16_t*)b, (long long)planes, hw); break;
+        case AFCM_BF16: hipLaunchKernelGGL((plane_dot_kernel<bf16_t>), grid, block, 0, st, out, (const bf16_t*)a, (const bf16_t*)b, (long long)planes, hw); break;
+        default: set_error("plane_dot: bad dtype"); return AFCM_E_INVALID;
+    }
+    return hip_status(hipGetLastError());
+}

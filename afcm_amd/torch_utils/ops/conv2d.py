@@ -1,0 +1,162 @@
+"""Dense stride-1 convolution with per-plane input/output scaling on the MFMA kernels of
+afcm_amd/csrc/conv2d.hip -- the compute behind ``modulated_conv2d`` (NET:25-64) and the encoder's
+``conv2d_gradfix.conv2d`` call (NET:505).
+
+    y[n, o] = out_scale[n, o] * sum_{i, r, s} w[o, i, r, s] * (in_scale[n, i] * x[n, i, p + r - pad, q + s - pad])
+
+The weights are shared by the batch; the style modulation and the demodulation of the reference's
+per-sample weights are the two per-plane scales (identical algebra).  Backward runs on
+the same kernels: the data gradient is the forward kernel with transposed/flipped weights, the
+weight gradient is a pixel-contraction GEMM, the scale gradients are per-plane dot products.
+"""
+import torch
+
+from ... import _lib
+
+
+def _pad64(n):
+    return (n + 63) // 64 * 64
+
+
+def pack_weights(w, dtype, mode):
+    """fp32 [O, I, k, k] -> the kernels' K-chunked layout in `dtype` (C ABI afcm_conv2d_pack_weights)."""
+    lib = _lib.load()
+    o, i, kh, kw = w.shape
+    assert kh == kw and kh in (1, 3), 'only 1x1 and 3x3 kernels are supported'
+    w = w.detach().to(torch.float32).contiguous()
+    code = _lib._DTYPES[dtype]
+    bk = lib.afcm_conv2d_block_k(code)
+    rows, cols = (o, i) if mode == 0 else (i, o)
+    rows_pad = _pad64(rows)
+    nkc = (cols + bk - 1) // bk
+    dst = torch.empty([nkc, kh * kw, rows_pad, bk], dtype=dtype, device=w.device)
+    _lib.check(lib.afcm_conv2d_pack_weights(dst.data_ptr(), w.data_ptr(), code, o, i, kh, mode, rows_pad, _lib.stream_ptr(w)),
+               'conv2d_pack_weights')
+    return dst, rows_pad
+
+
+def scale_planes(x, scale, out_dtype=None):
+    """y[n, c] = x[n, c] * scale[n, c] (scale None: cast only)."""
+    lib = _lib.load()
+    out_dtype = out_dtype or x.dtype
+    x = x.contiguous()
+    y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    n, c, h, w = x.shape
+    if scale is not None:
+        scale = scale.to(torch.float32).contiguous()
+        assert scale.numel() == n * c
+    _lib.check(lib.afcm_scale_planes(y.data_ptr(), x.data_ptr(), _lib.ptr(scale), _lib.dtype_code(x), _lib._DTYPES[out_dtype],
+                                     n * c, h * w, _lib.stream_ptr(x)), 'scale_planes')
+    return y
+
+
+def plane_dot(a, b=None):
+    """[N, C] fp32: sum over H, W of a * b (b None: plain sum)."""
+    lib = _lib.load()
+    a = a.contiguous()
+    n, c, h, w = a.shape
+    if b is not None:
+        b = b.contiguous()
+        assert b.shape == a.shape and b.dtype == a.dtype
+    out = torch.empty([n, c], dtype=torch.float32, device=a.device)
+    _lib.check(lib.afcm_plane_dot(out.data_ptr(), a.data_ptr(), _lib.ptr(b), _lib.dtype_code(a), n * c, h * w, _lib.stream_ptr(a)),
+               'plane_dot')
+    return out
+
+
+def _conv_raw(x, wp, rows_pad, oscale, cout, ks, pad):
+    lib = _lib.load()
+    n, cin, h, w = x.shape
+    p, q = h + 2 * pad - ks + 1, w + 2 * pad - ks + 1
+    y = torch.empty([n, cout, p, q], dtype=x.dtype, device=x.device)
+    if oscale is not None:
+        oscale = oscale.to(torch.float32).contiguous()
+    _lib.check(lib.afcm_conv2d(y.data_ptr(), x.data_ptr(), wp.data_ptr(), _lib.ptr(oscale), _lib.dtype_code(x), n, cin, cout, h, w,
+                               ks, pad, rows_pad, _lib.stream_ptr(x)), 'conv2d')
+    return y
+
+
+def _wgrad_raw(dy, x, cout, cin, ks, pad):
+    lib = _lib.load()
+    n, _, h, w = x.shape
+    p = h + 2 * pad - ks + 1
+    splits = lib.afcm_conv2d_wgrad_splits(n, cout, cin, p)
+    dw = torch.empty([cout, cin, ks, ks], dtype=torch.float32, device=x.device)
+    ws = torch.empty([splits, cout, cin, ks, ks], dtype=torch.float32, device=x.device)
+    _lib.check(lib.afcm_conv2d_wgrad(dw.data_ptr(), ws.data_ptr(), dy.data_ptr(), x.data_ptr(), _lib.dtype_code(x), n, cin, cout,
+                                     h, w, ks, pad, _lib.stream_ptr(x)), 'conv2d_wgrad')
+    return dw
+
+
+class _ScaledConv2d(torch.autograd.Function):
+    """y = out_scale * conv(w, in_scale * x); scales are [N, C] fp32 tensors or None."""
+
+    @staticmethod
+    def forward(ctx, x, w, in_scale, out_scale, padding):
+        _lib.require_gpu(x, w, in_scale, out_scale)
+        if x.ndim != 4 or w.ndim != 4 or x.shape[1] != w.shape[1]:
+            raise RuntimeError(f'conv2d: incompatible shapes x{tuple(x.shape)} w{tuple(w.shape)}')
+        if x.numel() == 0:
+            raise RuntimeError('x is empty')
+        _lib.dtype_code(x)
+        cout, cin, ks, _ = w.shape
+        x = x.contiguous()
+        xs = scale_planes(x, in_scale) if in_scale is not None else x
+        wp, rows_pad = pack_weights(w, x.dtype, 0)
+        y = _conv_raw(xs, wp, rows_pad, out_scale, cout, ks, padding)
+        ctx.save_for_backward(xs, w, in_scale, out_scale, y if (out_scale is not None and ctx.needs_input_grad[3]) else None)
+        ctx.padding = padding
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        xs, w, in_scale, out_scale, y = ctx.saved_tensors
+        pad = ctx.padding
+        cout, cin, ks, _ = w.shape
+        dy = dy.contiguous()
+        dx = dw = d_in = d_out = None
+        dys = scale_planes(dy, out_scale) if out_scale is not None else dy
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[2]:
+            wpt, rows_pad = pack_weights(w, dy.dtype, 1)
+            # data gradient of a pad-p correlation = correlation of dy with the flipped kernel at pad k-1-p;
+            # the style factor of dx rides in the epilogue scale.
+            dx = _conv_raw(dys, wpt, rows_pad, in_scale, cin, ks, ks - 1 - pad)
+            if ctx.needs_input_grad[2]:
+                # d in_scale[n,i] = sum_pix x * g with xs = s*x and dx = s*g  =>  <xs, dx> / s^2
+                s2 = in_scale.to(torch.float32).square()
+                d_in = torch.where(s2 > 0, plane_dot(xs, dx) / s2.clamp_min(1e-30), torch.zeros_like(s2)).to(in_scale.dtype)
+        if ctx.needs_input_grad[1]:
+            dw = _wgrad_raw(dys, xs, cout, cin, ks, pad).to(w.dtype)
+        if ctx.needs_input_grad[3]:
+            # y = d * c  =>  d d[n,o] = <dy, c> = <dy, y> / d
+            d_out = (plane_dot(dy, y) / out_scale.to(torch.float32)).to(out_scale.dtype)
+        return dx, dw, d_in, d_out, None
+
+
+def scaled_conv2d(x, w, in_scale=None, out_scale=None, padding=0):
+    return _ScaledConv2d.apply(x, w, in_scale, out_scale, int(padding))
+
+
+def modulated_conv2d(x, w, s, demodulate=True, padding=0, input_gain=None):
+    """Drop-in for the reference's ``modulated_conv2d(x, w, s, demodulate, padding, input_gain)`` (NET:25-64).
+
+    x [N, I, H, W]; w [O, I, k, k]; s [N, I]; input_gain [], [I] or [N, I].  Returns [N, O, H + 2p - k + 1, ...].
+    """
+    n = int(x.shape[0])
+    o, i, kh, kw = w.shape
+    assert x.shape[1] == i and tuple(s.shape) == (n, i)
+    w = w.to(torch.float32)
+    s = s.to(torch.float32)
+    d = None
+    if demodulate:
+        w = w * w.square().mean([1, 2, 3], keepdim=True).rsqrt()      # NET:42
+        s = s * s.square().mean().rsqrt()                              # NET:43 (whole batch)
+        # NET:50-52: rsqrt(sum_{i,k} (w[o,i,k] s[n,i])^2 + 1e-8), factorised as s^2 @ (sum_k w^2)^T
+        d = (s.square() @ w.square().sum([2, 3]).t() + 1e-8).rsqrt()   # [N, O]
+    if input_gain is not None:
+        s = s * input_gain.to(torch.float32).expand(n, i)              # NET:55-57
+    if isinstance(padding, (list, tuple)):
+        assert padding[0] == padding[1]
+        padding = padding[0]
+    return scaled_conv2d(x, w, s, d, padding)

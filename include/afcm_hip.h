@@ -116,6 +116,47 @@ int afcm_bias_act(void* y, const void* x, const void* b, const void* xref, const
                   int32_t dtype, int64_t numel, int64_t inner, int32_t nb, int32_t grad, int32_t act, float alpha,
                   float gain, float clamp, void* stream);
 
+
+/* ------------------------------------------------------------------------------------------
+ * Dense convolution behind modulated_conv2d / the encoder convs.
+ *
+ * The reference has no native conv: `modulated_conv2d` (NET:25-64) builds per-sample weights
+ * and calls a grouped F.conv2d (cuDNN) through conv2d_gradfix.conv2d (SG3OPS/conv2d_gradfix.py:37-58),
+ * and EncoderLayer calls conv2d_gradfix.conv2d directly (NET:505).  These entry points replace that
+ * conv call with MFMA implicit-GEMM kernels using the equivalent shared-weight form
+ *     y[n,o] = oscale[n,o] * conv(W, x[n]),   x pre-scaled per (n,i) plane by afcm_scale_planes.
+ * All of them are cross-correlations (F.conv2d semantics) with stride 1, k in {1,3}, 0 <= pad <= k-1.
+ * ---------------------------------------------------------------------------------------- */
+
+/* K-chunk of the packed weight layout for a dtype (16 for 16-bit, 8 for fp32). */
+int afcm_conv2d_block_k(int32_t dtype);
+
+/* Pack fp32 weights w[cout][cin][k][k] into the kernel layout [ceil(cols/BK)][k*k][rows_pad][BK] of
+ * `dtype`, zero padded.  mode 0: forward (rows = cout, cols = cin).  mode 1: data gradient
+ * (rows = cin, cols = cout, taps flipped).  rows_pad: multiple of 64, >= rows. */
+int afcm_conv2d_pack_weights(void* dst, const float* w, int32_t dtype, int32_t cout, int32_t cin, int32_t ks,
+                             int32_t mode, int32_t rows_pad, void* stream);
+
+/* y[n, cout, h+2*pad-k+1, w+2*pad-k+1] = oscale[n*cout+o] * sum W * x.   oscale may be NULL.
+ * For the data gradient call it with the mode-1 packing, cin/cout swapped and pad' = k-1-pad. */
+int afcm_conv2d(void* y, const void* x, const void* wpacked, const float* oscale, int32_t dtype, int32_t n, int32_t cin,
+                int32_t cout, int32_t h, int32_t w, int32_t ks, int32_t pad, int32_t rows_pad, void* stream);
+
+/* Weight gradient dw[cout][cin][k][k] (fp32) = sum_n sum_pixels dy[n,o,p,q] * x[n,i,p+r-pad,q+s-pad].
+ * workspace: fp32 [afcm_conv2d_wgrad_splits(...)][cout][cin][k][k]. */
+int afcm_conv2d_wgrad_splits(int32_t n, int32_t cout, int32_t cin, int32_t p_rows);
+int afcm_conv2d_wgrad(float* dw, float* workspace, const void* dy, const void* x, int32_t dtype, int32_t n, int32_t cin,
+                      int32_t cout, int32_t h, int32_t w, int32_t ks, int32_t pad, void* stream);
+
+/* y[plane, :] = x[plane, :] * scale[plane] with dtype conversion (style modulation s[n,i] of NET:46-47 and the
+ * demodulation d[n,o] of NET:50-52 applied to activations instead of weights).  scale may be NULL (pure cast). */
+int afcm_scale_planes(void* y, const void* x, const float* scale, int32_t dtype_in, int32_t dtype_out, int64_t planes,
+                      int32_t hw, void* stream);
+
+/* out[plane] = sum_i a[plane,i] * b[plane,i]  (b == NULL: plain sum); fp32 accumulation.  Used for the style /
+ * demodulation / bias gradients. */
+int afcm_plane_dot(float* out, const void* a, const void* b, int32_t dtype, int64_t planes, int32_t hw, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
