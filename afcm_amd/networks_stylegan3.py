@@ -1,0 +1,381 @@
+"""Conditional, U-shaped alias-free (StyleGAN3-style) generator of AFCM on the MI355X kernels.
+
+Drop-in for the reference module ``models/networks/stylegan3/networks_stylegan3.py`` (NET): the class
+names, constructor arguments, ``forward()`` signatures, parameter/buffer names (state-dict keys) and
+the layer schedule are the reference's, so reference checkpoints load and ``--model stylegan3`` code can
+swap the import.  What differs is underneath: every hot op goes to the HIP library --
+``filtered_lrelu`` / ``bias_act`` (afcm_amd/csrc/*.hip) and the MFMA convolution with the
+shared-weight form of the style modulation (see torch_utils/ops/conv2d.py).
+
+New capability relative to the reference: ``compute_dtype`` (fp32 default, bf16/fp16 optional) selects the
+storage type of the activation stream; the reference hard-codes fp32 (NET:619,653).  Weights, styles,
+demodulation coefficients and every accumulation stay fp32.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import layer_schedule as sched
+from .torch_utils.ops import bias_act, conv2d_gradfix, filtered_lrelu
+from .torch_utils.ops.conv2d import modulated_conv2d  # noqa: F401  (re-exported: NET:25 lives in this module)
+
+
+def _assert_shape(t, ref):
+    if t.ndim != len(ref):
+        raise AssertionError(f'Wrong number of dimensions: got {t.ndim}, expected {len(ref)}')
+    for idx, (size, want) in enumerate(zip(t.shape, ref)):
+        if want is not None and size != want:
+            raise AssertionError(f'Wrong size for dimension {idx}: got {size}, expected {want}')
+
+
+class FullyConnectedLayer(torch.nn.Module):
+    """Equalised-learning-rate dense layer (NET:69-104)."""
+
+    def __init__(self, in_features, out_features, activation='linear', bias=True, lr_multiplier=1, weight_init=1, bias_init=0):
+        super().__init__()
+        self.in_features = in_features
+        self.out_features = out_features
+        self.activation = activation
+        self.weight = torch.nn.Parameter(torch.randn([out_features, in_features]) * (weight_init / lr_multiplier))
+        bias_init = np.broadcast_to(np.asarray(bias_init, dtype=np.float32), [out_features])
+        self.bias = torch.nn.Parameter(torch.from_numpy(bias_init / lr_multiplier)) if bias else None
+        self.weight_gain = lr_multiplier / np.sqrt(in_features)
+        self.bias_gain = lr_multiplier
+
+    def forward(self, x):
+        w = self.weight.to(x.dtype) * self.weight_gain
+        b = self.bias
+        if b is not None:
+            b = b.to(x.dtype)
+            if self.bias_gain != 1:
+                b = b * self.bias_gain
+        if self.activation == 'linear' and b is not None:
+            return torch.addmm(b.unsqueeze(0), x, w.t())
+        return bias_act.bias_act(x.matmul(w.t()), b, act=self.activation)
+
+    def extra_repr(self):
+        return f'in_features={self.in_features:d}, out_features={self.out_features:d}, activation={self.activation:s}'
+
+
+class MappingNetwork(torch.nn.Module):
+    """z, c -> ws (NET:109-164)."""
+
+    def __init__(self, z_dim, c_dim, w_dim, num_ws, num_layers=2, lr_multiplier=0.01, w_avg_beta=0.998):
+        super().__init__()
+        self.z_dim, self.c_dim, self.w_dim, self.num_ws = z_dim, c_dim, w_dim, num_ws
+        self.num_layers = num_layers
+        self.w_avg_beta = w_avg_beta
+        self.embed = FullyConnectedLayer(c_dim, w_dim) if c_dim > 0 else None
+        features = [z_dim + (w_dim if c_dim > 0 else 0)] + [w_dim] * num_layers
+        for idx, (fin, fout) in enumerate(zip(features[:-1], features[1:])):
+            setattr(self, f'fc{idx}', FullyConnectedLayer(fin, fout, activation='lrelu', lr_multiplier=lr_multiplier))
+        self.register_buffer('w_avg', torch.zeros([w_dim]))
+
+    def forward(self, z, c, truncation_psi=1, truncation_cutoff=None, update_emas=False, **kwargs):
+        _assert_shape(z, [None, self.z_dim])
+        if truncation_cutoff is None:
+            truncation_cutoff = self.num_ws
+        x = z.to(torch.float32)
+        x = x * (x.square().mean(1, keepdim=True) + 1e-8).rsqrt()
+        if self.c_dim > 0:
+            _assert_shape(c, [None, self.c_dim])
+            y = self.embed(c.to(torch.float32))
+            y = y * (y.square().mean(1, keepdim=True) + 1e-8).rsqrt()
+            x = torch.cat([x, y], dim=1)
+        for idx in range(self.num_layers):
+            x = getattr(self, f'fc{idx}')(x)
+        if update_emas:
+            self.w_avg.copy_(x.detach().mean(dim=0).lerp(self.w_avg, self.w_avg_beta))
+        x = x.unsqueeze(1).repeat([1, self.num_ws, 1])
+        if truncation_psi != 1:
+            x[:, :truncation_cutoff] = self.w_avg.lerp(x[:, :truncation_cutoff], truncation_psi)
+        return x
+
+    def extra_repr(self):
+        return f'z_dim={self.z_dim:d}, c_dim={self.c_dim:d}, w_dim={self.w_dim:d}, num_ws={self.num_ws:d}'
+
+
+class _ResampleGeometry:
+    """Shared constructor arithmetic of SynthesisLayer / EncoderLayer (NET:294-334, 453-489)."""
+
+    def _setup_resampling(self, in_size, out_size, in_sampling_rate, out_sampling_rate, in_cutoff, out_cutoff, in_half_width,
+                          out_half_width, conv_kernel, filter_size, lrelu_upsampling, use_radial_filters, is_torgb,
+                          is_critically_sampled):
+        self.in_size = np.broadcast_to(np.asarray(in_size), [2])
+        self.out_size = np.broadcast_to(np.asarray(out_size), [2])
+        self.in_sampling_rate, self.out_sampling_rate = in_sampling_rate, out_sampling_rate
+        self.in_cutoff, self.out_cutoff = in_cutoff, out_cutoff
+        self.in_half_width, self.out_half_width = in_half_width, out_half_width
+        (self.tmp_sampling_rate, self.up_factor, self.up_taps, self.down_factor, self.down_taps,
+         self.padding) = sched.resample_geometry(in_size, out_size, in_sampling_rate, out_sampling_rate, conv_kernel, filter_size,
+                                                 lrelu_upsampling, is_torgb)
+        self.down_radial = use_radial_filters and not is_critically_sampled
+        self.register_buffer('up_filter', sched.design_lowpass_filter(
+            numtaps=self.up_taps, cutoff=in_cutoff, width=in_half_width * 2, fs=self.tmp_sampling_rate))
+        self.register_buffer('down_filter', sched.design_lowpass_filter(
+            numtaps=self.down_taps, cutoff=out_cutoff, width=out_half_width * 2, fs=self.tmp_sampling_rate, radial=self.down_radial))
+
+    @staticmethod
+    def design_lowpass_filter(numtaps, cutoff, width, fs, radial=False):
+        return sched.design_lowpass_filter(numtaps, cutoff, width, fs, radial)
+
+
+class SynthesisLayer(torch.nn.Module, _ResampleGeometry):
+    """Style-modulated conv + filtered leaky ReLU (+ encoder skip) (NET:253-412)."""
+
+    def __init__(self, w_dim, global_w_dim, is_torgb, is_critically_sampled, use_fp16, in_channels, out_channels, in_size, out_size,
+                 in_sampling_rate, out_sampling_rate, in_cutoff, out_cutoff, in_half_width, out_half_width, conv_kernel=3,
+                 filter_size=6, lrelu_upsampling=2, use_radial_filters=False, conv_clamp=256, magnitude_ema_beta=0.999,
+                 cond_mod=False):
+        super().__init__()
+        self.w_dim = w_dim
+        self.is_torgb = is_torgb
+        self.is_critically_sampled = is_critically_sampled
+        self.use_fp16 = use_fp16
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.conv_kernel = 1 if is_torgb else conv_kernel
+        self.conv_clamp = conv_clamp
+        self.magnitude_ema_beta = magnitude_ema_beta
+        self.cond_mod = cond_mod
+        if not cond_mod:
+            global_w_dim = 0
+        self.affine = FullyConnectedLayer(self.w_dim + global_w_dim, self.in_channels, bias_init=1)
+        self.weight = torch.nn.Parameter(torch.randn([self.out_channels, self.in_channels, self.conv_kernel, self.conv_kernel]))
+        self.bias = torch.nn.Parameter(torch.zeros([self.out_channels]))
+        self.register_buffer('magnitude_ema', torch.ones([]))
+        self._setup_resampling(in_size, out_size, in_sampling_rate, out_sampling_rate, in_cutoff, out_cutoff, in_half_width,
+                               out_half_width, self.conv_kernel, filter_size, lrelu_upsampling, use_radial_filters, is_torgb,
+                               is_critically_sampled)
+
+    def forward(self, x, w, global_w, E_features=None, include_skip=True, noise_mode='random', force_fp32=False, update_emas=False):
+        assert noise_mode in ['random', 'const', 'none']  # unused, as in the reference
+        _assert_shape(x, [None, self.in_channels, int(self.in_size[1]), int(self.in_size[0])])
+        _assert_shape(w, [x.shape[0], self.w_dim])
+        if update_emas:
+            with torch.autograd.profiler.record_function('update_magnitude_ema'):
+                magnitude_cur = x.detach().to(torch.float32).square().mean()
+                self.magnitude_ema.copy_(magnitude_cur.lerp(self.magnitude_ema, self.magnitude_ema_beta))
+        input_gain = self.magnitude_ema.rsqrt()
+        if self.cond_mod:
+            w = torch.cat((w, global_w), 1)
+        styles = self.affine(w)
+        if self.is_torgb:
+            styles = styles * (1 / np.sqrt(self.in_channels * (self.conv_kernel ** 2)))
+        dtype = x.dtype
+        x_skip = E_features[self.out_size[0]].to(dtype) if (E_features is not None and include_skip) else None
+        with torch.autograd.profiler.record_function('modulated_conv2d'):
+            x = modulated_conv2d(x=x, w=self.weight, s=styles, padding=self.conv_kernel - 1, demodulate=(not self.is_torgb),
+                                 input_gain=input_gain)
+        gain = 1 if self.is_torgb else np.sqrt(2)
+        slope = 1 if self.is_torgb else 0.2
+        x = filtered_lrelu.filtered_lrelu(x=x, fu=self.up_filter, fd=self.down_filter, b=self.bias.to(x.dtype), up=self.up_factor,
+                                          down=self.down_factor, padding=self.padding, gain=gain, slope=slope, clamp=self.conv_clamp)
+        _assert_shape(x, [None, self.out_channels, int(self.out_size[1]), int(self.out_size[0])])
+        if include_skip and x_skip is not None:
+            x = x + x_skip
+        assert x.dtype == dtype
+        return x
+
+    def extra_repr(self):
+        return (f'w_dim={self.w_dim:d}, is_torgb={self.is_torgb}, in_channels={self.in_channels:d}, out_channels={self.out_channels:d}, '
+                f'in_size={list(self.in_size)}, out_size={list(self.out_size)}, up={self.up_factor}, down={self.down_factor}')
+
+
+class EncoderLayer(torch.nn.Module, _ResampleGeometry):
+    """Plain conv + filtered leaky ReLU of the alias-free encoder (NET:417-549)."""
+
+    def __init__(self, is_critically_sampled, use_fp16, in_channels, out_channels, in_size, out_size, in_sampling_rate,
+                 out_sampling_rate, in_cutoff, out_cutoff, in_half_width, out_half_width, conv_kernel=3, filter_size=6,
+                 lrelu_upsampling=1, use_radial_filters=False, conv_clamp=256, magnitude_ema_beta=0.999, cond_mod=False):
+        super().__init__()
+        self.is_critically_sampled = is_critically_sampled
+        self.use_fp16 = use_fp16
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.conv_kernel = conv_kernel
+        self.conv_clamp = conv_clamp
+        self.magnitude_ema_beta = magnitude_ema_beta
+        self.weight = torch.nn.Parameter(torch.randn([self.out_channels, self.in_channels, self.conv_kernel, self.conv_kernel]))
+        self.weight_gain = 1 / np.sqrt(in_channels * (conv_kernel ** 2))
+        self.bias = torch.nn.Parameter(torch.zeros([self.out_channels]))
+        self.register_buffer('magnitude_ema', torch.ones([]))
+        self._setup_resampling(in_size, out_size, in_sampling_rate, out_sampling_rate, in_cutoff, out_cutoff, in_half_width,
+                               out_half_width, conv_kernel, filter_size, lrelu_upsampling, use_radial_filters, False,
+                               is_critically_sampled)
+
+    def forward(self, x, force_fp32=False, update_emas=False):
+        _assert_shape(x, [None, self.in_channels, int(self.in_size[1]), int(self.in_size[0])])
+        if update_emas:
+            with torch.autograd.profiler.record_function('update_magnitude_ema'):
+                magnitude_cur = x.detach().to(torch.float32).square().mean()
+                self.magnitude_ema.copy_(magnitude_cur.lerp(self.magnitude_ema, self.magnitude_ema_beta))
+        dtype = x.dtype
+        w = self.weight * self.weight_gain
+        x = conv2d_gradfix.conv2d(input=x, weight=w, padding=self.conv_kernel - 1)
+        x = filtered_lrelu.filtered_lrelu(x=x, fu=self.up_filter, fd=self.down_filter, b=self.bias.to(x.dtype), up=self.up_factor,
+                                          down=self.down_factor, padding=self.padding, gain=np.sqrt(2), slope=0.2, clamp=self.conv_clamp)
+        _assert_shape(x, [None, self.out_channels, int(self.out_size[1]), int(self.out_size[0])])
+        assert x.dtype == dtype
+        return x
+
+    def extra_repr(self):
+        return (f'in_channels={self.in_channels:d}, out_channels={self.out_channels:d}, in_size={list(self.in_size)}, '
+                f'out_size={list(self.out_size)}, up={self.up_factor}, down={self.down_factor}')
+
+
+class Conv2dLayer(torch.nn.Module):
+    """The bottleneck's 3x3 conv + bias + activation (`e_16x16`, NET:635).  Mirrors the subset of
+    models/networks/CoModGAN/layers.py:115-162 the generator uses: no resampling (up = down = 1)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, bias=True, activation='linear', up=1, down=1,
+                 resample_filter=(1, 3, 3, 1), conv_clamp=None, channels_last=False, trainable=True):
+        super().__init__()
+        if up != 1 or down != 1:
+            raise NotImplementedError('afcm_amd Conv2dLayer covers the generator bottleneck only (up = down = 1)')
+        from .torch_utils.ops import upfirdn2d
+        self.activation = activation
+        self.up, self.down = up, down
+        self.conv_clamp = conv_clamp
+        self.register_buffer('resample_filter', upfirdn2d.setup_filter(list(resample_filter)))
+        self.padding = kernel_size // 2
+        self.weight_gain = 1 / np.sqrt(in_channels * (kernel_size ** 2))
+        self.act_gain = bias_act.activation_funcs[activation].def_gain
+        weight = torch.randn([out_channels, in_channels, kernel_size, kernel_size])
+        b = torch.zeros([out_channels]) if bias else None
+        if trainable:
+            self.weight = torch.nn.Parameter(weight)
+            self.bias = torch.nn.Parameter(b) if b is not None else None
+        else:
+            self.register_buffer('weight', weight)
+            if b is not None:
+                self.register_buffer('bias', b)
+            else:
+                self.bias = None
+
+    def forward(self, x, gain=1):
+        w = self.weight * self.weight_gain
+        b = self.bias.to(x.dtype) if self.bias is not None else None
+        x = conv2d_gradfix.conv2d(input=x, weight=w, padding=self.padding)
+        act_gain = self.act_gain * gain
+        act_clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
+        return bias_act.bias_act(x, b, act=self.activation, gain=act_gain, clamp=act_clamp)
+
+
+class SynthesisNetwork(torch.nn.Module):
+    """Alias-free encoder (14 layers) -> global vector -> co-modulated alias-free decoder (15 layers) (NET:556-712)."""
+
+    def __init__(self, w_dim, img_resolution, img_channels_in, img_channels_out, channel_base=32768, channel_max=512, num_layers=14,
+                 num_critical=2, first_cutoff=2, first_stopband=2 ** 2.1, last_stopband_rel=2 ** 0.3, margin_size=10,
+                 output_scale=0.25, num_fp16_res=4, dropout_rate=0.5, skip_resolution=256, compute_dtype=torch.float32,
+                 **layer_kwargs):
+        super().__init__()
+        self.w_dim = w_dim
+        self.num_ws = num_layers + 2
+        self.img_resolution = img_resolution
+        self.img_channels_in, self.img_channels_out = img_channels_in, img_channels_out
+        self.num_layers, self.num_critical = num_layers, num_critical
+        self.margin_size = margin_size
+        self.output_scale = output_scale
+        self.num_fp16_res = num_fp16_res
+        self.img_resolution_log2 = int(np.log2(img_resolution))
+        self.compute_dtype = compute_dtype
+
+        if skip_resolution >= 4:
+            final_skip = int(np.log2(skip_resolution))
+            self.skip_connects = [True] * (final_skip - 1) + [False] * (self.img_resolution_log2 - final_skip)
+        else:
+            self.skip_connects = [False] * self.img_resolution_log2
+
+        bs = sched.band_schedule(img_resolution, img_channels_out, num_layers, num_critical, first_cutoff, first_stopband,
+                                 last_stopband_rel, margin_size, channel_base, channel_max)
+        cutoffs, half_widths, sampling_rates = bs['cutoffs'], bs['half_widths'], bs['sampling_rates']
+        sizes, sizes_for_encoder = bs['sizes'], bs['sizes_for_encoder']
+        self.sizes = sizes
+        self.channels = channels = bs['channels']
+
+        for idx in range(num_layers):
+            rev_idx = num_layers - idx - 1
+            rev_prev = num_layers - max(idx - 1, 0) - 1
+            layer = EncoderLayer(
+                is_critically_sampled=(idx < num_layers - num_critical), use_fp16=False,
+                in_channels=img_channels_in if idx == 0 else int(channels[rev_prev]), out_channels=int(channels[rev_idx]),
+                in_size=int(sizes_for_encoder[rev_prev]), out_size=int(sizes_for_encoder[rev_idx]),
+                in_sampling_rate=int(sampling_rates[rev_prev]), out_sampling_rate=int(sampling_rates[rev_idx]),
+                in_cutoff=cutoffs[rev_prev], out_cutoff=cutoffs[rev_idx],
+                in_half_width=half_widths[rev_prev], out_half_width=half_widths[rev_idx], **layer_kwargs)
+            setattr(self, f'encoder_{idx}', layer)
+
+        self.e_16x16 = Conv2dLayer(int(channels[0]), int(channels[0]), kernel_size=3, activation='lrelu', conv_clamp=None)
+        self.pool = torch.nn.AdaptiveAvgPool2d((4, 4))
+        self.fc_in = FullyConnectedLayer(int(channels[0]) * (4 ** 2), 512 * 2, activation='lrelu')
+        self.dropout = torch.nn.Dropout(p=dropout_rate)
+
+        self.layer_names = []
+        for idx in range(num_layers + 1):
+            prev = max(idx - 1, 0)
+            layer = SynthesisLayer(
+                w_dim=self.w_dim, global_w_dim=512 * 2, is_torgb=(idx == num_layers),
+                is_critically_sampled=(idx >= num_layers - num_critical), use_fp16=False,
+                in_channels=int(channels[prev]), out_channels=int(channels[idx]),
+                in_size=int(sizes[prev]), out_size=int(sizes[idx]),
+                in_sampling_rate=int(sampling_rates[prev]), out_sampling_rate=int(sampling_rates[idx]),
+                in_cutoff=cutoffs[prev], out_cutoff=cutoffs[idx],
+                in_half_width=half_widths[prev], out_half_width=half_widths[idx], **layer_kwargs)
+            name = f'L{idx}_{layer.out_size[0]}_{layer.out_channels}'
+            setattr(self, name, layer)
+            self.layer_names.append(name)
+
+    def forward(self, ws, img_in, **layer_kwargs):
+        _assert_shape(ws, [None, self.num_ws, self.w_dim])
+        ws = ws.to(torch.float32).unbind(dim=1)
+        img_in = F.pad(img_in.to(self.compute_dtype), [self.margin_size] * 4, 'constant', 0)
+
+        E_features = {}
+        for idx in range(self.num_layers):
+            rev_idx = self.num_layers - idx - 1
+            rev_prev = self.num_layers - max(idx - 1, 0) - 1
+            img_in = getattr(self, f'encoder_{idx}')(img_in)   # the reference passes no kwargs to the encoder (NET:678)
+            if (self.sizes[rev_idx] != self.sizes[rev_prev]) and self.sizes[rev_prev] != self.sizes[0]:
+                E_features[self.sizes[rev_idx]] = img_in
+
+        img_pool = self.e_16x16(img_in)
+        img_pool = self.pool(img_pool.to(torch.float32))
+        img_pool = self.fc_in(img_pool.flatten(1))
+        img_global = self.dropout(img_pool)
+
+        x = img_in
+        res_idx = 1
+        for idx, (name, w) in enumerate(zip(self.layer_names, ws[1:])):
+            nxt = min(idx + 1, len(self.layer_names) - 1)
+            if (self.sizes[idx] != self.sizes[nxt]) and self.sizes[idx] != self.sizes[0]:
+                include_skip = self.skip_connects[res_idx]
+                res_idx += 1
+            else:
+                include_skip = False
+            x = getattr(self, name)(x, w, img_global, E_features, include_skip, **layer_kwargs)
+        if self.output_scale != 1:
+            x = x * self.output_scale
+        _assert_shape(x, [None, self.img_channels_out, self.img_resolution, self.img_resolution])
+        return x.to(torch.float32)
+
+    def extra_repr(self):
+        return (f'w_dim={self.w_dim:d}, num_ws={self.num_ws:d}, img_resolution={self.img_resolution:d}, '
+                f'num_layers={self.num_layers:d}, num_critical={self.num_critical:d}, margin_size={self.margin_size:d}, '
+                f'compute_dtype={self.compute_dtype}')
+
+
+class Stylegan3Generator(torch.nn.Module):
+    """Mapping + synthesis; ``forward(z, c, cond_img, ref_img=None, truncation_psi=1, truncation_cutoff=None,
+    update_emas=False, **synthesis_kwargs)`` as NET:717-740."""
+
+    def __init__(self, z_dim, c_dim, w_dim, img_resolution, img_channels_in, img_channels_out, mapping_kwargs={}, synthesis_kwargs={}):
+        super().__init__()
+        self.z_dim, self.c_dim, self.w_dim = z_dim, c_dim, w_dim
+        self.img_resolution = img_resolution
+        self.synthesis = SynthesisNetwork(w_dim=w_dim, img_resolution=img_resolution, img_channels_in=img_channels_in,
+                                          img_channels_out=img_channels_out, **synthesis_kwargs)
+        self.num_ws = self.synthesis.num_ws
+        self.mapping = MappingNetwork(z_dim=z_dim, c_dim=c_dim, w_dim=w_dim, num_ws=self.num_ws, **mapping_kwargs)
+
+    def forward(self, z, c, cond_img, ref_img=None, truncation_psi=1, truncation_cutoff=None, update_emas=False, **synthesis_kwargs):
+        ws = self.mapping(z, c, img_in=ref_img, truncation_psi=truncation_psi, truncation_cutoff=truncation_cutoff, update_emas=update_emas)
+        return self.synthesis(ws, cond_img, update_emas=update_emas, **synthesis_kwargs)

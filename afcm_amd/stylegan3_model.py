@@ -1,0 +1,67 @@
+"""Generator half of the `--model stylegan3` training step.
+
+Mirrors the reference's model wrapper for the path SURVEY.md section 8 scopes in: ``set_input``
+(models/pix2pix_model.py:111-113 + models/comodgan_model.py:93-99), ``run_G`` / ``forward``
+(models/stylegan3_model.py:13-22,85-87), the G update of ``optimize_parameters`` (:127-135: zero_grad,
+forward, backward_G, NaN/Inf scrub of the gradients, Adam(beta=(0, 0.99)) step -- comodgan_model.py:19-20).
+The adversarial term of ``backward_G`` needs the discriminator (not built yet); the loss
+here is the lambda_L1-weighted L1 term of models/stylegan3_model.py:107 (+ a caller-supplied extra term).
+
+Unlike the reference (which dereferences ``netG.module`` and therefore cannot run without DataParallel,
+comodgan_model.py:14), the wrapper owns a bare module and shards by batch across ranks through
+``afcm_amd.distributed.GradientBuckets``.
+"""
+import torch
+
+from .distributed import GradientBuckets
+
+
+class StyleGAN3GeneratorStep:
+    def __init__(self, netG, lr_G=0.0025, lambda_L1=100.0, distributed=False, bucket_bytes=25 * 1024 * 1024, style_mixing_prob=0):
+        self.netG = netG
+        self.G_mapping = netG.mapping
+        self.G_synthesis = netG.synthesis
+        self.optimizer_G = torch.optim.Adam(netG.parameters(), lr=lr_G, betas=(0, 0.99), eps=1e-8)
+        self.criterionL1 = torch.nn.L1Loss()
+        self.lambda_L1 = lambda_L1
+        self.style_mixing_prob = style_mixing_prob
+        self.real_A = self.real_B = self.fake_B = None
+        self.gen_z = self.gen_c = None
+        self.buckets = GradientBuckets(netG.parameters(), bucket_bytes=bucket_bytes) if distributed else None
+        if self.buckets is not None:
+            self.buckets.broadcast_parameters(netG)
+
+    def set_input(self, real_A, real_B, gen_z=None, gen_c=None):
+        dev = next(self.netG.parameters()).device
+        self.real_A = real_A.to(dev)
+        self.real_B = real_B.to(dev)
+        self.gen_z = torch.randn([real_A.shape[0], self.netG.z_dim], device=dev) if gen_z is None else gen_z.to(dev)
+        self.gen_c = gen_c.to(dev) if gen_c is not None else torch.zeros([real_A.shape[0], self.netG.c_dim], device=dev)
+
+    def run_G(self, cond_img, update_emas=False, noise_mode='random'):
+        ref_img = self.real_B
+        ws = self.G_mapping(z=self.gen_z, c=self.gen_c, img_in=ref_img, update_emas=False)
+        if self.style_mixing_prob > 0:
+            cutoff = torch.empty([], dtype=torch.int64, device=ws.device).random_(1, ws.shape[1])
+            cutoff = torch.where(torch.rand([], device=ws.device) < self.style_mixing_prob, cutoff, torch.full_like(cutoff, ws.shape[1]))
+            ws[:, cutoff:] = self.G_mapping(z=torch.randn_like(self.gen_z), c=self.gen_c, img_in=ref_img)[:, cutoff:]
+        return self.G_synthesis(ws, cond_img, update_emas=False, noise_mode=noise_mode)
+
+    def forward(self, update_emas=False):
+        self.fake_B = self.run_G(self.real_A, update_emas=update_emas)
+
+    def backward_G(self, extra_loss=None):
+        self.loss_G_L1 = self.criterionL1(self.fake_B, self.real_B) * self.lambda_L1
+        self.loss_G = self.loss_G_L1 if extra_loss is None else self.loss_G_L1 + extra_loss
+        self.loss_G.backward()
+
+    def optimize_parameters(self):
+        self.optimizer_G.zero_grad(set_to_none=True)
+        self.forward(update_emas=False)
+        self.backward_G()
+        if self.buckets is not None:
+            self.buckets.finish()
+        for p in self.netG.parameters():
+            if p.grad is not None:
+                torch.nan_to_num(p.grad, nan=0, posinf=1e5, neginf=-1e5, out=p.grad)
+        self.optimizer_G.step()

@@ -111,10 +111,11 @@ def fully_connected(x, weight, bias, act='linear', lr_mul=1.0):
 
 def mapping(sd, z, c, num_ws, num_layers, lr_mul=0.01, prefix='mapping.'):
     """MappingNetwork.forward with truncation_psi=1, update_emas=False (NET:135-161)."""
-    x = z.float()
+    dt = sd[prefix + 'fc0.weight'].dtype          # fp32 normally; fp64 when the oracle is run as ground truth
+    x = z.to(dt)
     x = x * (x.square().mean(1, keepdim=True) + 1e-8).rsqrt()
     if (prefix + 'embed.weight') in sd:
-        y = fully_connected(c.float(), sd[prefix + 'embed.weight'], sd[prefix + 'embed.bias'])
+        y = fully_connected(c.to(dt), sd[prefix + 'embed.weight'], sd[prefix + 'embed.bias'])
         y = y * (y.square().mean(1, keepdim=True) + 1e-8).rsqrt()
         x = torch.cat([x, y], 1)
     for i in range(num_layers):
@@ -128,9 +129,10 @@ def synthesis(sd, pl, ws, img_in, dropout_mask=None, prefix='synthesis.', taps=N
     ``dropout_mask`` (already scaled by 1/(1-p)) stands in for torch's Dropout in training mode;
     ``None`` is eval mode.  ``taps`` optionally receives every resampling layer's output.
     """
-    ws = ws.float().unbind(1)
+    dt = sd[prefix + 'fc_in.weight'].dtype
+    ws = ws.to(dt).unbind(1)
     m = pl['margin']
-    x = F.pad(img_in, [m] * 4)
+    x = F.pad(img_in.to(dt), [m] * 4)
     feats = {}
     clamp = pl['conv_clamp']
     for L in pl['enc']:                                                    # EncoderLayer.forward NET:491-516
@@ -171,7 +173,7 @@ def synthesis(sd, pl, ws, img_in, dropout_mask=None, prefix='synthesis.', taps=N
             taps[L['name']] = x
     if pl['output_scale'] != 1:
         x = x * pl['output_scale']
-    return x.float()
+    return x.to(dt)
 
 
 def generator(sd, pl, z, c, cond_img, mapping_layers, dropout_mask=None, taps=None):
