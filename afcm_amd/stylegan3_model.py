@@ -21,7 +21,7 @@ class StyleGAN3GeneratorStep:
         self.netG = netG
         self.G_mapping = netG.mapping
         self.G_synthesis = netG.synthesis
-        self.optimizer_G = torch.optim.Adam(netG.parameters(), lr=lr_G, betas=(0, 0.99), eps=1e-8)
+        self.optimizer_G = torch.optim.Adam(netG.parameters(), lr=lr_G, betas=(0.0, 0.99), eps=1e-8)
         self.criterionL1 = torch.nn.L1Loss()
         self.lambda_L1 = lambda_L1
         self.style_mixing_prob = style_mixing_prob

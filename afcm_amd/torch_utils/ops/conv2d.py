@@ -12,6 +12,7 @@ weight gradient is a pixel-contraction GEMM, the scale gradients are per-plane d
 import torch
 
 from ... import _lib
+from ... import profiling
 
 
 def _pad64(n):
@@ -71,8 +72,11 @@ def _conv_raw(x, wp, rows_pad, oscale, cout, ks, pad):
     y = torch.empty([n, cout, p, q], dtype=x.dtype, device=x.device)
     if oscale is not None:
         oscale = oscale.to(torch.float32).contiguous()
+    span = profiling.span('conv2d', 2.0 * n * cout * cin * ks * ks * p * q)
     _lib.check(lib.afcm_conv2d(y.data_ptr(), x.data_ptr(), wp.data_ptr(), _lib.ptr(oscale), _lib.dtype_code(x), n, cin, cout, h, w,
                                ks, pad, rows_pad, _lib.stream_ptr(x)), 'conv2d')
+    if span is not None:
+        span.end()
     return y
 
 
@@ -83,8 +87,11 @@ def _wgrad_raw(dy, x, cout, cin, ks, pad):
     splits = lib.afcm_conv2d_wgrad_splits(n, cout, cin, p)
     dw = torch.empty([cout, cin, ks, ks], dtype=torch.float32, device=x.device)
     ws = torch.empty([splits, cout, cin, ks, ks], dtype=torch.float32, device=x.device)
+    span = profiling.span('conv2d_wgrad', 2.0 * n * cout * cin * ks * ks * p * (w + 2 * pad - ks + 1))
     _lib.check(lib.afcm_conv2d_wgrad(dw.data_ptr(), ws.data_ptr(), dy.data_ptr(), x.data_ptr(), _lib.dtype_code(x), n, cin, cout,
                                      h, w, ks, pad, _lib.stream_ptr(x)), 'conv2d_wgrad')
+    if span is not None:
+        span.end()
     return dw
 
 

@@ -16,6 +16,7 @@ import numpy as np
 import torch
 
 from ... import _lib
+from ... import profiling
 from . import upfirdn2d as _ufd
 
 
@@ -120,7 +121,11 @@ class _FilteredLRelu(torch.autograd.Function):
             a.signs = si.data_ptr()
         a.x, a.y, a.b = x.data_ptr(), y.data_ptr(), _lib.ptr(b)
         a.fu, a.fd = _lib.ptr(fu_t), _lib.ptr(fd_t)
+        span = profiling.span('filtered_lrelu', (x.numel() + y.numel()) * x.element_size()
+                              + (so.numel() if so is not None else (si.numel() if si is not None else 0)))
         rc = _lib.check(lib.afcm_filtered_lrelu(a, _lib.stream_ptr(x)), 'filtered_lrelu')
+        if span is not None:
+            span.end()
 
         if rc == _lib.E_NOKERNEL:
             # Generic path, still on the GPU and still keeping only the packed signs for backward.

@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""bench.py -- generator fwd+bwd images/sec at 256^2 on N MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One step = one generator training step of the `--model stylegan3` path on one batch of synthetic MR-like slices:
+mapping + encoder + co-modulated decoder forward (HIP filtered_lrelu / bias_act / MFMA convs), lambda_L1 * L1 loss,
+backward, gradient all-reduce across ranks (RCCL), NaN scrub, Adam step -- StyleGAN3GeneratorStep.optimize_parameters.
+Workload at N=1: BASELINE.json configs[1] (256x256, bf16, batch 16 on one GPU); for N>1 the same per-GPU batch on
+every rank (weak scaling).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+# Peaks from /opt/skills/guides/MI355X_MICROARCH.md (chip-level parameters)
+PEAK_HBM_GBS = 8000.0            # HBM3E spec; 6.29 TB/s measured float4 copy
+PEAK_MFMA_TFLOPS = {'bf16': 2500.0, 'fp16': 2500.0, 'fp32': 157.3}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=8)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--batch', type=int, default=int(os.environ.get('AFCM_BENCH_BATCH', 16)), help='per-GPU batch')
+    ap.add_argument('--res', type=int, default=256)
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp16', 'fp32'])
+    ap.add_argument('--cpu-baseline', default='auto', choices=['auto', 'off'])
+    ap.add_argument('--cpu-baseline-worker', action='store_true', help=argparse.SUPPRESS)
+    ap.add_argument('--no-kernel-timing', action='store_true', help='skip the HIP-event spans around the hot kernels')
+    return ap.parse_args()
+
+
+def cpu_baseline_worker(res):
+    """Child process: time the CPU oracle (pure-aten restatement of the reference's impl='ref' path) on a bounded
+    sample -- full-width generator, batch 1, ONE fwd+bwd, all host cores."""
+    import torch
+    from oracle import generator as ogen
+    torch.set_num_threads(os.cpu_count())
+    from afcm_amd import synthetic
+    pl = ogen.plan(res, 4, 1, {})
+    sd = ogen.random_state_dict(pl, 512, 1, 512, 8, seed=0)
+    params = {k: v.requires_grad_(True) for k, v in sd.items() if not k.endswith(('magnitude_ema', 'w_avg'))}
+    real_A, real_B, z, c = synthetic.generator_inputs(1, size=res, seed=0)
+    t0 = time.time()
+    y = ogen.generator(sd, pl, z, c, real_A, mapping_layers=8, dropout_mask=(torch.rand(1, 1024) > 0.5).float() * 2)
+    loss = (y - real_B).abs().mean() * 100.0
+    loss.backward()
+    dt = time.time() - t0
+    del params
+    print(json.dumps(dict(seconds=dt, images=1, cores=os.cpu_count())))
+
+
+def run_cpu_baseline(res, timeout=240):
+    try:
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-baseline-worker', '--res', str(res)],
+                             capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+        line = [l for l in out.stdout.splitlines() if l.startswith('{')][-1]
+        r = json.loads(line)
+        return dict(value=r['images'] / r['seconds'], unit='images/sec', cores=r['cores'], kind='port',
+                    sample=f'oracle/ (aten restatement of the reference impl=ref path), full-width {res}x{res} generator, batch 1, '
+                           f'one fwd+bwd incl. first-call overheads, {r["seconds"]:.1f} s on {r["cores"]} threads')
+    except Exception as e:  # timeout or failure: report, never block the GPU number
+        return dict(value=None, unit='images/sec', cores=os.cpu_count(), kind='port', sample=f'not measured: {type(e).__name__}: {e}'[:200])
+
+
+def main():
+    args = parse()
+    if args.cpu_baseline_worker:
+        cpu_baseline_worker(args.res)
+        return
+    import torch
+    import torch.distributed as dist
+    from afcm_amd import layer_schedule as sched
+    from afcm_amd import profiling, synthetic
+    from afcm_amd.networks_stylegan3 import Stylegan3Generator
+    from afcm_amd.stylegan3_model import StyleGAN3GeneratorStep
+
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit(f'--gpus {args.gpus} needs a torch.distributed.run launch with {args.gpus} ranks (see the module docstring)')
+        raise SystemExit(f'--gpus {args.gpus} does not match WORLD_SIZE {world}')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        dist.init_process_group('nccl', device_id=dev)
+
+    dtype = {'bf16': torch.bfloat16, 'fp16': torch.float16, 'fp32': torch.float32}[args.dtype]
+    torch.manual_seed(0)      # identical init on every rank (the step also broadcasts from rank 0)
+    kw = dict(sched.DEFAULT_SYNTHESIS_KWARGS)
+    G = Stylegan3Generator(z_dim=512, c_dim=1, w_dim=512, img_resolution=args.res, img_channels_in=4, img_channels_out=1,
+                           mapping_kwargs=dict(num_layers=8), synthesis_kwargs=dict(kw, compute_dtype=dtype)).to(dev).train()
+    step = StyleGAN3GeneratorStep(G, lr_G=0.0025, lambda_L1=100.0, distributed=(world > 1))
+    real_A, real_B, z, c = synthetic.generator_inputs(args.batch, size=args.res, seed=rank, device=dev)
+
+    def one_step():
+        step.set_input(real_A, real_B, z, c)
+        step.optimize_parameters()
+
+    for _ in range(args.warmup):
+        one_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    if not args.no_kernel_timing:
+        profiling.start()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    profiling.stop()
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+
+    if rank == 0:
+        fams = profiling.summary()
+        kernels = {}
+        for fam, d in fams.items():
+            avg_ms = d['total_ms'] / d['launches']
+            if fam == 'filtered_lrelu':
+                ach = d['work'] / (d['total_ms'] * 1e-3) / 1e9
+                kernels[fam] = dict(bound='hbm', achieved=ach, peak=PEAK_HBM_GBS, unit='GB/s', frac=ach / PEAK_HBM_GBS, traffic=None,
+                                    launches=d['launches'], avg_launch_ms=avg_ms, total_ms=d['total_ms'])
+            else:
+                ach = d['work'] / (d['total_ms'] * 1e-3) / 1e12
+                peak = PEAK_MFMA_TFLOPS[args.dtype]
+                kernels[fam] = dict(bound='mfma', achieved=ach, peak=peak, unit='TFLOP/s', frac=ach / peak, traffic=None,
+                                    launches=d['launches'], avg_launch_ms=avg_ms, total_ms=d['total_ms'])
+        dominant = max(kernels, key=lambda k: kernels[k]['total_ms']) if kernels else None
+        roofline = dict(kernels[dominant], kernel=dominant) if dominant else None
+        # HBM traffic from rocprofv3 PMC passes of this same command, when a summary has been committed
+        tpath = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+        if roofline and os.path.exists(tpath):
+            try:
+                roofline['traffic'] = json.load(open(tpath)).get(dominant)
+            except Exception:
+                pass
+        cpu = run_cpu_baseline(args.res) if (world == 1 and args.cpu_baseline == 'auto') else None
+        images = world * args.batch * args.steps
+        out = {
+            'metric': 'generator fwd+bwd images/sec @256^2',
+            'value': images / elapsed,
+            'unit': 'images/sec',
+            'n_gpus': world,
+            'steps': args.steps,
+            'warmup': args.warmup,
+            'ms_per_step': elapsed / args.steps * 1e3,
+            'higher_is_better': True,
+            'scaling': 'weak',
+            'vs_baseline': None,
+            'dtype': args.dtype,
+            'data': 'synthetic',
+            'config': {'workload': f'AFCM --model stylegan3 generator training step (fwd + L1 loss + bwd + grad all-reduce + Adam), '
+                                   f'IXI T1->T2 shape: {args.res}x{args.res}, 4->1 channels, full-width 58.5M-param generator, random init',
+                       'global_batch': world * args.batch, 'per_gpu_batch': args.batch, 'resolution': args.res,
+                       'parallelism': f'dp{world}'},
+            'roofline': roofline,
+            'kernels': kernels,
+            'cpu_baseline': cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
