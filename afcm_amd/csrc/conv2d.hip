@@ -40,7 +40,7 @@ struct ConvParams {
 };
 
 template <typename T, int BM_O, int KS>
-__global__ __launch_bounds__(256, 2) void conv2d_fwd_kernel(ConvParams p) {
+__global__ __launch_bounds__(256, (sizeof(T) == 4 ? 1 : 2)) void conv2d_fwd_kernel(ConvParams p) {
     typedef ConvCfg<T> C;
     constexpr int BK = C::BK, PITCH = C::PITCH, MI = BM_O / 64, KK = KS * KS;
     constexpr bool F32 = sizeof(T) == 4;
@@ -93,16 +93,14 @@ __global__ __launch_bounds__(256, 2) void conv2d_fwd_kernel(ConvParams p) {
             for (int e = 0; e < 16; e++) acc[mi][ti][e] = 0.f;
 
     // ---- staging descriptors -------------------------------------------------------------------------------
-    // weights: 16-byte pieces, straight copies
-    int wsrc[NWP], wdst[NWP];
-#pragma unroll
-    for (int i = 0; i < NWP; i++) {
-        const int j = tid + i * 256;
-        const int tap = j / (BM_O * PPR), q = j - tap * (BM_O * PPR);
-        const int o = q / PPR, pc = q - o * PPR;
-        wsrc[i] = ((tap * p.Opad) + o0 + o) * BK + pc * EPV;
-        wdst[i] = (tap * BM_O + o) * PITCH + pc * EPV;
-    }
+    // weights: 16-byte pieces, straight copies.  piece j = tid + 256*i -> (tap, o, half-row); 256 is a multiple of the
+    // pieces per tap, so both addresses advance by a constant per i.
+    constexpr int PPT = BM_O * PPR;                  // pieces per tap (256 or 128)
+    constexpr int TPI = 256 / PPT;                   // taps advanced per i
+    const int wq = tid % PPT, wtap0 = tid / PPT;
+    const int wsrc0 = ((wtap0 * p.Opad) + o0 + wq / PPR) * BK + (wq % PPR) * EPV;
+    const int wdst0 = (wtap0 * BM_O + wq / PPR) * PITCH + (wq % PPR) * EPV;
+    const int wsrc_step = TPI * p.Opad * BK, wdst_step = TPI * BM_O * PITCH;
     const size_t wchunk = (size_t)KK * p.Opad * BK;
     // patch: one item = 4 pixels x 8 channels
     const int cg = tid % NCG, pg = tid / NCG;
@@ -115,14 +113,17 @@ __global__ __launch_bounds__(256, 2) void conv2d_fwd_kernel(ConvParams p) {
     const long long pix_off = (long long)(rowok ? iy : 0) * p.W + ix;
     const int pdst = (prow * PWL + 4 * pcol4) * PITCH + cg * 8;
 
-    uint4 wreg[NWP];
+    unsigned wreg[NWP][4];
     unsigned preg[8][F32 ? 4 : 2];
 
-    auto issue_loads = [&](int kc) {
+    auto issue_loads = [&](int kc) __attribute__((always_inline)) {
         const T* wsrcp = (const T*)p.wp + (size_t)kc * wchunk;
 #pragma unroll
         for (int i = 0; i < NWP; i++)
-            if (tid + i * 256 < NPIECES) wreg[i] = *(const uint4*)(wsrcp + wsrc[i]);
+            if ((NPIECES % 256 == 0) || tid + i * 256 < NPIECES) {
+                const uint4 t = *(const uint4*)(wsrcp + wsrc0 + i * wsrc_step);
+                wreg[i][0] = t.x; wreg[i][1] = t.y; wreg[i][2] = t.z; wreg[i][3] = t.w;
+            }
 #pragma unroll
         for (int c = 0; c < 8; c++) {
             const int ch = kc * BK + cg * 8 + c;
@@ -137,15 +138,15 @@ __global__ __launch_bounds__(256, 2) void conv2d_fwd_kernel(ConvParams p) {
             }
         }
     };
-    auto write_lds = [&]() {
+    auto write_lds = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < NWP; i++)
-            if (tid + i * 256 < NPIECES) {
+            if ((NPIECES % 256 == 0) || tid + i * 256 < NPIECES) {
                 if (F32) {
-                    unsigned* d = (unsigned*)(lds_w + wdst[i]);
-                    d[0] = wreg[i].x; d[1] = wreg[i].y; d[2] = wreg[i].z; d[3] = wreg[i].w;
+                    unsigned* d = (unsigned*)(lds_w + wdst0 + i * wdst_step);
+                    d[0] = wreg[i][0]; d[1] = wreg[i][1]; d[2] = wreg[i][2]; d[3] = wreg[i][3];
                 } else {
-                    *(uint4*)(lds_w + wdst[i]) = wreg[i];
+                    *(uint4*)(lds_w + wdst0 + i * wdst_step) = make_uint4(wreg[i][0], wreg[i][1], wreg[i][2], wreg[i][3]);
                 }
             }
         if (pvalid) {
@@ -316,24 +317,31 @@ struct WgradParams {
     const void* x;    // [N, I, H, W]
     float* part;      // [splits][O][I][KK]
     int N, O, I, H, W, P, Q, pad;
-    int splits, rows_per_split;   // K rows = N * P
+    int splits, steps_per_split;  // K macro-steps = N * rowgroups * qchunks
     int qchunks;                  // ceil(Q / kWgKQ)
+    int rowgroups;                // ceil(P / R)
 };
 
-template <typename T, int KS>
-__global__ __launch_bounds__(256, 2) void conv2d_wgrad_kernel(WgradParams p) {
+// R = output rows per K macro-step (2 for 16-bit: halves the barriers and re-uses the overlapping input rows).
+template <typename T, int KS, int R>
+__global__ __launch_bounds__(512, (sizeof(T) == 4 ? 1 : 2)) void conv2d_wgrad_kernel(WgradParams p) {
     constexpr bool F32 = sizeof(T) == 4;
     constexpr int KK = KS * KS;
+    constexpr int EPD = F32 ? 1 : 2;               // elements per staged dword
     constexpr int PDY = kWgKQ + 8;                 // 72 elements: 16-bit rows of 144 B (odd x 16 B)
-    constexpr int PX = kWgKQ + 24;                 // 88 elements: 176 B rows; 3 rows per channel -> 528 B (odd x 16 B)
-    constexpr int XW = kWgKQ + 8;                  // staged x columns per row (covers shifts 0..KS-1, +1 alignment, rounded)
-    __shared__ __attribute__((aligned(16))) T lds[64 * PDY + 64 * KS * PX];
+    constexpr int PX = kWgKQ + 24;                 // 88 elements: 176 B rows (odd x 16 B)
+    constexpr int XW = kWgKQ + 8;                  // staged x columns per row (shifts 0..KS-1, +1 alignment, rounded)
+    constexpr int XR = R + KS - 1;                 // staged x rows per channel
+    constexpr int DPR_DY = kWgKQ / EPD, DPR_X = XW / EPD;
+    __shared__ __attribute__((aligned(16))) T lds[64 * R * PDY + 64 * XR * PX];
     T* lds_dy = lds;
-    T* lds_x = lds + 64 * PDY;
+    T* lds_x = lds + 64 * R * PDY;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wo = wave & 1, wi = wave >> 1;
+    const int wo = wave & 1, wi = (wave >> 1) & 1, th = wave >> 2;     // th: which half of the taps this wave accumulates
     const int r32 = lane & 31, h = lane >> 5;
+    constexpr int T0 = (KK + 1) / 2;                                   // taps [0, T0) -> th 0, [T0, KK) -> th 1
+    constexpr int NACC = T0;
 
     int bid = blockIdx.x;
     const int split = bid % p.splits; bid /= p.splits;
@@ -347,89 +355,160 @@ __global__ __launch_bounds__(256, 2) void conv2d_wgrad_kernel(WgradParams p) {
 #pragma unroll
         for (int e = 0; e < 16; e++) acc[t][e] = 0.f;
 
-    const int krow0 = split * p.rows_per_split;
-    const int krow1 = min(krow0 + p.rows_per_split, p.N * p.P);
-    const int EPD = F32 ? 1 : 2;                   // elements per staged dword
-    for (int krow = krow0; krow < krow1; krow++) {
-        const int n = krow / p.P, prow = krow - n * p.P;
-        for (int qc = 0; qc < p.qchunks; qc++) {
-            const int q0 = qc * kWgKQ;
-            const int xorg = (q0 - p.pad) & ~1;    // even origin: dword-aligned 16-bit loads
-            const int xoff = (q0 - p.pad) - xorg;
-            __syncthreads();                        // previous macro-step's reads are done
-            // ---- stage dy: 64 rows x kWgKQ pixels (zero beyond Q / beyond O)
-            {
-                const T* dyn = (const T*)p.dy + (size_t)n * p.O * p.P * p.Q;
-                constexpr int DPR = kWgKQ / (F32 ? 1 : 2);          // dwords per row
-                for (int j = tid; j < 64 * DPR; j += 256) {
-                    const int o = j / DPR, d = j - o * DPR;
-                    const int q = q0 + d * EPD;
-                    unsigned v = 0u;
-                    if (o0 + o < p.O && q < p.Q) v = *(const unsigned*)(dyn + ((size_t)(o0 + o) * p.P + prow) * p.Q + q);
-                    *(unsigned*)(lds_dy + o * PDY + d * EPD) = v;
-                }
+    // ---- staging maps.  Rows of 32 dwords are spread as (row = tid/32 + 8*i, dword = tid%32), so the row-dependent
+    // parts of an address advance by a constant per i; the 4-dword tail of every x row is a second small map.
+    constexpr int NC = DPR_DY / 32;                 // 32-dword column groups per row (1 for 16-bit, 2 for fp32)
+    constexpr int TAILD = DPR_X - 32 * NC;          // dwords of the x-row tail (4 / 8)
+    static_assert(DPR_DY % 32 == 0 && TAILD > 0 && TAILD <= 8, "staging maps assume 64-pixel chunks");
+    constexpr int NDY = (64 * R) / 16;              // dy rows (o * R + rr) per thread
+    constexpr int NXM = (64 * XR) / 16;             // x rows (ic * XR + r), main 32*NC dwords
+    constexpr int NXT = cdiv(64 * XR * TAILD, 512); // x tail
+    const int rb = tid >> 5, dlane = tid & 31;
+    unsigned rdy[NDY][NC], rxm[NXM][NC], rxt[NXT];
+
+    const int steps_per_img = p.rowgroups * p.qchunks;
+    const int s0 = split * p.steps_per_split;
+    const int s1 = min(s0 + p.steps_per_split, p.N * steps_per_img);
+
+    auto issue_loads = [&](int step) __attribute__((always_inline)) {
+        const int n = step / steps_per_img;
+        const int rem = step - n * steps_per_img;
+        const int rg = rem / p.qchunks, qc = rem - rg * p.qchunks;
+        const int prow0 = rg * R, q0 = qc * kWgKQ;
+        const int xorg = (q0 - p.pad) & ~1;
+        const T* dyn = (const T*)p.dy + (size_t)n * p.O * p.P * p.Q;
+        const T* xn = (const T*)p.x + (size_t)n * p.I * p.H * p.W;
+#pragma unroll
+        for (int i = 0; i < NDY; i++) {
+            const int row = rb + 16 * i;
+            const int o = o0 + row / R, pr = prow0 + row % R;
+            const bool rok = o < p.O && pr < p.P;
+            const T* src = dyn + ((size_t)o * p.P + pr) * p.Q + q0;
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                const int dcol = (dlane + 32 * c) * EPD;
+                rdy[i][c] = (rok && q0 + dcol < p.Q) ? *(const unsigned*)(src + dcol) : 0u;
             }
-            // ---- stage x: 64 channels x KS rows x XW pixels starting at column xorg (zero outside the image)
-            {
-                const T* xn = (const T*)p.x + (size_t)n * p.I * p.H * p.W;
-                constexpr int DPR = XW / (F32 ? 1 : 2);
-                for (int j = tid; j < 64 * KS * DPR; j += 256) {
-                    const int rowi = j / DPR, d = j - rowi * DPR;
-                    const int ic = rowi / KS, r = rowi - ic * KS;
-                    const int iy = prow + r - p.pad, ixx = xorg + d * EPD;
-                    unsigned v = 0u;
-                    if (i0 + ic < p.I && (unsigned)iy < (unsigned)p.H && (unsigned)ixx < (unsigned)p.W)
-                        v = *(const unsigned*)(xn + ((size_t)(i0 + ic) * p.H + iy) * p.W + ixx);
-                    *(unsigned*)(lds_x + (ic * KS + r) * PX + d * EPD) = v;
-                }
+        }
+#pragma unroll
+        for (int i = 0; i < NXM; i++) {
+            const int row = rb + 16 * i;
+            const int ic = i0 + row / XR, iy = prow0 + row % XR - p.pad;
+            const bool rok = ic < p.I && (unsigned)iy < (unsigned)p.H;
+            const T* src = xn + ((size_t)ic * p.H + iy) * p.W + xorg;
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                const int dcol = (dlane + 32 * c) * EPD;
+                rxm[i][c] = (rok && (unsigned)(xorg + dcol) < (unsigned)p.W) ? *(const unsigned*)(src + dcol) : 0u;
             }
-            __syncthreads();
-            // ---- MFMA over the chunk
+        }
+#pragma unroll
+        for (int i = 0; i < NXT; i++) {
+            const int j = tid + i * 512;
+            const int row = j / TAILD, ixx = xorg + (32 * NC + j % TAILD) * EPD;
+            const int ic = i0 + row / XR, iy = prow0 + row % XR - p.pad;
+            rxt[i] = (row < 64 * XR && ic < p.I && (unsigned)iy < (unsigned)p.H && (unsigned)ixx < (unsigned)p.W)
+                         ? *(const unsigned*)(xn + ((size_t)ic * p.H + iy) * p.W + ixx) : 0u;
+        }
+    };
+    auto write_lds = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NDY; i++)
+#pragma unroll
+            for (int c = 0; c < NC; c++) *(unsigned*)(lds_dy + (rb + 16 * i) * PDY + (dlane + 32 * c) * EPD) = rdy[i][c];
+#pragma unroll
+        for (int i = 0; i < NXM; i++)
+#pragma unroll
+            for (int c = 0; c < NC; c++) *(unsigned*)(lds_x + (rb + 16 * i) * PX + (dlane + 32 * c) * EPD) = rxm[i][c];
+#pragma unroll
+        for (int i = 0; i < NXT; i++) {
+            const int j = tid + i * 512;
+            if (j / TAILD < 64 * XR) *(unsigned*)(lds_x + (j / TAILD) * PX + (32 * NC + j % TAILD) * EPD) = rxt[i];
+        }
+    };
+
+    if (s0 < s1) issue_loads(s0);
+    for (int step = s0; step < s1; step++) {
+        const int rem = step % steps_per_img;
+        const int q0 = (rem % p.qchunks) * kWgKQ;
+        const int xoff = (q0 - p.pad) - ((q0 - p.pad) & ~1);
+        __syncthreads();                            // previous macro-step's LDS reads are done
+        write_lds();
+        __syncthreads();
+        if (step + 1 < s1) issue_loads(step + 1);   // in flight while this step computes
+        auto compute = [&](auto thc) __attribute__((always_inline)) {
+            constexpr int TH = decltype(thc)::value;
+            constexpr int TLO = TH == 0 ? 0 : T0, THI = TH == 0 ? T0 : KK;
             if constexpr (F32) {
+#pragma unroll
+                for (int rr = 0; rr < R; rr++)
 #pragma unroll 4
-                for (int k2 = 0; k2 < kWgKQ / 2; k2++) {
-                    const float a = lds_dy[(wo * 32 + r32) * PDY + 2 * k2 + h];
+                    for (int k2 = 0; k2 < kWgKQ / 2; k2++) {
+                        const float a = lds_dy[((wo * 32 + r32) * R + rr) * PDY + 2 * k2 + h];
 #pragma unroll
-                    for (int r = 0; r < KS; r++)
-#pragma unroll
-                        for (int s = 0; s < KS; s++) {
-                            const float b = lds_x[((wi * 32 + r32) * KS + r) * PX + 2 * k2 + h + s + xoff];
-                            acc[r * KS + s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[r * KS + s], 0, 0, 0);
+                        for (int t = TLO; t < THI; t++) {
+                            const int r = t / KS, sft = t - r * KS;
+                            const float b = lds_x[((wi * 32 + r32) * XR + rr + r) * PX + 2 * k2 + h + sft + xoff];
+                            acc[t - TLO] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t - TLO], 0, 0, 0);
                         }
-                }
+                    }
             } else {
                 typedef typename std::conditional<std::is_same<T, bf16_t>::value, bf16x8, f16x8>::type frag_t;
 #pragma unroll
                 for (int k16 = 0; k16 < kWgKQ / 16; k16++) {
-                    const frag_t a = *(const frag_t*)(lds_dy + (wo * 32 + r32) * PDY + k16 * 16 + 8 * h);
+                    frag_t a[R];
 #pragma unroll
-                    for (int r = 0; r < KS; r++) {
-                        // 6 dwords = 12 elements starting at element k16*16 + 8h of the staged row
-                        const unsigned* src = (const unsigned*)(lds_x + ((wi * 32 + r32) * KS + r) * PX + k16 * 16 + 8 * h);
+                    for (int rr = 0; rr < R; rr++) a[rr] = *(const frag_t*)(lds_dy + ((wo * 32 + r32) * R + rr) * PDY + k16 * 16 + 8 * h);
+                    // the staged rows of this lane's channel: each read once, shifted variants built in registers
+#pragma unroll
+                    for (int xr = 0; xr < XR; xr++) {
+                        // is staged row xr used by any (rr, tap) of this half?
+                        bool used = false;
+#pragma unroll
+                        for (int rr = 0; rr < R; rr++)
+#pragma unroll
+                            for (int t = TLO; t < THI; t++) used = used || (t / KS == xr - rr);
+                        if (!used) continue;
+                        const unsigned* src = (const unsigned*)(lds_x + ((wi * 32 + r32) * XR + xr) * PX + k16 * 16 + 8 * h);
                         const uint4 lo = *(const uint4*)src;
                         const uint2 hi = *(const uint2*)(src + 4);
                         const unsigned d[6] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y};
 #pragma unroll
-                        for (int s = 0; s < KS; s++) {
-                            // element shift s + xoff in [0, 3]
+                        for (int sft = 0; sft < KS; sft++) {
+                            bool sused = false;
+#pragma unroll
+                            for (int rr = 0; rr < R; rr++) {
+                                const int t = (xr - rr) * KS + sft;
+                                sused = sused || (xr - rr >= 0 && xr - rr < KS && t >= TLO && t < THI);
+                            }
+                            if (!sused) continue;
                             union { unsigned u[4]; frag_t f; } b;
-                            const int sh = s + xoff;                          // runtime xoff in {0,1}: resolved by selects
+                            const int sh = sft + xoff;                            // element shift in [0, 3]
 #pragma unroll
                             for (int w = 0; w < 4; w++) {
                                 const unsigned e0 = d[w], e1 = d[w + 1], e2 = d[w + 2];
-                                const unsigned odd_lo = __builtin_amdgcn_alignbyte(e1, e0, 2);   // shift 1
-                                const unsigned odd_hi = __builtin_amdgcn_alignbyte(e2, e1, 2);   // shift 3
+                                const unsigned odd_lo = __builtin_amdgcn_alignbyte(e1, e0, 2);
+                                const unsigned odd_hi = __builtin_amdgcn_alignbyte(e2, e1, 2);
                                 b.u[w] = (sh == 0) ? e0 : (sh == 1) ? odd_lo : (sh == 2) ? e1 : odd_hi;
                             }
-                            if constexpr (std::is_same<T, bf16_t>::value)
-                                acc[r * KS + s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b.f, acc[r * KS + s], 0, 0, 0);
-                            else
-                                acc[r * KS + s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b.f, acc[r * KS + s], 0, 0, 0);
+#pragma unroll
+                            for (int rr = 0; rr < R; rr++) {
+                                const int r = xr - rr;
+                                const int t = r * KS + sft;
+                                if (r >= 0 && r < KS && t >= TLO && t < THI) {
+                                    if constexpr (std::is_same<T, bf16_t>::value)
+                                        acc[t - TLO] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[rr], b.f, acc[t - TLO], 0, 0, 0);
+                                    else
+                                        acc[t - TLO] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[rr], b.f, acc[t - TLO], 0, 0, 0);
+                                }
+                            }
                         }
                     }
                 }
             }
-        }
+        };
+        if (th == 0) compute(std::integral_constant<int, 0>{});
+        else compute(std::integral_constant<int, 1>{});
     }
     // ---- write the partial tile: D[row = o][col = i]
     float* out = p.part + (size_t)split * p.O * p.I * KK;
@@ -439,8 +518,13 @@ __global__ __launch_bounds__(256, 2) void conv2d_wgrad_kernel(WgradParams p) {
         const int i = i0 + wi * 32 + r32;
         if (o < p.O && i < p.I) {
             float* dst = out + ((size_t)o * p.I + i) * KK;
+            if (th == 0) {
 #pragma unroll
-            for (int t = 0; t < KK; t++) dst[t] = acc[t][reg];
+                for (int t = 0; t < T0; t++) dst[t] = acc[t][reg];
+            } else {
+#pragma unroll
+                for (int t = T0; t < KK; t++) dst[t] = acc[t - T0][reg];
+            }
         }
     }
 }
@@ -542,12 +626,14 @@ extern "C" int afcm_conv2d(void* y, const void* x, const void* wpacked, const fl
 }
 
 
-// Split count for the weight gradient: enough workgroups to fill the chip, bounded by the K rows.
+// Split count for the weight gradient: enough workgroups to fill the chip, bounded by the K macro-steps.
+static int wgrad_rows_per_step(int dtype) { return dtype == AFCM_F32 ? 1 : 2; }
+
 extern "C" int afcm_conv2d_wgrad_splits(int32_t n, int32_t cout, int32_t cin, int32_t p_rows) {
     const int tiles = cdiv(cout, 64) * cdiv(cin, 64);
     int splits = cdiv(768, tiles);
-    const long long krows = (long long)n * p_rows;
-    if (splits > krows) splits = (int)krows;
+    const long long ksteps = (long long)n * p_rows;   // upper bound on the macro-steps of any dtype
+    if (splits > ksteps) splits = (int)ksteps;
     if (splits < 1) splits = 1;
     return splits;
 }
@@ -564,18 +650,22 @@ extern "C" int afcm_conv2d_wgrad(float* dw, float* workspace, const void* dy, co
     p.P = h + 2 * pad - ks + 1; p.Q = w + 2 * pad - ks + 1;
     AFCM_REQUIRE(p.P >= 1 && p.Q >= 1, "output must be at least 1x1");
     AFCM_REQUIRE(dtype == AFCM_F32 || (w % 2 == 0 && p.Q % 2 == 0), "16-bit conv2d_wgrad needs even widths (got %d, %d)", w, p.Q);
-    p.splits = afcm_conv2d_wgrad_splits(n, cout, cin, p.P);
-    p.rows_per_split = cdiv(n * p.P, p.splits);
+    const int R = wgrad_rows_per_step(dtype);
     p.qchunks = cdiv(p.Q, kWgKQ);
+    p.rowgroups = cdiv(p.P, R);
+    const long long ksteps = (long long)n * p.rowgroups * p.qchunks;
+    p.splits = afcm_conv2d_wgrad_splits(n, cout, cin, p.P);
+    if (p.splits > ksteps) p.splits = (int)ksteps;
+    p.steps_per_split = (int)((ksteps + p.splits - 1) / p.splits);
     const long long blocks = (long long)cdiv(cout, 64) * cdiv(cin, 64) * p.splits;
-    dim3 grid((unsigned)blocks), block(256);
+    dim3 grid((unsigned)blocks), block(512);
     hipStream_t st = (hipStream_t)stream;
-#define AFCM_WG(T) do { if (ks == 3) hipLaunchKernelGGL((conv2d_wgrad_kernel<T, 3>), grid, block, 0, st, p); \
-                        else hipLaunchKernelGGL((conv2d_wgrad_kernel<T, 1>), grid, block, 0, st, p); } while (0)
+#define AFCM_WG(T, R) do { if (ks == 3) hipLaunchKernelGGL((conv2d_wgrad_kernel<T, 3, R>), grid, block, 0, st, p); \
+                           else hipLaunchKernelGGL((conv2d_wgrad_kernel<T, 1, R>), grid, block, 0, st, p); } while (0)
     switch (dtype) {
-        case AFCM_F32: AFCM_WG(float); break;
-        case AFCM_F16: AFCM_WG(f16_t); break;
-        default: AFCM_WG(bf16_t); break;
+        case AFCM_F32: AFCM_WG(float, 1); break;
+        case AFCM_F16: AFCM_WG(f16_t, 2); break;
+        default: AFCM_WG(bf16_t, 2); break;
     }
 #undef AFCM_WG
     int rc = hip_status(hipGetLastError());
@@ -583,6 +673,7 @@ extern "C" int afcm_conv2d_wgrad(float* dw, float* workspace, const void* dy, co
     const long long numel = (long long)cout * cin * ks * ks;
     long long rb = (numel + 255) / 256;
     if (rb > 2048) rb = 2048;
+    // splits beyond the last populated one were never launched with work: they still wrote zeros (acc = 0)
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)rb), dim3(256), 0, st, dw, (const float*)workspace, numel, p.splits);
     return hip_status(hipGetLastError());
 }
