@@ -27,6 +27,7 @@ class FilteredLReluArgs(C.Structure):
         ('sx', C.c_int32), ('sy', C.c_int32), ('sh', C.c_int32), ('swb', C.c_int32),
         ('gain', C.c_float), ('slope', C.c_float), ('clamp', C.c_float),
         ('flip_filter', C.c_int32), ('sign_mode', C.c_int32),
+        ('workspace', C.c_void_p), ('sign_layout', C.c_int32), ('reserved_', C.c_int32),
     ]
 
 
@@ -40,6 +41,8 @@ SIGNATURES = {
     'afcm_last_error': (C.c_char_p, []),
     'afcm_filtered_lrelu_shapes': (C.c_int, [C.POINTER(FilteredLReluArgs)]),
     'afcm_filtered_lrelu': (C.c_int, [C.POINTER(FilteredLReluArgs), _vp]),
+    'afcm_filtered_lrelu_workspace_bytes': (C.c_int64, []),
+    'afcm_filtered_lrelu_prepare': (C.c_int, [C.POINTER(FilteredLReluArgs), _vp]),
     'afcm_filtered_lrelu_act': (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _f32, _i32, _vp]),
     'afcm_upfirdn2d': (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32,
                                  _i32, _i32, _i32, _f32, _vp]),
@@ -67,8 +70,8 @@ def load():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
-        if lib.afcm_abi_version() != 1:
-            raise RuntimeError(f'libafcm_hip.so ABI version {lib.afcm_abi_version()} does not match this package (1); rebuild it')
+        if lib.afcm_abi_version() != 2:
+            raise RuntimeError(f'libafcm_hip.so ABI version {lib.afcm_abi_version()} does not match this package (2); rebuild it')
         _lib = lib
     return _lib
 

@@ -349,9 +349,9 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 1 : 2)) void conv2d_wgrad_ke
     const int obk = bid / cdiv(p.I, 64);
     const int o0 = obk * 64, i0 = ib * 64;
 
-    f32x16 acc[KK];
+    f32x16 acc[NACC];
 #pragma unroll
-    for (int t = 0; t < KK; t++)
+    for (int t = 0; t < NACC; t++)
 #pragma unroll
         for (int e = 0; e < 16; e++) acc[t][e] = 0.f;
 

@@ -468,6 +468,9 @@ static int dispatch(const afcm_filtered_lrelu_args* a, const FlreluParams& p, hi
     return AFCM_E_NOKERNEL;
 }
 
+int flrelu_mfma_supported(const afcm_filtered_lrelu_args* a);
+int flrelu_mfma_launch(const afcm_filtered_lrelu_args* a, bool prepare, hipStream_t st);
+
 }  // namespace afcm
 
 using namespace afcm;
@@ -488,8 +491,16 @@ extern "C" int afcm_filtered_lrelu_shapes(afcm_filtered_lrelu_args* a) {
     a->yh = (int)yh;
     if (a->sign_mode == AFCM_SIGNS_WRITE) {
         const long long sw_active = yw * a->down - (a->down - 1) + fdt_w;
-        a->sh = (int)(yh * a->down - (a->down - 1) + fdt_h);
-        a->swb = (int)(((sw_active + 15) & ~15ll) >> 2);
+        const long long sh = yh * a->down - (a->down - 1) + fdt_h;
+        if (a->workspace != nullptr && flrelu_mfma_supported(a)) {
+            a->sign_layout = 1;                                   // row-quad bytes: one byte = 4 rows of one column
+            a->sh = (int)((sh + 3) >> 2);
+            a->swb = (int)((sw_active + 15) & ~15ll);
+        } else {
+            a->sign_layout = 0;
+            a->sh = (int)sh;
+            a->swb = (int)(((sw_active + 15) & ~15ll) >> 2);
+        }
     }
     return AFCM_OK;
 }
@@ -507,10 +518,15 @@ extern "C" int afcm_filtered_lrelu(const afcm_filtered_lrelu_args* a, void* stre
         AFCM_REQUIRE(a->signs != nullptr && a->sh > 0 && a->swb > 0 && (a->swb & 3) == 0, "signs must be a [N,C,sh,4k] uint8 tensor");
         if (a->sign_mode == AFCM_SIGNS_WRITE) {
             AFCM_REQUIRE(a->sx == 0 && a->sy == 0, "sign offsets must be zero when writing signs");
-            AFCM_REQUIRE(chk.sh == a->sh && chk.swb == a->swb, "signs has shape [%d, %d], expected [%d, %d]", a->sh, a->swb, chk.sh, chk.swb);
+            AFCM_REQUIRE(chk.sh == a->sh && chk.swb == a->swb && chk.sign_layout == a->sign_layout,
+                         "signs has shape [%d, %d] layout %d, expected [%d, %d] layout %d", a->sh, a->swb, a->sign_layout, chk.sh, chk.swb, chk.sign_layout);
         }
     }
     hipStream_t st = (hipStream_t)stream;
+    const bool mfma = a->workspace != nullptr && flrelu_mfma_supported(a);
+    if (a->sign_mode == AFCM_SIGNS_READ)
+        AFCM_REQUIRE((a->sign_layout == 1) == mfma, "sign tensor layout %d does not match the kernel family selected for this call", a->sign_layout);
+    if (mfma) return flrelu_mfma_launch(a, false, st);
 
     FlreluParams p;
     p.x = a->x; p.y = a->y; p.b = a->b; p.s = a->signs;
@@ -538,6 +554,12 @@ extern "C" int afcm_filtered_lrelu(const afcm_filtered_lrelu_args* a, void* stre
         case AFCM_F16: return dispatch<f16_t>(a, p, st);
         default: return dispatch<bf16_t>(a, p, st);
     }
+}
+
+extern "C" int afcm_filtered_lrelu_prepare(const afcm_filtered_lrelu_args* a, void* stream) {
+    AFCM_REQUIRE(a != nullptr && a->workspace != nullptr && a->fu != nullptr && a->fd != nullptr, "filtered_lrelu_prepare: workspace, fu and fd must be non-null");
+    if (!flrelu_mfma_supported(a)) return AFCM_E_NOKERNEL;
+    return flrelu_mfma_launch(a, true, (hipStream_t)stream);
 }
 
 extern "C" int afcm_filtered_lrelu_act(void* x, uint8_t* signs, int32_t dtype, int32_t n, int32_t c, int32_t h, int32_t w,

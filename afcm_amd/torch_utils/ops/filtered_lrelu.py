@@ -74,12 +74,34 @@ def _act_inplace(y, si, sx, sy, gain, slope, clamp, write_signs):
     return so
 
 
+_workspaces = {}   # layer configuration -> prepared constant-fragment buffer (or None: no matrix-core kernel)
+
+
+def _mfma_workspace(a, fu_t, fd_t, x):
+    """Constant Toeplitz fragments of the matrix-core kernels, built once per layer configuration
+    (C ABI afcm_filtered_lrelu_prepare).  Returns a device tensor or None."""
+    if x.dtype not in (torch.bfloat16, torch.float16) or fu_t is None or fd_t is None:
+        return None
+    key = (x.device, x.dtype, fu_t.data_ptr(), fu_t._version, fd_t.data_ptr(), fd_t._version, a.fuw, a.fuh, a.fdw, a.fdh,
+           a.up, a.down, a.px0, a.py0, a.gain, a.flip_filter)
+    if key not in _workspaces:
+        lib = _lib.load()
+        ws = torch.empty([lib.afcm_filtered_lrelu_workspace_bytes()], dtype=torch.uint8, device=x.device)
+        a.workspace = ws.data_ptr()
+        a.fu, a.fd = fu_t.data_ptr(), fd_t.data_ptr()
+        rc = _lib.check(lib.afcm_filtered_lrelu_prepare(a, _lib.stream_ptr(x)), 'filtered_lrelu_prepare')
+        # keep the filters alive with the workspace: the key holds their addresses
+        _workspaces[key] = (ws, fu_t, fd_t) if rc == 0 else None
+    ent = _workspaces[key]
+    return None if ent is None else ent[0]
+
+
 class _FilteredLRelu(torch.autograd.Function):
     """x, fu, fd, b, si are tensors (or None); cfg carries the scalars of one call."""
 
     @staticmethod
     def forward(ctx, x, fu, fd, b, si, cfg):
-        up, down, px0, px1, py0, py1, gain, slope, clamp, flip_filter, sx, sy = cfg
+        up, down, px0, px1, py0, py1, gain, slope, clamp, flip_filter, sx, sy, si_layout = cfg
         assert isinstance(x, torch.Tensor) and x.ndim == 4
         _lib.require_gpu(x, fu, fd, b, si)
         lib = _lib.load()
@@ -108,6 +130,14 @@ class _FilteredLRelu(torch.autograd.Function):
         a.gain, a.slope, a.clamp = gain, slope, clamp
         a.flip_filter = int(flip_filter)
         a.sign_mode = _lib.SIGNS_WRITE if write_signs else (_lib.SIGNS_READ if si is not None else _lib.SIGNS_NONE)
+        # 16-bit activations: matrix-core kernels (signs in the row-quad layout); a given sign tensor fixes the family
+        ws = None
+        if si is None or si_layout == 1:
+            ws = _mfma_workspace(a, fu_t, fd_t, x)
+            if si is not None and ws is None:
+                raise RuntimeError('filtered_lrelu: sign tensor was written by the matrix-core kernels but this call has none')
+        a.workspace = _lib.ptr(ws)
+        a.sign_layout = si_layout if si is not None else 0
         _lib.check(lib.afcm_filtered_lrelu_shapes(a), 'filtered_lrelu')
         y = torch.empty([a.n, a.c, a.yh, a.yw], dtype=x.dtype, device=x.device)
         so = None
@@ -139,13 +169,14 @@ class _FilteredLRelu(torch.autograd.Function):
 
         ctx.save_for_backward(fu, fd, si if si is not None else so)
         ctx.cfg = cfg
+        ctx.sign_layout = a.sign_layout if rc == 0 else 0
         ctx.x_shape = x.shape
         ctx.y_shape = y.shape
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        up, down, px0, px1, py0, py1, gain, slope, clamp, flip_filter, sx, sy = ctx.cfg
+        up, down, px0, px1, py0, py1, gain, slope, clamp, flip_filter, sx, sy, _ = ctx.cfg
         fu, fd, si = ctx.saved_tensors
         _, _, xh, xw = ctx.x_shape
         _, _, yh, yw = ctx.y_shape
@@ -167,7 +198,7 @@ class _FilteredLRelu(torch.autograd.Function):
                 xh * up - yh * down + py0 - (up - 1),
             )
             gg = gain * (up ** 2) / (down ** 2)
-            cfg = (down, up) + pp + (gg, slope, float('inf'), not flip_filter, sx - (fuw - 1) + px0, sy - (fuh - 1) + py0)
+            cfg = (down, up) + pp + (gg, slope, float('inf'), not flip_filter, sx - (fuw - 1) + px0, sy - (fuh - 1) + py0, ctx.sign_layout)
             dx = _FilteredLRelu.apply(dy, fd, fu, None, si, cfg)
         if ctx.needs_input_grad[3]:
             db = dx.sum([0, 2, 3])
@@ -196,5 +227,5 @@ def filtered_lrelu(x, fu=None, fd=None, b=None, up=1, down=1, padding=0, gain=np
     assert clamp is None or (clamp == float(clamp) and clamp >= 0)
     clamp = float(clamp if clamp is not None else 'inf')
     _lib.require_gpu(x, fu, fd, b)
-    cfg = (int(up), int(down), px0, px1, py0, py1, float(gain), float(slope), clamp, bool(flip_filter), 0, 0)
+    cfg = (int(up), int(down), px0, px1, py0, py1, float(gain), float(slope), clamp, bool(flip_filter), 0, 0, 0)
     return _FilteredLRelu.apply(x, fu, fd, b, None, cfg)

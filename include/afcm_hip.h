@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define AFCM_ABI_VERSION 1
+#define AFCM_ABI_VERSION 2
 
 enum { AFCM_F32 = 0, AFCM_F16 = 1, AFCM_BF16 = 2 };
 enum { AFCM_OK = 0, AFCM_E_NOKERNEL = -1, AFCM_E_INVALID = -2 };
@@ -77,12 +77,27 @@ typedef struct afcm_filtered_lrelu_args {
     float   gain, slope, clamp;     /* clamp = +inf to disable                 */
     int32_t flip_filter;
     int32_t sign_mode;      /* AFCM_SIGNS_*                                    */
+    void*   workspace;      /* NULL, or afcm_filtered_lrelu_workspace_bytes() of device memory filled by
+                               afcm_filtered_lrelu_prepare() for THIS (fu, fd, up, down, px0, py0, gain, flip, dtype):
+                               enables the matrix-core kernels for 16-bit dtypes                              */
+    int32_t sign_layout;    /* 0: row-major 2-bit codes (reference layout); 1: row-quad bytes written by the
+                               matrix-core kernels ([N,C,ceil(sh/4),swq]); set by afcm_filtered_lrelu_shapes(),
+                               must be passed back unchanged with the sign tensor in READ mode                 */
+    int32_t reserved_;
 } afcm_filtered_lrelu_args;
 
 /* Output / sign-tensor geometry for the arguments above (filtered_lrelu.cpp:61-94). Fills yh, yw
  * and, for WRITE mode, sh, swb.  Pure host arithmetic. */
 int afcm_filtered_lrelu_shapes(afcm_filtered_lrelu_args* a);
 int afcm_filtered_lrelu(const afcm_filtered_lrelu_args* a, void* stream);
+
+/* Matrix-core path (16-bit dtypes, the separable 12/24-tap cases of the generator): the FIR passes run as banded
+ * Toeplitz products on v_mfma_f32_16x16x32_{bf16,f16}.  The constant Toeplitz fragments depend only on the layer
+ * configuration; build them once per layer with afcm_filtered_lrelu_prepare() into `workspace` (this replaces the
+ * reference's per-call setup_filters_kernel + copy to __constant__ memory, filtered_lrelu.cu:87-117, without any
+ * global state).  Returns AFCM_E_NOKERNEL when the configuration has no matrix-core kernel. */
+int64_t afcm_filtered_lrelu_workspace_bytes(void);
+int afcm_filtered_lrelu_prepare(const afcm_filtered_lrelu_args* a, void* stream);
 
 /* In-place gain -> leaky ReLU -> clamp with sign write/read, used by the generic fallback.
  * Replaces plugin `filtered_lrelu_act_(x, si, sx, sy, gain, slope, clamp, writeSigns) -> so`

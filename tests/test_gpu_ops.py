@@ -71,7 +71,7 @@ def test_filtered_lrelu_sign_codes_bit_exact(name):
     up, down, pad = kw['up'], kw['down'], kw['padding']
     x = _dev(g['x'], True)
     b = _dev(g.get('b'))
-    cfg = (up, down, *pad, kw['gain'], kw['slope'], float('inf') if kw['clamp'] is None else kw['clamp'], kw['flip_filter'], 0, 0)
+    cfg = (up, down, *pad, kw['gain'], kw['slope'], float('inf') if kw['clamp'] is None else kw['clamp'], kw['flip_filter'], 0, 0, 0)
     y = _FilteredLRelu.apply(x, _dev(g['fu']), _dev(g['fd']), b, None, cfg)
     signs = y.grad_fn.saved_tensors[2].cpu().numpy()
     xb = g['x'].astype(np.float64) + (g['b'].astype(np.float64).reshape(1, -1, 1, 1) if 'b' in g else 0)
@@ -233,3 +233,35 @@ def test_bias_act_second_order(act):
             assert a is None or a.abs().max().item() == 0
         else:
             _close(a, b_, tol=1e-4, what=f'{act} {nm}')
+
+
+@pytest.mark.parametrize('dtype,tol', [(torch.float16, 6e-3), (torch.bfloat16, 4e-2)])
+@pytest.mark.parametrize('lname', ['encoder_1', 'encoder_4', 'L10_276_128', 'L13_256_64'])
+def test_filtered_lrelu_16bit_matrix_core_path(lname, dtype, tol):
+    """16-bit activations run the matrix-core kernels (banded-Toeplitz MFMA): multi-tile planes, several (n, c) planes,
+    forward and backward (sign codes in the row-quad layout) vs the fp32 CPU oracle on the same 16-bit inputs.
+    Bound: 16-bit rounding of operands/intermediates only (fp32 accumulation) -- 6e-3 (f16) / 4e-2 (bf16) x scale."""
+    from afcm_amd.torch_utils.ops import filtered_lrelu as flr
+    from oracle import aten_ops as ops
+    from oracle import generator as ogen
+    pl = ogen.plan(256, 4, 1, {})
+    L = [l for l in pl['enc'] + pl['dec'] if l['name'] == lname][0]
+    h = L['in_size'] + 2
+    torch.manual_seed(5)
+    x = torch.randn(2, 3, h, h).to(dtype)
+    b = (torch.randn(3) * 0.2).to(dtype)
+    kw = dict(up=L['up'], down=L['down'], padding=L['padding'], gain=float(np.sqrt(2)), slope=0.2, clamp=256.0)
+    xr = x.float().requires_grad_(True)
+    ref = ops.filtered_lrelu(xr, fu=L['fu'], fd=L['fd'], b=b.float(), **kw)
+    r = torch.randn_like(ref).to(dtype)
+    gref, = torch.autograd.grad((ref * r.float()).sum(), xr)
+    xg = x.cuda().requires_grad_(True)
+    got = flr.filtered_lrelu(xg, fu=L['fu'].cuda(), fd=L['fd'].cuda(), b=b.cuda(), **kw)
+    assert got.dtype == dtype and got.shape == ref.shape
+    assert got.grad_fn.sign_layout == 1, 'expected the matrix-core kernel family'
+    _close(got, ref, tol=tol, what=f'{lname} {dtype} y')
+    ggot, = torch.autograd.grad((got.float() * r.cuda().float()).sum(), xg)
+    # leaky-ReLU kinks: 16-bit forward rounding flips the branch of elements near 0, so compare in relative L2
+    d = (ggot.float().cpu() - gref)
+    rel = (d.norm() / gref.norm()).item()
+    assert rel <= 2 * tol, f'{lname} {dtype} dx: relative L2 {rel:.3e}'
