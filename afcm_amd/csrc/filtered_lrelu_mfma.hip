@@ -170,21 +170,27 @@ __global__ __launch_bounds__((64 * MfmaGeom<UP, DOWN, TOW, TOH>::NG)) void flrel
     const int U0x = O0x * DOWN, U0y = O0y * DOWN;
     const int I0x = -floor_div(p.px0 - U0x, UP), I0y = -floor_div(p.py0 - U0y, UP);
 
-    // ---- stage the input tile (+ bias inside the image; zero outside: the bias is added before padding)
+    // ---- stage the input tile (+ bias inside the image; zero outside: the bias is added before padding).
+    // One item = 8 consecutive columns of one row: 4 (or 5, odd column origin) aligned dword loads, realigned in
+    // registers, written with one 16-byte LDS store.  Needs an even plane width (all layers of the model).
     {
         const T* xp = (const T*)p.x + (size_t)plane * p.xh * p.xw;
         const float bias = p.b ? to_f32(((const T*)p.b)[plane % p.C]) : 0.f;
-        constexpr int CW = G::TIW;
-        constexpr int NLD = cdiv(G::IROWS * CW, NT);
-        T raw[NLD];
-        bool ok[NLD];
+        constexpr int CH = G::PIN / 8;                       // 8-column chunks per staged row (incl. pitch padding)
+        constexpr int NIT = cdiv(G::IROWS * CH, NT);
+        const int odd = I0x & 1;
+        unsigned raw[NIT][5];
 #pragma unroll
-        for (int i = 0; i < NLD; i++) {
+        for (int i = 0; i < NIT; i++) {
             const int idx = tid + i * NT;
-            const int r = idx / CW, c = idx - r * CW;
-            const int iy = I0y + r, ix = I0x + c;
-            ok[i] = idx < G::IROWS * CW && (unsigned)ix < (unsigned)p.xw && (unsigned)iy < (unsigned)p.xh;
-            raw[i] = ok[i] ? xp[(size_t)iy * p.xw + ix] : from_f32<T>(0.f);
+            const int r = idx / CH, c8 = idx - r * CH;
+            const int iy = I0y + r;
+            const int ix0 = I0x - odd + 8 * c8;              // even column of the first dword
+            const bool rok = idx < G::IROWS * CH && (unsigned)iy < (unsigned)p.xh;
+            const T* src = xp + (long long)iy * p.xw + ix0;
+#pragma unroll
+            for (int w = 0; w < 5; w++)
+                raw[i][w] = (rok && (w < 4 || odd) && (unsigned)(ix0 + 2 * w) < (unsigned)p.xw) ? *(const unsigned*)(src + 2 * w) : 0u;
         }
         // rows of X3T beyond the computed columns are read (with zero weights) by the last down-x window: keep them finite
         for (int idx = tid; idx < (G::X3ROWS - G::XCOLS) * G::PX3; idx += NT) lds_x3[G::XCOLS * G::PX3 + idx] = from_f32<T>(0.f);
@@ -212,11 +218,24 @@ __global__ __launch_bounds__((64 * MfmaGeom<UP, DOWN, TOW, TOH>::NG)) void flrel
             }
         }
 #pragma unroll
-        for (int i = 0; i < NLD; i++) {
+        for (int i = 0; i < NIT; i++) {
             const int idx = tid + i * NT;
-            if (idx < G::IROWS * CW) {
-                const int r = idx / CW, c = idx - r * CW;
-                lds_in[r * G::PIN + c] = ok[i] ? from_f32<T>(to_f32(raw[i]) + bias) : from_f32<T>(0.f);
+            if (idx < G::IROWS * CH) {
+                const int r = idx / CH, c8 = idx - r * CH;
+                const int iy = I0y + r;
+                const int ix0 = I0x + 8 * c8;
+                const bool rok = (unsigned)iy < (unsigned)p.xh;
+                unsigned o[4];
+#pragma unroll
+                for (int w = 0; w < 4; w++) {
+                    const unsigned d = odd ? __builtin_amdgcn_alignbyte(raw[i][w + 1], raw[i][w], 2) : raw[i][w];
+                    union { unsigned u; T t[2]; } e;
+                    e.u = d;
+                    const bool in0 = rok && (unsigned)(ix0 + 2 * w) < (unsigned)p.xw;
+                    const bool in1 = rok && (unsigned)(ix0 + 2 * w + 1) < (unsigned)p.xw;
+                    o[w] = pack2<T>(in0 ? to_f32(e.t[0]) + bias : 0.f, in1 ? to_f32(e.t[1]) + bias : 0.f);
+                }
+                *(uint4*)(lds_in + r * G::PIN + 8 * c8) = make_uint4(o[0], o[1], o[2], o[3]);
             }
         }
     }
@@ -277,20 +296,47 @@ __global__ __launch_bounds__((64 * MfmaGeom<UP, DOWN, TOW, TOH>::NG)) void flrel
                         codes = ((lo | (hi << 8)) >> sh) & 0xffu;
                     }
                     unsigned wcode = 0;
-#pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        float v = x2[r];
-                        if (SIGN == AFCM_SIGNS_READ) {
-                            const unsigned c = codes >> (2 * r);
-                            if (c & 1u) v *= p.slope;
-                            if (c & 2u) v = 0.f;
+                    if (SIGN == AFCM_SIGNS_READ) {
+                        // spread the four 2-bit codes to one per byte: byte r of `d` = code of row r
+                        const unsigned d = (codes * 0x00041041u) & 0x03030303u;
+                        if (__builtin_amdgcn_ballot_w64((d & 0x02020202u) != 0) == 0) {
+                            // common case, no clamped element in the tile: factor = 1 + bit0 * (slope - 1)
+                            const float sm1 = p.slope - 1.f;
+                            x2[0] *= fmaf((float)((d >> 0) & 0xffu), sm1, 1.f);
+                            x2[1] *= fmaf((float)((d >> 8) & 0xffu), sm1, 1.f);
+                            x2[2] *= fmaf((float)((d >> 16) & 0xffu), sm1, 1.f);
+                            x2[3] *= fmaf((float)((d >> 24) & 0xffu), sm1, 1.f);
                         } else {
-                            unsigned c = __float_as_uint(v) >> 31;
-                            if (c) v *= p.slope;
-                            if (fabsf(v) > p.clamp) { c = 2u; v = (v < 0.f) ? -p.clamp : p.clamp; }
-                            wcode |= c << (2 * r);
+#pragma unroll
+                            for (int r = 0; r < 4; r++) {
+                                const unsigned c = codes >> (2 * r);
+                                float v = x2[r];
+                                if (c & 1u) v *= p.slope;
+                                if (c & 2u) v = 0.f;
+                                x2[r] = v;
+                            }
                         }
-                        x2[r] = v;
+                    } else {
+                        const float amax = fmaxf(fmaxf(fabsf(x2[0]), fabsf(x2[1])), fmaxf(fabsf(x2[2]), fabsf(x2[3])));
+                        if (p.slope <= 1.f && __builtin_amdgcn_ballot_w64(amax > p.clamp) == 0) {
+                            // common case: nothing in the tile can reach the clamp (|lrelu(v)| <= |v| for slope <= 1)
+#pragma unroll
+                            for (int r = 0; r < 4; r++) {
+                                const float v = x2[r];
+                                wcode |= (__float_as_uint(v) >> 31) << (2 * r);
+                                x2[r] = fmaxf(v, v * p.slope);
+                            }
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 4; r++) {
+                                float v = x2[r];
+                                unsigned c = __float_as_uint(v) >> 31;
+                                if (c) v *= p.slope;
+                                if (fabsf(v) > p.clamp) { c = 2u; v = (v < 0.f) ? -p.clamp : p.clamp; }
+                                wcode |= c << (2 * r);
+                                x2[r] = v;
+                            }
+                        }
                     }
                     if (SIGN == AFCM_SIGNS_WRITE) {
                         const bool own = ((ucol < TOW * DOWN) || lastX) && ((16 * vb + 4 * g < TOH * DOWN) || lastY);

@@ -13,7 +13,7 @@ for f in glob.glob(d + '/**/*counter_collection.csv', recursive=True):
         acc[row['Kernel_Name'][:70]][row['Counter_Name']].append(float(row['Counter_Value']))
     print('==', f)
     for k, cs in acc.items():
-        if 'flrelu' not in k and 'conv' not in k:
+        if 'flrelu' not in k and 'conv' not in k and 'mfma' not in k:
             continue
         print(k)
         for c, v in sorted(cs.items()):
