@@ -323,7 +323,7 @@ struct WgradParams {
 };
 
 // R = output rows per K macro-step (2 for 16-bit: halves the barriers and re-uses the overlapping input rows).
-template <typename T, int KS, int R>
+template <typename T, int KS, int R, int XOFF>
 __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 1 : 2)) void conv2d_wgrad_kernel(WgradParams p) {
     constexpr bool F32 = sizeof(T) == 4;
     constexpr int KK = KS * KS;
@@ -365,6 +365,36 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 1 : 2)) void conv2d_wgrad_ke
     constexpr int NXT = cdiv(64 * XR * TAILD, 512); // x tail
     const int rb = tid >> 5, dlane = tid & 31;
     unsigned rdy[NDY][NC], rxm[NXM][NC], rxt[NXT];
+    // step-invariant parts of the staging addresses (32-bit element offsets inside one image) and channel validity
+    int dyo[NDY], xo[NXM], xto[NXT];
+    unsigned dyok = 0, xok = 0, xtok = 0;
+    int dyr[NDY], xr_[NXM], xtr[NXT], xtc[NXT];
+#pragma unroll
+    for (int i = 0; i < NDY; i++) {
+        const int row = rb + 16 * i;
+        const int o = o0 + row / R;
+        dyr[i] = row % R;
+        dyo[i] = (o * p.P + dyr[i]) * p.Q;
+        dyok |= (unsigned)(o < p.O) << i;
+    }
+#pragma unroll
+    for (int i = 0; i < NXM; i++) {
+        const int row = rb + 16 * i;
+        const int ic = i0 + row / XR;
+        xr_[i] = row % XR;
+        xo[i] = (ic * p.H + xr_[i]) * p.W;
+        xok |= (unsigned)(ic < p.I) << i;
+    }
+#pragma unroll
+    for (int i = 0; i < NXT; i++) {
+        const int j = tid + i * 512;
+        const int row = j / TAILD;
+        const int ic = i0 + row / XR;
+        xtr[i] = row % XR;
+        xtc[i] = (32 * NC + j % TAILD) * EPD;
+        xto[i] = (ic * p.H + xtr[i]) * p.W;
+        xtok |= (unsigned)(row < 64 * XR && ic < p.I) << i;
+    }
 
     const int steps_per_img = p.rowgroups * p.qchunks;
     const int s0 = split * p.steps_per_split;
@@ -376,62 +406,50 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 1 : 2)) void conv2d_wgrad_ke
         const int rg = rem / p.qchunks, qc = rem - rg * p.qchunks;
         const int prow0 = rg * R, q0 = qc * kWgKQ;
         const int xorg = (q0 - p.pad) & ~1;
-        const T* dyn = (const T*)p.dy + (size_t)n * p.O * p.P * p.Q;
-        const T* xn = (const T*)p.x + (size_t)n * p.I * p.H * p.W;
+        // uniform bases: everything that does not depend on the lane
+        const T* dyb = (const T*)p.dy + (size_t)n * p.O * p.P * p.Q + (size_t)prow0 * p.Q + q0;
+        const T* xb = (const T*)p.x + (size_t)n * p.I * p.H * p.W + (long long)(prow0 - p.pad) * p.W + xorg;
+        unsigned dyrows = 0, xrows = 0;               // validity of the R / XR rows of this step
 #pragma unroll
-        for (int i = 0; i < NDY; i++) {
-            const int row = rb + 16 * i;
-            const int o = o0 + row / R, pr = prow0 + row % R;
-            const bool rok = o < p.O && pr < p.P;
-            const T* src = dyn + ((size_t)o * p.P + pr) * p.Q + q0;
+        for (int r = 0; r < R; r++) dyrows |= (unsigned)(prow0 + r < p.P) << r;
 #pragma unroll
-            for (int c = 0; c < NC; c++) {
-                const int dcol = (dlane + 32 * c) * EPD;
-                rdy[i][c] = (rok && q0 + dcol < p.Q) ? *(const unsigned*)(src + dcol) : 0u;
-            }
+        for (int r = 0; r < XR; r++) xrows |= (unsigned)((unsigned)(prow0 + r - p.pad) < (unsigned)p.H) << r;
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            const int dcol = (dlane + 32 * c) * EPD;
+            const bool dcok = q0 + dcol < p.Q;
+            const bool xcok = (unsigned)(xorg + dcol) < (unsigned)p.W;
+#pragma unroll
+            for (int i = 0; i < NDY; i++)
+                rdy[i][c] = (dcok && ((dyok >> i) & 1) && ((dyrows >> dyr[i]) & 1)) ? *(const unsigned*)(dyb + dyo[i] + dcol) : 0u;
+#pragma unroll
+            for (int i = 0; i < NXM; i++)
+                rxm[i][c] = (xcok && ((xok >> i) & 1) && ((xrows >> xr_[i]) & 1)) ? *(const unsigned*)(xb + xo[i] + dcol) : 0u;
         }
 #pragma unroll
-        for (int i = 0; i < NXM; i++) {
-            const int row = rb + 16 * i;
-            const int ic = i0 + row / XR, iy = prow0 + row % XR - p.pad;
-            const bool rok = ic < p.I && (unsigned)iy < (unsigned)p.H;
-            const T* src = xn + ((size_t)ic * p.H + iy) * p.W + xorg;
-#pragma unroll
-            for (int c = 0; c < NC; c++) {
-                const int dcol = (dlane + 32 * c) * EPD;
-                rxm[i][c] = (rok && (unsigned)(xorg + dcol) < (unsigned)p.W) ? *(const unsigned*)(src + dcol) : 0u;
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < NXT; i++) {
-            const int j = tid + i * 512;
-            const int row = j / TAILD, ixx = xorg + (32 * NC + j % TAILD) * EPD;
-            const int ic = i0 + row / XR, iy = prow0 + row % XR - p.pad;
-            rxt[i] = (row < 64 * XR && ic < p.I && (unsigned)iy < (unsigned)p.H && (unsigned)ixx < (unsigned)p.W)
-                         ? *(const unsigned*)(xn + ((size_t)ic * p.H + iy) * p.W + ixx) : 0u;
-        }
+        for (int i = 0; i < NXT; i++)
+            rxt[i] = (((xtok >> i) & 1) && ((xrows >> xtr[i]) & 1) && (unsigned)(xorg + xtc[i]) < (unsigned)p.W)
+                         ? *(const unsigned*)(xb + xto[i] + xtc[i]) : 0u;
     };
     auto write_lds = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < NDY; i++)
 #pragma unroll
-            for (int c = 0; c < NC; c++) *(unsigned*)(lds_dy + (rb + 16 * i) * PDY + (dlane + 32 * c) * EPD) = rdy[i][c];
+            for (int c = 0; c < NC; c++) *(unsigned*)(lds_dy + (dyr[i] * 64 + (rb + 16 * i) / R) * PDY + (dlane + 32 * c) * EPD) = rdy[i][c];
 #pragma unroll
         for (int i = 0; i < NXM; i++)
 #pragma unroll
-            for (int c = 0; c < NC; c++) *(unsigned*)(lds_x + (rb + 16 * i) * PX + (dlane + 32 * c) * EPD) = rxm[i][c];
+            for (int c = 0; c < NC; c++) *(unsigned*)(lds_x + (xr_[i] * 64 + (rb + 16 * i) / XR) * PX + (dlane + 32 * c) * EPD) = rxm[i][c];
 #pragma unroll
         for (int i = 0; i < NXT; i++) {
             const int j = tid + i * 512;
-            if (j / TAILD < 64 * XR) *(unsigned*)(lds_x + (j / TAILD) * PX + (32 * NC + j % TAILD) * EPD) = rxt[i];
+            if (j / TAILD < 64 * XR) *(unsigned*)(lds_x + (xtr[i] * 64 + (j / TAILD) / XR) * PX + xtc[i]) = rxt[i];
         }
     };
 
     if (s0 < s1) issue_loads(s0);
     for (int step = s0; step < s1; step++) {
-        const int rem = step % steps_per_img;
-        const int q0 = (rem % p.qchunks) * kWgKQ;
-        const int xoff = (q0 - p.pad) - ((q0 - p.pad) & ~1);
+        constexpr int xoff = XOFF;                  // (q0 - pad) & 1 with q0 a multiple of 64: launch-wide constant
         __syncthreads();                            // previous macro-step's LDS reads are done
         write_lds();
         __syncthreads();
@@ -444,11 +462,11 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 1 : 2)) void conv2d_wgrad_ke
                 for (int rr = 0; rr < R; rr++)
 #pragma unroll 4
                     for (int k2 = 0; k2 < kWgKQ / 2; k2++) {
-                        const float a = lds_dy[((wo * 32 + r32) * R + rr) * PDY + 2 * k2 + h];
+                        const float a = lds_dy[(rr * 64 + wo * 32 + r32) * PDY + 2 * k2 + h];
 #pragma unroll
                         for (int t = TLO; t < THI; t++) {
                             const int r = t / KS, sft = t - r * KS;
-                            const float b = lds_x[((wi * 32 + r32) * XR + rr + r) * PX + 2 * k2 + h + sft + xoff];
+                            const float b = lds_x[((rr + r) * 64 + wi * 32 + r32) * PX + 2 * k2 + h + sft + xoff];
                             acc[t - TLO] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t - TLO], 0, 0, 0);
                         }
                     }
@@ -458,7 +476,7 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 1 : 2)) void conv2d_wgrad_ke
                 for (int k16 = 0; k16 < kWgKQ / 16; k16++) {
                     frag_t a[R];
 #pragma unroll
-                    for (int rr = 0; rr < R; rr++) a[rr] = *(const frag_t*)(lds_dy + ((wo * 32 + r32) * R + rr) * PDY + k16 * 16 + 8 * h);
+                    for (int rr = 0; rr < R; rr++) a[rr] = *(const frag_t*)(lds_dy + (rr * 64 + wo * 32 + r32) * PDY + k16 * 16 + 8 * h);
                     // the staged rows of this lane's channel: each read once, shifted variants built in registers
 #pragma unroll
                     for (int xr = 0; xr < XR; xr++) {
@@ -469,7 +487,7 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 1 : 2)) void conv2d_wgrad_ke
 #pragma unroll
                             for (int t = TLO; t < THI; t++) used = used || (t / KS == xr - rr);
                         if (!used) continue;
-                        const unsigned* src = (const unsigned*)(lds_x + ((wi * 32 + r32) * XR + xr) * PX + k16 * 16 + 8 * h);
+                        const unsigned* src = (const unsigned*)(lds_x + (xr * 64 + wi * 32 + r32) * PX + k16 * 16 + 8 * h);
                         const uint4 lo = *(const uint4*)src;
                         const uint2 hi = *(const uint2*)(src + 4);
                         const unsigned d[6] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y};
@@ -483,7 +501,8 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 1 : 2)) void conv2d_wgrad_ke
                             }
                             if (!sused) continue;
                             union { unsigned u[4]; frag_t f; } b;
-                            const int sh = sft + xoff;                            // element shift in [0, 3]
+                            constexpr int dummy_ = 0; (void)dummy_;
+                            const int sh = sft + xoff;                            // element shift in [0, 3], compile-time
 #pragma unroll
                             for (int w = 0; w < 4; w++) {
                                 const unsigned e0 = d[w], e1 = d[w + 1], e2 = d[w + 2];
@@ -660,8 +679,9 @@ extern "C" int afcm_conv2d_wgrad(float* dw, float* workspace, const void* dy, co
     const long long blocks = (long long)cdiv(cout, 64) * cdiv(cin, 64) * p.splits;
     dim3 grid((unsigned)blocks), block(512);
     hipStream_t st = (hipStream_t)stream;
-#define AFCM_WG(T, R) do { if (ks == 3) hipLaunchKernelGGL((conv2d_wgrad_kernel<T, 3, R>), grid, block, 0, st, p); \
-                           else hipLaunchKernelGGL((conv2d_wgrad_kernel<T, 1, R>), grid, block, 0, st, p); } while (0)
+#define AFCM_WG(T, R) do { if (ks == 3 && (pad & 1) == 0) hipLaunchKernelGGL((conv2d_wgrad_kernel<T, 3, R, 0>), grid, block, 0, st, p); \
+                           else if (ks == 3) hipLaunchKernelGGL((conv2d_wgrad_kernel<T, 3, R, 1>), grid, block, 0, st, p); \
+                           else hipLaunchKernelGGL((conv2d_wgrad_kernel<T, 1, R, 0>), grid, block, 0, st, p); } while (0)
     switch (dtype) {
         case AFCM_F32: AFCM_WG(float, 1); break;
         case AFCM_F16: AFCM_WG(f16_t, 2); break;
