@@ -27,7 +27,8 @@ class FilteredLReluArgs(C.Structure):
         ('sx', C.c_int32), ('sy', C.c_int32), ('sh', C.c_int32), ('swb', C.c_int32),
         ('gain', C.c_float), ('slope', C.c_float), ('clamp', C.c_float),
         ('flip_filter', C.c_int32), ('sign_mode', C.c_int32),
-        ('workspace', C.c_void_p), ('sign_layout', C.c_int32), ('reserved_', C.c_int32),
+        ('workspace', C.c_void_p), ('sign_layout', C.c_int32), ('plane_sum_slots', C.c_int32),
+        ('plane_sum', C.c_void_p),
     ]
 
 

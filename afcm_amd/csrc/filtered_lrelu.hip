@@ -469,6 +469,7 @@ static int dispatch(const afcm_filtered_lrelu_args* a, const FlreluParams& p, hi
 }
 
 int flrelu_mfma_supported(const afcm_filtered_lrelu_args* a);
+int flrelu_mfma_tiles(const afcm_filtered_lrelu_args* a);
 int flrelu_mfma_launch(const afcm_filtered_lrelu_args* a, bool prepare, hipStream_t st);
 
 }  // namespace afcm
@@ -489,6 +490,7 @@ extern "C" int afcm_filtered_lrelu_shapes(afcm_filtered_lrelu_args* a) {
     AFCM_REQUIRE(yw > 0 && yh > 0 && yw < (1ll << 31) && yh < (1ll << 31), "output must be at least 1x1");
     a->yw = (int)yw;
     a->yh = (int)yh;
+    a->plane_sum_slots = (a->workspace != nullptr && flrelu_mfma_supported(a)) ? flrelu_mfma_tiles(a) : 0;
     if (a->sign_mode == AFCM_SIGNS_WRITE) {
         const long long sw_active = yw * a->down - (a->down - 1) + fdt_w;
         const long long sh = yh * a->down - (a->down - 1) + fdt_h;

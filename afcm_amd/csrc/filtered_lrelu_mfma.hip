@@ -34,6 +34,7 @@ struct FlreluMfmaParams {
     const void* b;
     unsigned char* s;
     const void* ws;        // constant fragments
+    float* plane_sum;      // optional fp32 [N*C][tilesX*tilesY]: per-tile sums of this launch's outputs (bias gradient without a second pass)
     int xw, xh, yw, yh, C;
     int px0, py0;
     int tilesX, tilesY;
@@ -263,11 +264,20 @@ __global__ __launch_bounds__((64 * MfmaGeom<UP, DOWN, TOW, TOH>::NG)) void flrel
 #pragma unroll
         for (int t = 0; t < G::NDVK; t++) dv[t] = cfrag(G::NB + UP + t);
         const bool lastX = (tx == p.tilesX - 1), lastY = (ty == p.tilesY - 1);
+        // sign-code store: byte (quad-row (U0y + 16vb + 4g)/4, column U0x + ucol); pointer and validity hoisted out of the loops
+        unsigned char* sgl = p.s + ((size_t)plane * p.shq + ((U0y >> 2) + g)) * p.swq + U0x + G::GW * Gi + l15;
+        unsigned rowmask = 0;
+        if (SIGN == AFCM_SIGNS_WRITE) {
+#pragma unroll
+            for (int vb = 0; vb < G::NVB; vb++)
+                rowmask |= (unsigned)(((16 * vb + 4 * g < TOH * DOWN) || lastY) && ((U0y >> 2) + 4 * vb + g) < p.shq) << vb;
+        }
 
 #pragma unroll
         for (int nb = 0; nb < G::NB; nb++) {
             const frag uh = cfrag(nb);
             const int ucol = G::GW * Gi + 16 * nb + l15;       // tile-relative upsampled column of this lane
+            const bool colown = ((ucol < TOW * DOWN) || lastX) && (U0x + ucol < p.swq);
             // up-x: X1[mb] = In[mb] * UH
             f32x4 x1[G::NMB];
 #pragma unroll
@@ -283,8 +293,6 @@ __global__ __launch_bounds__((64 * MfmaGeom<UP, DOWN, TOW, TOH>::NG)) void flrel
                 f32x4 x2 = zero4;
                 if (vb < G::NVB) {
                     x2 = M::mma(uv[vb % UP], q[vb / UP], zero4);
-                    const int Y = U0y + 16 * vb + 4 * g;        // first of this lane's 4 rows (absolute upsampled row)
-                    const int X = U0x + ucol;
                     unsigned codes = 0;
                     if (SIGN == AFCM_SIGNS_READ) {
                         // codes of rows Y+sy .. Y+sy+3 at column X+sx: two staged quad bytes, funnel-shifted
@@ -339,9 +347,7 @@ __global__ __launch_bounds__((64 * MfmaGeom<UP, DOWN, TOW, TOH>::NG)) void flrel
                         }
                     }
                     if (SIGN == AFCM_SIGNS_WRITE) {
-                        const bool own = ((ucol < TOW * DOWN) || lastX) && ((16 * vb + 4 * g < TOH * DOWN) || lastY);
-                        if (own && X < p.swq && (Y >> 2) < p.shq)
-                            p.s[((size_t)plane * p.shq + (Y >> 2)) * p.swq + X] = (unsigned char)wcode;
+                        if (colown && ((rowmask >> vb) & 1)) sgl[(size_t)(4 * vb) * p.swq + 16 * nb] = (unsigned char)wcode;
                     }
                 }
                 if (vb & 1) pr[vb >> 1] = pack_pair<T>(held, x2);
@@ -367,25 +373,47 @@ __global__ __launch_bounds__((64 * MfmaGeom<UP, DOWN, TOW, TOH>::NG)) void flrel
         frag dh[G::NDVK];
 #pragma unroll
         for (int t = 0; t < G::NDVK; t++) dh[t] = cfrag(G::NB + UP + G::NDVK + t);
-        T* yp = (T*)p.y + (size_t)plane * p.yh * p.yw;
         const int q4 = l15 >> 2, p4 = l15 & 3;
+        // this lane's output pointer at (row O0y + 4g, column O0x + l15); units advance it by constants
+        T* ylane = (T*)p.y + (size_t)plane * p.yh * p.yw + (size_t)(O0y + 4 * g) * p.yw + O0x + l15;
+        const T* xlane = lds_x3 + (8 * g + q4) * G::PX3 + 4 * p4;
+        float psum = 0.f;
         for (int unit = wave; unit < G::NOB * G::NCB; unit += G::NG) {
             const int ob = unit / G::NCB, cb = unit - ob * G::NCB;
             f32x4 acc = zero4;
 #pragma unroll
             for (int t = 0; t < G::NDVK; t++) {
-                const int kb = 16 * DOWN * cb + 32 * t + 8 * g;          // first ucol of this lane group's 8-deep K slice
-                const T* a0 = lds_x3 + (kb + q4) * G::PX3 + 16 * ob + 4 * p4;
+                const T* a0 = xlane + (16 * DOWN * cb + 32 * t) * G::PX3 + 16 * ob;
                 union { s16x4 h[2]; frag f; } a;
                 a.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a0);
                 a.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + 4 * G::PX3));
                 acc = M::mma(a.f, dh[t], acc);
             }
-            const int ox = O0x + 16 * cb + l15;
+            const bool colok = O0x + 16 * cb + l15 < p.yw;
+            const int rows_left = p.yh - (O0y + 16 * ob + 4 * g);        // rows of this lane's 4 that are inside the image
+            T* dst = ylane + (size_t)(16 * ob) * p.yw + 16 * cb;
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int oy = O0y + 16 * ob + 4 * g + r;
-                if (oy < p.yh && ox < p.yw) yp[(size_t)oy * p.yw + ox] = from_f32<T>(acc[r]);
+            for (int r = 0; r < 4; r++)
+                if (colok && r < rows_left) {
+                    const T o = from_f32<T>(acc[r]);
+                    dst[(size_t)r * p.yw] = o;
+                    psum += to_f32(o);
+                }
+        }
+        if (p.plane_sum != nullptr) {
+            // wave reduction -> workgroup reduction through LDS -> one plain store into this tile's slot (no atomics:
+            // deterministic, and no same-address contention between the tiles of a plane)
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) psum += __shfl_down(psum, off, 64);
+            __syncthreads();                                   // phase-B reads of lds_x3 are finished
+            float* red = (float*)lds_x3;
+            if (lane == 0) red[wave] = psum;
+            __syncthreads();
+            if (tid == 0) {
+                float t = 0.f;
+#pragma unroll
+                for (int w = 0; w < G::NG; w++) t += red[w];
+                p.plane_sum[(size_t)plane * (p.tilesX * p.tilesY) + ty * p.tilesX + tx] = t;
             }
         }
     }
@@ -402,7 +430,7 @@ static int launch_mfma(const afcm_filtered_lrelu_args* a, hipStream_t st) {
     constexpr int TOW = MfmaTile<UP, DOWN>::TOW, TOH = MfmaTile<UP, DOWN>::TOH;
     typedef MfmaGeom<UP, DOWN, TOW, TOH> G;
     FlreluMfmaParams p;
-    p.x = a->x; p.y = a->y; p.b = a->b; p.s = a->signs; p.ws = a->workspace;
+    p.x = a->x; p.y = a->y; p.b = a->b; p.s = a->signs; p.ws = a->workspace; p.plane_sum = a->plane_sum;
     p.xw = a->xw; p.xh = a->xh; p.yw = a->yw; p.yh = a->yh; p.C = a->c;
     p.px0 = a->px0; p.py0 = a->py0;
     p.tilesX = cdiv(a->yw, TOW); p.tilesY = cdiv(a->yh, TOH);
@@ -439,6 +467,15 @@ static int mfma_case(const afcm_filtered_lrelu_args* a) {
 }
 
 int flrelu_mfma_supported(const afcm_filtered_lrelu_args* a) { return mfma_case(a) != 0; }
+
+int flrelu_mfma_tiles(const afcm_filtered_lrelu_args* a) {
+    switch (mfma_case(a)) {
+        case 22: return cdiv(a->yw, MfmaTile<2, 2>::TOW) * cdiv(a->yh, MfmaTile<2, 2>::TOH);
+        case 24: return cdiv(a->yw, MfmaTile<2, 4>::TOW) * cdiv(a->yh, MfmaTile<2, 4>::TOH);
+        case 42: return cdiv(a->yw, MfmaTile<4, 2>::TOW) * cdiv(a->yh, MfmaTile<4, 2>::TOH);
+        default: return 0;
+    }
+}
 
 int flrelu_mfma_launch(const afcm_filtered_lrelu_args* a, bool prepare, hipStream_t st) {
 #define AFCM_MF(T) do { switch (mfma_case(a)) { \

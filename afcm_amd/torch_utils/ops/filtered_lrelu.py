@@ -96,112 +96,130 @@ def _mfma_workspace(a, fu_t, fd_t, x):
     return None if ent is None else ent[0]
 
 
+def _run(x, fu, fd, b, si, cfg, write_signs, want_plane_sum=False):
+    """One launch of the op (C ABI afcm_filtered_lrelu, or the generic GPU path when there is no fused kernel).
+    Returns (y, signs written or None, sign layout, per-plane output sums or None)."""
+    up, down, px0, px1, py0, py1, gain, slope, clamp, flip_filter, sx, sy, si_layout = cfg
+    assert isinstance(x, torch.Tensor) and x.ndim == 4
+    _lib.require_gpu(x, fu, fd, b, si)
+    lib = _lib.load()
+    if x.numel() == 0:
+        raise RuntimeError('x is empty')
+    x = x.contiguous()
+    if b is not None:
+        if b.dtype != x.dtype:
+            raise RuntimeError('x and b must have the same dtype')
+        if b.ndim != 1 or b.shape[0] != x.shape[1]:
+            raise RuntimeError('b must be a vector with the same number of channels as x')
+        b = b.contiguous()
+    fu_t, fuw, fuh = _filter_arg(fu, x.device)
+    fd_t, fdw, fdh = _filter_arg(fd, x.device)
+
+    a = _lib.FilteredLReluArgs()
+    a.dtype = _lib.dtype_code(x)
+    a.n, a.c, a.xh, a.xw = x.shape
+    a.fuw, a.fuh, a.fdw, a.fdh = fuw, fuh, fdw, fdh
+    a.up, a.down = up, down
+    a.px0, a.px1, a.py0, a.py1 = px0, px1, py0, py1
+    a.sx, a.sy = sx, sy
+    a.gain, a.slope, a.clamp = gain, slope, clamp
+    a.flip_filter = int(flip_filter)
+    a.sign_mode = _lib.SIGNS_WRITE if write_signs else (_lib.SIGNS_READ if si is not None else _lib.SIGNS_NONE)
+    # 16-bit activations: matrix-core kernels (signs in the row-quad layout); a given sign tensor fixes the family
+    ws = None
+    if si is None or si_layout == 1:
+        ws = _mfma_workspace(a, fu_t, fd_t, x)
+        if si is not None and ws is None:
+            raise RuntimeError('filtered_lrelu: sign tensor was written by the matrix-core kernels but this call has none')
+    a.workspace = _lib.ptr(ws)
+    a.sign_layout = si_layout if si is not None else 0
+    _lib.check(lib.afcm_filtered_lrelu_shapes(a), 'filtered_lrelu')
+    y = torch.empty([a.n, a.c, a.yh, a.yw], dtype=x.dtype, device=x.device)
+    so = None
+    if write_signs:
+        so = torch.empty([a.n, a.c, a.sh, a.swb], dtype=torch.uint8, device=x.device)
+        a.signs = so.data_ptr()
+    elif si is not None:
+        if si.dtype != torch.uint8 or si.ndim != 4 or not si.is_contiguous() or si.shape[:2] != x.shape[:2]:
+            raise RuntimeError('signs must be a contiguous uint8 tensor with the same batch & channels as x')
+        a.sh, a.swb = si.shape[2], si.shape[3]
+        a.signs = si.data_ptr()
+    a.x, a.y, a.b = x.data_ptr(), y.data_ptr(), _lib.ptr(b)
+    psum = None
+    if ws is not None and want_plane_sum and a.plane_sum_slots > 0:
+        psum = torch.empty([a.n, a.c, a.plane_sum_slots], dtype=torch.float32, device=x.device)   # every slot is written
+        a.plane_sum = psum.data_ptr()
+    a.fu, a.fd = _lib.ptr(fu_t), _lib.ptr(fd_t)
+    span = profiling.span('filtered_lrelu', (x.numel() + y.numel()) * x.element_size()
+                          + (so.numel() if so is not None else (si.numel() if si is not None else 0)))
+    rc = _lib.check(lib.afcm_filtered_lrelu(a, _lib.stream_ptr(x)), 'filtered_lrelu')
+    if span is not None:
+        span.end()
+    layout = a.sign_layout
+
+    if rc == _lib.E_NOKERNEL:
+        # Generic path, still on the GPU and still keeping only the packed signs for backward.
+        warnings.warn('filtered_lrelu called with parameters that have no fused HIP kernel, using generic fallback', RuntimeWarning)
+        y = x if b is None else x + b.reshape(1, -1, 1, 1)
+        y = _ufd._forward_raw(y, fu, (up, up), (1, 1), (px0, px1, py0, py1), flip_filter, float(up ** 2))
+        if y is x:
+            y = y.clone()
+        so = _act_inplace(y, si, sx, sy, gain, slope, clamp, write_signs)
+        y = _ufd._forward_raw(y, fd, (1, 1), (down, down), (0, 0, 0, 0), flip_filter, 1.0)
+        layout, psum = 0, None
+    return y, so, layout, psum
+
+
+def _backward_cfg(cfg, fu, fd, x_shape, y_shape, sign_layout):
+    """Configuration of the transposed op (SG3OPS/filtered_lrelu.py:252-263): swap the resampling roles, flip the filters,
+    drop the clamp (the codes already carry it) and shift the sign window."""
+    up, down, px0, px1, py0, py1, gain, slope, clamp, flip_filter, sx, sy, _ = cfg
+    _, _, xh, xw = x_shape
+    _, _, yh, yw = y_shape
+    fuw, fuh = _get_filter_size(fu)
+    fdw, fdh = _get_filter_size(fd)
+    if fu is not None and fu.ndim == 1:
+        fuh = fuw
+    if fd is not None and fd.ndim == 1:
+        fdh = fdw
+    pp = ((fuw - 1) + (fdw - 1) - px0, xw * up - yw * down + px0 - (up - 1),
+          (fuh - 1) + (fdh - 1) - py0, xh * up - yh * down + py0 - (up - 1))
+    gg = gain * (up ** 2) / (down ** 2)
+    return (down, up) + pp + (gg, slope, float('inf'), not flip_filter, sx - (fuw - 1) + px0, sy - (fuh - 1) + py0, sign_layout)
+
+
 class _FilteredLRelu(torch.autograd.Function):
     """x, fu, fd, b, si are tensors (or None); cfg carries the scalars of one call."""
 
     @staticmethod
     def forward(ctx, x, fu, fd, b, si, cfg):
-        up, down, px0, px1, py0, py1, gain, slope, clamp, flip_filter, sx, sy, si_layout = cfg
-        assert isinstance(x, torch.Tensor) and x.ndim == 4
-        _lib.require_gpu(x, fu, fd, b, si)
-        lib = _lib.load()
-        if x.numel() == 0:
-            raise RuntimeError('x is empty')
-        x = x.contiguous()
-        if b is not None:
-            if b.dtype != x.dtype:
-                raise RuntimeError('x and b must have the same dtype')
-            if b.ndim != 1 or b.shape[0] != x.shape[1]:
-                raise RuntimeError('b must be a vector with the same number of channels as x')
-            b = b.contiguous()
-        fu_t, fuw, fuh = _filter_arg(fu, x.device)
-        fd_t, fdw, fdh = _filter_arg(fd, x.device)
         if si is not None and si.numel() == 0:
             si = None
         write_signs = si is None and (ctx.needs_input_grad[0] or ctx.needs_input_grad[3])
-
-        a = _lib.FilteredLReluArgs()
-        a.dtype = _lib.dtype_code(x)
-        a.n, a.c, a.xh, a.xw = x.shape
-        a.fuw, a.fuh, a.fdw, a.fdh = fuw, fuh, fdw, fdh
-        a.up, a.down = up, down
-        a.px0, a.px1, a.py0, a.py1 = px0, px1, py0, py1
-        a.sx, a.sy = sx, sy
-        a.gain, a.slope, a.clamp = gain, slope, clamp
-        a.flip_filter = int(flip_filter)
-        a.sign_mode = _lib.SIGNS_WRITE if write_signs else (_lib.SIGNS_READ if si is not None else _lib.SIGNS_NONE)
-        # 16-bit activations: matrix-core kernels (signs in the row-quad layout); a given sign tensor fixes the family
-        ws = None
-        if si is None or si_layout == 1:
-            ws = _mfma_workspace(a, fu_t, fd_t, x)
-            if si is not None and ws is None:
-                raise RuntimeError('filtered_lrelu: sign tensor was written by the matrix-core kernels but this call has none')
-        a.workspace = _lib.ptr(ws)
-        a.sign_layout = si_layout if si is not None else 0
-        _lib.check(lib.afcm_filtered_lrelu_shapes(a), 'filtered_lrelu')
-        y = torch.empty([a.n, a.c, a.yh, a.yw], dtype=x.dtype, device=x.device)
-        so = None
-        if write_signs:
-            so = torch.empty([a.n, a.c, a.sh, a.swb], dtype=torch.uint8, device=x.device)
-            a.signs = so.data_ptr()
-        elif si is not None:
-            if si.dtype != torch.uint8 or si.ndim != 4 or not si.is_contiguous() or si.shape[:2] != x.shape[:2]:
-                raise RuntimeError('signs must be a contiguous uint8 tensor with the same batch & channels as x')
-            a.sh, a.swb = si.shape[2], si.shape[3]
-            a.signs = si.data_ptr()
-        a.x, a.y, a.b = x.data_ptr(), y.data_ptr(), _lib.ptr(b)
-        a.fu, a.fd = _lib.ptr(fu_t), _lib.ptr(fd_t)
-        span = profiling.span('filtered_lrelu', (x.numel() + y.numel()) * x.element_size()
-                              + (so.numel() if so is not None else (si.numel() if si is not None else 0)))
-        rc = _lib.check(lib.afcm_filtered_lrelu(a, _lib.stream_ptr(x)), 'filtered_lrelu')
-        if span is not None:
-            span.end()
-
-        if rc == _lib.E_NOKERNEL:
-            # Generic path, still on the GPU and still keeping only the packed signs for backward.
-            warnings.warn('filtered_lrelu called with parameters that have no fused HIP kernel, using generic fallback', RuntimeWarning)
-            y = x if b is None else x + b.reshape(1, -1, 1, 1)
-            y = _ufd._forward_raw(y, fu, (up, up), (1, 1), (px0, px1, py0, py1), flip_filter, float(up ** 2))
-            if y is x:
-                y = y.clone()
-            so = _act_inplace(y, si, sx, sy, gain, slope, clamp, write_signs)
-            y = _ufd._forward_raw(y, fd, (1, 1), (down, down), (0, 0, 0, 0), flip_filter, 1.0)
-
+        y, so, layout, _ = _run(x, fu, fd, b, si, cfg, write_signs)
         ctx.save_for_backward(fu, fd, si if si is not None else so)
         ctx.cfg = cfg
-        ctx.sign_layout = a.sign_layout if rc == 0 else 0
+        ctx.sign_layout = layout
         ctx.x_shape = x.shape
         ctx.y_shape = y.shape
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        up, down, px0, px1, py0, py1, gain, slope, clamp, flip_filter, sx, sy, _ = ctx.cfg
         fu, fd, si = ctx.saved_tensors
-        _, _, xh, xw = ctx.x_shape
-        _, _, yh, yw = ctx.y_shape
         assert not (ctx.needs_input_grad[1] or ctx.needs_input_grad[2] or ctx.needs_input_grad[4])
         dx = db = None
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[3]:
-            fuw, fuh = _get_filter_size(fu)
-            fdw, fdh = _get_filter_size(fd)
-            if fu is not None and fu.ndim == 1:
-                fuh = fuw
-            if fd is not None and fd.ndim == 1:
-                fdh = fdw
-            # Transposed op (SG3OPS/filtered_lrelu.py:252-263): swap the resampling roles, flip the
-            # filters, drop the clamp (the codes already carry it) and shift the sign window.
-            pp = (
-                (fuw - 1) + (fdw - 1) - px0,
-                xw * up - yw * down + px0 - (up - 1),
-                (fuh - 1) + (fdh - 1) - py0,
-                xh * up - yh * down + py0 - (up - 1),
-            )
-            gg = gain * (up ** 2) / (down ** 2)
-            cfg = (down, up) + pp + (gg, slope, float('inf'), not flip_filter, sx - (fuw - 1) + px0, sy - (fuh - 1) + py0, ctx.sign_layout)
-            dx = _FilteredLRelu.apply(dy, fd, fu, None, si, cfg)
-        if ctx.needs_input_grad[3]:
-            db = dx.sum([0, 2, 3])
+            cfg = _backward_cfg(ctx.cfg, fu, fd, ctx.x_shape, ctx.y_shape, ctx.sign_layout)
+            if torch.is_grad_enabled():
+                # a higher-order graph is being recorded: stay differentiable, reduce the bias gradient with torch
+                dx = _FilteredLRelu.apply(dy, fd, fu, None, si, cfg)
+                psum = None
+            else:
+                dx, _, _, psum = _run(dy, fd, fu, None, si, cfg, False, want_plane_sum=bool(ctx.needs_input_grad[3]))
+            if ctx.needs_input_grad[3]:
+                # db = dx.sum([0, 2, 3]) (SG3OPS/filtered_lrelu.py:266); the matrix-core kernels already summed each plane
+                db = psum.sum([0, 2]).to(dx.dtype) if psum is not None else dx.sum([0, 2, 3])
         return dx, None, None, db, None, None
 
 

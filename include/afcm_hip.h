@@ -83,7 +83,10 @@ typedef struct afcm_filtered_lrelu_args {
     int32_t sign_layout;    /* 0: row-major 2-bit codes (reference layout); 1: row-quad bytes written by the
                                matrix-core kernels ([N,C,ceil(sh/4),swq]); set by afcm_filtered_lrelu_shapes(),
                                must be passed back unchanged with the sign tensor in READ mode                 */
-    int32_t reserved_;
+    int32_t plane_sum_slots;/* set by afcm_filtered_lrelu_shapes(): partial sums per plane the selected kernel emits (0: none) */
+    float*  plane_sum;      /* NULL, or fp32 [N*C][plane_sum_slots]: the matrix-core kernels store the sum of every output tile
+                               (no atomics); summed over slots and N in a backward call this is the bias gradient
+                               (db = dx.sum([0,2,3]), SG3OPS/filtered_lrelu.py:266) without a second pass over dx.        */
 } afcm_filtered_lrelu_args;
 
 /* Output / sign-tensor geometry for the arguments above (filtered_lrelu.cpp:61-94). Fills yh, yw

@@ -259,6 +259,14 @@ def test_filtered_lrelu_16bit_matrix_core_path(lname, dtype, tol):
     got = flr.filtered_lrelu(xg, fu=L['fu'].cuda(), fd=L['fd'].cuda(), b=b.cuda(), **kw)
     assert got.dtype == dtype and got.shape == ref.shape
     assert got.grad_fn.sign_layout == 1, 'expected the matrix-core kernel family'
+    # bias gradient: summed per tile inside the backward kernel (no second pass over dx)
+    bb = b.cuda().requires_grad_(True)
+    got2 = flr.filtered_lrelu(xg, fu=L['fu'].cuda(), fd=L['fd'].cuda(), b=bb, **kw)
+    gb, = torch.autograd.grad((got2.float() * r.cuda().float()).sum(), bb)
+    bref = b.float().requires_grad_(True)
+    ref2 = ops.filtered_lrelu(x.float(), fu=L['fu'], fd=L['fd'], b=bref, **kw)
+    gbref, = torch.autograd.grad((ref2 * r.float()).sum(), bref)
+    assert (gb.float().cpu() - gbref).abs().max().item() <= 4 * tol * max(1.0, gbref.abs().max().item()), 'fused bias gradient'
     _close(got, ref, tol=tol, what=f'{lname} {dtype} y')
     ggot, = torch.autograd.grad((got.float() * r.cuda().float()).sum(), xg)
     # leaky-ReLU kinks: 16-bit forward rounding flips the branch of elements near 0, so compare in relative L2
