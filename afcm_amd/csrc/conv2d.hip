@@ -10,6 +10,8 @@
 //   D = fp32 accumulators in registers; the per-(n,o) scale is applied in the epilogue.
 // bf16/f16 use v_mfma_f32_32x32x16_{bf16,f16}; fp32 uses v_mfma_f32_32x32x2_f32 (exact fp32, for the <=1e-3 parity path).
 // The same kernel computes the data gradient (weights packed transposed + flipped, pad' = k-1-pad).
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "common.h"
@@ -489,7 +491,7 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 1 : 2)) void conv2d_wgrad_ke
                         if (!used) continue;
                         const unsigned* src = (const unsigned*)(lds_x + (xr * 64 + wi * 32 + r32) * PX + k16 * 16 + 8 * h);
                         const uint4 lo = *(const uint4*)src;
-                        const uint2 hi = *(const uint2*)(src + 4);
+                        const uint4 hi = *(const uint4*)(src + 4);        // 16-byte read (conflict-free); only .x/.y are used
                         const unsigned d[6] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y};
 #pragma unroll
                         for (int sft = 0; sft < KS; sft++) {
@@ -636,7 +638,8 @@ extern "C" int afcm_conv2d(void* y, const void* x, const void* wpacked, const fl
     p.nkc = cdiv(cin, afcm_conv2d_block_k(dtype));
     hipStream_t st = (hipStream_t)stream;
     // 64-row blocks when they waste fewer padded rows than 128-row blocks
-    const bool small = (rows_pad % 128 != 0) || cout <= 64;
+    const char* force = getenv("AFCM_CONV_BM");   // tuning aid: force the 64- or 128-row block
+    const bool small = force ? (atoi(force) == 64) : ((rows_pad % 128 != 0) || cout <= 64);
     switch (dtype) {
         case AFCM_F32: return small ? launch_conv<float, 64>(p, ks, st) : launch_conv<float, 128>(p, ks, st);
         case AFCM_F16: return small ? launch_conv<f16_t, 64>(p, ks, st) : launch_conv<f16_t, 128>(p, ks, st);
