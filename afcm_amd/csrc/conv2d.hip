@@ -335,7 +335,9 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 1 : 2)) void conv2d_wgrad_ke
     constexpr int XW = kWgKQ + 8;                  // staged x columns per row (shifts 0..KS-1, +1 alignment, rounded)
     constexpr int XR = R + KS - 1;                 // staged x rows per channel
     constexpr int DPR_DY = kWgKQ / EPD, DPR_X = XW / EPD;
-    __shared__ __attribute__((aligned(16))) T lds[64 * R * PDY + 64 * XR * PX];
+    constexpr int LDS_ONE = 64 * R * PDY + 64 * XR * PX;
+    constexpr int NBUF = (LDS_ONE * (int)sizeof(T) * 2 <= 150 * 1024) ? 2 : 1;     // double-buffer when it fits the 160 KB LDS
+    __shared__ __attribute__((aligned(16))) T lds[NBUF * LDS_ONE];
     T* lds_dy = lds;
     T* lds_x = lds + 64 * R * PDY;
 
@@ -449,13 +451,34 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 1 : 2)) void conv2d_wgrad_ke
         }
     };
 
-    if (s0 < s1) issue_loads(s0);
+    // Pipeline.  Double-buffered (16-bit): while a wave runs the MFMAs of step s from buffer s&1, the others may already be
+    // writing step s+1 into the other buffer and have step s+2's global loads in flight: one barrier per step.
+    // Single-buffered (fp32): write / barrier / compute / barrier.
+    if (s0 < s1) {
+        issue_loads(s0);
+        write_lds();
+        if (NBUF == 2 && s0 + 1 < s1) issue_loads(s0 + 1);
+    }
+    __syncthreads();
     for (int step = s0; step < s1; step++) {
         constexpr int xoff = XOFF;                  // (q0 - pad) & 1 with q0 a multiple of 64: launch-wide constant
-        __syncthreads();                            // previous macro-step's LDS reads are done
-        write_lds();
-        __syncthreads();
-        if (step + 1 < s1) issue_loads(step + 1);   // in flight while this step computes
+        if (NBUF == 2) {
+            if (step + 1 < s1) {
+                lds_dy = lds + ((step + 1 - s0) & 1) * LDS_ONE;
+                lds_x = lds_dy + 64 * R * PDY;
+                write_lds();                        // step+1 (its loads were issued one step ago)
+                if (step + 2 < s1) issue_loads(step + 2);
+            }
+            lds_dy = lds + ((step - s0) & 1) * LDS_ONE;
+            lds_x = lds_dy + 64 * R * PDY;
+        } else {
+            if (step > s0) {
+                __syncthreads();
+                write_lds();
+                __syncthreads();
+            }
+            if (step + 1 < s1) issue_loads(step + 1);
+        }
         auto compute = [&](auto thc) __attribute__((always_inline)) {
             constexpr int TH = decltype(thc)::value;
             constexpr int TLO = TH == 0 ? 0 : T0, THI = TH == 0 ? T0 : KK;
@@ -530,6 +553,7 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 1 : 2)) void conv2d_wgrad_ke
         };
         if (th == 0) compute(std::integral_constant<int, 0>{});
         else compute(std::integral_constant<int, 1>{});
+        if (NBUF == 2) __syncthreads();            // everyone done with buffer step&1 and step+1 fully written
     }
     // ---- write the partial tile: D[row = o][col = i]
     float* out = p.part + (size_t)split * p.O * p.I * KK;
