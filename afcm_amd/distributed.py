@@ -16,9 +16,10 @@ import torch.distributed as dist
 
 
 class GradientBuckets:
-    def __init__(self, params, bucket_bytes=25 * 1024 * 1024, process_group=None, comm_dtype=None):
+    def __init__(self, params, bucket_bytes=25 * 1024 * 1024, process_group=None, comm_dtype=None, force=False):
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.active = self.world > 1 or (force and dist.is_initialized())   # force: exercise the hooks/collectives on one rank
         self.params = [p for p in params if p.requires_grad]
         self.comm_dtype = comm_dtype
         self._buckets = []          # list of dict(params, flat, pending, handle)
@@ -34,7 +35,7 @@ class GradientBuckets:
         if cur:
             self._add_bucket(cur)
         self._hooks = []
-        if self.world > 1:
+        if self.active:
             for p in self.params:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
         self._inflight = []
@@ -56,7 +57,7 @@ class GradientBuckets:
 
     def broadcast_parameters(self, module, src=0):
         """Initial weight (and buffer) broadcast from rank `src` so that every replica starts identical."""
-        if self.world <= 1:
+        if not self.active:
             return
         for t in list(module.parameters()) + list(module.buffers()):
             dist.broadcast(t.data, src=src, group=self.group)
@@ -74,7 +75,7 @@ class GradientBuckets:
     def finish(self):
         """Wait for the collectives, average, and scatter the reduced values back into .grad.
         Parameters that received no gradient this iteration are reduced as zeros."""
-        if self.world <= 1:
+        if not self.active:
             return
         launched = {i for i, _ in self._inflight}
         for idx, b in enumerate(self._buckets):

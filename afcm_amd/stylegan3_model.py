@@ -17,7 +17,8 @@ from .distributed import GradientBuckets
 
 
 class StyleGAN3GeneratorStep:
-    def __init__(self, netG, lr_G=0.0025, lambda_L1=100.0, distributed=False, bucket_bytes=25 * 1024 * 1024, style_mixing_prob=0):
+    def __init__(self, netG, lr_G=0.0025, lambda_L1=100.0, distributed=False, bucket_bytes=25 * 1024 * 1024, style_mixing_prob=0,
+                 force_collectives=False):
         self.netG = netG
         self.G_mapping = netG.mapping
         self.G_synthesis = netG.synthesis
@@ -27,7 +28,7 @@ class StyleGAN3GeneratorStep:
         self.style_mixing_prob = style_mixing_prob
         self.real_A = self.real_B = self.fake_B = None
         self.gen_z = self.gen_c = None
-        self.buckets = GradientBuckets(netG.parameters(), bucket_bytes=bucket_bytes) if distributed else None
+        self.buckets = GradientBuckets(netG.parameters(), bucket_bytes=bucket_bytes, force=force_collectives) if distributed else None
         if self.buckets is not None:
             self.buckets.broadcast_parameters(netG)
 

@@ -37,6 +37,7 @@ def parse():
     ap.add_argument('--cpu-baseline', default='auto', choices=['auto', 'off'])
     ap.add_argument('--cpu-baseline-worker', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--no-kernel-timing', action='store_true', help='skip the HIP-event spans around the hot kernels')
+    ap.add_argument('--force-dist', action='store_true', help='initialise RCCL and run the gradient buckets even with one rank (path check)')
     return ap.parse_args()
 
 
@@ -101,15 +102,18 @@ def main():
         raise SystemExit(f'--gpus {args.gpus} does not match WORLD_SIZE {world}')
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    if world > 1:
-        dist.init_process_group('nccl', device_id=dev)
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
     dtype = {'bf16': torch.bfloat16, 'fp16': torch.float16, 'fp32': torch.float32}[args.dtype]
     torch.manual_seed(0)      # identical init on every rank (the step also broadcasts from rank 0)
     kw = dict(sched.DEFAULT_SYNTHESIS_KWARGS)
     G = Stylegan3Generator(z_dim=512, c_dim=1, w_dim=512, img_resolution=args.res, img_channels_in=4, img_channels_out=1,
                            mapping_kwargs=dict(num_layers=8), synthesis_kwargs=dict(kw, compute_dtype=dtype)).to(dev).train()
-    step = StyleGAN3GeneratorStep(G, lr_G=0.0025, lambda_L1=100.0, distributed=(world > 1))
+    step = StyleGAN3GeneratorStep(G, lr_G=0.0025, lambda_L1=100.0, distributed=use_dist, force_collectives=args.force_dist)
     real_A, real_B, z, c = synthetic.generator_inputs(args.batch, size=args.res, seed=rank, device=dev)
 
     def one_step():
@@ -185,7 +189,7 @@ def main():
             'cpu_baseline': cpu,
         }
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
