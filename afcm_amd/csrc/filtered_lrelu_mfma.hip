@@ -422,7 +422,7 @@ __global__ __launch_bounds__((64 * MfmaGeom<UP, DOWN, TOW, TOH>::NG)) void flrel
 // ---------------------------------------------------------------------------------------------
 template <int UP, int DOWN> struct MfmaTile;
 template <> struct MfmaTile<2, 2> { static constexpr int TOW = 64, TOH = 32; };
-template <> struct MfmaTile<2, 4> { static constexpr int TOW = 32, TOH = 16; };
+template <> struct MfmaTile<2, 4> { static constexpr int TOW = 32, TOH = 32; };
 template <> struct MfmaTile<4, 2> { static constexpr int TOW = 64, TOH = 32; };
 
 template <typename T, int UP, int DOWN>
@@ -460,6 +460,7 @@ static int prepare_mfma(const afcm_filtered_lrelu_args* a, hipStream_t st) {
 static int mfma_case(const afcm_filtered_lrelu_args* a) {
     if (a->dtype != AFCM_BF16 && a->dtype != AFCM_F16) return 0;
     if (a->fuh != 0 || a->fdh != 0) return 0;
+    if (a->xw & 1) return 0;                   // the staged loads are aligned dword pairs: even plane width (all layers of the model)
     if (a->up == 2 && a->down == 2 && a->fuw == 12 && a->fdw == 12) return 22;
     if (a->up == 2 && a->down == 4 && a->fuw == 12 && a->fdw == 24) return 24;
     if (a->up == 4 && a->down == 2 && a->fuw == 24 && a->fdw == 12) return 42;

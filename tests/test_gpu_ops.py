@@ -273,3 +273,20 @@ def test_filtered_lrelu_16bit_matrix_core_path(lname, dtype, tol):
     d = (ggot.float().cpu() - gref)
     rel = (d.norm() / gref.norm()).item()
     assert rel <= 2 * tol, f'{lname} {dtype} dx: relative L2 {rel:.3e}'
+
+
+def test_filtered_lrelu_16bit_odd_width_uses_exact_kernels():
+    """Odd plane widths cannot use the aligned-pair loads of the matrix-core kernels: the op must silently take the
+    other kernel family (row-major signs) and still match the oracle."""
+    from afcm_amd.torch_utils.ops import filtered_lrelu as flr
+    from oracle import aten_ops as ops
+    g = load_golden('F1_up2_down2')
+    kw = _flrelu_args(g)
+    torch.manual_seed(2)
+    x = torch.randn(1, 2, 21, 23).to(torch.bfloat16)
+    ref = ops.filtered_lrelu(x.float(), fu=torch.from_numpy(g['fu']), fd=torch.from_numpy(g['fd']), **kw)
+    xg = x.cuda().requires_grad_(True)
+    got = flr.filtered_lrelu(xg, fu=_dev(g['fu']), fd=_dev(g['fd']), **kw)
+    assert got.grad_fn.sign_layout == 0
+    _close(got, ref, tol=3e-2, what='odd width bf16')
+    torch.autograd.grad(got.float().sum(), xg)
