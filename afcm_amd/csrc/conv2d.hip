@@ -268,25 +268,37 @@ __global__ __launch_bounds__(256) void conv2d_pack_kernel(T* __restrict__ dst, c
     }
 }
 
+// 4 consecutive elements as one vector access (8 B for 16-bit types, 16 B for fp32); planes are 4-element aligned when hw % 4 == 0
+template <typename T> struct Vec4 { T v[4]; } __attribute__((aligned(sizeof(T) * 4)));
+
 // y[plane, :] = x[plane, :] * scale[plane]  (dtype conversion fused).  HBM-bound elementwise pass.
 template <typename TI, typename TO>
 __global__ __launch_bounds__(256) void scale_planes_kernel(TO* __restrict__ y, const TI* __restrict__ x, const float* __restrict__ scale,
                                                            long long planes, int hw) {
     const int per = (hw + 3) >> 2;
     const long long total = planes * per;
+    const bool vec = (hw & 3) == 0;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
         const long long plane = idx / per;
         const int i0 = (int)(idx - plane * per) << 2;
         const float sc = scale ? scale[plane] : 1.f;
         const TI* xp = x + plane * hw + i0;
         TO* yp = y + plane * hw + i0;
+        if (vec) {
+            const Vec4<TI> in = *(const Vec4<TI>*)xp;
+            Vec4<TO> out;
 #pragma unroll
-        for (int e = 0; e < 4; e++)
-            if (i0 + e < hw) yp[e] = from_f32<TO>(to_f32(xp[e]) * sc);
+            for (int e = 0; e < 4; e++) out.v[e] = from_f32<TO>(to_f32(in.v[e]) * sc);
+            *(Vec4<TO>*)yp = out;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+                if (i0 + e < hw) yp[e] = from_f32<TO>(to_f32(xp[e]) * sc);
+        }
     }
 }
 
-// Per-plane reductions: out0[plane] = sum a*b (or sum a when b == null).  One wave per plane chunk, fp32 accumulate.
+// Per-plane reductions: out[plane] = sum a*b (or sum a when b == null).  One workgroup per plane, fp32 accumulate.
 template <typename T>
 __global__ __launch_bounds__(256) void plane_dot_kernel(float* __restrict__ out, const T* __restrict__ a, const T* __restrict__ b,
                                                         long long planes, int hw) {
@@ -296,14 +308,28 @@ __global__ __launch_bounds__(256) void plane_dot_kernel(float* __restrict__ out,
     const T* ap = a + plane * hw;
     const T* bp = b ? b + plane * hw : nullptr;
     float s = 0.f;
-    for (int i = threadIdx.x; i < hw; i += 256) s += to_f32(ap[i]) * (bp ? to_f32(bp[i]) : 1.f);
+    if ((hw & 3) == 0) {
+        const int nv = hw >> 2;
+        for (int i = threadIdx.x; i < nv; i += 256) {
+            const Vec4<T> va = ((const Vec4<T>*)ap)[i];
+            if (bp) {
+                const Vec4<T> vb = ((const Vec4<T>*)bp)[i];
+#pragma unroll
+                for (int e = 0; e < 4; e++) s = fmaf(to_f32(va.v[e]), to_f32(vb.v[e]), s);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; e++) s += to_f32(va.v[e]);
+            }
+        }
+    } else {
+        for (int i = threadIdx.x; i < hw; i += 256) s += to_f32(ap[i]) * (bp ? to_f32(bp[i]) : 1.f);
+    }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
     __syncthreads();
     if (threadIdx.x == 0) out[plane] = part[0] + part[1] + part[2] + part[3];
 }
-
 
 // ---------------------------------------------------------------------------------------------
 // Weight gradient: dW[o][i][r][s] = sum_n sum_{p,q} dy[n,o,p,q] * x[n,i,p+r-pad,q+s-pad]   (inputs already scaled per plane)
