@@ -395,25 +395,26 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 1 : 2)) void conv2d_wgrad_ke
     constexpr int NXT = cdiv(64 * XR * TAILD, 512); // x tail
     const int rb = tid >> 5, dlane = tid & 31;
     unsigned rdy[NDY][NC], rxm[NXM][NC], rxt[NXT];
-    // step-invariant parts of the staging addresses (32-bit element offsets inside one image) and channel validity
-    int dyo[NDY], xo[NXM], xto[NXT];
-    unsigned dyok = 0, xok = 0, xtok = 0;
+    // Loads are raw buffer loads: an invalid element (padding row / column, channel past the end) gets the byte offset
+    // kOob >= num_records and reads as zero -- no branches, one v_cndmask per load.  The step-dependent part of every address
+    // is wave-uniform and lives in the buffer base; the per-thread byte offsets below never change.
+    constexpr unsigned kOob = 0x80000000u;
+    constexpr bool ROWSAME = (16 % R == 0) && (16 % XR == 0);      // row-in-step index of a thread is the same for all its loads
+    unsigned dyoff[NDY], xoff_[NXM], xtoff[NXT];
     int dyr[NDY], xr_[NXM], xtr[NXT], xtc[NXT];
 #pragma unroll
     for (int i = 0; i < NDY; i++) {
         const int row = rb + 16 * i;
         const int o = o0 + row / R;
         dyr[i] = row % R;
-        dyo[i] = (o * p.P + dyr[i]) * p.Q;
-        dyok |= (unsigned)(o < p.O) << i;
+        dyoff[i] = o < p.O ? (unsigned)(((o * p.P + dyr[i]) * p.Q + dlane * EPD) * (int)sizeof(T)) : kOob;
     }
 #pragma unroll
     for (int i = 0; i < NXM; i++) {
         const int row = rb + 16 * i;
         const int ic = i0 + row / XR;
         xr_[i] = row % XR;
-        xo[i] = (ic * p.H + xr_[i]) * p.W;
-        xok |= (unsigned)(ic < p.I) << i;
+        xoff_[i] = ic < p.I ? (unsigned)(((ic * p.H + xr_[i]) * p.W + dlane * EPD) * (int)sizeof(T)) : kOob;
     }
 #pragma unroll
     for (int i = 0; i < NXT; i++) {
@@ -422,23 +423,26 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 1 : 2)) void conv2d_wgrad_ke
         const int ic = i0 + row / XR;
         xtr[i] = row % XR;
         xtc[i] = (32 * NC + j % TAILD) * EPD;
-        xto[i] = (ic * p.H + xtr[i]) * p.W;
-        xtok |= (unsigned)(row < 64 * XR && ic < p.I) << i;
+        xtoff[i] = (row < 64 * XR && ic < p.I) ? (unsigned)(((ic * p.H + xtr[i]) * p.W + xtc[i]) * (int)sizeof(T)) : kOob;
     }
 
     const int steps_per_img = p.rowgroups * p.qchunks;
     const int s0 = split * p.steps_per_split;
     const int s1 = min(s0 + p.steps_per_split, p.N * steps_per_img);
+    // (image, row group, column chunk) of the next step to load; steps are loaded in order, so this advances by carries
+    int ld_n = s0 / steps_per_img;
+    int ld_rg = (s0 - ld_n * steps_per_img) / p.qchunks;
+    int ld_qc = s0 - ld_n * steps_per_img - ld_rg * p.qchunks;
 
-    auto issue_loads = [&](int step) __attribute__((always_inline)) {
-        const int n = step / steps_per_img;
-        const int rem = step - n * steps_per_img;
-        const int rg = rem / p.qchunks, qc = rem - rg * p.qchunks;
-        const int prow0 = rg * R, q0 = qc * kWgKQ;
+    auto issue_loads = [&]() __attribute__((always_inline)) {
+        const int prow0 = ld_rg * R, q0 = ld_qc * kWgKQ;
         const int xorg = (q0 - p.pad) & ~1;
-        // uniform bases: everything that does not depend on the lane
-        const T* dyb = (const T*)p.dy + (size_t)n * p.O * p.P * p.Q + (size_t)prow0 * p.Q + q0;
-        const T* xb = (const T*)p.x + (size_t)n * p.I * p.H * p.W + (long long)(prow0 - p.pad) * p.W + xorg;
+        // uniform bases: everything that does not depend on the lane (may point before the tensor for padding rows: those
+        // elements are never fetched)
+        const T* dyb = (const T*)p.dy + (size_t)ld_n * p.O * p.P * p.Q + (size_t)prow0 * p.Q + q0;
+        const T* xb = (const T*)p.x + (long long)ld_n * p.I * p.H * p.W + (long long)(prow0 - p.pad) * p.W + xorg;
+        const __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc((void*)dyb, 0, kOob, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, kOob, 0x00020000);
         unsigned dyrows = 0, xrows = 0;               // validity of the R / XR rows of this step
 #pragma unroll
         for (int r = 0; r < R; r++) dyrows |= (unsigned)(prow0 + r < p.P) << r;
@@ -449,17 +453,28 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 1 : 2)) void conv2d_wgrad_ke
             const int dcol = (dlane + 32 * c) * EPD;
             const bool dcok = q0 + dcol < p.Q;
             const bool xcok = (unsigned)(xorg + dcol) < (unsigned)p.W;
+            // validity as an offset mask: 0 or kOob, OR-ed into the byte offset (kept arithmetic so that no branch is formed)
+            const unsigned dym0 = (unsigned)!(dcok && ((dyrows >> dyr[0]) & 1)) << 31, xm0 = (unsigned)!(xcok && ((xrows >> xr_[0]) & 1)) << 31;
 #pragma unroll
-            for (int i = 0; i < NDY; i++)
-                rdy[i][c] = (dcok && ((dyok >> i) & 1) && ((dyrows >> dyr[i]) & 1)) ? *(const unsigned*)(dyb + dyo[i] + dcol) : 0u;
+            for (int i = 0; i < NDY; i++) {
+                const unsigned m = ROWSAME ? dym0 : (unsigned)!(dcok && ((dyrows >> dyr[i]) & 1)) << 31;
+                rdy[i][c] = __builtin_amdgcn_raw_buffer_load_b32(rs_dy, (dyoff[i] + 32 * c * 4) | m, 0, 0);
+            }
 #pragma unroll
-            for (int i = 0; i < NXM; i++)
-                rxm[i][c] = (xcok && ((xok >> i) & 1) && ((xrows >> xr_[i]) & 1)) ? *(const unsigned*)(xb + xo[i] + dcol) : 0u;
+            for (int i = 0; i < NXM; i++) {
+                const unsigned m = ROWSAME ? xm0 : (unsigned)!(xcok && ((xrows >> xr_[i]) & 1)) << 31;
+                rxm[i][c] = __builtin_amdgcn_raw_buffer_load_b32(rs_x, (xoff_[i] + 32 * c * 4) | m, 0, 0);
+            }
         }
 #pragma unroll
-        for (int i = 0; i < NXT; i++)
-            rxt[i] = (((xtok >> i) & 1) && ((xrows >> xtr[i]) & 1) && (unsigned)(xorg + xtc[i]) < (unsigned)p.W)
-                         ? *(const unsigned*)(xb + xto[i] + xtc[i]) : 0u;
+        for (int i = 0; i < NXT; i++) {
+            const unsigned m = (unsigned)!(((xrows >> xtr[i]) & 1) && (unsigned)(xorg + xtc[i]) < (unsigned)p.W) << 31;
+            rxt[i] = __builtin_amdgcn_raw_buffer_load_b32(rs_x, xtoff[i] | m, 0, 0);
+        }
+        if (++ld_qc == p.qchunks) {
+            ld_qc = 0;
+            if (++ld_rg == p.rowgroups) { ld_rg = 0; ld_n++; }
+        }
     };
     auto write_lds = [&]() __attribute__((always_inline)) {
 #pragma unroll
@@ -481,9 +496,9 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 1 : 2)) void conv2d_wgrad_ke
     // writing step s+1 into the other buffer and have step s+2's global loads in flight: one barrier per step.
     // Single-buffered (fp32): write / barrier / compute / barrier.
     if (s0 < s1) {
-        issue_loads(s0);
+        issue_loads();
         write_lds();
-        if (NBUF == 2 && s0 + 1 < s1) issue_loads(s0 + 1);
+        if (NBUF == 2 && s0 + 1 < s1) issue_loads();
     }
     __syncthreads();
     for (int step = s0; step < s1; step++) {
@@ -493,7 +508,7 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 1 : 2)) void conv2d_wgrad_ke
                 lds_dy = lds + ((step + 1 - s0) & 1) * LDS_ONE;
                 lds_x = lds_dy + 64 * R * PDY;
                 write_lds();                        // step+1 (its loads were issued one step ago)
-                if (step + 2 < s1) issue_loads(step + 2);
+                if (step + 2 < s1) issue_loads();
             }
             lds_dy = lds + ((step - s0) & 1) * LDS_ONE;
             lds_x = lds_dy + 64 * R * PDY;
@@ -503,7 +518,7 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 1 : 2)) void conv2d_wgrad_ke
                 write_lds();
                 __syncthreads();
             }
-            if (step + 1 < s1) issue_loads(step + 1);
+            if (step + 1 < s1) issue_loads();
         }
         auto compute = [&](auto thc) __attribute__((always_inline)) {
             constexpr int TH = decltype(thc)::value;
