@@ -368,10 +368,9 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 1 : 2)) void conv2d_wgrad_ke
     T* lds_x = lds + 64 * R * PDY;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wo = wave & 1, wi = (wave >> 1) & 1, th = wave >> 2;     // th: which half of the taps this wave accumulates
+    const int wo = wave & 1, wi = (wave >> 1) & 1, th = wave >> 2;     // th: which half of the chunk's pixels this wave accumulates
     const int r32 = lane & 31, h = lane >> 5;
-    constexpr int T0 = (KK + 1) / 2;                                   // taps [0, T0) -> th 0, [T0, KK) -> th 1
-    constexpr int NACC = T0;
+    constexpr int NACC = KK;
 
     int bid = blockIdx.x;
     const int split = bid % p.splits; bid /= p.splits;
@@ -520,96 +519,103 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 1 : 2)) void conv2d_wgrad_ke
             }
             if (step + 1 < s1) issue_loads();
         }
-        auto compute = [&](auto thc) __attribute__((always_inline)) {
-            constexpr int TH = decltype(thc)::value;
-            constexpr int TLO = TH == 0 ? 0 : T0, THI = TH == 0 ? T0 : KK;
-            if constexpr (F32) {
+        // Both wave halves accumulate every tap; they split the 64 pixels of the chunk (th 0: first 32, th 1: last 32), so a
+        // staged x row is read once per 16 pixels and feeds all KS shifts x R rows x KS tap rows.
+        if constexpr (F32) {
 #pragma unroll
-                for (int rr = 0; rr < R; rr++)
+            for (int rr = 0; rr < R; rr++)
 #pragma unroll 4
-                    for (int k2 = 0; k2 < kWgKQ / 2; k2++) {
-                        const float a = lds_dy[(rr * 64 + wo * 32 + r32) * PDY + 2 * k2 + h];
+                for (int kq = 0; kq < kWgKQ / 4; kq++) {
+                    const int k2 = th * (kWgKQ / 4) + kq;
+                    const float a = lds_dy[(rr * 64 + wo * 32 + r32) * PDY + 2 * k2 + h];
 #pragma unroll
-                        for (int t = TLO; t < THI; t++) {
-                            const int r = t / KS, sft = t - r * KS;
-                            const float b = lds_x[((rr + r) * 64 + wi * 32 + r32) * PX + 2 * k2 + h + sft + xoff];
-                            acc[t - TLO] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t - TLO], 0, 0, 0);
-                        }
+                    for (int t = 0; t < KK; t++) {
+                        const int r = t / KS, sft = t - r * KS;
+                        const float b = lds_x[((rr + r) * 64 + wi * 32 + r32) * PX + 2 * k2 + h + sft + xoff];
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
                     }
-            } else {
-                typedef typename std::conditional<std::is_same<T, bf16_t>::value, bf16x8, f16x8>::type frag_t;
+                }
+        } else {
+            typedef typename std::conditional<std::is_same<T, bf16_t>::value, bf16x8, f16x8>::type frag_t;
+            const T* dy_w = lds_dy + (wo * 32 + r32) * PDY + th * (kWgKQ / 2) + 8 * h;
+            const T* x_w = lds_x + (wi * 32 + r32) * PX + th * (kWgKQ / 2) + 8 * h;
 #pragma unroll
-                for (int k16 = 0; k16 < kWgKQ / 16; k16++) {
-                    frag_t a[R];
+            for (int kq = 0; kq < kWgKQ / 32; kq++) {
+                frag_t a[R];
 #pragma unroll
-                    for (int rr = 0; rr < R; rr++) a[rr] = *(const frag_t*)(lds_dy + (rr * 64 + wo * 32 + r32) * PDY + k16 * 16 + 8 * h);
-                    // the staged rows of this lane's channel: each read once, shifted variants built in registers
+                for (int rr = 0; rr < R; rr++) a[rr] = *(const frag_t*)(dy_w + rr * 64 * PDY + kq * 16);
+                // the staged rows of this lane's channel: each read once, shifted variants built in registers
 #pragma unroll
-                    for (int xr = 0; xr < XR; xr++) {
-                        // is staged row xr used by any (rr, tap) of this half?
-                        bool used = false;
+                for (int xr = 0; xr < XR; xr++) {
+                    const unsigned* src = (const unsigned*)(x_w + xr * 64 * PX + kq * 16);
+                    const uint4 lo = *(const uint4*)src;
+                    const uint4 hi = *(const uint4*)(src + 4);        // 16-byte read (conflict-free); only .x/.y are used
+                    const unsigned d[6] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y};
 #pragma unroll
-                        for (int rr = 0; rr < R; rr++)
+                    for (int sft = 0; sft < KS; sft++) {
+                        union { unsigned u[4]; frag_t f; } b;
+                        const int sh = sft + xoff;                            // element shift in [0, 3], compile-time
 #pragma unroll
-                            for (int t = TLO; t < THI; t++) used = used || (t / KS == xr - rr);
-                        if (!used) continue;
-                        const unsigned* src = (const unsigned*)(lds_x + (xr * 64 + wi * 32 + r32) * PX + k16 * 16 + 8 * h);
-                        const uint4 lo = *(const uint4*)src;
-                        const uint4 hi = *(const uint4*)(src + 4);        // 16-byte read (conflict-free); only .x/.y are used
-                        const unsigned d[6] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y};
+                        for (int w = 0; w < 4; w++) {
+                            const unsigned e0 = d[w], e1 = d[w + 1], e2 = d[w + 2];
+                            const unsigned odd_lo = __builtin_amdgcn_alignbyte(e1, e0, 2);
+                            const unsigned odd_hi = __builtin_amdgcn_alignbyte(e2, e1, 2);
+                            b.u[w] = (sh == 0) ? e0 : (sh == 1) ? odd_lo : (sh == 2) ? e1 : odd_hi;
+                        }
 #pragma unroll
-                        for (int sft = 0; sft < KS; sft++) {
-                            bool sused = false;
-#pragma unroll
-                            for (int rr = 0; rr < R; rr++) {
-                                const int t = (xr - rr) * KS + sft;
-                                sused = sused || (xr - rr >= 0 && xr - rr < KS && t >= TLO && t < THI);
-                            }
-                            if (!sused) continue;
-                            union { unsigned u[4]; frag_t f; } b;
-                            constexpr int dummy_ = 0; (void)dummy_;
-                            const int sh = sft + xoff;                            // element shift in [0, 3], compile-time
-#pragma unroll
-                            for (int w = 0; w < 4; w++) {
-                                const unsigned e0 = d[w], e1 = d[w + 1], e2 = d[w + 2];
-                                const unsigned odd_lo = __builtin_amdgcn_alignbyte(e1, e0, 2);
-                                const unsigned odd_hi = __builtin_amdgcn_alignbyte(e2, e1, 2);
-                                b.u[w] = (sh == 0) ? e0 : (sh == 1) ? odd_lo : (sh == 2) ? e1 : odd_hi;
-                            }
-#pragma unroll
-                            for (int rr = 0; rr < R; rr++) {
-                                const int r = xr - rr;
-                                const int t = r * KS + sft;
-                                if (r >= 0 && r < KS && t >= TLO && t < THI) {
-                                    if constexpr (std::is_same<T, bf16_t>::value)
-                                        acc[t - TLO] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[rr], b.f, acc[t - TLO], 0, 0, 0);
-                                    else
-                                        acc[t - TLO] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[rr], b.f, acc[t - TLO], 0, 0, 0);
-                                }
+                        for (int rr = 0; rr < R; rr++) {
+                            const int r = xr - rr;
+                            const int t = r * KS + sft;
+                            if (r >= 0 && r < KS) {
+                                if constexpr (std::is_same<T, bf16_t>::value)
+                                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[rr], b.f, acc[t], 0, 0, 0);
+                                else
+                                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[rr], b.f, acc[t], 0, 0, 0);
                             }
                         }
                     }
                 }
             }
-        };
-        if (th == 0) compute(std::integral_constant<int, 0>{});
-        else compute(std::integral_constant<int, 1>{});
+        }
         if (NBUF == 2) __syncthreads();            // everyone done with buffer step&1 and step+1 fully written
     }
-    // ---- write the partial tile: D[row = o][col = i]
-    float* out = p.part + (size_t)split * p.O * p.I * KK;
+    // ---- add the two pixel halves through LDS (the staging buffers are free now): th 1 parks its accumulators, th 0 adds
+    // them and writes the partial tile D[row = o][col = i].
+    if (NBUF == 1) __syncthreads();
+    {
+        float* red = (float*)lds;
+        constexpr int TPR_CAP = (int)((size_t)NBUF * LDS_ONE * sizeof(T) / (4 * 16 * 64 * sizeof(float)));     // taps per round
+        constexpr int TPR = TPR_CAP < KK ? TPR_CAP : KK;
+        static_assert(TPR >= 1, "LDS too small for the half-sum");
+        const int wv4 = wave & 3;
 #pragma unroll
-    for (int reg = 0; reg < 16; reg++) {
-        const int o = o0 + wo * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-        const int i = i0 + wi * 32 + r32;
-        if (o < p.O && i < p.I) {
-            float* dst = out + ((size_t)o * p.I + i) * KK;
+        for (int t0 = 0; t0 < KK; t0 += TPR) {
+            if (t0 > 0) __syncthreads();
+            if (th == 1) {
+#pragma unroll
+                for (int t = t0; t < t0 + TPR && t < KK; t++)
+#pragma unroll
+                    for (int reg = 0; reg < 16; reg++) red[((wv4 * TPR + (t - t0)) * 16 + reg) * 64 + lane] = acc[t][reg];
+            }
+            __syncthreads();
             if (th == 0) {
 #pragma unroll
-                for (int t = 0; t < T0; t++) dst[t] = acc[t][reg];
-            } else {
+                for (int t = t0; t < t0 + TPR && t < KK; t++)
 #pragma unroll
-                for (int t = T0; t < KK; t++) dst[t] = acc[t - T0][reg];
+                    for (int reg = 0; reg < 16; reg++) acc[t][reg] += red[((wv4 * TPR + (t - t0)) * 16 + reg) * 64 + lane];
+            }
+        }
+    }
+    if (th == 0) {
+        float* out = p.part + (size_t)split * p.O * p.I * KK;
+#pragma unroll
+        for (int reg = 0; reg < 16; reg++) {
+            const int o = o0 + wo * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+            const int i = i0 + wi * 32 + r32;
+            if (o < p.O && i < p.I) {
+                float* dst = out + ((size_t)o * p.I + i) * KK;
+#pragma unroll
+                for (int t = 0; t < KK; t++) dst[t] = acc[t][reg];
             }
         }
     }
