@@ -506,8 +506,10 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 1 : 2)) void conv2d_wgrad_ke
             if (step + 1 < s1) {
                 lds_dy = lds + ((step + 1 - s0) & 1) * LDS_ONE;
                 lds_x = lds_dy + 64 * R * PDY;
+#ifndef AFCM_WG_ABLATE_STAGE
                 write_lds();                        // step+1 (its loads were issued one step ago)
                 if (step + 2 < s1) issue_loads();
+#endif
             }
             lds_dy = lds + ((step - s0) & 1) * LDS_ONE;
             lds_x = lds_dy + 64 * R * PDY;
@@ -585,6 +587,276 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 1 : 2)) void conv2d_wgrad_ke
     {
         float* red = (float*)lds;
         constexpr int TPR_CAP = (int)((size_t)NBUF * LDS_ONE * sizeof(T) / (4 * 16 * 64 * sizeof(float)));     // taps per round
+        constexpr int TPR = TPR_CAP < KK ? TPR_CAP : KK;
+        static_assert(TPR >= 1, "LDS too small for the half-sum");
+        const int wv4 = wave & 3;
+#pragma unroll
+        for (int t0 = 0; t0 < KK; t0 += TPR) {
+            if (t0 > 0) __syncthreads();
+            if (th == 1) {
+#pragma unroll
+                for (int t = t0; t < t0 + TPR && t < KK; t++)
+#pragma unroll
+                    for (int reg = 0; reg < 16; reg++) red[((wv4 * TPR + (t - t0)) * 16 + reg) * 64 + lane] = acc[t][reg];
+            }
+            __syncthreads();
+            if (th == 0) {
+#pragma unroll
+                for (int t = t0; t < t0 + TPR && t < KK; t++)
+#pragma unroll
+                    for (int reg = 0; reg < 16; reg++) acc[t][reg] += red[((wv4 * TPR + (t - t0)) * 16 + reg) * 64 + lane];
+            }
+        }
+    }
+    if (th == 0) {
+        float* out = p.part + (size_t)split * p.O * p.I * KK;
+#pragma unroll
+        for (int reg = 0; reg < 16; reg++) {
+            const int o = o0 + wo * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+            const int i = i0 + wi * 32 + r32;
+            if (o < p.O && i < p.I) {
+                float* dst = out + ((size_t)o * p.I + i) * KK;
+#pragma unroll
+                for (int t = 0; t < KK; t++) dst[t] = acc[t][reg];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// 16-bit weight gradient, LDS-DMA staged.  Same tiling as conv2d_wgrad_kernel (64 o x 64 i x all taps per workgroup, R = 2
+// output rows x 64 pixels per K step, 8 waves = 2(o) x 2(i) x 2(pixel halves)), but the operands go HBM -> LDS directly
+// (buffer_load_dword ... lds): no staging VGPRs, no ds_write pass, no per-load VALU.  One wave instruction fills 64
+// consecutive LDS dwords = two 128-byte rows (64 pixels of two channels), so rows cannot be padded; bank conflicts are
+// avoided by an XOR swizzle of the 16-byte granules, applied on the SOURCE address of the load and again on the read:
+//     granule g of row r sits at physical granule g ^ ((r >> 1) & 7)            (conflict-free for ds_read_b128's lane groups)
+// LDS image of one step (NBUF of them in a ring):
+//     dy  [rr 0..1][o 0..63][128 B]                                             16 KB
+//     x   [xr 0..XR-1] { main [ch 0..63][128 B] (cols 0..63), tail [ch 0..63][16 B] (cols 64..71) }   XR x 9 KB
+// Every piece is predicated by the buffer descriptor: rows outside the image get num_records = 0, channels past the end
+// fall behind num_records, columns past the end get the out-of-range offset bit -- all of them read as zero.
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+
+template <int LO, int HI, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (LO < HI) {
+        f(std::integral_constant<int, LO>{});
+        static_for<LO + 1, HI>(f);
+    }
+}
+
+__device__ __forceinline__ void lds_dma_dword(i32x4 rsrc, unsigned voff, unsigned lds_addr) {
+    // M0 carries the wave-uniform LDS destination; lane l lands at lds_addr + 4*l
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, 0 offen lds" : : "s"(lds_addr), "v"(voff), "s"(rsrc));
+}
+
+__device__ __forceinline__ i32x4 make_rsrc(const void* base, int num_records) {
+    const unsigned long long a = (unsigned long long)base;
+    i32x4 r;
+    r.x = (int)(unsigned)a;
+    r.y = (int)(unsigned)(a >> 32) & 0xffff;       // stride 0
+    r.z = num_records;
+    r.w = 0x00020000;
+    return r;
+}
+
+template <typename T, int KS, int XOFF, int NBUF>
+__global__ __launch_bounds__(512, 1) void conv2d_wgrad16_kernel(WgradParams p) {
+    static_assert(sizeof(T) == 2, "16-bit types only");
+    constexpr int R = 2, KK = KS * KS, XR = R + KS - 1;
+    constexpr int ROWB = 128;                       // bytes of one staged row (64 pixels)
+    constexpr int DY_BYTES = R * 64 * ROWB;
+    constexpr int XBLK = 64 * ROWB + 64 * 16;       // one staged x row of all 64 channels: main + tail
+    constexpr int BUF = DY_BYTES + XR * XBLK;
+    constexpr bool TAIL = KS > 1;
+    constexpr int NTAILP = TAIL ? (4 * XR) / 8 : 0; // tail pieces per wave
+    static_assert(!TAIL || (4 * XR) % 8 == 0, "tail pieces must divide over the 8 waves");
+    constexpr int NPIECE = 8 + 4 * XR + NTAILP;     // LDS-DMA instructions per wave and step
+    constexpr unsigned kOob = 0x80000000u;
+    __shared__ __attribute__((aligned(256))) char lds[NBUF * BUF];
+    const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) void*)lds;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wo = wave & 1, wi = (wave >> 1) & 1, th = wave >> 2;     // th: which half of the chunk's pixels this wave accumulates
+    const int r32 = lane & 31, h = lane >> 5;
+
+    // XCD-aware block order: the 8 XCDs take workgroups round-robin, so give XCD x a contiguous range of logical ids;
+    // logical id = split-major, i.e. one XCD's L2 sees all (o, i) tiles of the same pixels.
+    const int tiles_i = cdiv(p.I, 64), tiles = tiles_i * cdiv(p.O, 64);
+    int bid = blockIdx.x;
+    const int total = tiles * p.splits;
+    if ((total & 7) == 0) bid = (bid & 7) * (total >> 3) + (bid >> 3);
+    const int split = bid / tiles;
+    const int tile = bid - split * tiles;
+    const int ib = tile % tiles_i, obk = tile / tiles_i;
+    const int o0 = obk * 64, i0 = ib * 64;
+
+    f32x16 acc[KK];
+#pragma unroll
+    for (int t = 0; t < KK; t++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) acc[t][e] = 0.f;
+
+    // ---- load maps.  Wave w owns the row pairs {w, w+8, w+16, w+24} of every 64-row block, so its swizzle key
+    // ((row >> 1) & 7) == w is a constant and one per-lane offset serves all of its pieces.
+    const int half = lane >> 5, slot = lane & 31;
+    const int cdw = ((((slot >> 2) ^ wave) & 7) << 2) | (slot & 3);          // logical dword column of this lane's LDS slot
+    const unsigned lp_dy = (unsigned)((2 * wave + half) * p.P * p.Q * 2 + cdw * 4);
+    const unsigned lp_x = (unsigned)((2 * wave + half) * p.H * p.W * 2 + cdw * 4);
+    const int trow = lane >> 2, tdw = lane & 3;                               // tail piece: 16 channels x 4 dwords
+    const unsigned lp_t = (unsigned)(trow * p.H * p.W * 2 + (32 + tdw) * 4);
+
+    const int steps_per_img = p.rowgroups * p.qchunks;
+    const int s0 = split * p.steps_per_split;
+    const int s1 = min(s0 + p.steps_per_split, p.N * steps_per_img);
+    int ld_n = s0 / steps_per_img;
+    int ld_rg = (s0 - ld_n * steps_per_img) / p.qchunks;
+    int ld_qc = s0 - ld_n * steps_per_img - ld_rg * p.qchunks;
+    int ld_buf = 0;
+
+    // Loads of one step: begin_loads() latches the step's uniform state, issue_piece<I>() issues LDS-DMA instruction I of the
+    // wave's NPIECE.  The pieces are spread between the MFMAs of the previous step's compute: a dword load occupies the
+    // address unit for 16 cycles, so a burst of 26 x 8 waves would stall every wave at the head of the step.
+    int c_prow0 = 0, c_q0 = 0, c_xorg = 0, c_live = 0;
+    unsigned c_bufa = 0, v_dy = 0, v_x = 0, v_t = 0;
+    const T* c_dyn = nullptr;
+    const T* c_xn = nullptr;
+    const int pq = p.P * p.Q, hw = p.H * p.W;
+    auto begin_loads = [&](bool live) __attribute__((always_inline)) {
+        c_live = live ? -1 : 0;                                   // a dead step still issues its pieces (with 0 records)
+        c_prow0 = ld_rg * R; c_q0 = ld_qc * kWgKQ;
+        c_xorg = (c_q0 - p.pad) & ~1;
+        c_bufa = lds0 + ld_buf * BUF;
+        // per-lane column validity -> offset masks
+        v_dy = lp_dy | ((unsigned)!(c_q0 + 2 * cdw < p.Q) << 31);
+        v_x = lp_x | ((unsigned)!((unsigned)(c_xorg + 2 * cdw) < (unsigned)p.W) << 31);
+        v_t = lp_t | ((unsigned)!((unsigned)(c_xorg + 64 + 2 * tdw) < (unsigned)p.W) << 31);
+        c_dyn = (const T*)p.dy + (size_t)ld_n * p.O * pq;
+        c_xn = (const T*)p.x + (size_t)ld_n * p.I * hw;
+        if (live) {
+            if (++ld_qc == p.qchunks) {
+                ld_qc = 0;
+                if (++ld_rg == p.rowgroups) { ld_rg = 0; ld_n++; }
+            }
+        }
+        if (++ld_buf == NBUF) ld_buf = 0;
+    };
+    auto issue_piece = [&](auto idx) __attribute__((always_inline)) {
+        constexpr int I = decltype(idx)::value;
+        if constexpr (I < 8) {
+            constexpr int rr = I >> 2, mm = I & 3;
+            const int ch0 = o0 + 16 * mm, row = c_prow0 + rr;
+            const int inimg = row * p.Q + c_q0;                                // element offset of the piece origin inside a channel
+            int nr = ((p.O - ch0) * pq - inimg) * 2;
+            nr = (row < p.P && nr > 0) ? (nr & c_live) : 0;
+            lds_dma_dword(make_rsrc(c_dyn + (long long)ch0 * pq + inimg, nr), v_dy, c_bufa + rr * (64 * ROWB) + (wave + 8 * mm) * 256);
+        } else if constexpr (I < 8 + 4 * XR) {
+            constexpr int m = I - 8, xr = m >> 2, mm = m & 3;
+            const int ch0 = i0 + 16 * mm, row = c_prow0 - p.pad + xr;
+            const int inimg = row * p.W + c_xorg;
+            int nr = ((p.I - ch0) * hw - inimg) * 2;
+            nr = ((unsigned)row < (unsigned)p.H && nr > 0) ? (nr & c_live) : 0;
+            lds_dma_dword(make_rsrc(c_xn + (long long)ch0 * hw + inimg, nr), v_x, c_bufa + DY_BYTES + xr * XBLK + (wave + 8 * mm) * 256);
+        } else {
+            constexpr int u = I - 8 - 4 * XR;
+            const int q = wave + 8 * u;
+            const int xr = q >> 2, t = q & 3;
+            const int ch0 = i0 + 16 * t, row = c_prow0 - p.pad + xr;
+            const int inimg = row * p.W + c_xorg;
+            int nr = ((p.I - ch0) * hw - inimg) * 2;
+            nr = ((unsigned)row < (unsigned)p.H && nr > 0) ? (nr & c_live) : 0;
+            lds_dma_dword(make_rsrc(c_xn + (long long)ch0 * hw + inimg, nr), v_t, c_bufa + DY_BYTES + xr * XBLK + 64 * ROWB + t * 256);
+        }
+    };
+    // pieces [lo, hi) as one unrolled run
+    auto issue_range = [&](auto lo, auto hi) __attribute__((always_inline)) {
+        constexpr int LO = decltype(lo)::value, HI = decltype(hi)::value;
+        static_for<LO, HI>([&](auto i) __attribute__((always_inline)) { issue_piece(i); });
+    };
+
+    // ---- fragment read offsets inside a buffer (swizzled); the two 16-pixel groups of this wave's half need their own
+    const int rowA = wo * 32 + r32, rowB = wi * 32 + r32;
+    const int fA = (rowA >> 1) & 7, fB = (rowB >> 1) & 7;
+    unsigned a_off[2], xlo_off[2], xhi_off[2];
+#pragma unroll
+    for (int kq = 0; kq < 2; kq++) {
+        const int g = th * 4 + kq * 2 + h;
+        a_off[kq] = rowA * ROWB + ((g ^ fA) << 4);
+        xlo_off[kq] = DY_BYTES + rowB * ROWB + ((g ^ fB) << 4);
+        xhi_off[kq] = (g + 1 < 8) ? DY_BYTES + rowB * ROWB + (((g + 1) ^ fB) << 4) : DY_BYTES + 64 * ROWB + rowB * 16;
+    }
+
+    // ---- pipeline: NBUF-1 steps of loads in flight; a step's loads are waited for (counted vmcnt) before the barrier that
+    // precedes its use.
+#pragma unroll
+    for (int i = 0; i < NBUF - 1; i++) {
+        begin_loads(s0 + i < s1);
+        issue_range(std::integral_constant<int, 0>{}, std::integral_constant<int, NPIECE>{});
+    }
+    if (NBUF == 3) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(NPIECE));
+    else asm volatile("s_waitcnt vmcnt(0)");
+    __syncthreads();
+    int cbuf = 0;
+    for (int step = s0; step < s1; step++) {
+        constexpr int xoff = XOFF;
+        begin_loads(step + NBUF - 1 < s1);                 // into the buffer everyone left at the last barrier
+        const char* buf = lds + cbuf * BUF;
+        typedef typename std::conditional<std::is_same<T, bf16_t>::value, bf16x8, f16x8>::type frag_t;
+        static_for<0, 2>([&](auto kqc) __attribute__((always_inline)) {
+            constexpr int kq = decltype(kqc)::value;
+            frag_t a[R];
+#pragma unroll
+            for (int rr = 0; rr < R; rr++) a[rr] = *(const frag_t*)(buf + a_off[kq] + rr * (64 * ROWB));
+            static_for<0, XR>([&](auto xrc) __attribute__((always_inline)) {
+                constexpr int xr = decltype(xrc)::value;
+                constexpr int it = kq * XR + xr, NIT = 2 * XR;
+                issue_range(std::integral_constant<int, (it * NPIECE) / NIT>{}, std::integral_constant<int, ((it + 1) * NPIECE) / NIT>{});
+                const uint4 lo = *(const uint4*)(buf + xlo_off[kq] + xr * XBLK);
+                uint4 hi = lo;
+                if (TAIL) {
+                    hi = *(const uint4*)(buf + xhi_off[kq] + xr * XBLK);
+                    asm volatile("" : : "v"(hi.y), "v"(hi.z), "v"(hi.w));     // keep the read a full (conflict-free) b128
+                }
+                const unsigned d[6] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y};
+#pragma unroll
+                for (int sft = 0; sft < KS; sft++) {
+                    union { unsigned u[4]; frag_t f; } b;
+                    const int sh = sft + xoff;                            // element shift in [0, 3], compile-time
+#pragma unroll
+                    for (int w = 0; w < 4; w++) {
+                        const unsigned e0 = d[w], e1 = d[w + 1], e2 = d[(w + 2) % 6];
+                        const unsigned odd_lo = __builtin_amdgcn_alignbyte(e1, e0, 2);
+                        const unsigned odd_hi = __builtin_amdgcn_alignbyte(e2, e1, 2);
+                        b.u[w] = (sh == 0) ? e0 : (sh == 1) ? odd_lo : (sh == 2) ? e1 : odd_hi;
+                    }
+#pragma unroll
+                    for (int rr = 0; rr < R; rr++) {
+                        const int r = xr - rr;
+                        const int t = r * KS + sft;
+                        if (r >= 0 && r < KS) {
+                            if constexpr (std::is_same<T, bf16_t>::value)
+                                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[rr], b.f, acc[t], 0, 0, 0);
+                            else
+                                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[rr], b.f, acc[t], 0, 0, 0);
+                        }
+                    }
+                }
+            });
+        });
+        // the next step's loads (issued NBUF-2 iterations ago, or just now when NBUF == 2) must have landed
+        if (NBUF == 3) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(NPIECE));
+        else asm volatile("s_waitcnt vmcnt(0)");
+        __syncthreads();
+        if (++cbuf == NBUF) cbuf = 0;
+    }
+    // ---- add the two pixel halves through LDS (the ring is free now): th 1 parks its accumulators, th 0 adds them and
+    // writes the partial tile D[row = o][col = i].
+    asm volatile("s_waitcnt vmcnt(0)");
+    __syncthreads();
+    {
+        float* red = (float*)lds;
+        constexpr int TPR_CAP = (NBUF * BUF) / (4 * 16 * 64 * (int)sizeof(float));     // taps per round
         constexpr int TPR = TPR_CAP < KK ? TPR_CAP : KK;
         static_assert(TPR >= 1, "LDS too small for the half-sum");
         const int wv4 = wave & 3;
@@ -756,11 +1028,17 @@ extern "C" int afcm_conv2d_wgrad(float* dw, float* workspace, const void* dy, co
 #define AFCM_WG(T, R) do { if (ks == 3 && (pad & 1) == 0) hipLaunchKernelGGL((conv2d_wgrad_kernel<T, 3, R, 0>), grid, block, 0, st, p); \
                            else if (ks == 3) hipLaunchKernelGGL((conv2d_wgrad_kernel<T, 3, R, 1>), grid, block, 0, st, p); \
                            else hipLaunchKernelGGL((conv2d_wgrad_kernel<T, 1, R, 0>), grid, block, 0, st, p); } while (0)
+#define AFCM_WG16(T) do { constexpr int NB = 3; \
+                           if (ks == 3 && (pad & 1) == 0) hipLaunchKernelGGL((conv2d_wgrad16_kernel<T, 3, 0, NB>), grid, block, 0, st, p); \
+                           else if (ks == 3) hipLaunchKernelGGL((conv2d_wgrad16_kernel<T, 3, 1, NB>), grid, block, 0, st, p); \
+                           else hipLaunchKernelGGL((conv2d_wgrad16_kernel<T, 1, 0, NB>), grid, block, 0, st, p); } while (0)
+    const bool legacy = getenv("AFCM_WGRAD_LEGACY") != nullptr;     // tuning aid: the register-staged kernel
     switch (dtype) {
         case AFCM_F32: AFCM_WG(float, 1); break;
-        case AFCM_F16: AFCM_WG(f16_t, 2); break;
-        default: AFCM_WG(bf16_t, 2); break;
+        case AFCM_F16: if (legacy) AFCM_WG(f16_t, 2); else AFCM_WG16(f16_t); break;
+        default: if (legacy) AFCM_WG(bf16_t, 2); else AFCM_WG16(bf16_t); break;
     }
+#undef AFCM_WG16
 #undef AFCM_WG
     int rc = hip_status(hipGetLastError());
     if (rc != AFCM_OK) return rc;
