@@ -11,6 +11,7 @@
 // bf16/f16 use v_mfma_f32_32x32x16_{bf16,f16}; fp32 uses v_mfma_f32_32x32x2_f32 (exact fp32, for the <=1e-3 parity path).
 // The same kernel computes the data gradient (weights packed transposed + flipped, pad' = k-1-pad).
 #include <stdlib.h>
+#include <string.h>
 
 #include <type_traits>
 
@@ -651,11 +652,12 @@ __device__ __forceinline__ void lds_dma_dword(i32x4 rsrc, unsigned voff, unsigne
 }
 
 __device__ __forceinline__ i32x4 make_rsrc(const void* base, int num_records) {
+    // the descriptor is wave-uniform by construction; readfirstlane pins it to SGPRs for the "s" asm operand
     const unsigned long long a = (unsigned long long)base;
     i32x4 r;
-    r.x = (int)(unsigned)a;
-    r.y = (int)(unsigned)(a >> 32) & 0xffff;       // stride 0
-    r.z = num_records;
+    r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+    r.y = __builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32) & 0xffff);       // stride 0
+    r.z = __builtin_amdgcn_readfirstlane(num_records);
     r.w = 0x00020000;
     return r;
 }
@@ -893,6 +895,272 @@ __global__ __launch_bounds__(512, 1) void conv2d_wgrad16_kernel(WgradParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// 16-bit weight gradient, 16-byte LDS-DMA pieces.  The address unit spends about the same time on a wave instruction
+// whatever its width, and conv2d_wgrad16_kernel is bound by exactly that (208 dword pieces per step); this variant moves
+// the same bytes in 56 pieces of 16 B per lane.  A lane fetches one granule = 8 pixels from a 4-byte aligned address, so
+// validity is per granule, not per pixel:
+//   * x is staged from column q0 - 8: the granule left of the image is dropped whole (pad = 2: taps reach back 2 columns);
+//   * the granule that straddles the right edge of x brings the head of the next row: the wave that loaded it zeroes those
+//     pixels in LDS before the barrier;
+//   * dy beyond its right edge then multiplies zeros of x (its columns q >= Q pair with x columns >= W), whatever it holds.
+// Supported: KS = 3 with pad = 2 (the generator's convs) and KS = 1 with pad = 0; everything else takes the dword kernel.
+// LDS image of one step:   dy [rr 0..1][o 64][8 granules]   x main [xr][ch 64][8 granules]   x tail [ch>>3][xr][ch&7][1 granule]
+// with granule g of row r at slot g ^ ((r >> 1) & 7); B fragments of tap column s are the 5-dword window
+// (granule g).d3, (granule g+1).d0..3 shifted by s.
+__device__ __forceinline__ void lds_dma_b128(i32x4 rsrc, unsigned voff, unsigned lds_addr) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" : : "s"(lds_addr), "v"(voff), "s"(rsrc));
+}
+
+template <typename T, int KS, int NBUF>
+__global__ __launch_bounds__(512, 1) void conv2d_wgrad16g_kernel(WgradParams p) {
+    static_assert(sizeof(T) == 2, "16-bit types only");
+    constexpr int R = 2, KK = KS * KS, XR = R + KS - 1;
+    constexpr int ROWB = 128;                       // bytes of one staged row (64 pixels)
+    constexpr int DY_BYTES = R * 64 * ROWB;
+    constexpr int XMAIN = XR * 64 * ROWB;
+    constexpr bool TAIL = KS > 1;
+    constexpr int XTAIL = TAIL ? 8 * XR * 8 * 16 : 0;               // [ch>>3][xr][ch&7][16 B]
+    constexpr int BUF = DY_BYTES + XMAIN + XTAIL;
+    constexpr int NPIECE = R + XR + (TAIL ? 1 : 0);                 // LDS-DMA instructions per wave and step
+    constexpr int XLEAD = TAIL ? 8 : 0;                             // x is staged from column q0 - XLEAD
+    constexpr unsigned kOob = 0x80000000u;
+    static_assert(XR * 8 <= 64, "tail piece: one lane per (xr, channel)");
+    __shared__ __attribute__((aligned(1024))) char lds[NBUF * BUF];
+    const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) void*)lds;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wo = wave & 1, wi = (wave >> 1) & 1, th = wave >> 2;     // th: which half of the chunk's pixels this wave accumulates
+    const int r32 = lane & 31, h = lane >> 5;
+
+    const int tiles_i = cdiv(p.I, 64), tiles = tiles_i * cdiv(p.O, 64);
+    int bid = blockIdx.x;
+    const int total = tiles * p.splits;
+    if ((total & 7) == 0) bid = (bid & 7) * (total >> 3) + (bid >> 3);          // XCD x: contiguous logical ids (split-major)
+    const int split = bid / tiles;
+    const int tile = bid - split * tiles;
+    const int ib = tile % tiles_i, obk = tile / tiles_i;
+    const int o0 = obk * 64, i0 = ib * 64;
+
+    f32x16 acc[KK];
+#pragma unroll
+    for (int t = 0; t < KK; t++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) acc[t][e] = 0.f;
+
+    // ---- load maps.  Wave w stages rows (channels) 8w..8w+7 of both operands: lane = (row, slot) of an 8-row piece.
+    const int prow = 8 * wave + (lane >> 3), pslot = lane & 7;
+    const int pg = pslot ^ ((prow >> 1) & 7);                                    // logical granule that lives in this slot
+    const int pq = p.P * p.Q, hw = p.H * p.W;
+    const unsigned lp_dy = (o0 + prow < p.O) ? (unsigned)(prow * pq * 2 + pg * 16) : kOob;
+    const unsigned lp_x = (i0 + prow < p.I) ? (unsigned)(prow * hw * 2 + pg * 16) : kOob;
+    const int txr = lane >> 3, trow = 8 * wave + (lane & 7);                     // tail piece: lane = (xr, row), lanes >= 8 XR idle
+    const unsigned lp_t = (i0 + trow < p.I) ? (unsigned)((trow * hw + txr * p.W + 64) * 2) : kOob;
+    const long long dy_bytes = (long long)p.N * p.O * pq * 2, x_bytes = (long long)p.N * p.I * hw * 2;
+
+    const int steps_per_img = p.rowgroups * p.qchunks;
+    const int s0 = split * p.steps_per_split;
+    const int s1 = min(s0 + p.steps_per_split, p.N * steps_per_img);
+    int ld_n = s0 / steps_per_img;
+    int ld_rg = (s0 - ld_n * steps_per_img) / p.qchunks;
+    int ld_qc = s0 - ld_n * steps_per_img - ld_rg * p.qchunks;
+    int ld_buf = 0;
+
+    // state of the step being loaded (c_*) and of the one before it (f_*: the step whose x edge is fixed up next)
+    int c_prow0 = 0, c_q0 = 0, c_live = 0, f_q0 = 0, f_live = 0;
+    unsigned c_bufa = 0, f_bufa = 0, v_dy = 0, v_x = 0, v_t = 0;
+    long long c_dyoff = 0, c_xoff = 0;                                           // byte offsets of the image (n) in dy / x
+    auto begin_loads = [&](bool live) __attribute__((always_inline)) {
+        f_q0 = c_q0; f_live = c_live; f_bufa = c_bufa;
+        c_live = live ? -1 : 0;                                                  // a dead step still issues its pieces (0 records)
+        c_prow0 = ld_rg * R; c_q0 = ld_qc * kWgKQ;
+        c_bufa = ld_buf * BUF;
+        const int xorg = c_q0 - XLEAD;
+        v_dy = lp_dy | ((unsigned)!(c_q0 + 8 * pg < p.Q) << 31);
+        v_x = lp_x | ((unsigned)!((unsigned)(xorg + 8 * pg) < (unsigned)p.W) << 31);
+        v_t = lp_t | ((unsigned)!((unsigned)(xorg + 64) < (unsigned)p.W && (unsigned)(c_prow0 - p.pad + txr) < (unsigned)p.H) << 31);
+        c_dyoff = (long long)ld_n * p.O * pq * 2;
+        c_xoff = (long long)ld_n * p.I * hw * 2;
+        if (live) {
+            if (++ld_qc == p.qchunks) {
+                ld_qc = 0;
+                if (++ld_rg == p.rowgroups) { ld_rg = 0; ld_n++; }
+            }
+        }
+        if (++ld_buf == NBUF) ld_buf = 0;
+    };
+    // records = bytes up to the end of the tensor (a straddling granule's dwords beyond it read as zero), 0 for a dead row
+    auto records = [&](long long remaining, bool ok) __attribute__((always_inline)) -> int {
+        const int r = remaining > 0x7fffffffll ? 0x7fffffff : (int)remaining;
+        return (ok && r > 0) ? (r & c_live) : 0;
+    };
+    auto issue_piece = [&](auto idx) __attribute__((always_inline)) {
+        constexpr int I = decltype(idx)::value;
+        if constexpr (I < R) {
+            constexpr int rr = I;
+            const int row = c_prow0 + rr;
+            const long long off = c_dyoff + ((long long)o0 * pq + row * p.Q + c_q0) * 2;
+            lds_dma_b128(make_rsrc((const char*)p.dy + off, records(dy_bytes - off, row < p.P)), v_dy,
+                         lds0 + c_bufa + rr * (64 * ROWB) + wave * 1024);
+        } else if constexpr (I < R + XR) {
+            constexpr int xr = I - R;
+            const int row = c_prow0 - p.pad + xr;
+            const long long off = c_xoff + ((long long)i0 * hw + row * p.W + c_q0 - XLEAD) * 2;
+            lds_dma_b128(make_rsrc((const char*)p.x + off, records(x_bytes - off, (unsigned)row < (unsigned)p.H)), v_x,
+                         lds0 + c_bufa + DY_BYTES + xr * (64 * ROWB) + wave * 1024);
+        } else {
+            const int row = c_prow0 - p.pad;                                     // lanes add their xr
+            const long long off = c_xoff + ((long long)i0 * hw + row * p.W + c_q0 - XLEAD) * 2;
+            if (lane < 8 * XR)
+                lds_dma_b128(make_rsrc((const char*)p.x + off, records(x_bytes - off, true)), v_t,
+                             lds0 + c_bufa + DY_BYTES + XMAIN + wave * (XR * 128));
+        }
+    };
+    auto issue_range = [&](auto lo, auto hi) __attribute__((always_inline)) {
+        constexpr int LO = decltype(lo)::value, HI = decltype(hi)::value;
+        static_for<LO, HI>([&](auto i) __attribute__((always_inline)) { issue_piece(i); });
+    };
+    // zero the pixels right of x's edge inside the granule that straddles it, in the rows this wave loaded (step f_*)
+    auto fix_edge = [&]() __attribute__((always_inline)) {
+        const int rel = p.W - (f_q0 - XLEAD);                                    // edge column relative to the staged origin
+        const int gw = rel >> 3, vw = rel & 7;                                   // granule, valid pixels in it (even)
+        if (f_live && vw != 0 && gw >= 0 && gw <= (TAIL ? 8 : 7) && lane < 8 * XR) {
+            const int xr = lane >> 3, row = 8 * wave + (lane & 7);
+            char* g = lds + f_bufa + DY_BYTES +
+                      (gw < 8 ? xr * (64 * ROWB) + row * ROWB + ((gw ^ ((row >> 1) & 7)) << 4) : XMAIN + wave * (XR * 128) + lane * 16);
+#pragma unroll
+            for (int d = 1; d < 4; d++)
+                if (2 * d >= vw) *(unsigned*)(g + 4 * d) = 0u;
+        }
+    };
+
+    // ---- fragment read offsets inside a buffer (swizzled)
+    const int rowA = wo * 32 + r32, rowB = wi * 32 + r32;
+    const int fA = (rowA >> 1) & 7, fB = (rowB >> 1) & 7;
+    unsigned a_off[2], x0_off[2], x1_off[2][XR];
+#pragma unroll
+    for (int kq = 0; kq < 2; kq++) {
+        const int g = th * 4 + kq * 2 + h;
+        a_off[kq] = rowA * ROWB + ((g ^ fA) << 4);
+        x0_off[kq] = DY_BYTES + rowB * ROWB + ((g ^ fB) << 4);
+#pragma unroll
+        for (int xr = 0; xr < XR; xr++)
+            x1_off[kq][xr] = (g + 1 < 8) ? DY_BYTES + xr * (64 * ROWB) + rowB * ROWB + (((g + 1) ^ fB) << 4)
+                                         : DY_BYTES + XMAIN + (rowB >> 3) * (XR * 128) + xr * 128 + (rowB & 7) * 16;
+    }
+
+    // ---- pipeline: NBUF-1 steps of loads in flight; a step's loads are waited for (counted vmcnt) before the barrier that
+    // precedes its use.
+#pragma unroll
+    for (int i = 0; i < NBUF - 1; i++) {
+        begin_loads(s0 + i < s1);
+        issue_range(std::integral_constant<int, 0>{}, std::integral_constant<int, NPIECE>{});
+    }
+    asm volatile("s_waitcnt vmcnt(0)");
+    if (NBUF == 3) {                       // both prologue steps have landed: fix both edges
+        fix_edge();
+        { const int q = f_q0, l = f_live; const unsigned b = f_bufa; f_q0 = c_q0; f_live = c_live; f_bufa = c_bufa; fix_edge(); f_q0 = q; f_live = l; f_bufa = b; }
+    } else {
+        f_q0 = c_q0; f_live = c_live; f_bufa = c_bufa;
+        fix_edge();
+    }
+    __syncthreads();
+    int cbuf = 0;
+    for (int step = s0; step < s1; step++) {
+        begin_loads(step + NBUF - 1 < s1);                 // into the buffer everyone left at the last barrier
+        const char* buf = lds + cbuf * BUF;
+        typedef typename std::conditional<std::is_same<T, bf16_t>::value, bf16x8, f16x8>::type frag_t;
+        static_for<0, 2>([&](auto kqc) __attribute__((always_inline)) {
+            constexpr int kq = decltype(kqc)::value;
+            frag_t a[R];
+#pragma unroll
+            for (int rr = 0; rr < R; rr++) a[rr] = *(const frag_t*)(buf + a_off[kq] + rr * (64 * ROWB));
+            static_for<0, XR>([&](auto xrc) __attribute__((always_inline)) {
+                constexpr int xr = decltype(xrc)::value;
+                constexpr int it = kq * XR + xr, NIT = 2 * XR;
+                issue_range(std::integral_constant<int, (it * NPIECE) / NIT>{}, std::integral_constant<int, ((it + 1) * NPIECE) / NIT>{});
+                if constexpr (!TAIL) {
+                    const frag_t b = *(const frag_t*)(buf + x0_off[kq] + xr * (64 * ROWB));
+                    constexpr int rr = xr;
+                    if constexpr (std::is_same<T, bf16_t>::value) acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[rr], b, acc[0], 0, 0, 0);
+                    else acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[rr], b, acc[0], 0, 0, 0);
+                } else {
+                    const uint4 lo = *(const uint4*)(buf + x0_off[kq] + xr * (64 * ROWB));
+                    asm volatile("" : : "v"(lo.x), "v"(lo.y), "v"(lo.z));       // keep the read a full (conflict-free) b128
+                    const uint4 hi = *(const uint4*)(buf + x1_off[kq][xr]);
+                    const unsigned d[5] = {lo.w, hi.x, hi.y, hi.z, hi.w};       // pixels 8g+6 .. 8g+15 of the staged row
+#pragma unroll
+                    for (int sft = 0; sft < KS; sft++) {
+                        union { unsigned u[4]; frag_t f; } b;
+#pragma unroll
+                        for (int w = 0; w < 4; w++)
+                            b.u[w] = (sft == 0) ? d[w] : (sft == 1) ? __builtin_amdgcn_alignbyte(d[w + 1], d[w], 2) : d[w + 1];
+#pragma unroll
+                        for (int rr = 0; rr < R; rr++) {
+                            const int r = xr - rr;
+                            const int t = r * KS + sft;
+                            if (r >= 0 && r < KS) {
+                                if constexpr (std::is_same<T, bf16_t>::value)
+                                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[rr], b.f, acc[t], 0, 0, 0);
+                                else
+                                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[rr], b.f, acc[t], 0, 0, 0);
+                            }
+                        }
+                    }
+                }
+            });
+        });
+        // the next step's loads (issued NBUF-2 iterations ago, or just now when NBUF == 2) must have landed; patch its edge
+        if (NBUF == 3) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(NPIECE));
+        else { asm volatile("s_waitcnt vmcnt(0)"); f_q0 = c_q0; f_live = c_live; f_bufa = c_bufa; }
+        fix_edge();
+        __syncthreads();
+        if (++cbuf == NBUF) cbuf = 0;
+    }
+    // ---- add the two pixel halves through LDS (the ring is free now): th 1 parks its accumulators, th 0 adds them and
+    // writes the partial tile D[row = o][col = i].
+    asm volatile("s_waitcnt vmcnt(0)");
+    __syncthreads();
+    {
+        float* red = (float*)lds;
+        constexpr int TPR_CAP = (NBUF * BUF) / (4 * 16 * 64 * (int)sizeof(float));     // taps per round
+        constexpr int TPR = TPR_CAP < KK ? TPR_CAP : KK;
+        static_assert(TPR >= 1, "LDS too small for the half-sum");
+        const int wv4 = wave & 3;
+#pragma unroll
+        for (int t0 = 0; t0 < KK; t0 += TPR) {
+            if (t0 > 0) __syncthreads();
+            if (th == 1) {
+#pragma unroll
+                for (int t = t0; t < t0 + TPR && t < KK; t++)
+#pragma unroll
+                    for (int reg = 0; reg < 16; reg++) red[((wv4 * TPR + (t - t0)) * 16 + reg) * 64 + lane] = acc[t][reg];
+            }
+            __syncthreads();
+            if (th == 0) {
+#pragma unroll
+                for (int t = t0; t < t0 + TPR && t < KK; t++)
+#pragma unroll
+                    for (int reg = 0; reg < 16; reg++) acc[t][reg] += red[((wv4 * TPR + (t - t0)) * 16 + reg) * 64 + lane];
+            }
+        }
+    }
+    if (th == 0) {
+        float* out = p.part + (size_t)split * p.O * p.I * KK;
+#pragma unroll
+        for (int reg = 0; reg < 16; reg++) {
+            const int o = o0 + wo * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+            const int i = i0 + wi * 32 + r32;
+            if (o < p.O && i < p.I) {
+                float* dst = out + ((size_t)o * p.I + i) * KK;
+#pragma unroll
+                for (int t = 0; t < KK; t++) dst[t] = acc[t][reg];
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(float* __restrict__ dw, const float* __restrict__ part, long long numel, int splits) {
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < numel; idx += (long long)gridDim.x * blockDim.x) {
         float s = 0.f;
@@ -1032,12 +1300,18 @@ extern "C" int afcm_conv2d_wgrad(float* dw, float* workspace, const void* dy, co
                            if (ks == 3 && (pad & 1) == 0) hipLaunchKernelGGL((conv2d_wgrad16_kernel<T, 3, 0, NB>), grid, block, 0, st, p); \
                            else if (ks == 3) hipLaunchKernelGGL((conv2d_wgrad16_kernel<T, 3, 1, NB>), grid, block, 0, st, p); \
                            else hipLaunchKernelGGL((conv2d_wgrad16_kernel<T, 1, 0, NB>), grid, block, 0, st, p); } while (0)
-    const bool legacy = getenv("AFCM_WGRAD_LEGACY") != nullptr;     // tuning aid: the register-staged kernel
+#define AFCM_WG16G(T) do { constexpr int NB = 3; \
+                            if (ks == 3) hipLaunchKernelGGL((conv2d_wgrad16g_kernel<T, 3, NB>), grid, block, 0, st, p); \
+                            else hipLaunchKernelGGL((conv2d_wgrad16g_kernel<T, 1, NB>), grid, block, 0, st, p); } while (0)
+    const char* wsel = getenv("AFCM_WGRAD_KERNEL");                 // tuning aid: "regs" (register-staged) or "dword" (4-byte LDS-DMA)
+    const bool legacy = wsel && !strcmp(wsel, "regs");
+    const bool granule = !(wsel && !strcmp(wsel, "dword")) && ((ks == 3 && pad == 2) || (ks == 1 && pad == 0));
     switch (dtype) {
         case AFCM_F32: AFCM_WG(float, 1); break;
-        case AFCM_F16: if (legacy) AFCM_WG(f16_t, 2); else AFCM_WG16(f16_t); break;
-        default: if (legacy) AFCM_WG(bf16_t, 2); else AFCM_WG16(bf16_t); break;
+        case AFCM_F16: if (legacy) AFCM_WG(f16_t, 2); else if (granule) AFCM_WG16G(f16_t); else AFCM_WG16(f16_t); break;
+        default: if (legacy) AFCM_WG(bf16_t, 2); else if (granule) AFCM_WG16G(bf16_t); else AFCM_WG16(bf16_t); break;
     }
+#undef AFCM_WG16G
 #undef AFCM_WG16
 #undef AFCM_WG
     int rc = hip_status(hipGetLastError());
