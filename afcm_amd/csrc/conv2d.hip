@@ -118,6 +118,20 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? 1 : 2)) void conv2d_fwd_kern
 
     unsigned wreg[NWP][4];
     unsigned preg[8][F32 ? 4 : 2];
+    // 16-bit patch loads are raw buffer loads of 8 bytes (4 pixels of one channel, 4-byte aligned): the row / column
+    // validity of a thread never changes, so it is baked into the offset (out of range -> zeros, no branches); a group
+    // that straddles the image border keeps its valid half through the and-masks below.
+    constexpr unsigned kOob = 0x80000000u;
+    const bool d0ok = rowok && (unsigned)ix < (unsigned)p.W, d1ok = rowok && (unsigned)(ix + 2) < (unsigned)p.W;
+    const unsigned pmask0 = d0ok ? ~0u : 0u, pmask1 = d1ok ? ~0u : 0u;
+    const bool any_partial = __builtin_amdgcn_ballot_w64(d0ok != d1ok) != 0;          // wave-uniform
+    // a group whose first half lies left of the image loads from its second half instead (never touch bytes before a row 0)
+    const bool lshift = !d0ok && d1ok;
+    const bool any_lshift = __builtin_amdgcn_ballot_w64(lshift) != 0;
+    const unsigned pvoff = (d0ok || d1ok) ? (unsigned)(((long long)cg * 8 * p.H * p.W + pix_off + (lshift ? 2 : 0)) * (long long)sizeof(T)) : kOob;
+    const long long img_bytes = (long long)p.Cin * p.H * p.W * (long long)sizeof(T);
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)xn, 0, (int)(img_bytes > 0x7fffffffll ? 0x7fffffffll : img_bytes), 0x00020000);
+    const int hw2 = p.H * p.W * (int)sizeof(T);
 
     auto issue_loads = [&](int kc) __attribute__((always_inline)) {
         const T* wsrcp = (const T*)p.wp + (size_t)kc * wchunk;
@@ -127,17 +141,29 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? 1 : 2)) void conv2d_fwd_kern
                 const uint4 t = *(const uint4*)(wsrcp + wsrc0 + i * wsrc_step);
                 wreg[i][0] = t.x; wreg[i][1] = t.y; wreg[i][2] = t.z; wreg[i][3] = t.w;
             }
+        if constexpr (F32) {
 #pragma unroll
-        for (int c = 0; c < 8; c++) {
-            const int ch = kc * BK + cg * 8 + c;
-            const bool chok = rowok && ch < p.Cin;
-            const T* src = xn + ((long long)ch * p.H * p.W + pix_off);
-            if (F32) {
+            for (int c = 0; c < 8; c++) {
+                const int ch = kc * BK + cg * 8 + c;
+                const bool chok = rowok && ch < p.Cin;
+                const T* src = xn + ((long long)ch * p.H * p.W + pix_off);
 #pragma unroll
                 for (int e = 0; e < 4; e++) preg[c][e] = (chok && (unsigned)(ix + e) < (unsigned)p.W) ? *(const unsigned*)(src + e) : 0u;
-            } else {
-                preg[c][0] = (chok && (unsigned)ix < (unsigned)p.W) ? *(const unsigned*)(src) : 0u;
-                preg[c][1] = (chok && (unsigned)(ix + 2) < (unsigned)p.W) ? *(const unsigned*)(src + 2) : 0u;
+            }
+        } else {
+            // channels past Cin only exist in the last chunk: they read whatever follows (or zeros past the image) and are
+            // cleared below; everything else needs no per-load work: the chunk's channel offset rides in the scalar offset
+            const bool tailchunk = (kc + 1) * BK > p.Cin;
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+                typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+                const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(xrs, pvoff, (kc * BK + c) * hw2, 0);
+                preg[c][0] = v.x; preg[c][1] = v.y;
+            }
+            if (tailchunk) {
+#pragma unroll
+                for (int c = 0; c < 8; c++)
+                    if (kc * BK + cg * 8 + c >= p.Cin) { preg[c][0] = 0u; preg[c][1] = 0u; }
             }
         }
     };
@@ -161,6 +187,14 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? 1 : 2)) void conv2d_fwd_kern
                     for (int c = 0; c < 8; c++) d[c] = preg[c][e];
                 }
             } else {
+                if (any_lshift) {
+#pragma unroll
+                    for (int c = 0; c < 8; c++) preg[c][1] = lshift ? preg[c][0] : preg[c][1];
+                }
+                if (any_partial) {
+#pragma unroll
+                    for (int c = 0; c < 8; c++) { preg[c][0] &= pmask0; preg[c][1] &= pmask1; }
+                }
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
                     const unsigned sel = (e & 1) ? 0x07060302u : 0x05040100u;
