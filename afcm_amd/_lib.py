@@ -5,7 +5,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libafcm_hip.so')
+LIB_PATH = os.environ.get('AFCM_HIP_LIB') or os.path.join(_HERE, 'libafcm_hip.so')     # AFCM_HIP_LIB: an alternative build (kernel experiments)
 
 F32, F16, BF16 = 0, 1, 2
 E_NOKERNEL, E_INVALID = -1, -2

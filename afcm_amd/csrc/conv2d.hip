@@ -106,7 +106,9 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? 1 : 2)) void conv2d_fwd_kern
     const int wsrc_step = TPI * p.Opad * BK, wdst_step = TPI * BM_O * PITCH;
     const size_t wchunk = (size_t)KK * p.Opad * BK;
     // patch: one item = 4 pixels x 8 channels
-    const int cg = tid % NCG, pg = tid / NCG;
+    // lanes 0-31 / 32-63 of a wave take the two channel groups of the same 32 pixel groups: one load instruction then reads
+    // two contiguous runs (one per channel) instead of two interleaved streams
+    const int cg = F32 ? 0 : (tid >> 5) & 1, pg = F32 ? tid : (tid & 31) + 32 * (tid >> 6);
     const int pcols = PWL >> 2;
     const int prow = pg / pcols, pcol4 = pg - prow * pcols;
     const bool pvalid = prow < PH;
@@ -135,12 +137,18 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? 1 : 2)) void conv2d_fwd_kern
 
     auto issue_loads = [&](int kc) __attribute__((always_inline)) {
         const T* wsrcp = (const T*)p.wp + (size_t)kc * wchunk;
+#ifdef AFCM_FWD_ABL_WLOADS
+        if (kc == 0)
+#endif
 #pragma unroll
         for (int i = 0; i < NWP; i++)
             if ((NPIECES % 256 == 0) || tid + i * 256 < NPIECES) {
                 const uint4 t = *(const uint4*)(wsrcp + wsrc0 + i * wsrc_step);
                 wreg[i][0] = t.x; wreg[i][1] = t.y; wreg[i][2] = t.z; wreg[i][3] = t.w;
             }
+#ifdef AFCM_FWD_ABL_PLOADS
+        if (kc > 0) return;
+#endif
         if constexpr (F32) {
 #pragma unroll
             for (int c = 0; c < 8; c++) {
@@ -213,7 +221,9 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? 1 : 2)) void conv2d_fwd_kern
     write_lds();
     __syncthreads();
     for (int kc = 0; kc < p.nkc; kc++) {
+#ifndef AFCM_FWD_ABL_LOADS
         if (kc + 1 < p.nkc) issue_loads(kc + 1);
+#endif
 #pragma unroll
         for (int r = 0; r < KS; r++)
 #pragma unroll
@@ -254,7 +264,9 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? 1 : 2)) void conv2d_fwd_kern
             }
         __syncthreads();
         if (kc + 1 < p.nkc) {
+#ifndef AFCM_FWD_ABL_WRITES
             write_lds();
+#endif
             __syncthreads();
         }
     }
@@ -1298,7 +1310,8 @@ static int wgrad_rows_per_step(int dtype) { return dtype == AFCM_F32 ? 1 : 2; }
 
 extern "C" int afcm_conv2d_wgrad_splits(int32_t n, int32_t cout, int32_t cin, int32_t p_rows) {
     const int tiles = cdiv(cout, 64) * cdiv(cin, 64);
-    int splits = cdiv(768, tiles);
+    const char* tgt = getenv("AFCM_WGRAD_WGS");            // tuning aid: workgroups to aim for
+    int splits = cdiv(tgt ? atoi(tgt) : 768, tiles);
     const long long ksteps = (long long)n * p_rows;   // upper bound on the macro-steps of any dtype
     if (splits > ksteps) splits = (int)ksteps;
     if (splits < 1) splits = 1;
