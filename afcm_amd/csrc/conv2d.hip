@@ -137,18 +137,12 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? 1 : 2)) void conv2d_fwd_kern
 
     auto issue_loads = [&](int kc) __attribute__((always_inline)) {
         const T* wsrcp = (const T*)p.wp + (size_t)kc * wchunk;
-#ifdef AFCM_FWD_ABL_WLOADS
-        if (kc == 0)
-#endif
 #pragma unroll
         for (int i = 0; i < NWP; i++)
             if ((NPIECES % 256 == 0) || tid + i * 256 < NPIECES) {
                 const uint4 t = *(const uint4*)(wsrcp + wsrc0 + i * wsrc_step);
                 wreg[i][0] = t.x; wreg[i][1] = t.y; wreg[i][2] = t.z; wreg[i][3] = t.w;
             }
-#ifdef AFCM_FWD_ABL_PLOADS
-        if (kc > 0) return;
-#endif
         if constexpr (F32) {
 #pragma unroll
             for (int c = 0; c < 8; c++) {
@@ -221,9 +215,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? 1 : 2)) void conv2d_fwd_kern
     write_lds();
     __syncthreads();
     for (int kc = 0; kc < p.nkc; kc++) {
-#ifndef AFCM_FWD_ABL_LOADS
         if (kc + 1 < p.nkc) issue_loads(kc + 1);
-#endif
 #pragma unroll
         for (int r = 0; r < KS; r++)
 #pragma unroll
@@ -264,9 +256,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? 1 : 2)) void conv2d_fwd_kern
             }
         __syncthreads();
         if (kc + 1 < p.nkc) {
-#ifndef AFCM_FWD_ABL_WRITES
             write_lds();
-#endif
             __syncthreads();
         }
     }
@@ -553,10 +543,8 @@ __global__ __launch_bounds__(512, (sizeof(T) == 4 ? 1 : 2)) void conv2d_wgrad_ke
             if (step + 1 < s1) {
                 lds_dy = lds + ((step + 1 - s0) & 1) * LDS_ONE;
                 lds_x = lds_dy + 64 * R * PDY;
-#ifndef AFCM_WG_ABLATE_STAGE
                 write_lds();                        // step+1 (its loads were issued one step ago)
                 if (step + 2 < s1) issue_loads();
-#endif
             }
             lds_dy = lds + ((step - s0) & 1) * LDS_ONE;
             lds_x = lds_dy + 64 * R * PDY;
