@@ -5,18 +5,31 @@
 // ~11 G FMA per 256^2 image against 0.62 GB of 16-bit traffic: on the vector pipe it is compute-bound at ~2x the
 // HBM time before any overhead.  The four separable FIR passes are banded-Toeplitz matrix products; run as
 // v_mfma_f32_16x16x32_{bf16,f16} they cost ~0.25 CU-cycles per output pixel even at ~19-25 % band occupancy.
+// What is left for the vector pipe is kept to ~1 instruction per upsampled element (r02):
+//   * the leaky ReLU itself runs on the matrix cores:  lrelu(v) = slope*v + (1-slope)*relu(v), so
+//         X3 = DV*lrelu(X2) = (slope*DV)*X2 + ((1-slope)*DV)*relu(X2)
+//     and relu() of packed 16-bit floats is ONE v_pk_max_i16 against 0 for two elements (sign-magnitude bit patterns
+//     order like signed integers below zero).  Backward is the same identity with relu(X2) replaced by X2 AND a
+//     16-bit-per-element mask looked up from the saved sign codes (256-entry LDS table).
+//   * the clamp (rarely reached: |v| > 256) is detected per 16x16 tile with a wave-uniform ballot; only then does a
+//     tile take the exact per-element path.
+//   * the input tile is copied HBM -> LDS without conversion (the caller's producer adds the bias; a template flag
+//     keeps the fused-bias staging for direct API users), sign codes and outputs leave through LDS as full 16-byte
+//     row segments.
 //
 // Dataflow per tile (fp32 accumulation everywhere, 16-bit operands):
-//   In (LDS, [row][col])  --A-->  X1 = In * UH        up-FIR along x   D[in-row][ucol]
-//   X1 (registers)        --B-->  X2 = UV * X1        up-FIR along y   D[urow][ucol]   (accumulator tile used as
-//   act(X2) (registers)   --B-->  X3 = DV * act(X2)   down-FIR along y D[orow][ucol]    the next B operand: no LDS)
-//   X3 (LDS, [ucol][orow]) -tr->  Y  = X3 * DH        down-FIR along x D[orow][ocol]   (ds_read_b64_tr_b16)
+//   In (LDS, [row][col])  --A-->  X1  = In * UH         up-FIR along x    D[in-row][ucol]
+//   X1 (registers)        --B-->  X2  = UV * X1         up-FIR along y    D[urow][ucol]    (accumulator tile used as
+//   X2, relu(X2) (regs)   --A-->  X3' = X2' * DV'       down-FIR along y  D[ucol][orow]     the next operand: no LDS)
+//   X3 (LDS, [orow][ucol]) -B-->  Y'  = DH' * X3'       down-FIR along x  D[ocol][orow]    (lane = 4 consecutive columns)
+//   Y (LDS, [orow][ocol])  ---->  16-byte row segments to HBM
 // UH/UV/DV/DH are constant Toeplitz fragments built once per layer by flrelu_mfma_prepare_kernel.
-// Only In and X3 touch LDS; the up^2-times-larger activated intermediate lives in accumulators.
+// Only In, X3 and Y touch LDS; the up^2-times-larger activated intermediate lives in accumulators.
 //
 // Sign codes use a private "row-quad" layout: one byte = the codes of 4 consecutive rows of one column
-// ([N*C][ceil(sh/4)][swq]); forward writes them from the X2 accumulator layout, backward (the same kernel with
-// up/down swapped) reads them with a funnel shift for the row offset.
+// ([N*C][ceil(sh/4)][swq], code of row r at bits 2r..2r+1: bit0 = negative, bit1 = clamped); forward assembles them
+// from the packed X2 words, backward (the same kernel with up/down swapped) reads them with a funnel shift for the
+// row offset.
 #include <type_traits>
 
 #include "common.h"
@@ -26,14 +39,16 @@ namespace afcm {
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 mbf16x8;
 typedef __attribute__((ext_vector_type(8))) _Float16 mf16x8;
-typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(2))) short s16x2;
+typedef __attribute__((ext_vector_type(2))) unsigned short u16x2;
 
 struct FlreluMfmaParams {
     const void* x;
     void* y;
     const void* b;
     unsigned char* s;
-    const void* ws;        // constant fragments
+    const void* ws;        // constant fragments + mask table
     float* plane_sum;      // optional fp32 [N*C][tilesX*tilesY]: per-tile sums of this launch's outputs (bias gradient without a second pass)
     int xw, xh, yw, yh, C;
     int px0, py0;
@@ -42,7 +57,9 @@ struct FlreluMfmaParams {
     int sx, sy, shq, swq;  // sign tensor: rows of quads, bytes per row
 };
 
-constexpr int kFUT = 6;   // taps per polyphase branch of the up filter (filter_size of the model)
+constexpr int kFUT = 6;            // taps per polyphase branch of the up filter (filter_size of the model)
+constexpr int kWsTable = 16384;    // byte offset of the 256-entry sign-code -> keep-mask table inside the workspace
+constexpr int kWsBytes = kWsTable + 256 * 8;
 
 // Geometry shared by the kernel, the prepare kernel and the host.
 template <int UP, int DOWN, int TOW, int TOH>
@@ -59,36 +76,43 @@ struct MfmaGeom {
     static constexpr int NQ = ((NVB - 1) / UP) + 1;            // packed X1 tile pairs (mb0 = vb / UP)
     static constexpr int IROWS = 16 * NMB;
     static constexpr int IWSTEP = GW / UP;                     // input-window advance per group
-    static constexpr int TIW = IWSTEP * (NG - 1) + 32;
+    static constexpr int TIW = IWSTEP * (NG - 1) + 32;         // staged columns; column 0 = input column I0x - (I0x & 1)
     static constexpr int PIN = ((TIW + 7) / 8) * 8 + ((((TIW + 7) / 8) % 2 == 0) ? 8 : 0);   // 16-B units, odd count
     static constexpr int XCOLS = NG * GW;                      // computed upsampled columns
-    static constexpr int PX3 = TOH + 4;                        // X3T pitch (elements)
-    static constexpr int X3ROWS = cmax(NG * GW, 16 * DOWN * (NCB - 1) + 32 * NDVK);   // the last K window of down-x overhangs
-    static constexpr int NFRAG = NB + UP + 2 * NDVK;           // UH[NB] UV[UP] DV[NDVK] DH[NDVK]
+    static constexpr int X3COLS = cmax(XCOLS, 16 * DOWN * (NCB - 1) + 32 * NDVK);   // the last K window of down-x overhangs
+    static constexpr int PX3 = 8 * (cdiv(X3COLS, 8) | 1);      // X3 pitch (elements): an odd number of 16-B units
+    static constexpr int POUT = TOW + 8;                       // staged output pitch (elements): odd number of 16-B units
+    static constexpr int NFRAG = NB + UP + 3 * NDVK;           // UH[NB] UV[UP] DVs[NDVK] DVr[NDVK] DH[NDVK]
+    static constexpr int SGW_ROWS = 4 * NVB;                   // staged sign quad-rows (WRITE)
+    static constexpr int SGW_PITCH = XCOLS;                    // bytes; XCOLS is a multiple of 16
     static constexpr int SGN_ROWS = 4 * NVB + 1;               // staged sign quad-rows (READ)
     static constexpr int SGN_WORDS = XCOLS / 4 + 1;            // aligned dwords covering one staged sign row
     static constexpr int SGN_PITCH = 4 * SGN_WORDS + 12;
-    static_assert(TOW % 16 == 0 && TOH % 16 == 0 && (TOW * DOWN) % UP == 0 && (TOH * DOWN) % UP == 0, "tile shape");
-    static_assert((TOH * DOWN) % 4 == 0, "sign quads");
+    static_assert(TOW % 16 == 0 && TOH % 16 == 0 && (TOW * DOWN) % (2 * UP) == 0 && (TOH * DOWN) % UP == 0, "tile shape");
+    static_assert((TOH * DOWN) % 4 == 0 && (TOW * DOWN) % 16 == 0, "sign quads / 16-byte sign segments");
+    static_assert((GW - 1) / UP + 1 + kFUT + 1 <= 32, "shifted input window must fit the 32-wide K window");
+    static_assert(NFRAG * 1024 <= kWsTable, "workspace");
+    static_assert((POUT / 8) % 2 == 1 && (PX3 / 8) % 2 == 1, "LDS pitches");
 };
 
 // row index inside a 32-row K window carried by fragment element (g, j): two stacked accumulator tiles
 __host__ __device__ __forceinline__ int krow(int g, int j) { return 16 * (j >> 2) + 4 * g + (j & 3); }
 
 // ---------------------------------------------------------------------------------------------
-// Constant fragments.  Layout: [frag][lane][8] elements of T.
+// Constant fragments.  Layout: [frag][lane][8] elements of T, then (byte kWsTable) the keep-mask table.
 template <typename T, int UP, int DOWN, int TOW, int TOH>
 __global__ void flrelu_mfma_prepare_kernel(T* __restrict__ ws, const float* __restrict__ fu, const float* __restrict__ fd,
-                                           int px0, int py0, int flip, float gain_total) {
+                                           int px0, int py0, int flip, float gain_total, float slope) {
     typedef MfmaGeom<UP, DOWN, TOW, TOH> G;
     const int phx = pos_mod(px0, UP), phy = pos_mod(py0, UP);
+    const int odd = (-floor_div(px0, UP)) & 1;                // the staged tile starts one column early when I0x is odd
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < G::NFRAG * 64 * 8; idx += gridDim.x * blockDim.x) {
         const int j = idx & 7, lane = (idx >> 3) & 63, frag = idx >> 9;
         const int l15 = lane & 15, g = lane >> 4;
         float v = 0.f;
         if (frag < G::NB) {
-            // UH[nb]: B[k][n], k = 8g + j (input column in the window), n = l15 (ucol 16nb + n of the group)
-            const int k = 8 * g + j, urel = 16 * frag + l15;
+            // UH[nb]: B[k][n], k = 8g + j (staged column of the window), n = l15 (ucol 16nb + n of the group)
+            const int k = 8 * g + j - odd, urel = 16 * frag + l15;
             const int a = urel % UP, o = (a > phx) ? 1 : 0;
             const int kmin = o ? UP - (a - phx) : phx - a;
             const int jj = k - urel / UP - o;
@@ -106,18 +130,29 @@ __global__ void flrelu_mfma_prepare_kernel(T* __restrict__ ws, const float* __re
                 const int tap = kmin + UP * jj;
                 v = (flip ? fu[tap] : fu[G::FU - 1 - tap]) * gain_total;
             }
-        } else if (frag < G::NB + UP + G::NDVK) {
-            // DV[t]: A[n][k], n = l15 (orow), k -> urow 32t + krow(g, j) of the window starting at 16*DOWN*ob
-            const int t = frag - G::NB - UP;
+        } else if (frag < G::NB + UP + 2 * G::NDVK) {
+            // DVs[t] / DVr[t]: [n][k], n = l15 (orow), k -> urow 32t + krow(g, j) of the window starting at 16*DOWN*ob;
+            // scaled by slope (applied to X2) and by 1 - slope (applied to relu(X2))
+            const int t2 = frag - G::NB - UP, t = t2 % G::NDVK;
             const int kk = 32 * t + krow(g, j) - DOWN * l15;
-            if (kk >= 0 && kk < G::FD) v = flip ? fd[kk] : fd[G::FD - 1 - kk];
+            if (kk >= 0 && kk < G::FD) v = (flip ? fd[kk] : fd[G::FD - 1 - kk]) * (t2 < G::NDVK ? slope : 1.f - slope);
         } else {
-            // DH[t]: B[k][n], k = 8g + j natural (ucol 32t + k of the window starting at 16*DOWN*cb), n = l15 (ocol)
-            const int t = frag - G::NB - UP - G::NDVK;
+            // DH[t]: [k][n], k = 8g + j natural (ucol 32t + k of the window starting at 16*DOWN*cb), n = l15 (ocol)
+            const int t = frag - G::NB - UP - 2 * G::NDVK;
             const int kk = 32 * t + 8 * g + j - DOWN * l15;
             if (kk >= 0 && kk < G::FD) v = flip ? fd[kk] : fd[G::FD - 1 - kk];
         }
         ws[idx] = from_f32<T>(v);
+    }
+    // keep-mask table: entry c (one sign byte = 4 rows) -> two dwords of 16-bit lanes, all ones where the element is
+    // neither negative nor clamped (rows 0,1 | rows 2,3)
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < 256; c += gridDim.x * blockDim.x) {
+        unsigned m[2];
+        for (int h = 0; h < 2; h++)
+            m[h] = (((c >> (4 * h)) & 3) ? 0u : 0xffffu) | (((c >> (4 * h + 2)) & 3) ? 0u : 0xffff0000u);
+        unsigned* tab = (unsigned*)((char*)ws + kWsTable);
+        tab[2 * c] = m[0];
+        tab[2 * c + 1] = m[1];
     }
 }
 
@@ -139,68 +174,125 @@ __device__ __forceinline__ unsigned pack2(float lo, float hi) {
     return r.u;
 }
 
-// Two accumulator tiles -> one 8-element B fragment: elements 0-3 from `lo`, 4-7 from `hi` (K order = krow()).
-template <typename T>
-__device__ __forceinline__ typename MfmaOps<T>::frag pack_pair(const f32x4& lo, const f32x4& hi) {
-    union { unsigned u[4]; typename MfmaOps<T>::frag f; } r;
-    r.u[0] = pack2<T>(lo[0], lo[1]);
-    r.u[1] = pack2<T>(lo[2], lo[3]);
-    r.u[2] = pack2<T>(hi[0], hi[1]);
-    r.u[3] = pack2<T>(hi[2], hi[3]);
+template <typename F>
+__device__ __forceinline__ F as_frag(const u32x4& v) {
+    union { u32x4 u; F f; } r;
+    r.u = v;
     return r.f;
 }
 
-template <typename T, int UP, int DOWN, int TOW, int TOH, int SIGN>
+// Two accumulator tiles -> one 8-element fragment: elements 0-3 from `lo`, 4-7 from `hi` (K order = krow()).
+template <typename T>
+__device__ __forceinline__ typename MfmaOps<T>::frag pack_pair(const f32x4& lo, const f32x4& hi) {
+    u32x4 r;
+    r[0] = pack2<T>(lo[0], lo[1]);
+    r[1] = pack2<T>(lo[2], lo[3]);
+    r[2] = pack2<T>(hi[0], hi[1]);
+    r[3] = pack2<T>(hi[2], hi[3]);
+    return as_frag<typename MfmaOps<T>::frag>(r);
+}
+
+// relu of two packed 16-bit floats: as signed 16-bit integers every negative float (sign bit set) is below zero
+__device__ __forceinline__ unsigned relu_pk(unsigned d) {
+    union { unsigned u; s16x2 s; } a, r;
+    a.u = d;
+    r.s = __builtin_elementwise_max(a.s, (s16x2){0, 0});
+    return r.u;
+}
+// sign bits of two packed 16-bit floats -> bit 0 and bit 16
+__device__ __forceinline__ unsigned signs_pk(unsigned d) {
+    union { unsigned u; u16x2 s; } a, r;
+    a.u = d;
+    r.s = a.s >> (u16x2){15, 15};
+    return r.u;
+}
+
+template <typename T, int UP, int DOWN, int TOW, int TOH, int SIGN, bool BIAS>
 __global__ __launch_bounds__((64 * MfmaGeom<UP, DOWN, TOW, TOH>::NG)) void flrelu_mfma_kernel(FlreluMfmaParams p) {
     typedef MfmaGeom<UP, DOWN, TOW, TOH> G;
     typedef MfmaOps<T> M;
     typedef typename M::frag frag;
     constexpr int NT = 64 * G::NG;
-    constexpr int SGN_BYTES = (SIGN == AFCM_SIGNS_READ) ? G::SGN_ROWS * G::SGN_PITCH : 0;
-    __shared__ __attribute__((aligned(16))) T lds_in[G::IROWS * G::PIN];
-    __shared__ __attribute__((aligned(16))) T lds_x3[G::X3ROWS * G::PX3];
+    constexpr int SGN_BYTES = (SIGN == AFCM_SIGNS_READ) ? G::SGN_ROWS * G::SGN_PITCH + 256 * 8
+                            : (SIGN == AFCM_SIGNS_WRITE) ? G::SGW_ROWS * G::SGW_PITCH : 0;
+    constexpr int IN_ELEMS = cmax(G::IROWS * G::PIN, TOH * G::POUT);          // the staged output tile reuses the input tile's space
+    __shared__ __attribute__((aligned(16))) T lds_in[IN_ELEMS];
+    __shared__ __attribute__((aligned(16))) T lds_x3[TOH * G::PX3];
     __shared__ __attribute__((aligned(16))) unsigned char lds_sg[SGN_BYTES > 0 ? SGN_BYTES : 16];
+    __shared__ unsigned lds_flag[G::NG];
+    T* const lds_out = lds_in;
+    const uint2* const lds_tab = (const uint2*)(lds_sg + G::SGN_ROWS * G::SGN_PITCH);   // READ only
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, g = lane >> 4;
+    // XCD-aware order: consecutive logical tiles (neighbours that share halos) stay on one XCD / one L2
     int bid = blockIdx.x;
+    {
+        const int total = gridDim.x;
+        if ((total & 7) == 0) bid = (bid & 7) * (total >> 3) + (bid >> 3);
+    }
     const int tx = bid % p.tilesX; bid /= p.tilesX;
     const int ty = bid % p.tilesY;
     const int plane = bid / p.tilesY;
     const int O0x = tx * TOW, O0y = ty * TOH;
     const int U0x = O0x * DOWN, U0y = O0y * DOWN;
     const int I0x = -floor_div(p.px0 - U0x, UP), I0y = -floor_div(p.py0 - U0y, UP);
+    const int S0x = I0x - (I0x & 1);                            // first staged column (even: aligned dword pairs)
+    const bool lastX = (tx == p.tilesX - 1), lastY = (ty == p.tilesY - 1);
+    bool has_clamp = false;                                     // READ: some staged code carries the clamp bit
 
-    // ---- stage the input tile (+ bias inside the image; zero outside: the bias is added before padding).
-    // One item = 8 consecutive columns of one row: 4 (or 5, odd column origin) aligned dword loads, realigned in
-    // registers, written with one 16-byte LDS store.  Needs an even plane width (all layers of the model).
+    // ---- stage the input tile: zero outside the image (the bias is added before padding).
+    // One item = 8 consecutive columns of one row = one 16-byte load from a 4-byte aligned address.  Rows outside the
+    // plane fall outside the buffer descriptor and read as zero; columns outside it are masked in the edge tiles.
     {
-        const T* xp = (const T*)p.x + (size_t)plane * p.xh * p.xw;
-        const float bias = p.b ? to_f32(((const T*)p.b)[plane % p.C]) : 0.f;
         constexpr int CH = G::PIN / 8;                       // 8-column chunks per staged row (incl. pitch padding)
         constexpr int NIT = cdiv(G::IROWS * CH, NT);
-        const int odd = I0x & 1;
-        unsigned raw[NIT][5];
+        const T* xp = (const T*)p.x + (size_t)plane * p.xh * p.xw;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)xp, 0, p.xh * p.xw * 2, 0x00020000);
+        const bool xedge = S0x < 0 || S0x + 8 * CH > p.xw;
+        u32x4 raw[NIT];
+        if (S0x < 0 && I0y <= 0) {
+            // the tile holds the plane's first row with columns left of it: byte offsets would go negative, so this one
+            // tile per plane fetches dword by dword with explicit column checks
 #pragma unroll
-        for (int i = 0; i < NIT; i++) {
-            const int idx = tid + i * NT;
-            const int r = idx / CH, c8 = idx - r * CH;
-            const int iy = I0y + r;
-            const int ix0 = I0x - odd + 8 * c8;              // even column of the first dword
-            const bool rok = idx < G::IROWS * CH && (unsigned)iy < (unsigned)p.xh;
-            const T* src = xp + (long long)iy * p.xw + ix0;
+            for (int i = 0; i < NIT; i++) {
+                const int idx = tid + i * NT;
+                const int r = idx / CH, c8 = idx - r * CH;
+                const int iy = I0y + r;
+                const int ix0 = S0x + 8 * c8;
+                const bool rok = (NIT * NT == G::IROWS * CH || idx < G::IROWS * CH) && (unsigned)iy < (unsigned)p.xh;
 #pragma unroll
-            for (int w = 0; w < 5; w++)
-                raw[i][w] = (rok && (w < 4 || odd) && (unsigned)(ix0 + 2 * w) < (unsigned)p.xw) ? *(const unsigned*)(src + 2 * w) : 0u;
+                for (int w = 0; w < 4; w++) {
+                    const bool ok = rok && (unsigned)(ix0 + 2 * w) < (unsigned)p.xw;
+                    raw[i][w] = __builtin_amdgcn_raw_buffer_load_b32(rs, ok ? (unsigned)((iy * p.xw + ix0 + 2 * w) * 2) : 0x80000000u, 0, 0);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NIT; i++) {
+                const int idx = tid + i * NT;
+                const int r = idx / CH, c8 = idx - r * CH;
+                const int iy = I0y + r;
+                const int ix0 = S0x + 8 * c8;
+                const bool rok = (NIT * NT == G::IROWS * CH || idx < G::IROWS * CH) && (unsigned)iy < (unsigned)p.xh;
+                const unsigned off = rok ? (unsigned)((iy * p.xw + ix0) * 2) : 0x80000000u;
+                raw[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+            }
         }
-        // rows of X3T beyond the computed columns are read (with zero weights) by the last down-x window: keep them finite
-        for (int idx = tid; idx < (G::X3ROWS - G::XCOLS) * G::PX3; idx += NT) lds_x3[G::XCOLS * G::PX3 + idx] = from_f32<T>(0.f);
+        if (G::X3COLS > G::XCOLS) {
+            // columns of X3 beyond the computed ones are read (with zero weights) by the last down-x window: keep them finite
+            constexpr int ZC = (G::X3COLS - G::XCOLS) / 8;
+            for (int idx = tid; idx < TOH * ZC; idx += NT)
+                *(uint4*)(lds_x3 + (idx / ZC) * G::PX3 + G::XCOLS + 8 * (idx % ZC)) = make_uint4(0, 0, 0, 0);
+        }
         if (SIGN == AFCM_SIGNS_READ) {
             // sign window: quad-rows [(U0y+sy)>>2, +SGN_ROWS), columns [U0x+sx, +XCOLS), fetched as aligned dwords
             const unsigned char* sp = p.s + (size_t)plane * p.shq * p.swq;
             const int qy0 = (U0y + p.sy) >> 2, w0 = (U0x + p.sx) >> 2, wpr = p.swq >> 2;
             constexpr int NSW = cdiv(G::SGN_ROWS * G::SGN_WORDS, NT);
             unsigned sv[NSW];
+            unsigned any = 0;
 #pragma unroll
             for (int i = 0; i < NSW; i++) {
                 const int idx = tid + i * NT;
@@ -209,38 +301,55 @@ __global__ __launch_bounds__((64 * MfmaGeom<UP, DOWN, TOW, TOH>::NG)) void flrel
                 sv[i] = (idx < G::SGN_ROWS * G::SGN_WORDS && (unsigned)qy < (unsigned)p.shq && (unsigned)wi < (unsigned)wpr)
                             ? ((const unsigned*)(sp + (size_t)qy * p.swq))[wi] : 0u;
             }
+            // keep-mask table: 2 KB from the workspace
+            const uint4 tabv = (tid < 128) ? ((const uint4*)((const char*)p.ws + kWsTable))[tid] : make_uint4(0, 0, 0, 0);
 #pragma unroll
             for (int i = 0; i < NSW; i++) {
                 const int idx = tid + i * NT;
+                any |= sv[i];
                 if (idx < G::SGN_ROWS * G::SGN_WORDS) {
                     const int r = idx / G::SGN_WORDS, c = idx - r * G::SGN_WORDS;
                     *(unsigned*)(lds_sg + r * G::SGN_PITCH + 4 * c) = sv[i];
                 }
             }
+            if (tid < 128) ((uint4*)lds_tab)[tid] = tabv;
+            const bool wc = __builtin_amdgcn_ballot_w64((any & 0xaaaaaaaau) != 0) != 0;
+            if (lane == 0) lds_flag[wave] = wc ? 1u : 0u;
         }
+        float bias = 0.f;
+        if (BIAS) bias = p.b ? to_f32(((const T*)p.b)[plane % p.C]) : 0.f;
 #pragma unroll
         for (int i = 0; i < NIT; i++) {
             const int idx = tid + i * NT;
-            if (idx < G::IROWS * CH) {
+            if (NIT * NT == G::IROWS * CH || idx < G::IROWS * CH) {
                 const int r = idx / CH, c8 = idx - r * CH;
-                const int iy = I0y + r;
-                const int ix0 = I0x + 8 * c8;
-                const bool rok = (unsigned)iy < (unsigned)p.xh;
-                unsigned o[4];
+                const int ix0 = S0x + 8 * c8;
+                u32x4 v = raw[i];
+                if (BIAS) {
+                    const bool rok = (unsigned)(I0y + r) < (unsigned)p.xh;
 #pragma unroll
-                for (int w = 0; w < 4; w++) {
-                    const unsigned d = odd ? __builtin_amdgcn_alignbyte(raw[i][w + 1], raw[i][w], 2) : raw[i][w];
-                    union { unsigned u; T t[2]; } e;
-                    e.u = d;
-                    const bool in0 = rok && (unsigned)(ix0 + 2 * w) < (unsigned)p.xw;
-                    const bool in1 = rok && (unsigned)(ix0 + 2 * w + 1) < (unsigned)p.xw;
-                    o[w] = pack2<T>(in0 ? to_f32(e.t[0]) + bias : 0.f, in1 ? to_f32(e.t[1]) + bias : 0.f);
+                    for (int w = 0; w < 4; w++) {
+                        union { unsigned u; T t[2]; } e;
+                        e.u = v[w];
+                        const bool in = rok && (unsigned)(ix0 + 2 * w) < (unsigned)p.xw;       // even width: pairs are in or out together
+                        v[w] = in ? pack2<T>(to_f32(e.t[0]) + bias, to_f32(e.t[1]) + bias) : 0u;
+                    }
+                } else if (xedge) {
+#pragma unroll
+                    for (int w = 0; w < 4; w++)
+                        if ((unsigned)(ix0 + 2 * w) >= (unsigned)p.xw) v[w] = 0u;
                 }
-                *(uint4*)(lds_in + r * G::PIN + 8 * c8) = make_uint4(o[0], o[1], o[2], o[3]);
+                *(u32x4*)(lds_in + r * G::PIN + 8 * c8) = v;
             }
         }
     }
     __syncthreads();
+    if (SIGN == AFCM_SIGNS_READ) {
+        unsigned f = 0;
+#pragma unroll
+        for (int w = 0; w < G::NG; w++) f |= lds_flag[w];
+        has_clamp = __builtin_amdgcn_readfirstlane(f) != 0;
+    }
 
     const frag* wsf = (const frag*)p.ws;
     auto cfrag = [&](int f) __attribute__((always_inline)) { return wsf[f * 64 + lane]; };
@@ -253,31 +362,31 @@ __global__ __launch_bounds__((64 * MfmaGeom<UP, DOWN, TOW, TOH>::NG)) void flrel
 #pragma unroll
         for (int mb = 0; mb < G::NMB; mb++) {
             const T* src = lds_in + (16 * mb + l15) * G::PIN + G::IWSTEP * Gi + 8 * g;
-            union { uint2 h[2]; frag f; } t;                   // 8-byte aligned halves (window start is 8-B aligned for UP=4)
-            t.h[0] = *(const uint2*)src;
-            t.h[1] = *(const uint2*)(src + 4);
+            union { uint2 h[2]; uint4 q; frag f; } t;
+            if ((G::IWSTEP * 2) % 16 == 0) {
+                t.q = *(const uint4*)src;
+            } else {                                            // 8-byte aligned halves (window start is 8-B aligned for UP=4)
+                t.h[0] = *(const uint2*)src;
+                t.h[1] = *(const uint2*)(src + 4);
+            }
             a_in[mb] = t.f;
         }
-        frag uv[UP], dv[G::NDVK];
+        frag uv[UP], dvs[G::NDVK], dvr[G::NDVK];
 #pragma unroll
         for (int v = 0; v < UP; v++) uv[v] = cfrag(G::NB + v);
 #pragma unroll
-        for (int t = 0; t < G::NDVK; t++) dv[t] = cfrag(G::NB + UP + t);
-        const bool lastX = (tx == p.tilesX - 1), lastY = (ty == p.tilesY - 1);
-        // sign-code store: byte (quad-row (U0y + 16vb + 4g)/4, column U0x + ucol); pointer and validity hoisted out of the loops
-        unsigned char* sgl = p.s + ((size_t)plane * p.shq + ((U0y >> 2) + g)) * p.swq + U0x + G::GW * Gi + l15;
-        unsigned rowmask = 0;
-        if (SIGN == AFCM_SIGNS_WRITE) {
-#pragma unroll
-            for (int vb = 0; vb < G::NVB; vb++)
-                rowmask |= (unsigned)(((16 * vb + 4 * g < TOH * DOWN) || lastY) && ((U0y >> 2) + 4 * vb + g) < p.shq) << vb;
+        for (int t = 0; t < G::NDVK; t++) {
+            dvs[t] = cfrag(G::NB + UP + t);
+            dvr[t] = cfrag(G::NB + UP + G::NDVK + t);
         }
+        // READ: row offset of the sign window inside its first staged quad / column offset inside its first aligned dword
+        const int yy = (U0y + p.sy) & 3, coff = (U0x + p.sx) & 3;
+        const float cscale = fmaxf(p.slope, 1.f);              // |lrelu(v)| <= max(1, slope) |v|
 
 #pragma unroll
         for (int nb = 0; nb < G::NB; nb++) {
             const frag uh = cfrag(nb);
             const int ucol = G::GW * Gi + 16 * nb + l15;       // tile-relative upsampled column of this lane
-            const bool colown = ((ucol < TOW * DOWN) || lastX) && (U0x + ucol < p.swq);
             // up-x: X1[mb] = In[mb] * UH
             f32x4 x1[G::NMB];
 #pragma unroll
@@ -285,35 +394,24 @@ __global__ __launch_bounds__((64 * MfmaGeom<UP, DOWN, TOW, TOH>::NG)) void flrel
             frag q[G::NQ];
 #pragma unroll
             for (int m = 0; m < G::NQ; m++) q[m] = pack_pair<T>(x1[m], (m + 1 < G::NMB) ? x1[m + 1] : zero4);
-            // up-y + activation, packed pairwise for the down-y pass
-            frag pr[G::NPAIR];
-            f32x4 held = zero4;
+            // up-y, then the two operands of the down-y pass: X2 itself and relu(X2) (forward) / keep-mask & X2 (backward)
+            u32x4 pv[G::NPAIR], rv[G::NPAIR];
 #pragma unroll
             for (int vb = 0; vb < 2 * G::NPAIR; vb++) {
-                f32x4 x2 = zero4;
+                unsigned d0 = 0, d1 = 0, r0 = 0, r1 = 0;
                 if (vb < G::NVB) {
-                    x2 = M::mma(uv[vb % UP], q[vb / UP], zero4);
-                    unsigned codes = 0;
+                    f32x4 x2 = M::mma(uv[vb % UP], q[vb / UP], zero4);
                     if (SIGN == AFCM_SIGNS_READ) {
                         // codes of rows Y+sy .. Y+sy+3 at column X+sx: two staged quad bytes, funnel-shifted
-                        const int yy = (U0y + p.sy) & 3;       // row offset inside the first staged quad
-                        const int qr = (16 * vb + 4 * g + yy) >> 2, sh = ((16 * vb + 4 * g + yy) & 3) << 1;
-                        const int coff = (U0x + p.sx) & 3;    // column of the window start inside its first aligned dword
-                        const unsigned lo = lds_sg[qr * G::SGN_PITCH + ucol + coff];
-                        const unsigned hi = lds_sg[(qr + 1) * G::SGN_PITCH + ucol + coff];
-                        codes = ((lo | (hi << 8)) >> sh) & 0xffu;
-                    }
-                    unsigned wcode = 0;
-                    if (SIGN == AFCM_SIGNS_READ) {
-                        // spread the four 2-bit codes to one per byte: byte r of `d` = code of row r
-                        const unsigned d = (codes * 0x00041041u) & 0x03030303u;
-                        if (__builtin_amdgcn_ballot_w64((d & 0x02020202u) != 0) == 0) {
-                            // common case, no clamped element in the tile: factor = 1 + bit0 * (slope - 1)
-                            const float sm1 = p.slope - 1.f;
-                            x2[0] *= fmaf((float)((d >> 0) & 0xffu), sm1, 1.f);
-                            x2[1] *= fmaf((float)((d >> 8) & 0xffu), sm1, 1.f);
-                            x2[2] *= fmaf((float)((d >> 16) & 0xffu), sm1, 1.f);
-                            x2[3] *= fmaf((float)((d >> 24) & 0xffu), sm1, 1.f);
+                        const unsigned lo = lds_sg[(4 * vb + g) * G::SGN_PITCH + ucol + coff];
+                        const unsigned hi = lds_sg[(4 * vb + g + 1) * G::SGN_PITCH + ucol + coff];
+                        const unsigned codes = __builtin_amdgcn_ubfe(lo | (hi << 8), 2 * yy, 8);
+                        if (!has_clamp) {
+                            const uint2 keep = lds_tab[codes];
+                            d0 = pack2<T>(x2[0], x2[1]);
+                            d1 = pack2<T>(x2[2], x2[3]);
+                            r0 = d0 & keep.x;
+                            r1 = d1 & keep.y;
                         } else {
 #pragma unroll
                             for (int r = 0; r < 4; r++) {
@@ -323,18 +421,22 @@ __global__ __launch_bounds__((64 * MfmaGeom<UP, DOWN, TOW, TOH>::NG)) void flrel
                                 if (c & 2u) v = 0.f;
                                 x2[r] = v;
                             }
+                            d0 = r0 = pack2<T>(x2[0], x2[1]);     // slope*v + (1-slope)*v
+                            d1 = r1 = pack2<T>(x2[2], x2[3]);
                         }
                     } else {
+                        unsigned wcode;
                         const float amax = fmaxf(fmaxf(fabsf(x2[0]), fabsf(x2[1])), fmaxf(fabsf(x2[2]), fabsf(x2[3])));
-                        if (p.slope <= 1.f && __builtin_amdgcn_ballot_w64(amax > p.clamp) == 0) {
-                            // common case: nothing in the tile can reach the clamp (|lrelu(v)| <= |v| for slope <= 1)
-#pragma unroll
-                            for (int r = 0; r < 4; r++) {
-                                const float v = x2[r];
-                                wcode |= (__float_as_uint(v) >> 31) << (2 * r);
-                                x2[r] = fmaxf(v, v * p.slope);
-                            }
+                        if (__builtin_amdgcn_ballot_w64(amax * cscale > p.clamp) == 0) {
+                            // common case: nothing in the tile can reach the clamp
+                            d0 = pack2<T>(x2[0], x2[1]);
+                            d1 = pack2<T>(x2[2], x2[3]);
+                            r0 = relu_pk(d0);
+                            r1 = relu_pk(d1);
+                            const unsigned f = (signs_pk(d1) << 4) | signs_pk(d0);       // bits 0 (row 0), 16 (row 1), 4 (row 2), 20 (row 3)
+                            wcode = f | (f >> 14);
                         } else {
+                            wcode = 0;
 #pragma unroll
                             for (int r = 0; r < 4; r++) {
                                 float v = x2[r];
@@ -344,69 +446,105 @@ __global__ __launch_bounds__((64 * MfmaGeom<UP, DOWN, TOW, TOH>::NG)) void flrel
                                 wcode |= c << (2 * r);
                                 x2[r] = v;
                             }
+                            d0 = r0 = pack2<T>(x2[0], x2[1]);
+                            d1 = r1 = pack2<T>(x2[2], x2[3]);
                         }
-                    }
-                    if (SIGN == AFCM_SIGNS_WRITE) {
-                        if (colown && ((rowmask >> vb) & 1)) sgl[(size_t)(4 * vb) * p.swq + 16 * nb] = (unsigned char)wcode;
+                        if (SIGN == AFCM_SIGNS_WRITE) lds_sg[(4 * vb + g) * G::SGW_PITCH + ucol] = (unsigned char)wcode;
                     }
                 }
-                if (vb & 1) pr[vb >> 1] = pack_pair<T>(held, x2);
-                else held = x2;
+                pv[vb >> 1][2 * (vb & 1)] = d0;
+                pv[vb >> 1][2 * (vb & 1) + 1] = d1;
+                rv[vb >> 1][2 * (vb & 1)] = r0;
+                rv[vb >> 1][2 * (vb & 1) + 1] = r1;
             }
-            // down-y: X3[ob] = sum_t DV[t] * P[(DOWN/2)*ob + t]  ->  LDS X3T[ucol][orow]
+            // down-y, transposed: X3'[ucol][orow] = sum_t P[(DOWN/2)*ob + t]' * DV[t]'  ->  LDS X3[orow][ucol], 4 columns per lane
 #pragma unroll
             for (int ob = 0; ob < G::NOB; ob++) {
                 f32x4 x3 = zero4;
 #pragma unroll
-                for (int t = 0; t < G::NDVK; t++) x3 = M::mma(dv[t], pr[(DOWN / 2) * ob + t], x3);
+                for (int t = 0; t < G::NDVK; t++) {
+                    x3 = M::mma(as_frag<frag>(pv[(DOWN / 2) * ob + t]), dvs[t], x3);
+                    x3 = M::mma(as_frag<frag>(rv[(DOWN / 2) * ob + t]), dvr[t], x3);
+                }
                 uint2 w;
                 w.x = pack2<T>(x3[0], x3[1]);
                 w.y = pack2<T>(x3[2], x3[3]);
-                *(uint2*)(lds_x3 + ucol * G::PX3 + 16 * ob + 4 * g) = w;
+                *(uint2*)(lds_x3 + (16 * ob + l15) * G::PX3 + G::GW * Gi + 16 * nb + 4 * g) = w;
             }
         }
     }
     __syncthreads();
 
-    // ---- phase B: down-x through LDS (transposed reads), then store
+    // ---- sign codes of the region this tile owns: LDS -> HBM in 16-byte row segments
+    if (SIGN == AFCM_SIGNS_WRITE) {
+        const int q0 = U0y >> 2;
+        const int rows = lastY ? min(G::SGW_ROWS, p.shq - q0) : (TOH * DOWN) / 4;
+        const int segs = (lastX ? min(G::XCOLS, p.swq - U0x) : TOW * DOWN) >> 4;
+        unsigned char* sg = p.s + ((size_t)plane * p.shq + q0) * p.swq + U0x;
+        for (int idx = tid; idx < rows * segs; idx += NT) {
+            const int r = idx / segs, c = idx - r * segs;
+            *(uint4*)(sg + (size_t)r * p.swq + 16 * c) = *(const uint4*)(lds_sg + r * G::SGW_PITCH + 16 * c);
+        }
+    }
+
+    // ---- phase B: down-x, transposed (each lane ends up with 4 consecutive output columns of one row)
     {
         frag dh[G::NDVK];
 #pragma unroll
-        for (int t = 0; t < G::NDVK; t++) dh[t] = cfrag(G::NB + UP + G::NDVK + t);
-        const int q4 = l15 >> 2, p4 = l15 & 3;
-        // this lane's output pointer at (row O0y + 4g, column O0x + l15); units advance it by constants
-        T* ylane = (T*)p.y + (size_t)plane * p.yh * p.yw + (size_t)(O0y + 4 * g) * p.yw + O0x + l15;
-        const T* xlane = lds_x3 + (8 * g + q4) * G::PX3 + 4 * p4;
+        for (int t = 0; t < G::NDVK; t++) dh[t] = cfrag(G::NB + UP + 2 * G::NDVK + t);
+        const bool inner = (O0x + TOW <= p.yw) && (O0y + TOH <= p.yh);
         float psum = 0.f;
         for (int unit = wave; unit < G::NOB * G::NCB; unit += G::NG) {
             const int ob = unit / G::NCB, cb = unit - ob * G::NCB;
             f32x4 acc = zero4;
 #pragma unroll
             for (int t = 0; t < G::NDVK; t++) {
-                const T* a0 = xlane + (16 * DOWN * cb + 32 * t) * G::PX3 + 16 * ob;
-                union { s16x4 h[2]; frag f; } a;
-                a.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a0);
-                a.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + 4 * G::PX3));
-                acc = M::mma(a.f, dh[t], acc);
+                union { uint4 q; frag f; } b;
+                b.q = *(const uint4*)(lds_x3 + (16 * ob + l15) * G::PX3 + 16 * DOWN * cb + 32 * t + 8 * g);
+                acc = M::mma(dh[t], b.f, acc);
             }
-            const bool colok = O0x + 16 * cb + l15 < p.yw;
-            const int rows_left = p.yh - (O0y + 16 * ob + 4 * g);        // rows of this lane's 4 that are inside the image
-            T* dst = ylane + (size_t)(16 * ob) * p.yw + 16 * cb;
+            uint2 w;
+            w.x = pack2<T>(acc[0], acc[1]);
+            w.y = pack2<T>(acc[2], acc[3]);
+            *(uint2*)(lds_out + (16 * ob + l15) * G::POUT + 16 * cb + 4 * g) = w;
+            if (p.plane_sum != nullptr) {
+                if (inner) {
+                    psum += (acc[0] + acc[1]) + (acc[2] + acc[3]);
+                } else if (O0y + 16 * ob + l15 < p.yh) {
+                    const int c0 = O0x + 16 * cb + 4 * g;
 #pragma unroll
-            for (int r = 0; r < 4; r++)
-                if (colok && r < rows_left) {
-                    const T o = from_f32<T>(acc[r]);
-                    dst[(size_t)r * p.yw] = o;
-                    psum += to_f32(o);
+                    for (int r = 0; r < 4; r++)
+                        if (c0 + r < p.yw) psum += acc[r];
                 }
+            }
+        }
+        __syncthreads();
+        // staged output tile -> HBM, 8 columns (16 bytes) per lane
+        {
+            constexpr int SEG = TOW / 8;
+            T* yp = (T*)p.y + (size_t)plane * p.yh * p.yw;
+            for (int idx = tid; idx < TOH * SEG; idx += NT) {
+                const int r = idx / SEG, c = idx - r * SEG;
+                const int oy = O0y + r, ox = O0x + 8 * c;
+                if (oy < p.yh && ox < p.yw) {
+                    const u32x4 v = *(const u32x4*)(lds_out + r * G::POUT + 8 * c);
+                    T* dst = yp + (size_t)oy * p.yw + ox;
+                    if (ox + 8 <= p.yw) {
+                        *(u32x4*)dst = v;
+                    } else {
+#pragma unroll
+                        for (int w = 0; w < 4; w++)
+                            if (ox + 2 * w < p.yw) ((unsigned*)dst)[w] = v[w];     // even width: pairs are in or out together
+                    }
+                }
+            }
         }
         if (p.plane_sum != nullptr) {
             // wave reduction -> workgroup reduction through LDS -> one plain store into this tile's slot (no atomics:
             // deterministic, and no same-address contention between the tiles of a plane)
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) psum += __shfl_down(psum, off, 64);
-            __syncthreads();                                   // phase-B reads of lds_x3 are finished
-            float* red = (float*)lds_x3;
+            float* red = (float*)lds_x3;                       // phase-B reads of lds_x3 finished before the barrier above
             if (lane == 0) red[wave] = psum;
             __syncthreads();
             if (tid == 0) {
@@ -425,6 +563,13 @@ template <> struct MfmaTile<2, 2> { static constexpr int TOW = 64, TOH = 32; };
 template <> struct MfmaTile<2, 4> { static constexpr int TOW = 32, TOH = 32; };
 template <> struct MfmaTile<4, 2> { static constexpr int TOW = 64, TOH = 32; };
 
+template <typename T, int UP, int DOWN, int SIGN>
+static void launch_one(const FlreluMfmaParams& p, bool bias, dim3 grid, dim3 block, hipStream_t st) {
+    constexpr int TOW = MfmaTile<UP, DOWN>::TOW, TOH = MfmaTile<UP, DOWN>::TOH;
+    if (bias) hipLaunchKernelGGL((flrelu_mfma_kernel<T, UP, DOWN, TOW, TOH, SIGN, true>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((flrelu_mfma_kernel<T, UP, DOWN, TOW, TOH, SIGN, false>), grid, block, 0, st, p);
+}
+
 template <typename T, int UP, int DOWN>
 static int launch_mfma(const afcm_filtered_lrelu_args* a, hipStream_t st) {
     constexpr int TOW = MfmaTile<UP, DOWN>::TOW, TOH = MfmaTile<UP, DOWN>::TOH;
@@ -438,11 +583,13 @@ static int launch_mfma(const afcm_filtered_lrelu_args* a, hipStream_t st) {
     p.sx = a->sx; p.sy = a->sy; p.shq = a->sh; p.swq = a->swb;
     const long long blocks = (long long)p.tilesX * p.tilesY * a->n * a->c;
     AFCM_REQUIRE(blocks > 0 && blocks < (1ll << 31), "filtered_lrelu: grid of %lld blocks is out of range", blocks);
+    AFCM_REQUIRE((long long)a->xh * a->xw < (1ll << 30), "filtered_lrelu: plane of %d x %d elements is out of range", a->xh, a->xw);
     dim3 grid((unsigned)blocks), block(64 * G::NG);
+    const bool bias = a->b != nullptr;
     switch (a->sign_mode) {
-        case AFCM_SIGNS_NONE: hipLaunchKernelGGL((flrelu_mfma_kernel<T, UP, DOWN, TOW, TOH, AFCM_SIGNS_NONE>), grid, block, 0, st, p); break;
-        case AFCM_SIGNS_WRITE: hipLaunchKernelGGL((flrelu_mfma_kernel<T, UP, DOWN, TOW, TOH, AFCM_SIGNS_WRITE>), grid, block, 0, st, p); break;
-        default: hipLaunchKernelGGL((flrelu_mfma_kernel<T, UP, DOWN, TOW, TOH, AFCM_SIGNS_READ>), grid, block, 0, st, p); break;
+        case AFCM_SIGNS_NONE: launch_one<T, UP, DOWN, AFCM_SIGNS_NONE>(p, bias, grid, block, st); break;
+        case AFCM_SIGNS_WRITE: launch_one<T, UP, DOWN, AFCM_SIGNS_WRITE>(p, bias, grid, block, st); break;
+        default: launch_one<T, UP, DOWN, AFCM_SIGNS_READ>(p, bias, grid, block, st); break;
     }
     return hip_status(hipGetLastError());
 }
@@ -453,14 +600,16 @@ static int prepare_mfma(const afcm_filtered_lrelu_args* a, hipStream_t st) {
     typedef MfmaGeom<UP, DOWN, TOW, TOH> G;
     const float gain_total = (float)a->up * (float)a->up * a->gain;
     hipLaunchKernelGGL((flrelu_mfma_prepare_kernel<T, UP, DOWN, TOW, TOH>), dim3(cdiv(G::NFRAG * 512, 256)), dim3(256), 0, st,
-                       (T*)a->workspace, a->fu, a->fd, a->px0, a->py0, a->flip_filter, gain_total);
+                       (T*)a->workspace, a->fu, a->fd, a->px0, a->py0, a->flip_filter, gain_total, a->slope);
     return hip_status(hipGetLastError());
 }
 
 static int mfma_case(const afcm_filtered_lrelu_args* a) {
     if (a->dtype != AFCM_BF16 && a->dtype != AFCM_F16) return 0;
     if (a->fuh != 0 || a->fdh != 0) return 0;
-    if (a->xw & 1) return 0;                   // the staged loads are aligned dword pairs: even plane width (all layers of the model)
+    if (a->xw & 1) return 0;                   // staged loads and stores move aligned 16-bit pairs: even plane widths
+    const long long yw = ((long long)a->xw * a->up + a->px0 + a->px1 - (a->fuw - 1) - (a->fdw - 1) + (a->down - 1)) / a->down;
+    if (yw & 1) return 0;
     if (a->up == 2 && a->down == 2 && a->fuw == 12 && a->fdw == 12) return 22;
     if (a->up == 2 && a->down == 4 && a->fuw == 12 && a->fdw == 24) return 24;
     if (a->up == 4 && a->down == 2 && a->fuw == 24 && a->fdw == 12) return 42;
@@ -491,4 +640,4 @@ int flrelu_mfma_launch(const afcm_filtered_lrelu_args* a, bool prepare, hipStrea
 
 }  // namespace afcm
 
-extern "C" int64_t afcm_filtered_lrelu_workspace_bytes(void) { return 16 * 64 * 8 * 2; }   // >= NFRAG (<= 13) fragments of 64 x 8 x 2 B
+extern "C" int64_t afcm_filtered_lrelu_workspace_bytes(void) { return afcm::kWsBytes; }

@@ -83,7 +83,7 @@ def _mfma_workspace(a, fu_t, fd_t, x):
     if x.dtype not in (torch.bfloat16, torch.float16) or fu_t is None or fd_t is None:
         return None
     key = (x.device, x.dtype, fu_t.data_ptr(), fu_t._version, fd_t.data_ptr(), fd_t._version, a.fuw, a.fuh, a.fdw, a.fdh,
-           a.up, a.down, a.px0, a.py0, a.gain, a.flip_filter)
+           a.up, a.down, a.px0, a.py0, a.gain, a.slope, a.flip_filter)
     if key not in _workspaces:
         lib = _lib.load()
         ws = torch.empty([lib.afcm_filtered_lrelu_workspace_bytes()], dtype=torch.uint8, device=x.device)

@@ -290,3 +290,38 @@ def test_filtered_lrelu_16bit_odd_width_uses_exact_kernels():
     assert got.grad_fn.sign_layout == 0
     _close(got, ref, tol=3e-2, what='odd width bf16')
     torch.autograd.grad(got.float().sum(), xg)
+
+
+@pytest.mark.parametrize('dtype,tol', [(torch.float16, 6e-3), (torch.bfloat16, 4e-2)])
+@pytest.mark.parametrize('lname', ['encoder_1', 'encoder_4', 'L10_276_128'])
+def test_filtered_lrelu_16bit_matrix_core_clamp_and_no_bias(lname, dtype, tol):
+    """Matrix-core kernels, the paths the generator-shaped test does not reach: (a) no bias (the generator's convs add it
+    in their epilogue), (b) inputs scaled so the clamp fires in some tiles and not in others -- the wave-uniform exact path
+    of the forward kernel and the clamp-code path of the backward kernel (gradient 0 where clamped)."""
+    from afcm_amd.torch_utils.ops import filtered_lrelu as flr
+    from oracle import aten_ops as ops
+    from oracle import generator as ogen
+    pl = ogen.plan(256, 4, 1, {})
+    L = [l for l in pl['enc'] + pl['dec'] if l['name'] == lname][0]
+    h = L['in_size'] + 2
+    torch.manual_seed(11)
+    x = torch.randn(2, 2, h, h)
+    x[0, 0] *= 40.0                      # clamp = 8 below: most of this plane clamps
+    x[1, 1, : h // 2] *= 12.0            # half of this one does; the other planes never do
+    x = x.to(dtype)
+    kw = dict(up=L['up'], down=L['down'], padding=L['padding'], gain=float(np.sqrt(2)), slope=0.2, clamp=8.0)
+    xr = x.float().requires_grad_(True)
+    ref = ops.filtered_lrelu(xr, fu=L['fu'], fd=L['fd'], b=None, **kw)
+    r = torch.randn_like(ref).to(dtype)
+    gref, = torch.autograd.grad((ref * r.float()).sum(), xr)
+    xg = x.cuda().requires_grad_(True)
+    got = flr.filtered_lrelu(xg, fu=L['fu'].cuda(), fd=L['fd'].cuda(), b=None, **kw)
+    assert got.grad_fn.sign_layout == 1, 'expected the matrix-core kernel family'
+    _close(got, ref, tol=tol, what=f'{lname} {dtype} clamp y')
+    ggot, = torch.autograd.grad((got.float() * r.cuda().float()).sum(), xg)
+    rel = ((ggot.float().cpu() - gref).norm() / gref.norm()).item()
+    assert rel <= 3 * tol, f'{lname} {dtype} clamp dx: relative L2 {rel:.3e}'
+    # planes that never clamp must take the fast path and still agree plane by plane
+    for n, c in [(0, 1), (1, 0)]:
+        d = (ggot[n, c].float().cpu() - gref[n, c]).norm() / gref[n, c].norm()
+        assert d.item() <= 2 * tol, (n, c, d.item())
