@@ -166,12 +166,24 @@ template <> struct MfmaOps<f16_t> {
     static __device__ __forceinline__ f32x4 mma(frag a, frag b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 };
 
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+
 template <typename T>
 __device__ __forceinline__ unsigned pack2(float lo, float hi) {
-    union { T t[2]; unsigned u; } r;
-    r.t[0] = from_f32<T>(lo);
-    r.t[1] = from_f32<T>(hi);
-    return r.u;
+    // an explicit two-element conversion: one v_cvt_pk_bf16_f32 of exactly this pair.  (Scalar casts left to the
+    // vectoriser get paired across dwords and re-shuffled with four extra instructions per pair; inline asm is not an
+    // option on accumulator values -- the hazard recogniser does not see MFMA -> asm dependencies.)
+    if constexpr (std::is_same<T, bf16_t>::value) {
+        union { bf16x2 v; unsigned u; } r;
+        r.v = __builtin_convertvector((f32x2){lo, hi}, bf16x2);
+        return r.u;
+    } else {
+        union { f16x2 v; unsigned u; } r;
+        r.v = __builtin_convertvector((f32x2){lo, hi}, f16x2);
+        return r.u;
+    }
 }
 
 template <typename F>
@@ -381,12 +393,19 @@ __global__ __launch_bounds__((64 * MfmaGeom<UP, DOWN, TOW, TOH>::NG)) void flrel
         }
         // READ: row offset of the sign window inside its first staged quad / column offset inside its first aligned dword
         const int yy = (U0y + p.sy) & 3, coff = (U0x + p.sx) & 3;
-        const float cscale = fmaxf(p.slope, 1.f);              // |lrelu(v)| <= max(1, slope) |v|
+        const float cthr = p.clamp / fmaxf(p.slope, 1.f);      // |lrelu(v)| <= max(1, slope) |v|: below cthr nothing clamps
+        // per-lane LDS bases, made opaque so they stay in one register each instead of being recomputed per tile
+        unsigned sgw_off = g * G::SGW_PITCH + G::GW * Gi + l15;                  // WRITE: + 4 vb rows + 16 nb
+        unsigned sgr_off = g * G::SGN_PITCH + G::GW * Gi + l15 + coff;           // READ
+        unsigned x3w_off = l15 * G::PX3 + G::GW * Gi + 4 * g;                    // elements; + 16 ob rows + 16 nb
+        asm volatile("" : "+v"(sgw_off), "+v"(sgr_off), "+v"(x3w_off));
+        unsigned char* const sgw = lds_sg + sgw_off;
+        const unsigned char* const sgr = lds_sg + sgr_off;
+        T* const x3w = lds_x3 + x3w_off;
 
 #pragma unroll
         for (int nb = 0; nb < G::NB; nb++) {
             const frag uh = cfrag(nb);
-            const int ucol = G::GW * Gi + 16 * nb + l15;       // tile-relative upsampled column of this lane
             // up-x: X1[mb] = In[mb] * UH
             f32x4 x1[G::NMB];
 #pragma unroll
@@ -403,10 +422,10 @@ __global__ __launch_bounds__((64 * MfmaGeom<UP, DOWN, TOW, TOH>::NG)) void flrel
                     f32x4 x2 = M::mma(uv[vb % UP], q[vb / UP], zero4);
                     if (SIGN == AFCM_SIGNS_READ) {
                         // codes of rows Y+sy .. Y+sy+3 at column X+sx: two staged quad bytes, funnel-shifted
-                        const unsigned lo = lds_sg[(4 * vb + g) * G::SGN_PITCH + ucol + coff];
-                        const unsigned hi = lds_sg[(4 * vb + g + 1) * G::SGN_PITCH + ucol + coff];
+                        const unsigned lo = sgr[(4 * vb) * G::SGN_PITCH + 16 * nb];
+                        const unsigned hi = sgr[(4 * vb + 1) * G::SGN_PITCH + 16 * nb];
                         const unsigned codes = __builtin_amdgcn_ubfe(lo | (hi << 8), 2 * yy, 8);
-                        if (!has_clamp) {
+                        if (__builtin_expect(!has_clamp, 1)) {
                             const uint2 keep = lds_tab[codes];
                             d0 = pack2<T>(x2[0], x2[1]);
                             d1 = pack2<T>(x2[2], x2[3]);
@@ -426,8 +445,11 @@ __global__ __launch_bounds__((64 * MfmaGeom<UP, DOWN, TOW, TOH>::NG)) void flrel
                         }
                     } else {
                         unsigned wcode;
-                        const float amax = fmaxf(fmaxf(fabsf(x2[0]), fabsf(x2[1])), fmaxf(fabsf(x2[2]), fabsf(x2[3])));
-                        if (__builtin_amdgcn_ballot_w64(amax * cscale > p.clamp) == 0) {
+                        // NaN-propagating maximum: two v_maximum3_f32 (fmaxf would add a canonicalisation per operand)
+                        const float amax = __builtin_elementwise_maximum(
+                            __builtin_elementwise_maximum(__builtin_fabsf(x2[0]), __builtin_fabsf(x2[1])),
+                            __builtin_elementwise_maximum(__builtin_fabsf(x2[2]), __builtin_fabsf(x2[3])));
+                        if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(amax <= cthr)) == 0, 1)) {    // NaN takes the exact path
                             // common case: nothing in the tile can reach the clamp
                             d0 = pack2<T>(x2[0], x2[1]);
                             d1 = pack2<T>(x2[2], x2[3]);
@@ -449,7 +471,7 @@ __global__ __launch_bounds__((64 * MfmaGeom<UP, DOWN, TOW, TOH>::NG)) void flrel
                             d0 = r0 = pack2<T>(x2[0], x2[1]);
                             d1 = r1 = pack2<T>(x2[2], x2[3]);
                         }
-                        if (SIGN == AFCM_SIGNS_WRITE) lds_sg[(4 * vb + g) * G::SGW_PITCH + ucol] = (unsigned char)wcode;
+                        if (SIGN == AFCM_SIGNS_WRITE) sgw[(4 * vb) * G::SGW_PITCH + 16 * nb] = (unsigned char)wcode;
                     }
                 }
                 pv[vb >> 1][2 * (vb & 1)] = d0;
@@ -469,7 +491,7 @@ __global__ __launch_bounds__((64 * MfmaGeom<UP, DOWN, TOW, TOH>::NG)) void flrel
                 uint2 w;
                 w.x = pack2<T>(x3[0], x3[1]);
                 w.y = pack2<T>(x3[2], x3[3]);
-                *(uint2*)(lds_x3 + (16 * ob + l15) * G::PX3 + G::GW * Gi + 16 * nb + 4 * g) = w;
+                *(uint2*)(x3w + (16 * ob) * G::PX3 + 16 * nb) = w;
             }
         }
     }

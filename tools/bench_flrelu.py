@@ -20,6 +20,7 @@ def main():
     ap.add_argument('--res', type=int, default=256)
     ap.add_argument('--dtype', default='fp32')
     ap.add_argument('--iters', type=int, default=10)
+    ap.add_argument('--no-bias', action='store_true', help='b=None: the generator path (the convs add the bias)')
     args = ap.parse_args()
     dt = {'fp32': torch.float32, 'bf16': torch.bfloat16, 'fp16': torch.float16}[args.dtype]
     pl = sched.plan(args.res, 4, 1, {})
@@ -29,7 +30,7 @@ def main():
         h = L['in_size'] + L['k'] - 1
         key = (L['cout'], h, L['up'], L['down'], tuple(L['padding']))
         x = torch.randn(args.batch, L['cout'], h, h, device='cuda', dtype=dt).requires_grad_(True)
-        b = torch.zeros(L['cout'], device='cuda', dtype=dt)
+        b = None if args.no_bias else torch.zeros(L['cout'], device='cuda', dtype=dt)
         fu = None if L['fu'] is None else L['fu'].cuda()
         fd = None if L['fd'] is None else L['fd'].cuda()
         kw = dict(up=L['up'], down=L['down'], padding=L['padding'], gain=1.0 if L.get('torgb') else math.sqrt(2),
