@@ -61,10 +61,12 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? 1 : 2)) void conv2d_fwd_kern
     const int r32 = lane & 31, h = lane >> 5;
 
     int bid = blockIdx.x;
-    const int tx = bid % p.tilesX; bid /= p.tilesX;
-    const int ty = bid % p.tilesY; bid /= p.tilesY;
-    const int n = bid % p.N;
-    const int ob = bid / p.N;
+    // integer division runs on the vector pipe even for uniform operands: pin the results to SGPRs, or everything derived
+    // from them (image base, buffer descriptor) sits in VGPRs and every buffer load gets a waterfall loop around it
+    const int tx = __builtin_amdgcn_readfirstlane(bid % p.tilesX); bid /= p.tilesX;
+    const int ty = __builtin_amdgcn_readfirstlane(bid % p.tilesY); bid /= p.tilesY;
+    const int n = __builtin_amdgcn_readfirstlane(bid % p.N);
+    const int ob = __builtin_amdgcn_readfirstlane(bid / p.N);
     const int y0 = ty * p.TH, x0 = tx * p.TW;
     const int o0 = ob * BM_O;
     const int PH = p.TH + KS - 1, PWL = p.PWL;
@@ -263,17 +265,239 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? 1 : 2)) void conv2d_fwd_kern
 
     // ---- epilogue: D[row = channel][col = pixel]; row = (reg&3) + 8*(reg>>2) + 4*h within the 32x32 tile.
     T* yn = (T*)p.y + (size_t)n * p.Cout * p.P * p.Q;
+    // all per-channel scales first (clamped index, no branch around the loads): one wait instead of 16 * MI round trips
+    float sc[MI][16];
+#pragma unroll
+    for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+        for (int reg = 0; reg < 16; reg++) sc[mi][reg] = 1.f;
+    if (p.oscale) {
+        const float* osn = p.oscale + (size_t)n * p.Cout;
+#pragma unroll
+        for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+            for (int reg = 0; reg < 16; reg++) {
+                const int o = o0 + wo * (BM_O / 2) + mi * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                sc[mi][reg] = osn[min(o, p.Cout - 1)];
+            }
+    }
 #pragma unroll
     for (int mi = 0; mi < MI; mi++)
 #pragma unroll
         for (int reg = 0; reg < 16; reg++) {
             const int o = o0 + wo * (BM_O / 2) + mi * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
             if (o < p.Cout) {
-                const float sc = p.oscale ? p.oscale[(size_t)n * p.Cout + o] : 1.f;
                 T* yo = yn + (size_t)o * p.P * p.Q;
 #pragma unroll
                 for (int ti = 0; ti < 4; ti++)
-                    if (pyv[ti] < p.P && pxv[ti] < p.Q) yo[(size_t)pyv[ti] * p.Q + pxv[ti]] = from_f32<T>(acc[mi][ti][reg] * sc);
+                    if (pyv[ti] < p.P && pxv[ti] < p.Q) yo[(size_t)pyv[ti] * p.Q + pxv[ti]] = from_f32<T>(acc[mi][ti][reg] * sc[mi][reg]);
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------------------------
+// 16-bit 3x3 forward / data-gradient kernel, r02 structure.  Same tile (BM_O channels x 256 pixels, 4 waves as 2(o) x
+// 2(pixel halves), 2 workgroups per CU), different operand paths:
+//   * weights never touch LDS: the packed layout [kc][tap][Opad][16] already IS the A-fragment image (lane (r32, h) ->
+//     16 bytes at row r32, half h; a wave reads one contiguous 1 KB), so every wave loads its fragments straight from
+//     L2 into a 3-tap-deep register ring, three taps ahead of their MFMAs.  That removes 9 of the 13 staging pieces per
+//     thread and K-chunk, the 36 staging VGPRs, a third of the LDS reads and 55 KB of LDS per workgroup;
+//   * the activation patch (transposed NCHW -> [pixel][channel] while staging) is double-buffered in the freed LDS:
+//     ONE barrier per K-chunk instead of two, and the transposing ds_writes sit among the MFMAs of the running chunk;
+//   * the patch writes are conflict-free: a thread owns 4 consecutive pixels (192 bytes apart from its neighbour's, a
+//     4-way conflict when every lane writes its pixel e at step e), so lane i writes pixel (e + (i >> 2)) & 3 at step e;
+//   * XCD-aware tile order: neighbouring tiles of one image (shared halos, same weights) stay on one XCD's L2.
+template <typename T, int BM_O>
+__global__ __launch_bounds__(256, 2) void conv2d_fwd16_kernel(ConvParams p) {
+    static_assert(sizeof(T) == 2, "16-bit types only");
+    typedef ConvCfg<T> C;
+    constexpr int KS = 3, KK = 9, BK = C::BK, PITCH = C::PITCH, MI = BM_O / 64, RING = 3;
+    typedef typename std::conditional<std::is_same<T, bf16_t>::value, bf16x8, f16x8>::type frag_t;
+    typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+    __shared__ __attribute__((aligned(16))) T lds[2 * kPatchMax * PITCH];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wo = wave & 1, wpx = wave >> 1;
+    const int r32 = lane & 31, h = lane >> 5;
+
+    int bid = blockIdx.x;
+    {
+        const int total = gridDim.x;
+        if ((total & 7) == 0) bid = (bid & 7) * (total >> 3) + (bid >> 3);
+    }
+    // integer division runs on the vector pipe even for uniform operands: pin the results to SGPRs, or everything derived
+    // from them (image base, buffer descriptor) sits in VGPRs and every buffer load gets a waterfall loop around it
+    const int tx = __builtin_amdgcn_readfirstlane(bid % p.tilesX); bid /= p.tilesX;
+    const int ty = __builtin_amdgcn_readfirstlane(bid % p.tilesY); bid /= p.tilesY;
+    const int n = __builtin_amdgcn_readfirstlane(bid % p.N);
+    const int ob = __builtin_amdgcn_readfirstlane(bid / p.N);
+    const int y0 = ty * p.TH, x0 = tx * p.TW;
+    const int o0 = ob * BM_O;
+    const int PH = p.TH + KS - 1, PWL = p.PWL;
+    const int xorg = (x0 - p.pad) & ~1;
+    const int xoff = (x0 - p.pad) - xorg;
+
+    int bbase[4], pyv[4], pxv[4];
+#pragma unroll
+    for (int ti = 0; ti < 4; ti++) {
+        const int j = wpx * 128 + ti * 32 + r32;
+        int py = j / p.TW, px = j - py * p.TW;
+        const bool valid = j < p.TH * p.TW;
+        if (!valid) { py = 0; px = 0; }
+        pyv[ti] = valid ? y0 + py : p.P;             // invalid slots fall outside the image -> never stored
+        pxv[ti] = x0 + px;
+        bbase[ti] = (py * PWL + px + xoff) * PITCH + h * 8;
+    }
+
+    f32x16 acc[MI][4];
+#pragma unroll
+    for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+        for (int ti = 0; ti < 4; ti++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[mi][ti][e] = 0.f;
+
+    // ---- A fragments: straight from the packed weights
+    const T* wlane = (const T*)p.wp + (size_t)(o0 + wo * (BM_O / 2) + r32) * BK + h * 8;
+    const size_t wtap = (size_t)p.Opad * BK;                       // elements per tap
+    auto load_a = [&](int kc, int tap, int mi) __attribute__((always_inline)) {
+        return *(const frag_t*)(wlane + ((size_t)kc * KK + tap) * wtap + mi * 32 * BK);
+    };
+
+    // ---- patch staging (one item = 4 pixels x 8 channels), as in conv2d_fwd_kernel
+    const int cg = (tid >> 5) & 1, pg = (tid & 31) + 32 * (tid >> 6);
+    const int pcols = PWL >> 2;
+    const int prow = pg / pcols, pcol4 = pg - prow * pcols;
+    const bool pvalid = prow < PH;
+    const int iy = y0 - p.pad + prow, ix = xorg + 4 * pcol4;
+    const bool rowok = pvalid && (unsigned)iy < (unsigned)p.H;
+    const T* xn = (const T*)p.x + (size_t)n * p.Cin * p.H * p.W;
+    const long long pix_off = (long long)(rowok ? iy : 0) * p.W + ix;
+    const int pdst = (prow * PWL + 4 * pcol4) * PITCH + cg * 8;
+    constexpr unsigned kOob = 0x80000000u;
+    const bool d0ok = rowok && (unsigned)ix < (unsigned)p.W, d1ok = rowok && (unsigned)(ix + 2) < (unsigned)p.W;
+    const unsigned pmask0 = d0ok ? ~0u : 0u, pmask1 = d1ok ? ~0u : 0u;
+    const bool any_partial = __builtin_amdgcn_ballot_w64(d0ok != d1ok) != 0;          // wave-uniform
+    const bool lshift = !d0ok && d1ok;                                                // never touch bytes before a row 0
+    const bool any_lshift = __builtin_amdgcn_ballot_w64(lshift) != 0;
+    const unsigned pvoff = (d0ok || d1ok) ? (unsigned)(((long long)cg * 8 * p.H * p.W + pix_off + (lshift ? 2 : 0)) * 2ll) : kOob;
+    const long long img_bytes = (long long)p.Cin * p.H * p.W * 2ll;
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)xn, 0, (int)(img_bytes > 0x7fffffffll ? 0x7fffffffll : img_bytes), 0x00020000);
+    const int hw2 = p.H * p.W * 2;
+    const int rot = (lane >> 2) & 3;                                                  // write rotation (see header)
+
+    unsigned preg[8][2];
+    auto issue_patch = [&](int kc) __attribute__((always_inline)) {
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(xrs, pvoff, (kc * BK + c) * hw2, 0);
+            preg[c][0] = v.x; preg[c][1] = v.y;
+        }
+    };
+    auto write_patch = [&](int kc, T* dstbuf) __attribute__((always_inline)) {
+        if ((kc + 1) * BK > p.Cin) {                                                  // channels past Cin: last chunk only
+#pragma unroll
+            for (int c = 0; c < 8; c++)
+                if (kc * BK + cg * 8 + c >= p.Cin) { preg[c][0] = 0u; preg[c][1] = 0u; }
+        }
+        if (pvalid) {
+            if (any_lshift) {
+#pragma unroll
+                for (int c = 0; c < 8; c++) preg[c][1] = lshift ? preg[c][0] : preg[c][1];
+            }
+            if (any_partial) {
+#pragma unroll
+                for (int c = 0; c < 8; c++) { preg[c][0] &= pmask0; preg[c][1] &= pmask1; }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int ei = (e + rot) & 3;
+                const unsigned sel = (ei & 1) ? 0x07060302u : 0x05040100u;
+                const bool hi2 = (ei & 2) != 0;
+                uint4 v;
+                v.x = __builtin_amdgcn_perm(hi2 ? preg[1][1] : preg[1][0], hi2 ? preg[0][1] : preg[0][0], sel);
+                v.y = __builtin_amdgcn_perm(hi2 ? preg[3][1] : preg[3][0], hi2 ? preg[2][1] : preg[2][0], sel);
+                v.z = __builtin_amdgcn_perm(hi2 ? preg[5][1] : preg[5][0], hi2 ? preg[4][1] : preg[4][0], sel);
+                v.w = __builtin_amdgcn_perm(hi2 ? preg[7][1] : preg[7][0], hi2 ? preg[6][1] : preg[6][0], sel);
+                *(uint4*)(dstbuf + pdst + ei * PITCH) = v;
+            }
+        }
+    };
+
+    frag_t ar[RING][MI];
+    issue_patch(0);
+#pragma unroll
+    for (int t = 0; t < RING; t++)
+#pragma unroll
+        for (int mi = 0; mi < MI; mi++) ar[t][mi] = load_a(0, t, mi);
+    write_patch(0, lds);
+    __syncthreads();
+
+    const int last = p.nkc - 1;
+    for (int kc = 0; kc < p.nkc; kc++) {
+        const T* cur = lds + (kc & 1) * (kPatchMax * PITCH);
+        T* nxt = lds + ((kc + 1) & 1) * (kPatchMax * PITCH);
+        const bool more = kc < last;
+        if (more) issue_patch(kc + 1);
+#pragma unroll
+        for (int tap = 0; tap < KK; tap++) {
+            const int r = tap / KS, s2 = tap - r * KS;
+            const int tapoff = (r * PWL + s2) * PITCH;
+            frag_t a[MI], b[4];
+#pragma unroll
+            for (int mi = 0; mi < MI; mi++) a[mi] = ar[tap % RING][mi];
+            // refill this ring slot with the fragments three taps ahead (clamped at the end: no branch around a load)
+            {
+                const int nt = (tap + RING) % KK;
+                const int nk = (tap + RING < KK) ? kc : (more ? kc + 1 : kc);
+#pragma unroll
+                for (int mi = 0; mi < MI; mi++) ar[tap % RING][mi] = load_a(nk, nt, mi);
+            }
+#pragma unroll
+            for (int ti = 0; ti < 4; ti++) b[ti] = *(const frag_t*)(cur + bbase[ti] + tapoff);
+#pragma unroll
+            for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+                for (int ti = 0; ti < 4; ti++) {
+                    if constexpr (std::is_same<T, bf16_t>::value)
+                        acc[mi][ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ti], acc[mi][ti], 0, 0, 0);
+                    else
+                        acc[mi][ti] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mi], b[ti], acc[mi][ti], 0, 0, 0);
+                }
+            if (tap == 5 && more) write_patch(kc + 1, nxt);          // the other buffer: last read one chunk ago
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: D[row = channel][col = pixel]; row = (reg&3) + 8*(reg>>2) + 4*h within the 32x32 tile.
+    T* yn = (T*)p.y + (size_t)n * p.Cout * p.P * p.Q;
+    // all per-channel scales first (clamped index, no branch around the loads): one wait instead of 16 * MI round trips
+    float sc[MI][16];
+#pragma unroll
+    for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+        for (int reg = 0; reg < 16; reg++) sc[mi][reg] = 1.f;
+    if (p.oscale) {
+        const float* osn = p.oscale + (size_t)n * p.Cout;
+#pragma unroll
+        for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+            for (int reg = 0; reg < 16; reg++) {
+                const int o = o0 + wo * (BM_O / 2) + mi * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                sc[mi][reg] = osn[min(o, p.Cout - 1)];
+            }
+    }
+#pragma unroll
+    for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+        for (int reg = 0; reg < 16; reg++) {
+            const int o = o0 + wo * (BM_O / 2) + mi * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+            if (o < p.Cout) {
+                T* yo = yn + (size_t)o * p.P * p.Q;
+#pragma unroll
+                for (int ti = 0; ti < 4; ti++)
+                    if (pyv[ti] < p.P && pxv[ti] < p.Q) yo[(size_t)pyv[ti] * p.Q + pxv[ti]] = from_f32<T>(acc[mi][ti][reg] * sc[mi][reg]);
             }
         }
 }
@@ -1228,6 +1452,13 @@ static int launch_conv(ConvParams p, int ks, hipStream_t st) {
     const long long blocks = (long long)p.tilesX * p.tilesY * p.N * cdiv(p.Cout, BM_O);
     AFCM_REQUIRE(blocks > 0 && blocks < (1ll << 31), "conv2d: grid of %lld blocks is out of range", blocks);
     dim3 grid((unsigned)blocks), block(256);
+    if constexpr (sizeof(T) == 2) {
+        static const bool legacy = getenv("AFCM_CONV_LEGACY") != nullptr;     // tuning aid: the r01 LDS-staged-weights kernel
+        if (ks == 3 && !legacy) {
+            hipLaunchKernelGGL((conv2d_fwd16_kernel<T, BM_O>), grid, block, 0, st, p);
+            return hip_status(hipGetLastError());
+        }
+    }
     if (ks == 3) hipLaunchKernelGGL((conv2d_fwd_kernel<T, BM_O, 3>), grid, block, 0, st, p);
     else hipLaunchKernelGGL((conv2d_fwd_kernel<T, BM_O, 1>), grid, block, 0, st, p);
     return hip_status(hipGetLastError());
