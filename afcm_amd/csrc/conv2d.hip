@@ -466,6 +466,15 @@ __global__ __launch_bounds__(256, 2) void conv2d_fwd16_kernel(ConvParams p) {
                         acc[mi][ti] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mi], b[ti], acc[mi][ti], 0, 0, 0);
                 }
             if (tap == 5 && more) write_patch(kc + 1, nxt);          // the other buffer: last read one chunk ago
+            else {
+                // pin the issue order of the tap: the ring refill first (left alone, the scheduler sinks the loads next to
+                // their uses and the three-tap prefetch distance collapses), then the B reads, then the MFMAs.
+                // (Also tried: B fragments one tap ahead in a second register set -- +3 % on the 512-channel layers, but
+                // the 16 extra VGPRs spill the epilogue state and the short-K layers lose more than that.)
+                __builtin_amdgcn_sched_group_barrier(0x020, MI, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4 * MI, 0);
+            }
         }
         __syncthreads();
     }
