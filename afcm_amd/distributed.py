@@ -99,6 +99,34 @@ class GradientBuckets:
             b['pending'] = b['n']
         self._inflight = []
 
+    def finish_flat(self):
+        """Like finish(), but leaves the SUMMED gradients in the buckets and returns ({parameter: bucket slice}, 1 / world)
+        for an optimizer that consumes them in place (afcm_amd.optim.FusedScrubAdam): no averaging pass and no copy back
+        into .grad -- the scale rides in the optimizer kernel."""
+        if not self.active:
+            return None, 1.0
+        launched = {i for i, _ in self._inflight}
+        for idx, b in enumerate(self._buckets):
+            if idx not in launched:
+                for p in b['params']:
+                    i, off = self._where[p]
+                    if p.grad is None:
+                        b['flat'][off:off + p.numel()].zero_()
+                    elif b['pending'] > 0:
+                        b['flat'][off:off + p.numel()].copy_(p.grad.reshape(-1))
+                self._inflight.append((idx, dist.all_reduce(b['flat'], op=dist.ReduceOp.SUM, group=self.group, async_op=True)))
+        views = {}
+        for idx, h in self._inflight:
+            h.wait()
+            b = self._buckets[idx]
+            off = 0
+            for p in b['params']:
+                views[p] = b['flat'][off:off + p.numel()].view(p.shape)
+                off += p.numel()
+            b['pending'] = b['n']
+        self._inflight = []
+        return views, 1.0 / self.world
+
     def remove_hooks(self):
         for h in self._hooks:
             h.remove()

@@ -324,6 +324,15 @@ class SynthesisNetwork(torch.nn.Module):
             setattr(self, name, layer)
             self.layer_names.append(name)
 
+    def _pool4(self, x):
+        """AdaptiveAvgPool2d((4, 4)) (NET:636,683).  When the plane divides evenly (36 -> 9x9 bins at every shipped
+        resolution) the adaptive bins are plain blocks: a reshape + mean, whose backward is a broadcast instead of the
+        atomic scatter kernel of adaptive_avg_pool2d_backward (0.38 ms per step at batch 16)."""
+        h, w = x.shape[-2:]
+        if h % 4 == 0 and w % 4 == 0:
+            return x.reshape(x.shape[0], x.shape[1], 4, h // 4, 4, w // 4).mean(dim=(3, 5))
+        return self.pool(x)
+
     def forward(self, ws, img_in, **layer_kwargs):
         _assert_shape(ws, [None, self.num_ws, self.w_dim])
         ws = ws.to(torch.float32).unbind(dim=1)
@@ -338,7 +347,7 @@ class SynthesisNetwork(torch.nn.Module):
                 E_features[self.sizes[rev_idx]] = img_in
 
         img_pool = self.e_16x16(img_in)
-        img_pool = self.pool(img_pool.to(torch.float32))
+        img_pool = self._pool4(img_pool.to(torch.float32))
         img_pool = self.fc_in(img_pool.flatten(1))
         img_global = self.dropout(img_pool)
 

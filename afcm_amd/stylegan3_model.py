@@ -14,6 +14,7 @@ comodgan_model.py:14), the wrapper owns a bare module and shards by batch across
 import torch
 
 from .distributed import GradientBuckets
+from .optim import FusedScrubAdam
 
 
 class StyleGAN3GeneratorStep:
@@ -22,7 +23,8 @@ class StyleGAN3GeneratorStep:
         self.netG = netG
         self.G_mapping = netG.mapping
         self.G_synthesis = netG.synthesis
-        self.optimizer_G = torch.optim.Adam(netG.parameters(), lr=lr_G, betas=(0.0, 0.99), eps=1e-8)
+        # nan_to_num of every gradient + Adam(betas=(0, 0.99)) (stylegan3_model.py:132-135, comodgan_model.py:19-20) as one HIP launch
+        self.optimizer_G = FusedScrubAdam(netG.parameters(), lr=lr_G, betas=(0.0, 0.99), eps=1e-8, scrub=True, posinf=1e5, neginf=-1e5)
         self.criterionL1 = torch.nn.L1Loss()
         self.lambda_L1 = lambda_L1
         self.style_mixing_prob = style_mixing_prob
@@ -60,9 +62,7 @@ class StyleGAN3GeneratorStep:
         self.optimizer_G.zero_grad(set_to_none=True)
         self.forward(update_emas=False)
         self.backward_G()
-        if self.buckets is not None:
-            self.buckets.finish()
-        for p in self.netG.parameters():
-            if p.grad is not None:
-                torch.nan_to_num(p.grad, nan=0, posinf=1e5, neginf=-1e5, out=p.grad)
-        self.optimizer_G.step()
+        grads, scale = (None, 1.0) if self.buckets is None else self.buckets.finish_flat()
+        # averaging (1 / world), the NaN/Inf scrub and the Adam update all happen inside the optimizer kernel; with buckets the
+        # reduced gradients are read where the all-reduce left them
+        self.optimizer_G.step(grads=grads, grad_scale=scale)

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define AFCM_ABI_VERSION 2
+#define AFCM_ABI_VERSION 3
 
 enum { AFCM_F32 = 0, AFCM_F16 = 1, AFCM_BF16 = 2 };
 enum { AFCM_OK = 0, AFCM_E_NOKERNEL = -1, AFCM_E_INVALID = -2 };
@@ -174,6 +174,31 @@ int afcm_scale_planes(void* y, const void* x, const float* scale, int32_t dtype_
 /* out[plane] = sum_i a[plane,i] * b[plane,i]  (b == NULL: plain sum); fp32 accumulation.  Used for the style /
  * demodulation / bias gradients. */
 int afcm_plane_dot(float* out, const void* a, const void* b, int32_t dtype, int64_t planes, int32_t hw, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Generator update: gradient scale (1/world after the all-reduce), the NaN/Inf scrub of the gradients
+ * (models/stylegan3_model.py:122-124,132-134: torch.nan_to_num(grad, nan=0, posinf=1e5, neginf=-1e5)) and the Adam step
+ * (models/comodgan_model.py:19-20: torch.optim.Adam(lr, betas=(0, 0.99), eps=1e-8)) for EVERY parameter tensor in one
+ * launch.  Replaces ~110 nan_to_num launches + torch's multi-tensor Adam passes; arithmetic follows torch's foreach
+ * implementation operation by operation.  All tensors fp32.
+ * `table` is a DEVICE array of n entries sorted by chunk0 (chunk0 = number of afcm_adam_chunk_elems()-sized chunks of
+ * the tensors before this one); total_chunks = chunk0 + chunks of the last entry.  step_size = lr / (1 - beta1^t),
+ * bias_correction2_sqrt = sqrt(1 - beta2^t), one_minus_beta* = 1 - beta*: all evaluated on the host in double as torch does
+ * (1.f - 0.999f differs from (float)(1.0 - 0.999) by 5e-5 relative).
+ * write_grad != 0 stores the scaled + scrubbed gradient back (what the reference leaves in .grad).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct afcm_adam_entry {
+    void*   p;        /* parameter, updated in place     */
+    void*   g;        /* gradient                        */
+    void*   m;        /* exp_avg, updated in place       */
+    void*   v;        /* exp_avg_sq, updated in place    */
+    int64_t numel;
+    int64_t chunk0;
+} afcm_adam_entry;
+int32_t afcm_adam_chunk_elems(void);
+int afcm_adam_multi(const afcm_adam_entry* table, int32_t n, int64_t total_chunks, float step_size, float beta1, float beta2,
+                    float one_minus_beta1, float one_minus_beta2, float bias_correction2_sqrt, float eps, float grad_scale, int32_t scrub, float posinf, float neginf,
+                    int32_t write_grad, void* stream);
 
 #ifdef __cplusplus
 }

@@ -51,6 +51,13 @@ def _worker(rank, world, port, bucket_bytes, out_dir):
         loss.backward()
         buckets.finish()
     torch.save({n: (p.grad.clone() if p.grad is not None else None) for n, p in m.named_parameters()}, os.path.join(out_dir, f'g{rank}.pt'))
+    # third iteration through finish_flat(): the optimizer path that reads the summed buckets in place
+    for p in m.parameters():
+        p.grad = None
+    (m[:5](xs) - ys).abs().mean().backward()
+    views, scale = buckets.finish_flat()
+    assert abs(scale - 1.0 / world) < 1e-12
+    torch.save({n: (views[p] * scale).clone() for n, p in m.named_parameters()}, os.path.join(out_dir, f'f{rank}.pt'))
     torch.save(buckets.num_buckets, os.path.join(out_dir, f'nb{rank}.pt'))
     dist.destroy_process_group()
 
@@ -75,6 +82,10 @@ def test_bucketed_allreduce_matches_full_batch(tmp_path, bucket_bytes):
             continue
         assert torch.allclose(g0[n], p.grad, atol=1e-6), n
         assert torch.allclose(g1[n], p.grad, atol=1e-6), n
+    f0 = torch.load(tmp_path / 'f0.pt')
+    for n, p in m.named_parameters():
+        want = p.grad if p.grad is not None else torch.zeros_like(p)
+        assert torch.allclose(f0[n], want, atol=1e-6), ('finish_flat', n)
     nb = torch.load(tmp_path / 'nb0.pt')
     assert nb >= (2 if bucket_bytes == 4096 else 1)
 
