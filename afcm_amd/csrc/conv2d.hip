@@ -1538,8 +1538,11 @@ static int wgrad_rows_per_step(int dtype) { return dtype == AFCM_F32 ? 1 : 2; }
 
 extern "C" int afcm_conv2d_wgrad_splits(int32_t n, int32_t cout, int32_t cin, int32_t p_rows) {
     const int tiles = cdiv(cout, 64) * cdiv(cin, 64);
+    // One workgroup per CU is resident (LDS ring), so aim for ONE full round of the 256 CUs and never one workgroup more:
+    // rounding up (258 workgroups = two rounds) halves the throughput, and every extra split costs a 36 x 64 x 64 x 4 B
+    // partial tile written and read back (at 768 workgroups the partials of a 64 -> 64 layer were 2/3 of its time).
     const char* tgt = getenv("AFCM_WGRAD_WGS");            // tuning aid: workgroups to aim for
-    int splits = cdiv(tgt ? atoi(tgt) : 768, tiles);
+    int splits = (tgt ? atoi(tgt) : 256) / tiles;
     const long long ksteps = (long long)n * p_rows;   // upper bound on the macro-steps of any dtype
     if (splits > ksteps) splits = (int)ksteps;
     if (splits < 1) splits = 1;
