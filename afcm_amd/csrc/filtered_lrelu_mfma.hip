@@ -53,6 +53,7 @@ struct FlreluMfmaParams {
     int xw, xh, yw, yh, C;
     int px0, py0;
     int tilesX, tilesY;
+    unsigned magicT, magicP;   // ceil(2^32 / tilesX), ceil(2^32 / (tilesX * tilesY)): block id -> (plane, tile) on the scalar unit
     float slope, clamp;
     int sx, sy, shq, swq;  // sign tensor: rows of quads, bytes per row
 };
@@ -225,14 +226,19 @@ __global__ __launch_bounds__((64 * MfmaGeom<UP, DOWN, TOW, TOH>::NG)) void flrel
     typedef MfmaOps<T> M;
     typedef typename M::frag frag;
     constexpr int NT = 64 * G::NG;
-    constexpr int SGN_BYTES = (SIGN == AFCM_SIGNS_READ) ? G::SGN_ROWS * G::SGN_PITCH + 256 * 8
-                            : (SIGN == AFCM_SIGNS_WRITE) ? G::SGW_ROWS * G::SGW_PITCH : 0;
-    constexpr int IN_ELEMS = cmax(G::IROWS * G::PIN, TOH * G::POUT);          // the staged output tile reuses the input tile's space
-    __shared__ __attribute__((aligned(16))) T lds_in[IN_ELEMS];
+    // LDS: ONE region (lds_a) is the input tile first, then -- once every wave holds its A fragments -- the sign staging
+    // (+ keep-mask table) and the staged output tile; X3 has its own.  ~19 KB per workgroup: 8 workgroups per CU.
+    constexpr int SG_BYTES = (SIGN == AFCM_SIGNS_READ) ? G::SGN_ROWS * G::SGN_PITCH + 256 * 8
+                           : (SIGN == AFCM_SIGNS_WRITE) ? G::SGW_ROWS * G::SGW_PITCH : 0;
+    constexpr int OUT_OFF = (SIGN == AFCM_SIGNS_WRITE) ? SG_BYTES : 0;        // WRITE: codes are copied out while phase B stages Y
+    constexpr int A_BYTES = cmax(cmax(G::IROWS * G::PIN * 2, OUT_OFF + TOH * G::POUT * 2), SG_BYTES);
+    static_assert(OUT_OFF % 16 == 0, "staged output alignment");
+    __shared__ __attribute__((aligned(16))) unsigned char lds_a[A_BYTES];
     __shared__ __attribute__((aligned(16))) T lds_x3[TOH * G::PX3];
-    __shared__ __attribute__((aligned(16))) unsigned char lds_sg[SGN_BYTES > 0 ? SGN_BYTES : 16];
     __shared__ unsigned lds_flag[G::NG];
-    T* const lds_out = lds_in;
+    T* const lds_in = (T*)lds_a;
+    unsigned char* const lds_sg = lds_a;
+    T* const lds_out = (T*)(lds_a + OUT_OFF);
     const uint2* const lds_tab = (const uint2*)(lds_sg + G::SGN_ROWS * G::SGN_PITCH);   // READ only
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -244,15 +250,21 @@ __global__ __launch_bounds__((64 * MfmaGeom<UP, DOWN, TOW, TOH>::NG)) void flrel
         const int total = gridDim.x;
         if ((total & 7) == 0) bid = (bid & 7) * (total >> 3) + (bid >> 3);
     }
-    const int tx = bid % p.tilesX; bid /= p.tilesX;
-    const int ty = bid % p.tilesY;
-    const int plane = bid / p.tilesY;
+    // divisions by multiply-high (exact for the grid sizes the host admits): the compiler's uniform integer division is a
+    // ~25-instruction float-reciprocal sequence on the VECTOR unit, three of them per wave
+    const int plane = p.magicP ? (int)__umulhi((unsigned)bid, p.magicP) : bid;            // magic 0: divisor 1
+    const int tile = bid - plane * (p.tilesX * p.tilesY);
+    const int ty = p.magicT ? (int)__umulhi((unsigned)tile, p.magicT) : tile;
+    const int tx = tile - ty * p.tilesX;
     const int O0x = tx * TOW, O0y = ty * TOH;
     const int U0x = O0x * DOWN, U0y = O0y * DOWN;
     const int I0x = -floor_div(p.px0 - U0x, UP), I0y = -floor_div(p.py0 - U0y, UP);
     const int S0x = I0x - (I0x & 1);                            // first staged column (even: aligned dword pairs)
     const bool lastX = (tx == p.tilesX - 1), lastY = (ty == p.tilesY - 1);
     bool has_clamp = false;                                     // READ: some staged code carries the clamp bit
+    constexpr int NSW = (SIGN == AFCM_SIGNS_READ) ? cdiv(G::SGN_ROWS * G::SGN_WORDS, NT) : 1;
+    unsigned sv[NSW];                                           // READ: this thread's words of the sign window
+    uint4 tabv = make_uint4(0, 0, 0, 0);                        // READ: its piece of the keep-mask table
 
     // ---- stage the input tile: zero outside the image (the bias is added before padding).
     // One item = 8 consecutive columns of one row = one 16-byte load from a 4-byte aligned address.  Rows outside the
@@ -302,29 +314,30 @@ __global__ __launch_bounds__((64 * MfmaGeom<UP, DOWN, TOW, TOH>::NG)) void flrel
             // sign window: quad-rows [(U0y+sy)>>2, +SGN_ROWS), columns [U0x+sx, +XCOLS), fetched as aligned dwords
             const unsigned char* sp = p.s + (size_t)plane * p.shq * p.swq;
             const int qy0 = (U0y + p.sy) >> 2, w0 = (U0x + p.sx) >> 2, wpr = p.swq >> 2;
-            constexpr int NSW = cdiv(G::SGN_ROWS * G::SGN_WORDS, NT);
-            unsigned sv[NSW];
             unsigned any = 0;
+            if (qy0 >= 0 && qy0 + G::SGN_ROWS <= p.shq && w0 >= 0 && w0 + G::SGN_WORDS <= wpr) {
+                // the whole window lies inside the sign tensor (every tile but the border ones): no per-word predicates
+                const unsigned* sbase = (const unsigned*)(sp + (size_t)qy0 * p.swq) + w0;
 #pragma unroll
-            for (int i = 0; i < NSW; i++) {
-                const int idx = tid + i * NT;
-                const int r = idx / G::SGN_WORDS, c = idx - r * G::SGN_WORDS;
-                const int qy = qy0 + r, wi = w0 + c;
-                sv[i] = (idx < G::SGN_ROWS * G::SGN_WORDS && (unsigned)qy < (unsigned)p.shq && (unsigned)wi < (unsigned)wpr)
-                            ? ((const unsigned*)(sp + (size_t)qy * p.swq))[wi] : 0u;
-            }
-            // keep-mask table: 2 KB from the workspace
-            const uint4 tabv = (tid < 128) ? ((const uint4*)((const char*)p.ws + kWsTable))[tid] : make_uint4(0, 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < NSW; i++) {
-                const int idx = tid + i * NT;
-                any |= sv[i];
-                if (idx < G::SGN_ROWS * G::SGN_WORDS) {
+                for (int i = 0; i < NSW; i++) {
+                    const int idx = min(tid + i * NT, G::SGN_ROWS * G::SGN_WORDS - 1);
                     const int r = idx / G::SGN_WORDS, c = idx - r * G::SGN_WORDS;
-                    *(unsigned*)(lds_sg + r * G::SGN_PITCH + 4 * c) = sv[i];
+                    sv[i] = sbase[r * wpr + c];
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < NSW; i++) {
+                    const int idx = tid + i * NT;
+                    const int r = idx / G::SGN_WORDS, c = idx - r * G::SGN_WORDS;
+                    const int qy = qy0 + r, wi = w0 + c;
+                    sv[i] = (idx < G::SGN_ROWS * G::SGN_WORDS && (unsigned)qy < (unsigned)p.shq && (unsigned)wi < (unsigned)wpr)
+                                ? ((const unsigned*)(sp + (size_t)qy * p.swq))[wi] : 0u;
                 }
             }
-            if (tid < 128) ((uint4*)lds_tab)[tid] = tabv;
+            // keep-mask table: 2 KB from the workspace.  Both stay in registers until the input tile has been consumed.
+            if (tid < 128) tabv = ((const uint4*)((const char*)p.ws + kWsTable))[tid];
+#pragma unroll
+            for (int i = 0; i < NSW; i++) any |= sv[i];
             const bool wc = __builtin_amdgcn_ballot_w64((any & 0xaaaaaaaau) != 0) != 0;
             if (lane == 0) lds_flag[wave] = wc ? 1u : 0u;
         }
@@ -356,21 +369,10 @@ __global__ __launch_bounds__((64 * MfmaGeom<UP, DOWN, TOW, TOH>::NG)) void flrel
         }
     }
     __syncthreads();
-    if (SIGN == AFCM_SIGNS_READ) {
-        unsigned f = 0;
-#pragma unroll
-        for (int w = 0; w < G::NG; w++) f |= lds_flag[w];
-        has_clamp = __builtin_amdgcn_readfirstlane(f) != 0;
-    }
-
-    const frag* wsf = (const frag*)p.ws;
-    auto cfrag = [&](int f) __attribute__((always_inline)) { return wsf[f * 64 + lane]; };
-    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-
-    // ---- phase A: one group of NB ucol blocks per wave: up-x, up-y, activation, down-y, all in registers
+    // every wave takes its A fragments (input rows x 32-column window) into registers; then lds_a changes hands
+    frag a_in[G::NMB];
     {
         const int Gi = wave;
-        frag a_in[G::NMB];
 #pragma unroll
         for (int mb = 0; mb < G::NMB; mb++) {
             const T* src = lds_in + (16 * mb + l15) * G::PIN + G::IWSTEP * Gi + 8 * g;
@@ -383,6 +385,32 @@ __global__ __launch_bounds__((64 * MfmaGeom<UP, DOWN, TOW, TOH>::NG)) void flrel
             }
             a_in[mb] = t.f;
         }
+    }
+    if (SIGN != AFCM_SIGNS_NONE) __syncthreads();
+    if (SIGN == AFCM_SIGNS_READ) {
+#pragma unroll
+        for (int i = 0; i < NSW; i++) {
+            const int idx = tid + i * NT;
+            if (idx < G::SGN_ROWS * G::SGN_WORDS) {
+                const int r = idx / G::SGN_WORDS, c = idx - r * G::SGN_WORDS;
+                *(unsigned*)(lds_sg + r * G::SGN_PITCH + 4 * c) = sv[i];
+            }
+        }
+        if (tid < 128) ((uint4*)lds_tab)[tid] = tabv;
+        unsigned f = 0;
+#pragma unroll
+        for (int w = 0; w < G::NG; w++) f |= lds_flag[w];
+        has_clamp = __builtin_amdgcn_readfirstlane(f) != 0;
+        __syncthreads();
+    }
+
+    const frag* wsf = (const frag*)p.ws;
+    auto cfrag = [&](int f) __attribute__((always_inline)) { return wsf[f * 64 + lane]; };
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+    // ---- phase A: one group of NB ucol blocks per wave: up-x, up-y, activation, down-y, all in registers
+    {
+        const int Gi = wave;
         frag uv[UP], dvs[G::NDVK], dvr[G::NDVK];
 #pragma unroll
         for (int v = 0; v < UP; v++) uv[v] = cfrag(G::NB + v);
@@ -503,9 +531,20 @@ __global__ __launch_bounds__((64 * MfmaGeom<UP, DOWN, TOW, TOH>::NG)) void flrel
         const int rows = lastY ? min(G::SGW_ROWS, p.shq - q0) : (TOH * DOWN) / 4;
         const int segs = (lastX ? min(G::XCOLS, p.swq - U0x) : TOW * DOWN) >> 4;
         unsigned char* sg = p.s + ((size_t)plane * p.shq + q0) * p.swq + U0x;
-        for (int idx = tid; idx < rows * segs; idx += NT) {
-            const int r = idx / segs, c = idx - r * segs;
-            *(uint4*)(sg + (size_t)r * p.swq + 16 * c) = *(const uint4*)(lds_sg + r * G::SGW_PITCH + 16 * c);
+        if (!lastX && !lastY) {
+            constexpr int SEGS = (TOW * DOWN) / 16, ROWS = (TOH * DOWN) / 4;     // compile-time index split for the common case
+#pragma unroll
+            for (int i = 0; i < cdiv(ROWS * SEGS, NT); i++) {
+                const int idx = tid + i * NT;
+                const int r = idx / SEGS, c = idx - r * SEGS;
+                if ((ROWS * SEGS) % NT == 0 || idx < ROWS * SEGS)
+                    *(uint4*)(sg + (size_t)r * p.swq + 16 * c) = *(const uint4*)(lds_sg + r * G::SGW_PITCH + 16 * c);
+            }
+        } else {
+            for (int idx = tid; idx < rows * segs; idx += NT) {
+                const int r = idx / segs, c = idx - r * segs;
+                *(uint4*)(sg + (size_t)r * p.swq + 16 * c) = *(const uint4*)(lds_sg + r * G::SGW_PITCH + 16 * c);
+            }
         }
     }
 
@@ -605,6 +644,11 @@ static int launch_mfma(const afcm_filtered_lrelu_args* a, hipStream_t st) {
     p.sx = a->sx; p.sy = a->sy; p.shq = a->sh; p.swq = a->swb;
     const long long blocks = (long long)p.tilesX * p.tilesY * a->n * a->c;
     AFCM_REQUIRE(blocks > 0 && blocks < (1ll << 31), "filtered_lrelu: grid of %lld blocks is out of range", blocks);
+    // q = umulhi(x, ceil(2^32 / d)) equals x / d whenever x * d < 2^32 (error term x * (M d - 2^32) < x d)
+    const long long tpp = (long long)p.tilesX * p.tilesY;
+    AFCM_REQUIRE(blocks * tpp < (1ll << 32), "filtered_lrelu: grid of %lld blocks x %lld tiles per plane is out of range", blocks, tpp);
+    p.magicT = p.tilesX == 1 ? 0u : (unsigned)(((1ull << 32) + p.tilesX - 1) / p.tilesX);
+    p.magicP = tpp == 1 ? 0u : (unsigned)(((1ull << 32) + tpp - 1) / tpp);
     AFCM_REQUIRE((long long)a->xh * a->xw < (1ll << 30), "filtered_lrelu: plane of %d x %d elements is out of range", a->xh, a->xw);
     dim3 grid((unsigned)blocks), block(64 * G::NG);
     const bool bias = a->b != nullptr;
