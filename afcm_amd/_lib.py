@@ -28,7 +28,7 @@ class FilteredLReluArgs(C.Structure):
         ('gain', C.c_float), ('slope', C.c_float), ('clamp', C.c_float),
         ('flip_filter', C.c_int32), ('sign_mode', C.c_int32),
         ('workspace', C.c_void_p), ('sign_layout', C.c_int32), ('plane_sum_slots', C.c_int32),
-        ('plane_sum', C.c_void_p),
+        ('plane_sum', C.c_void_p), ('oscale', C.c_void_p), ('skip', C.c_void_p),
     ]
 
 
@@ -50,7 +50,7 @@ SIGNATURES = {
     'afcm_bias_act': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i64, _i32, _i32, _i32, _f32, _f32, _f32, _vp]),
     'afcm_conv2d_block_k': (C.c_int, [_i32]),
     'afcm_conv2d_pack_weights': (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
-    'afcm_conv2d': (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    'afcm_conv2d': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     'afcm_conv2d_wgrad_splits': (C.c_int, [_i32, _i32, _i32, _i32]),
     'afcm_conv2d_wgrad': (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     'afcm_scale_planes': (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i64, _i32, _vp]),
@@ -73,8 +73,8 @@ def load():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
-        if lib.afcm_abi_version() != 3:
-            raise RuntimeError(f'libafcm_hip.so ABI version {lib.afcm_abi_version()} does not match this package (3); rebuild it')
+        if lib.afcm_abi_version() != 4:
+            raise RuntimeError(f'libafcm_hip.so ABI version {lib.afcm_abi_version()} does not match this package (4); rebuild it')
         _lib = lib
     return _lib
 

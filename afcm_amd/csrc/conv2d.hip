@@ -36,6 +36,7 @@ struct ConvParams {
     void* y;              // [N, Cout, P, Q]
     const void* wp;       // packed weights [nkc][KK][Opad][BK]
     const float* oscale;  // [N * Cout] or null
+    const float* obias;   // [Cout] or null: y = acc * oscale + obias
     int N, Cin, Cout, H, W, P, Q;
     int pad;
     int TH, TW, PWL, tilesX, tilesY;
@@ -265,34 +266,38 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? 1 : 2)) void conv2d_fwd_kern
 
     // ---- epilogue: D[row = channel][col = pixel]; row = (reg&3) + 8*(reg>>2) + 4*h within the 32x32 tile.
     T* yn = (T*)p.y + (size_t)n * p.Cout * p.P * p.Q;
-    // all per-channel scales first (clamped index, no branch around the loads): one wait instead of 16 * MI round trips
-    float sc[MI][16];
+    // per output-row block: all per-channel scales and biases first (clamped index, no branch around the loads: one wait
+    // instead of a round trip per row), then the stores
+    int poff[4];                                     // pixel offset inside a plane, -1: not stored
 #pragma unroll
-    for (int mi = 0; mi < MI; mi++)
+    for (int ti = 0; ti < 4; ti++) poff[ti] = (pyv[ti] < p.P && pxv[ti] < p.Q) ? pyv[ti] * p.Q + pxv[ti] : -1;
+    const float* osn = p.oscale ? p.oscale + (size_t)n * p.Cout : nullptr;
+    const int pq = p.P * p.Q;
 #pragma unroll
-        for (int reg = 0; reg < 16; reg++) sc[mi][reg] = 1.f;
-    if (p.oscale) {
-        const float* osn = p.oscale + (size_t)n * p.Cout;
+    for (int mi = 0; mi < MI; mi++) {
+        float sc[16], ob[16];
+        const int obase = o0 + wo * (BM_O / 2) + mi * 32 + 4 * h;
 #pragma unroll
-        for (int mi = 0; mi < MI; mi++)
+        for (int reg = 0; reg < 16; reg++) { sc[reg] = 1.f; ob[reg] = 0.f; }
+        if (osn != nullptr) {
 #pragma unroll
-            for (int reg = 0; reg < 16; reg++) {
-                const int o = o0 + wo * (BM_O / 2) + mi * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-                sc[mi][reg] = osn[min(o, p.Cout - 1)];
-            }
-    }
+            for (int reg = 0; reg < 16; reg++) sc[reg] = osn[min(obase + (reg & 3) + 8 * (reg >> 2), p.Cout - 1)];
+        }
+        if (p.obias != nullptr) {
 #pragma unroll
-    for (int mi = 0; mi < MI; mi++)
+            for (int reg = 0; reg < 16; reg++) ob[reg] = p.obias[min(obase + (reg & 3) + 8 * (reg >> 2), p.Cout - 1)];
+        }
 #pragma unroll
         for (int reg = 0; reg < 16; reg++) {
-            const int o = o0 + wo * (BM_O / 2) + mi * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+            const int o = obase + (reg & 3) + 8 * (reg >> 2);
             if (o < p.Cout) {
-                T* yo = yn + (size_t)o * p.P * p.Q;
+                T* yo = yn + (size_t)o * pq;
 #pragma unroll
                 for (int ti = 0; ti < 4; ti++)
-                    if (pyv[ti] < p.P && pxv[ti] < p.Q) yo[(size_t)pyv[ti] * p.Q + pxv[ti]] = from_f32<T>(acc[mi][ti][reg] * sc[mi][reg]);
+                    if (poff[ti] >= 0) yo[poff[ti]] = from_f32<T>(acc[mi][ti][reg] * sc[reg] + ob[reg]);
             }
         }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -480,35 +485,98 @@ __global__ __launch_bounds__(256, 2) void conv2d_fwd16_kernel(ConvParams p) {
     }
 
     // ---- epilogue: D[row = channel][col = pixel]; row = (reg&3) + 8*(reg>>2) + 4*h within the 32x32 tile.
-    T* yn = (T*)p.y + (size_t)n * p.Cout * p.P * p.Q;
-    // all per-channel scales first (clamped index, no branch around the loads): one wait instead of 16 * MI round trips
-    float sc[MI][16];
+    if ((p.TW & 7) == 0) {
+        // Tile rows that are multiples of 8 pixels: transpose through LDS (the patch buffers are free after the last barrier)
+        // and store 8 pixels = 16 bytes per lane.  Per thread: 128 conversions + 128 two-byte LDS writes + 16 b128 reads +
+        // 16 stores, instead of 128 predicated two-byte global stores with 64-bit address arithmetic each (~2900
+        // instructions -- more than the whole main loop of a 64-channel layer).
+        constexpr int EP = 264;                                   // bytes per staged channel row: 128 pixels + 8 pad
+        unsigned char* ebuf = (unsigned char*)lds + wave * (32 * EP);
+        T* yn = (T*)p.y + (size_t)n * p.Cout * p.P * p.Q;
+        const float* osn = p.oscale ? p.oscale + (size_t)n * p.Cout : nullptr;
+        const int pq = p.P * p.Q;
+        // this lane's granule of the read-back: pixels j0 .. j0+7 of the wave's 128, one tile row (TW % 8 == 0)
+        const int gq = lane & 15, j0 = wpx * 128 + gq * 8;
+        const int gpy = j0 / p.TW, gpx = j0 - gpy * p.TW;
+        const int gy = y0 + gpy, gx = x0 + gpx;
+        const bool gok = j0 < p.TH * p.TW && gy < p.P && gx < p.Q;
+        const bool gfull = gx + 8 <= p.Q;
+        const int goff = gy * p.Q + gx;
 #pragma unroll
-    for (int mi = 0; mi < MI; mi++)
+        for (int mi = 0; mi < MI; mi++) {
+            float sc[16], ob[16];
+            const int obase = o0 + wo * (BM_O / 2) + mi * 32 + 4 * h;
 #pragma unroll
-        for (int reg = 0; reg < 16; reg++) sc[mi][reg] = 1.f;
-    if (p.oscale) {
-        const float* osn = p.oscale + (size_t)n * p.Cout;
+            for (int reg = 0; reg < 16; reg++) { sc[reg] = 1.f; ob[reg] = 0.f; }
+            if (osn != nullptr) {
 #pragma unroll
-        for (int mi = 0; mi < MI; mi++)
+                for (int reg = 0; reg < 16; reg++) sc[reg] = osn[min(obase + (reg & 3) + 8 * (reg >> 2), p.Cout - 1)];
+            }
+            if (p.obias != nullptr) {
+#pragma unroll
+                for (int reg = 0; reg < 16; reg++) ob[reg] = p.obias[min(obase + (reg & 3) + 8 * (reg >> 2), p.Cout - 1)];
+            }
 #pragma unroll
             for (int reg = 0; reg < 16; reg++) {
-                const int o = o0 + wo * (BM_O / 2) + mi * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-                sc[mi][reg] = osn[min(o, p.Cout - 1)];
-            }
-    }
-#pragma unroll
-    for (int mi = 0; mi < MI; mi++)
-#pragma unroll
-        for (int reg = 0; reg < 16; reg++) {
-            const int o = o0 + wo * (BM_O / 2) + mi * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-            if (o < p.Cout) {
-                T* yo = yn + (size_t)o * p.P * p.Q;
+                const int row = (reg & 3) + 8 * (reg >> 2) + 4 * h;
 #pragma unroll
                 for (int ti = 0; ti < 4; ti++)
-                    if (pyv[ti] < p.P && pxv[ti] < p.Q) yo[(size_t)pyv[ti] * p.Q + pxv[ti]] = from_f32<T>(acc[mi][ti][reg] * sc[mi][reg]);
+                    *(T*)(ebuf + row * EP + (ti * 32 + r32) * 2) = from_f32<T>(acc[mi][ti][reg] * sc[reg] + ob[reg]);
+            }
+            // same wave wrote and reads: LDS operations of a wave complete in order, no barrier needed
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int ol = 4 * k + (lane >> 4);
+                const uint4 v = *(const uint4*)(ebuf + ol * EP + gq * 16);
+                const int o = o0 + wo * (BM_O / 2) + mi * 32 + ol;
+                if (gok && o < p.Cout) {
+                    T* dst = yn + (size_t)o * pq + goff;
+                    if (gfull) {
+                        *(uint4*)dst = v;
+                    } else {                                      // the granule straddles the right edge (even width: whole pairs)
+                        const unsigned vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                        for (int w2 = 0; w2 < 4; w2++)
+                            if (gx + 2 * w2 < p.Q) ((unsigned*)dst)[w2] = vv[w2];
+                    }
+                }
             }
         }
+        return;
+    }
+    T* yn = (T*)p.y + (size_t)n * p.Cout * p.P * p.Q;
+    // per output-row block: all per-channel scales and biases first (clamped index, no branch around the loads: one wait
+    // instead of a round trip per row), then the stores
+    int poff[4];                                     // pixel offset inside a plane, -1: not stored
+#pragma unroll
+    for (int ti = 0; ti < 4; ti++) poff[ti] = (pyv[ti] < p.P && pxv[ti] < p.Q) ? pyv[ti] * p.Q + pxv[ti] : -1;
+    const float* osn = p.oscale ? p.oscale + (size_t)n * p.Cout : nullptr;
+    const int pq = p.P * p.Q;
+#pragma unroll
+    for (int mi = 0; mi < MI; mi++) {
+        float sc[16], ob[16];
+        const int obase = o0 + wo * (BM_O / 2) + mi * 32 + 4 * h;
+#pragma unroll
+        for (int reg = 0; reg < 16; reg++) { sc[reg] = 1.f; ob[reg] = 0.f; }
+        if (osn != nullptr) {
+#pragma unroll
+            for (int reg = 0; reg < 16; reg++) sc[reg] = osn[min(obase + (reg & 3) + 8 * (reg >> 2), p.Cout - 1)];
+        }
+        if (p.obias != nullptr) {
+#pragma unroll
+            for (int reg = 0; reg < 16; reg++) ob[reg] = p.obias[min(obase + (reg & 3) + 8 * (reg >> 2), p.Cout - 1)];
+        }
+#pragma unroll
+        for (int reg = 0; reg < 16; reg++) {
+            const int o = obase + (reg & 3) + 8 * (reg >> 2);
+            if (o < p.Cout) {
+                T* yo = yn + (size_t)o * pq;
+#pragma unroll
+                for (int ti = 0; ti < 4; ti++)
+                    if (poff[ti] >= 0) yo[poff[ti]] = from_f32<T>(acc[mi][ti][reg] * sc[reg] + ob[reg]);
+            }
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1440,6 +1508,7 @@ static void choose_tile(int P, int Q, int KS, int* TH, int* TW, int* PWL) {
     // Tile of TH x TW output pixels with TH*TW <= 256 slots and an LDS patch (TH+KS-1) x round4(TW+KS) <= kPatchMax,
     // chosen to maximise the fraction of useful slots.
     double best = -1;
+    static const double gran_bonus = getenv("AFCM_CONV_GRAN_BONUS") ? atof(getenv("AFCM_CONV_GRAN_BONUS")) : 0.03;   // tuning aid
     for (int tw = 2; tw <= 128; tw += 2) {
         int th = kSlots / tw;
         if (th > P) th = P;
@@ -1448,8 +1517,9 @@ static void choose_tile(int P, int Q, int KS, int* TH, int* TW, int* PWL) {
             if ((th + KS - 1) * pwl > kPatchMax) continue;
             const double tiles = (double)cdiv(P, th) * cdiv(Q, tw);
             const double util = (double)P * Q / (tiles * kSlots);
-            // small preference for wide tiles (longer contiguous runs for loads/stores)
-            const double score = util + 1e-4 * tw;
+            // small preference for wide tiles (longer contiguous runs for loads/stores); rows of whole 8-pixel granules
+            // get the 16-byte LDS-transposed epilogue of the 16-bit kernel: worth a few % of slot utilisation
+            const double score = util + 1e-4 * tw + ((tw & 7) == 0 ? gran_bonus : 0.0);
             if (score > best) { best = score; *TH = th; *TW = tw; *PWL = pwl; }
             break;
         }
@@ -1502,8 +1572,8 @@ extern "C" int afcm_conv2d_pack_weights(void* dst, const float* w, int32_t dtype
     return hip_status(hipGetLastError());
 }
 
-extern "C" int afcm_conv2d(void* y, const void* x, const void* wpacked, const float* oscale, int32_t dtype, int32_t n, int32_t cin,
-                           int32_t cout, int32_t h, int32_t w, int32_t ks, int32_t pad, int32_t rows_pad, void* stream) {
+extern "C" int afcm_conv2d(void* y, const void* x, const void* wpacked, const float* oscale, const float* obias, int32_t dtype, int32_t n,
+                           int32_t cin, int32_t cout, int32_t h, int32_t w, int32_t ks, int32_t pad, int32_t rows_pad, void* stream) {
     AFCM_REQUIRE(y != nullptr && x != nullptr && wpacked != nullptr, "conv2d: null pointer");
     AFCM_REQUIRE(dtype == AFCM_F32 || dtype == AFCM_F16 || dtype == AFCM_BF16, "x must be float32, float16 or bfloat16");
     AFCM_REQUIRE(n > 0 && cin > 0 && cout > 0 && h > 0 && w > 0, "x is empty");
@@ -1512,7 +1582,7 @@ extern "C" int afcm_conv2d(void* y, const void* x, const void* wpacked, const fl
     AFCM_REQUIRE(dtype == AFCM_F32 || (w % 2 == 0), "16-bit conv2d needs an even input width (got %d)", w);
     AFCM_REQUIRE(rows_pad >= cout && rows_pad % 64 == 0, "rows_pad must be a multiple of 64 covering cout");
     ConvParams p;
-    p.x = x; p.y = y; p.wp = wpacked; p.oscale = oscale;
+    p.x = x; p.y = y; p.wp = wpacked; p.oscale = oscale; p.obias = obias;
     p.N = n; p.Cin = cin; p.Cout = cout; p.H = h; p.W = w;
     p.P = h + 2 * pad - ks + 1; p.Q = w + 2 * pad - ks + 1;
     AFCM_REQUIRE(p.P >= 1 && p.Q >= 1, "output must be at least 1x1");

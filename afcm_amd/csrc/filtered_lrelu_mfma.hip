@@ -50,6 +50,8 @@ struct FlreluMfmaParams {
     unsigned char* s;
     const void* ws;        // constant fragments + mask table
     float* plane_sum;      // optional fp32 [N*C][tilesX*tilesY]: per-tile sums of this launch's outputs (bias gradient without a second pass)
+    const float* oscale;   // optional fp32 [N*C]: per-plane factor of the output
+    const void* skip;      // optional [N*C][yh][yw]: added to the output before the factor
     int xw, xh, yw, yh, C;
     int px0, py0;
     int tilesX, tilesY;
@@ -554,6 +556,8 @@ __global__ __launch_bounds__((64 * MfmaGeom<UP, DOWN, TOW, TOH>::NG)) void flrel
 #pragma unroll
         for (int t = 0; t < G::NDVK; t++) dh[t] = cfrag(G::NB + UP + 2 * G::NDVK + t);
         const bool inner = (O0x + TOW <= p.yw) && (O0y + TOH <= p.yh);
+        const float osc = p.oscale ? p.oscale[plane] : 1.f;
+        const T* skp = p.skip ? (const T*)p.skip + (size_t)plane * p.yh * p.yw : nullptr;
         float psum = 0.f;
         for (int unit = wave; unit < G::NOB * G::NCB; unit += G::NG) {
             const int ob = unit / G::NCB, cb = unit - ob * G::NCB;
@@ -564,6 +568,22 @@ __global__ __launch_bounds__((64 * MfmaGeom<UP, DOWN, TOW, TOH>::NG)) void flrel
                 b.q = *(const uint4*)(lds_x3 + (16 * ob + l15) * G::PX3 + 16 * DOWN * cb + 32 * t + 8 * g);
                 acc = M::mma(dh[t], b.f, acc);
             }
+            if (skp != nullptr) {
+                // encoder feature of this lane's 4 columns (x + x_skip, NET:376-377); pairs are in or out together (even width)
+                const int oy = O0y + 16 * ob + l15, ox = O0x + 16 * cb + 4 * g;
+                if (oy < p.yh) {
+                    const unsigned* sp2 = (const unsigned*)(skp + (size_t)oy * p.yw + ox);
+#pragma unroll
+                    for (int w = 0; w < 2; w++)
+                        if (ox + 2 * w < p.yw) {
+                            union { unsigned u; T t[2]; } e;
+                            e.u = sp2[w];
+                            acc[2 * w] += to_f32(e.t[0]);
+                            acc[2 * w + 1] += to_f32(e.t[1]);
+                        }
+                }
+            }
+            if (p.oscale) acc *= osc;
             uint2 w;
             w.x = pack2<T>(acc[0], acc[1]);
             w.y = pack2<T>(acc[2], acc[3]);
@@ -637,6 +657,7 @@ static int launch_mfma(const afcm_filtered_lrelu_args* a, hipStream_t st) {
     typedef MfmaGeom<UP, DOWN, TOW, TOH> G;
     FlreluMfmaParams p;
     p.x = a->x; p.y = a->y; p.b = a->b; p.s = a->signs; p.ws = a->workspace; p.plane_sum = a->plane_sum;
+    p.oscale = a->oscale; p.skip = a->skip;
     p.xw = a->xw; p.xh = a->xh; p.yw = a->yw; p.yh = a->yh; p.C = a->c;
     p.px0 = a->px0; p.py0 = a->py0;
     p.tilesX = cdiv(a->yw, TOW); p.tilesY = cdiv(a->yh, TOH);

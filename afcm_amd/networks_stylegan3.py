@@ -16,7 +16,8 @@ import torch
 import torch.nn.functional as F
 
 from . import layer_schedule as sched
-from .torch_utils.ops import bias_act, conv2d_gradfix, filtered_lrelu
+from .torch_utils.ops import bias_act, conv2d_gradfix, filtered_lrelu, fused_layer
+from .torch_utils.ops.conv2d import modulation_coefficients, scaled_conv2d
 from .torch_utils.ops.conv2d import modulated_conv2d  # noqa: F401  (re-exported: NET:25 lives in this module)
 
 
@@ -147,32 +148,54 @@ class SynthesisLayer(torch.nn.Module, _ResampleGeometry):
                                out_half_width, self.conv_kernel, filter_size, lrelu_upsampling, use_radial_filters, is_torgb,
                                is_critically_sampled)
 
-    def forward(self, x, w, global_w, E_features=None, include_skip=True, noise_mode='random', force_fp32=False, update_emas=False):
-        assert noise_mode in ['random', 'const', 'none']  # unused, as in the reference
-        _assert_shape(x, [None, self.in_channels, int(self.in_size[1]), int(self.in_size[0])])
-        _assert_shape(w, [x.shape[0], self.w_dim])
-        if update_emas:
-            with torch.autograd.profiler.record_function('update_magnitude_ema'):
-                magnitude_cur = x.detach().to(torch.float32).square().mean()
-                self.magnitude_ema.copy_(magnitude_cur.lerp(self.magnitude_ema, self.magnitude_ema_beta))
-        input_gain = self.magnitude_ema.rsqrt()
+    def modulation(self, w, global_w):
+        """Style path of the layer (NET:349-352 + the small-tensor half of modulated_conv2d, NET:41-57): returns
+        (w_hat, in_scale [N, Cin], out_scale [N, Cout] or None).  Depends on the latents only, not on the activations."""
         if self.cond_mod:
             w = torch.cat((w, global_w), 1)
         styles = self.affine(w)
         if self.is_torgb:
             styles = styles * (1 / np.sqrt(self.in_channels * (self.conv_kernel ** 2)))
+        return modulation_coefficients(self.weight, styles, demodulate=(not self.is_torgb), input_gain=self.magnitude_ema.rsqrt())
+
+    def _act_args(self):
+        return dict(up=self.up_factor, down=self.down_factor, padding=self.padding, gain=(1 if self.is_torgb else np.sqrt(2)),
+                    slope=(1 if self.is_torgb else 0.2), clamp=self.conv_clamp)
+
+    def fusable(self, x):
+        """Can this call run as the single fused node (torch_utils/ops/fused_layer.py)?"""
+        return fused_layer.available(x, self.weight, self.up_filter, self.down_filter, conv_pad=self.conv_kernel - 1, **self._act_args())
+
+    def forward(self, x, w, global_w, E_features=None, include_skip=True, noise_mode='random', force_fp32=False, update_emas=False,
+                _mod=None, _prescaled=False, _next_scale=None):
+        """Reference signature (NET:336).  The underscore arguments are SynthesisNetwork's fusion hooks: `_mod` = this layer's
+        precomputed modulation(), `_prescaled` = x already carries this layer's styles, `_next_scale` = the next layer's
+        styles to fold into this layer's output (fused node only)."""
+        assert noise_mode in ['random', 'const', 'none']  # unused, as in the reference
+        _assert_shape(x, [None, self.in_channels, int(self.in_size[1]), int(self.in_size[0])])
+        _assert_shape(w, [x.shape[0], self.w_dim])
+        if update_emas:
+            assert not _prescaled, 'magnitude EMA needs the unscaled activations'
+            with torch.autograd.profiler.record_function('update_magnitude_ema'):
+                magnitude_cur = x.detach().to(torch.float32).square().mean()
+                self.magnitude_ema.copy_(magnitude_cur.lerp(self.magnitude_ema, self.magnitude_ema_beta))
+            _mod = None
+        w_hat, in_scale, out_scale = _mod if _mod is not None else self.modulation(w, global_w)
         dtype = x.dtype
         x_skip = E_features[self.out_size[0]].to(dtype) if (E_features is not None and include_skip) else None
-        with torch.autograd.profiler.record_function('modulated_conv2d'):
-            x = modulated_conv2d(x=x, w=self.weight, s=styles, padding=self.conv_kernel - 1, demodulate=(not self.is_torgb),
-                                 input_gain=input_gain)
-        gain = 1 if self.is_torgb else np.sqrt(2)
-        slope = 1 if self.is_torgb else 0.2
-        x = filtered_lrelu.filtered_lrelu(x=x, fu=self.up_filter, fd=self.down_filter, b=self.bias.to(x.dtype), up=self.up_factor,
-                                          down=self.down_factor, padding=self.padding, gain=gain, slope=slope, clamp=self.conv_clamp)
+        act = self._act_args()
+        if self.fusable(x):
+            x = fused_layer.conv_filtered_lrelu(x, w_hat, in_scale, out_scale, self.bias, self.up_filter, self.down_filter,
+                                                conv_pad=self.conv_kernel - 1, skip=x_skip, next_scale=_next_scale,
+                                                prescaled=_prescaled, **act)
+        else:
+            assert _next_scale is None, 'only the fused node can pre-scale its output'
+            with torch.autograd.profiler.record_function('modulated_conv2d'):
+                x = scaled_conv2d(x, w_hat, in_scale, out_scale, self.conv_kernel - 1, prescaled=_prescaled)
+            x = filtered_lrelu.filtered_lrelu(x=x, fu=self.up_filter, fd=self.down_filter, b=self.bias.to(x.dtype), **act)
+            if x_skip is not None:
+                x = x + x_skip
         _assert_shape(x, [None, self.out_channels, int(self.out_size[1]), int(self.out_size[0])])
-        if include_skip and x_skip is not None:
-            x = x + x_skip
         assert x.dtype == dtype
         return x
 
@@ -210,9 +233,14 @@ class EncoderLayer(torch.nn.Module, _ResampleGeometry):
                 self.magnitude_ema.copy_(magnitude_cur.lerp(self.magnitude_ema, self.magnitude_ema_beta))
         dtype = x.dtype
         w = self.weight * self.weight_gain
-        x = conv2d_gradfix.conv2d(input=x, weight=w, padding=self.conv_kernel - 1)
-        x = filtered_lrelu.filtered_lrelu(x=x, fu=self.up_filter, fd=self.down_filter, b=self.bias.to(x.dtype), up=self.up_factor,
-                                          down=self.down_factor, padding=self.padding, gain=np.sqrt(2), slope=0.2, clamp=self.conv_clamp)
+        act = dict(up=self.up_factor, down=self.down_factor, padding=self.padding, gain=np.sqrt(2), slope=0.2, clamp=self.conv_clamp)
+        if fused_layer.available(x, self.weight, self.up_filter, self.down_filter, conv_pad=self.conv_kernel - 1, **act):
+            # conv (+ bias in its epilogue) -> filtered_lrelu as one autograd node (16-bit activations)
+            x = fused_layer.conv_filtered_lrelu(x, w, None, None, self.bias, self.up_filter, self.down_filter,
+                                                conv_pad=self.conv_kernel - 1, **act)
+        else:
+            x = conv2d_gradfix.conv2d(input=x, weight=w, padding=self.conv_kernel - 1)
+            x = filtered_lrelu.filtered_lrelu(x=x, fu=self.up_filter, fd=self.down_filter, b=self.bias.to(x.dtype), **act)
         _assert_shape(x, [None, self.out_channels, int(self.out_size[1]), int(self.out_size[0])])
         assert x.dtype == dtype
         return x
@@ -353,14 +381,23 @@ class SynthesisNetwork(torch.nn.Module):
 
         x = img_in
         res_idx = 1
-        for idx, (name, w) in enumerate(zip(self.layer_names, ws[1:])):
+        # Every layer's styles depend on the latents only: compute them up front, so that a layer running as the fused node
+        # can fold the NEXT layer's style factor into its own output epilogue (no separate pass over the activations).
+        fuse = not layer_kwargs.get('update_emas', False)
+        layers = [getattr(self, name) for name in self.layer_names]
+        mods = [layer.modulation(w, img_global) for layer, w in zip(layers, ws[1:])] if fuse else [None] * len(layers)
+        prescaled = False
+        for idx, (layer, w) in enumerate(zip(layers, ws[1:])):
             nxt = min(idx + 1, len(self.layer_names) - 1)
             if (self.sizes[idx] != self.sizes[nxt]) and self.sizes[idx] != self.sizes[0]:
                 include_skip = self.skip_connects[res_idx]
                 res_idx += 1
             else:
                 include_skip = False
-            x = getattr(self, name)(x, w, img_global, E_features, include_skip, **layer_kwargs)
+            next_scale = mods[idx + 1][1] if (fuse and idx + 1 < len(layers) and layer.fusable(x)) else None
+            x = layer(x, w, img_global, E_features, include_skip, _mod=mods[idx], _prescaled=prescaled, _next_scale=next_scale,
+                      **layer_kwargs)
+            prescaled = next_scale is not None
         if self.output_scale != 1:
             x = x * self.output_scale
         _assert_shape(x, [None, self.img_channels_out, self.img_resolution, self.img_resolution])

@@ -65,7 +65,7 @@ def plane_dot(a, b=None):
     return out
 
 
-def _conv_raw(x, wp, rows_pad, oscale, cout, ks, pad):
+def _conv_raw(x, wp, rows_pad, oscale, cout, ks, pad, obias=None):
     lib = _lib.load()
     n, cin, h, w = x.shape
     p, q = h + 2 * pad - ks + 1, w + 2 * pad - ks + 1
@@ -73,7 +73,10 @@ def _conv_raw(x, wp, rows_pad, oscale, cout, ks, pad):
     if oscale is not None:
         oscale = oscale.to(torch.float32).contiguous()
     span = profiling.span('conv2d', 2.0 * n * cout * cin * ks * ks * p * q)
-    _lib.check(lib.afcm_conv2d(y.data_ptr(), x.data_ptr(), wp.data_ptr(), _lib.ptr(oscale), _lib.dtype_code(x), n, cin, cout, h, w,
+    if obias is not None:
+        obias = obias.to(torch.float32).contiguous()
+        assert obias.numel() == cout
+    _lib.check(lib.afcm_conv2d(y.data_ptr(), x.data_ptr(), wp.data_ptr(), _lib.ptr(oscale), _lib.ptr(obias), _lib.dtype_code(x), n, cin, cout, h, w,
                                ks, pad, rows_pad, _lib.stream_ptr(x)), 'conv2d')
     if span is not None:
         span.end()
@@ -99,7 +102,7 @@ class _ScaledConv2d(torch.autograd.Function):
     """y = out_scale * conv(w, in_scale * x); scales are [N, C] fp32 tensors or None."""
 
     @staticmethod
-    def forward(ctx, x, w, in_scale, out_scale, padding):
+    def forward(ctx, x, w, in_scale, out_scale, padding, prescaled=False):
         _lib.require_gpu(x, w, in_scale, out_scale)
         if x.ndim != 4 or w.ndim != 4 or x.shape[1] != w.shape[1]:
             raise RuntimeError(f'conv2d: incompatible shapes x{tuple(x.shape)} w{tuple(w.shape)}')
@@ -108,11 +111,13 @@ class _ScaledConv2d(torch.autograd.Function):
         _lib.dtype_code(x)
         cout, cin, ks, _ = w.shape
         x = x.contiguous()
-        xs = scale_planes(x, in_scale) if in_scale is not None else x
+        # prescaled: the producer of x already applied in_scale (fused into its epilogue) and owns the gradient of in_scale
+        xs = scale_planes(x, in_scale) if (in_scale is not None and not prescaled) else x
         wp, rows_pad = pack_weights(w, x.dtype, 0)
         y = _conv_raw(xs, wp, rows_pad, out_scale, cout, ks, padding)
         ctx.save_for_backward(xs, w, in_scale, out_scale, y if (out_scale is not None and ctx.needs_input_grad[3]) else None)
         ctx.padding = padding
+        ctx.prescaled = bool(prescaled)
         return y
 
     @staticmethod
@@ -120,6 +125,8 @@ class _ScaledConv2d(torch.autograd.Function):
     def backward(ctx, dy):
         xs, w, in_scale, out_scale, y = ctx.saved_tensors
         pad = ctx.padding
+        if ctx.prescaled:
+            in_scale = None
         cout, cin, ks, _ = w.shape
         dy = dy.contiguous()
         dx = dw = d_in = d_out = None
@@ -129,7 +136,7 @@ class _ScaledConv2d(torch.autograd.Function):
             # data gradient of a pad-p correlation = correlation of dy with the flipped kernel at pad k-1-p;
             # the style factor of dx rides in the epilogue scale.
             dx = _conv_raw(dys, wpt, rows_pad, in_scale, cin, ks, ks - 1 - pad)
-            if ctx.needs_input_grad[2]:
+            if ctx.needs_input_grad[2] and in_scale is not None:
                 # d in_scale[n,i] = sum_pix x * g with xs = s*x and dx = s*g  =>  <xs, dx> / s^2
                 s2 = in_scale.to(torch.float32).square()
                 d_in = torch.where(s2 > 0, plane_dot(xs, dx) / s2.clamp_min(1e-30), torch.zeros_like(s2)).to(in_scale.dtype)
@@ -138,21 +145,17 @@ class _ScaledConv2d(torch.autograd.Function):
         if ctx.needs_input_grad[3]:
             # y = d * c  =>  d d[n,o] = <dy, c> = <dy, y> / d
             d_out = (plane_dot(dy, y) / out_scale.to(torch.float32)).to(out_scale.dtype)
-        return dx, dw, d_in, d_out, None
+        return dx, dw, d_in, d_out, None, None
 
 
-def scaled_conv2d(x, w, in_scale=None, out_scale=None, padding=0):
-    return _ScaledConv2d.apply(x, w, in_scale, out_scale, int(padding))
+def scaled_conv2d(x, w, in_scale=None, out_scale=None, padding=0, prescaled=False):
+    return _ScaledConv2d.apply(x, w, in_scale, out_scale, int(padding), bool(prescaled))
 
 
-def modulated_conv2d(x, w, s, demodulate=True, padding=0, input_gain=None):
-    """Drop-in for the reference's ``modulated_conv2d(x, w, s, demodulate, padding, input_gain)`` (NET:25-64).
-
-    x [N, I, H, W]; w [O, I, k, k]; s [N, I]; input_gain [], [I] or [N, I].  Returns [N, O, H + 2p - k + 1, ...].
-    """
-    n = int(x.shape[0])
-    o, i, kh, kw = w.shape
-    assert x.shape[1] == i and tuple(s.shape) == (n, i)
+def modulation_coefficients(w, s, demodulate=True, input_gain=None):
+    """The small-tensor half of ``modulated_conv2d`` (NET:41-57): returns (w_hat [O,I,k,k], in_scale [N,I], out_scale [N,O]
+    or None), all fp32 and differentiable, such that  y = out_scale * conv(w_hat, in_scale * x)."""
+    n, i = int(s.shape[0]), int(w.shape[1])
     w = w.to(torch.float32)
     s = s.to(torch.float32)
     d = None
@@ -163,6 +166,18 @@ def modulated_conv2d(x, w, s, demodulate=True, padding=0, input_gain=None):
         d = (s.square() @ w.square().sum([2, 3]).t() + 1e-8).rsqrt()   # [N, O]
     if input_gain is not None:
         s = s * input_gain.to(torch.float32).expand(n, i)              # NET:55-57
+    return w, s, d
+
+
+def modulated_conv2d(x, w, s, demodulate=True, padding=0, input_gain=None):
+    """Drop-in for the reference's ``modulated_conv2d(x, w, s, demodulate, padding, input_gain)`` (NET:25-64).
+
+    x [N, I, H, W]; w [O, I, k, k]; s [N, I]; input_gain [], [I] or [N, I].  Returns [N, O, H + 2p - k + 1, ...].
+    """
+    n = int(x.shape[0])
+    o, i, kh, kw = w.shape
+    assert x.shape[1] == i and tuple(s.shape) == (n, i)
+    w, s, d = modulation_coefficients(w, s, demodulate, input_gain)
     if isinstance(padding, (list, tuple)):
         assert padding[0] == padding[1]
         padding = padding[0]

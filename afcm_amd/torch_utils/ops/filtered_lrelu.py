@@ -96,7 +96,7 @@ def _mfma_workspace(a, fu_t, fd_t, x):
     return None if ent is None else ent[0]
 
 
-def _run(x, fu, fd, b, si, cfg, write_signs, want_plane_sum=False):
+def _run(x, fu, fd, b, si, cfg, write_signs, want_plane_sum=False, oscale=None, skip=None):
     """One launch of the op (C ABI afcm_filtered_lrelu, or the generic GPU path when there is no fused kernel).
     Returns (y, signs written or None, sign layout, per-plane output sums or None)."""
     up, down, px0, px1, py0, py1, gain, slope, clamp, flip_filter, sx, sy, si_layout = cfg
@@ -145,6 +145,17 @@ def _run(x, fu, fd, b, si, cfg, write_signs, want_plane_sum=False):
         a.sh, a.swb = si.shape[2], si.shape[3]
         a.signs = si.data_ptr()
     a.x, a.y, a.b = x.data_ptr(), y.data_ptr(), _lib.ptr(b)
+    if oscale is not None or skip is not None:
+        # epilogue factors of the fused layer op (matrix-core kernels only; the C side rejects anything else)
+        if ws is None:
+            raise RuntimeError('filtered_lrelu: oscale / skip need the matrix-core kernels')
+        if oscale is not None:
+            oscale = oscale.to(torch.float32).contiguous()
+            assert oscale.numel() == a.n * a.c
+        if skip is not None:
+            skip = skip.contiguous()
+            assert skip.dtype == x.dtype and tuple(skip.shape) == (a.n, a.c, a.yh, a.yw)
+        a.oscale, a.skip = _lib.ptr(oscale), _lib.ptr(skip)
     psum = None
     if ws is not None and want_plane_sum and a.plane_sum_slots > 0:
         psum = torch.empty([a.n, a.c, a.plane_sum_slots], dtype=torch.float32, device=x.device)   # every slot is written
@@ -247,3 +258,21 @@ def filtered_lrelu(x, fu=None, fd=None, b=None, up=1, down=1, padding=0, gain=np
     _lib.require_gpu(x, fu, fd, b)
     cfg = (int(up), int(down), px0, px1, py0, py1, float(gain), float(slope), clamp, bool(flip_filter), 0, 0, 0)
     return _FilteredLRelu.apply(x, fu, fd, b, None, cfg)
+
+
+def matrix_core_available(shape, dtype, device, fu, fd, cfg):
+    """True when a call on an input of this shape / dtype would run on the matrix-core kernels (16-bit dtype, separable
+    12/24-tap case, even widths): the condition for the epilogue factors of the fused layer op."""
+    if dtype not in (torch.bfloat16, torch.float16) or fu is None or fd is None or fu.ndim != 1 or fd.ndim != 1:
+        return False
+    up, down, px0, px1, py0, py1, gain, slope, clamp, flip_filter = cfg[:10]
+    a = _lib.FilteredLReluArgs()
+    a.dtype = _lib._DTYPES[dtype]
+    a.n, a.c, a.xh, a.xw = [int(v) for v in shape]
+    a.fuw, a.fuh, a.fdw, a.fdh = int(fu.shape[0]), 0, int(fd.shape[0]), 0
+    a.up, a.down = up, down
+    a.px0, a.px1, a.py0, a.py1 = px0, px1, py0, py1
+    a.gain, a.slope, a.clamp = gain, slope, clamp
+    a.flip_filter = int(flip_filter)
+    a.sign_mode = _lib.SIGNS_WRITE
+    return _mfma_workspace(a, fu.contiguous(), fd.contiguous(), torch.empty(0, dtype=dtype, device=device)) is not None

@@ -1,0 +1,106 @@
+"""One generator layer as ONE autograd node: conv (+ bias in its epilogue) -> filtered_lrelu (+ encoder skip, x next
+layer's style factor in ITS epilogue), for 16-bit activations on the matrix-core kernels.
+
+The reference composes a layer from separate ops (NET:366-377 / NET:503-511): modulated_conv2d (which multiplies the
+activations by the styles and the result by the demodulation coefficients), filtered_lrelu (which adds the bias first),
+``x + x_skip``.  Run op by op, each per-plane factor and the skip add is a full pass over the activations in HBM.  All of
+them are per-plane scalars or elementwise adds around linear operators, so they fold into the epilogues of the two
+kernels that touch the data anyway:
+
+    forward   y = d[n,o] * conv(w_hat, xs) + b[o]                  (conv epilogue: demodulation + bias)
+              z = (filtered_lrelu(y) + skip) * s_next[n,o]         (filtered_lrelu epilogue: skip + next layer's styles)
+    backward  dys = (d * s_next)[n,o] * filtered_lrelu^T(g)        (the transposed op is linear in g given the sign codes)
+              dxs = conv^T(w_hat, dys) (* s[n,i] when this node applied the styles itself),  dw_hat = wgrad(dys, xs)
+              db[o] = sum_n planesum(dys)[n,o] / d[n,o]            (per-tile sums emitted by the backward kernel)
+              dd    = (<dys, y> - b * planesum(dys)) / d^2,   ds_next = <g, z> / s_next,   dskip = g * s_next
+
+``z`` comes out already multiplied by the next layer's styles, so the consumer is called with ``prescaled=True`` and this
+node owns the gradient of those styles.  Same arithmetic as the op-by-op path up to 16-bit rounding (one rounding
+fewer per fused factor).
+"""
+import torch
+
+from ... import _lib
+from . import conv2d as _conv
+from . import filtered_lrelu as _flr
+
+
+class _ConvFilteredLRelu(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, in_scale, out_scale, bias, fu, fd, skip, next_scale, conv_pad, cfg, prescaled):
+        _lib.require_gpu(x, w, in_scale, out_scale, bias, fu, fd, skip, next_scale)
+        cout, cin, ks, _ = w.shape
+        x = x.contiguous()
+        xs = _conv.scale_planes(x, in_scale) if (in_scale is not None and not prescaled) else x
+        wp, rows_pad = _conv.pack_weights(w, x.dtype, 0)
+        y = _conv._conv_raw(xs, wp, rows_pad, out_scale, cout, ks, conv_pad, obias=bias)
+        need_grad = any(ctx.needs_input_grad[:5]) or ctx.needs_input_grad[7] or ctx.needs_input_grad[8]
+        z, signs, layout, _ = _flr._run(y, fu, fd, None, None, cfg, need_grad, oscale=next_scale, skip=skip)
+        keep_y = out_scale is not None and ctx.needs_input_grad[3]
+        keep_z = next_scale is not None and ctx.needs_input_grad[8]
+        ctx.save_for_backward(xs, w, in_scale, out_scale, bias, fu, fd, signs, next_scale, y if keep_y else None, z if keep_z else None)
+        ctx.meta = (conv_pad, cfg, bool(prescaled), layout, tuple(y.shape), tuple(z.shape), skip is not None)
+        return z
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        xs, w, in_scale, out_scale, bias, fu, fd, signs, next_scale, y, z = ctx.saved_tensors
+        conv_pad, cfg, prescaled, layout, y_shape, z_shape, has_skip = ctx.meta
+        cout, cin, ks, _ = w.shape
+        g = g.contiguous()
+        f32 = torch.float32
+        # dys = d * dL/dy: the transposed filtered_lrelu with both per-plane factors in its epilogue
+        comb = None
+        if out_scale is not None or next_scale is not None:
+            comb = (out_scale.to(f32) if out_scale is not None else 1.0) * (next_scale.to(f32) if next_scale is not None else 1.0)
+        bcfg = _flr._backward_cfg(cfg, fu, fd, y_shape, z_shape, layout)
+        dys, _, _, psum = _flr._run(g, fd, fu, None, signs, bcfg, False, want_plane_sum=True, oscale=comb)
+        ps = psum.sum(2) if psum is not None else _conv.plane_dot(dys)           # [N, O] plane sums of dys
+        dx = dw = d_in = d_out = db = d_skip = d_next = None
+        if ctx.needs_input_grad[4]:
+            db = ((ps / out_scale.to(f32)) if out_scale is not None else ps).sum(0).to(bias.dtype)
+        if ctx.needs_input_grad[8]:
+            ns = next_scale.to(f32)
+            d_next = torch.where(ns != 0, _conv.plane_dot(g, z) / torch.where(ns != 0, ns, torch.ones_like(ns)), torch.zeros_like(ns)).to(next_scale.dtype)
+        if has_skip and ctx.needs_input_grad[7]:
+            d_skip = _conv.scale_planes(g, next_scale) if next_scale is not None else g
+        if ctx.needs_input_grad[0] or (ctx.needs_input_grad[2] and not prescaled):
+            wpt, rows_pad = _conv.pack_weights(w, g.dtype, 1)
+            eff_in = None if prescaled else in_scale
+            dx = _conv._conv_raw(dys, wpt, rows_pad, eff_in, cin, ks, ks - 1 - conv_pad)
+            if ctx.needs_input_grad[2] and eff_in is not None:
+                s2 = in_scale.to(f32).square()
+                d_in = torch.where(s2 > 0, _conv.plane_dot(xs, dx) / s2.clamp_min(1e-30), torch.zeros_like(s2)).to(in_scale.dtype)
+        if ctx.needs_input_grad[1]:
+            dw = _conv._wgrad_raw(dys, xs, cout, cin, ks, conv_pad).to(w.dtype)
+        if ctx.needs_input_grad[3]:
+            # y = d * c + b  =>  dL/dd = <dL/dy, c> = (<dys, y> - b * sum(dys)) / d^2
+            d2 = out_scale.to(f32).square()
+            num = _conv.plane_dot(dys, y)
+            if bias is not None:
+                num = num - bias.to(f32).reshape(1, -1) * ps
+            d_out = (num / d2).to(out_scale.dtype)
+        return dx, dw, d_in, d_out, db, None, None, d_skip, d_next, None, None, None
+
+
+def _cfg(up, down, padding, gain, slope, clamp):
+    px0, px1, py0, py1 = _flr._parse_padding(padding)
+    return (int(up), int(down), px0, px1, py0, py1, float(gain), float(slope), float(clamp if clamp is not None else 'inf'), False, 0, 0, 0)
+
+
+def available(x, w, fu, fd, up, down, padding, gain, slope, clamp, conv_pad):
+    """The fused node needs the matrix-core filtered_lrelu (16-bit activations, 12/24-tap separable filters, even widths)
+    behind a 3x3 conv."""
+    if w.shape[2] != 3 or x.dtype not in (torch.bfloat16, torch.float16) or x.device.type != 'cuda':
+        return False
+    yshape = [x.shape[0], w.shape[0], x.shape[2] + 2 * conv_pad - 2, x.shape[3] + 2 * conv_pad - 2]
+    return _flr.matrix_core_available(yshape, x.dtype, x.device, fu, fd, _cfg(up, down, padding, gain, slope, clamp))
+
+
+def conv_filtered_lrelu(x, w, in_scale, out_scale, bias, fu, fd, up, down, padding, gain, slope, clamp, conv_pad, skip=None,
+                        next_scale=None, prescaled=False):
+    """z = (filtered_lrelu(out_scale * conv(w, in_scale * x) + bias; fu, fd, up, down, padding, gain, slope, clamp) + skip)
+    * next_scale.  ``prescaled``: x already carries in_scale (the producer's epilogue applied it)."""
+    cfg = _cfg(up, down, padding, gain, slope, clamp)
+    return _ConvFilteredLRelu.apply(x, w, in_scale, out_scale, bias, fu, fd, skip, next_scale, int(conv_pad), cfg, bool(prescaled))

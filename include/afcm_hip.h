@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define AFCM_ABI_VERSION 3
+#define AFCM_ABI_VERSION 4
 
 enum { AFCM_F32 = 0, AFCM_F16 = 1, AFCM_BF16 = 2 };
 enum { AFCM_OK = 0, AFCM_E_NOKERNEL = -1, AFCM_E_INVALID = -2 };
@@ -87,6 +87,12 @@ typedef struct afcm_filtered_lrelu_args {
     float*  plane_sum;      /* NULL, or fp32 [N*C][plane_sum_slots]: the matrix-core kernels store the sum of every output tile
                                (no atomics); summed over slots and N in a backward call this is the bias gradient
                                (db = dx.sum([0,2,3]), SG3OPS/filtered_lrelu.py:266) without a second pass over dx.        */
+    const float* oscale;    /* NULL, or fp32 [N*C]: y = (filtered_lrelu(...) + skip) * oscale[n*C + c].  Matrix-core kernels only.
+                               Lets the caller fold per-plane factors that would otherwise be separate passes over the tensor:
+                               the NEXT layer's style modulation s[n,i] (NET:46-47, forward) and the demodulation d[n,o]
+                               of the conv that produced x (NET:50-52, backward: the op is linear in dy given the codes). */
+    const void*  skip;      /* NULL, or [N, C, yh, yw] of x's dtype: the encoder feature added after the activation
+                               (x + x_skip, NET:376-377), added before oscale.  Matrix-core kernels only.                */
 } afcm_filtered_lrelu_args;
 
 /* Output / sign-tensor geometry for the arguments above (filtered_lrelu.cpp:61-94). Fills yh, yw
@@ -155,10 +161,13 @@ int afcm_conv2d_block_k(int32_t dtype);
 int afcm_conv2d_pack_weights(void* dst, const float* w, int32_t dtype, int32_t cout, int32_t cin, int32_t ks,
                              int32_t mode, int32_t rows_pad, void* stream);
 
-/* y[n, cout, h+2*pad-k+1, w+2*pad-k+1] = oscale[n*cout+o] * sum W * x.   oscale may be NULL.
+/* y[n, cout, h+2*pad-k+1, w+2*pad-k+1] = oscale[n*cout+o] * sum W * x + obias[o].   oscale / obias (fp32) may be NULL.
+ * obias is the layer bias the reference adds at the head of filtered_lrelu (x + b before the padding, NET:371 ->
+ * SG3OPS/filtered_lrelu.py:133): the conv output IS the whole unpadded image, so adding it in this epilogue is the same
+ * arithmetic and saves the conversion work in filtered_lrelu's input staging.
  * For the data gradient call it with the mode-1 packing, cin/cout swapped and pad' = k-1-pad. */
-int afcm_conv2d(void* y, const void* x, const void* wpacked, const float* oscale, int32_t dtype, int32_t n, int32_t cin,
-                int32_t cout, int32_t h, int32_t w, int32_t ks, int32_t pad, int32_t rows_pad, void* stream);
+int afcm_conv2d(void* y, const void* x, const void* wpacked, const float* oscale, const float* obias, int32_t dtype, int32_t n,
+                int32_t cin, int32_t cout, int32_t h, int32_t w, int32_t ks, int32_t pad, int32_t rows_pad, void* stream);
 
 /* Weight gradient dw[cout][cin][k][k] (fp32) = sum_n sum_pixels dy[n,o,p,q] * x[n,i,p+r-pad,q+s-pad].
  * workspace: fp32 [afcm_conv2d_wgrad_splits(...)][cout][cin][k][k]. */

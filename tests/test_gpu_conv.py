@@ -123,3 +123,74 @@ def test_full_size_layer_properties():
         # the batch-wide style normalisation (NET:43) uses all 16 samples: rescale the single-sample oracle
         # (it cancels under demodulation up to the 1e-8 epsilon, so plain comparison is valid)
         _close(y[ni, oi], ref[0, oi], 2e-2, f'plane {ni},{oi}')
+
+
+@pytest.mark.parametrize('dtype,tol', [(torch.bfloat16, 4e-2), (torch.float16, 8e-3)])
+@pytest.mark.parametrize('case', ['decoder_skip_next', 'decoder_prescaled', 'encoder'])
+def test_fused_layer_node_matches_op_by_op(case, dtype, tol):
+    """conv(+bias) -> filtered_lrelu(+skip, x next styles) as ONE autograd node (torch_utils/ops/fused_layer.py) vs the
+    reference composition of the same layer run in fp32 on the CPU oracle (NET:366-377): output and every gradient
+    (x, w, styles, demodulation, bias, skip, next styles)."""
+    from afcm_amd.torch_utils.ops import fused_layer
+    from oracle import aten_ops as ops
+    from oracle import generator as ogen
+    pl = ogen.plan(256, 4, 1, {})
+    L = [l for l in pl['dec'] if l['name'] == 'L9_148_181'][0] if case != 'encoder' else pl['enc'][5]
+    torch.manual_seed(7)
+    n, cin, cout, h = 2, 24, 16, L['in_size']
+    x = torch.randn(n, cin, h, h)
+    w = torch.randn(cout, cin, 3, 3) / np.sqrt(cin * 9)
+    s = torch.rand(n, cin) + 0.5
+    d = torch.rand(n, cout) + 0.5
+    b = torch.randn(cout) * 0.2
+    oh = L['out_size']
+    skip = torch.randn(n, cout, oh, oh) if case == 'decoder_skip_next' else None
+    ns = (torch.rand(n, cout) + 0.5) if case == 'decoder_skip_next' else None
+    modulated = case != 'encoder'
+    prescaled = case == 'decoder_prescaled'
+    act = dict(up=L['up'], down=L['down'], padding=L['padding'], gain=float(np.sqrt(2)), slope=0.2, clamp=256.0)
+
+    # fp32 reference on the 16-bit-rounded inputs
+    def q(t):
+        return None if t is None else t.to(dtype).float()
+    leaves = {k: (v.clone().requires_grad_(True) if v is not None else None)
+              for k, v in dict(x=q(x), w=w, s=s if modulated else None, d=d if modulated else None, b=b, skip=q(skip), ns=ns).items()}
+    xs = leaves['x'] * leaves['s'][:, :, None, None] if modulated else leaves['x']
+    y = torch.nn.functional.conv2d(xs, leaves['w'], padding=2)
+    if modulated:
+        y = y * leaves['d'][:, :, None, None]
+    z = ops.filtered_lrelu(y, fu=L['fu'], fd=L['fd'], b=leaves['b'], **act)
+    if skip is not None:
+        z = (z + leaves['skip']) * leaves['ns'][:, :, None, None]
+    r = torch.randn_like(z).to(dtype).float()
+    names = [k for k, v in leaves.items() if v is not None]
+    gref = dict(zip(names, torch.autograd.grad((z * r).sum(), [leaves[k] for k in names])))
+
+    dev = {k: (v.detach().cuda().requires_grad_(True) if v is not None else None)
+           for k, v in dict(x=x.to(dtype), w=w, s=s if modulated else None, d=d if modulated else None, b=b,
+                            skip=None if skip is None else skip.to(dtype), ns=ns).items()}
+    xin = dev['x']
+    if prescaled:      # the producer applied the styles: feed s * x and expect the gradient w.r.t. that product
+        xin = (x.to(dtype).float() * s[:, :, None, None]).to(dtype).cuda().requires_grad_(True)
+    assert fused_layer.available(xin, dev['w'], L['fu'].cuda(), L['fd'].cuda(), conv_pad=2, **act)
+    got = fused_layer.conv_filtered_lrelu(xin, dev['w'], dev['s'], dev['d'], dev['b'], L['fu'].cuda(), L['fd'].cuda(), conv_pad=2,
+                                          skip=dev['skip'], next_scale=dev['ns'], prescaled=prescaled, **act)
+    assert got.dtype == dtype
+    _close_rel(got, z, tol, f'{case} z')
+    wanted = [k for k in names if not (prescaled and k in ('x', 's'))]
+    ggot = dict(zip(wanted, torch.autograd.grad((got.float() * r.cuda()).sum(), [dev[k] for k in wanted])))
+    for k in wanted:
+        _close_rel(ggot[k], gref[k], 3 * tol, f'{case} d{k}')
+    if prescaled:
+        gx, = torch.autograd.grad((fused_layer.conv_filtered_lrelu(xin, dev['w'], dev['s'], dev['d'], dev['b'], L['fu'].cuda(), L['fd'].cuda(),
+                                                                   conv_pad=2, prescaled=True, **act).float() * r.cuda()).sum(), [xin])
+        # d/d(s*x) = (d/dx) / s
+        _close_rel(gx, gref['x'] / s[:, :, None, None], 3 * tol, 'prescaled dxs')
+
+
+def _close_rel(a, b, tol, what):
+    a = a.detach().float().cpu()
+    b = b.detach().float().cpu()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    rel = ((a - b).norm() / b.norm().clamp_min(1e-20)).item()
+    assert rel <= tol, f'{what}: relative L2 error {rel:.3e} (tol {tol:g})'
