@@ -55,6 +55,10 @@ SIGNATURES = {
     'afcm_conv2d_wgrad': (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     'afcm_scale_planes': (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i64, _i32, _vp]),
     'afcm_plane_dot': (C.c_int, [_vp, _vp, _vp, _i32, _i64, _i32, _vp]),
+    'afcm_weight_norm_fwd': (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
+    'afcm_weight_norm_bwd': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
+    'afcm_style_coefs_fwd': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    'afcm_style_coefs_bwd': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     'afcm_adam_chunk_elems': (C.c_int32, []),
     'afcm_adam_multi': (C.c_int, [_vp, _i32, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _i32, _f32, _f32, _i32, _vp]),
 }
@@ -73,8 +77,8 @@ def load():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
-        if lib.afcm_abi_version() != 4:
-            raise RuntimeError(f'libafcm_hip.so ABI version {lib.afcm_abi_version()} does not match this package (4); rebuild it')
+        if lib.afcm_abi_version() != 5:
+            raise RuntimeError(f'libafcm_hip.so ABI version {lib.afcm_abi_version()} does not match this package (5); rebuild it')
         _lib = lib
     return _lib
 

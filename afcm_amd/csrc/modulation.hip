@@ -1,0 +1,202 @@
+// The small-tensor half of modulated_conv2d (NET:41-57) as four launches instead of ~35 eager ones per layer and step:
+//   weight normalisation   w_hat = w * rsqrt(mean_{i,k} w^2)            (NET:42)      + wsq[o,i] = sum_k w_hat^2
+//   style coefficients     s_hat = t * rsqrt(mean_{n,i} t^2)            (NET:43, whole batch)
+//                          d[n,o] = rsqrt(sum_i s_hat[n,i]^2 wsq[o,i] + 1e-8)   (NET:50-52, factorised: the per-sample
+//                                   weights w[n,o,i,k] = w_hat[o,i,k] s_hat[n,i] are never materialised)
+//                          s_eff = s_hat * input_gain                   (NET:55-57)
+// and their exact backward passes.  All tensors fp32, sizes <= 512 x 512 x 9: launch-bound work, one workgroup per
+// output row / sample, no attempt at bandwidth.
+#include "common.h"
+
+namespace afcm {
+
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    // 256 threads: wave shuffles, then 4 partials through LDS; every thread returns the total
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+// one workgroup per output channel o
+__global__ __launch_bounds__(256) void weight_norm_fwd_kernel(float* __restrict__ w_hat, float* __restrict__ wsq, float* __restrict__ scale,
+                                                              const float* __restrict__ w, int I, int KK) {
+    __shared__ float red[4];
+    const int o = blockIdx.x, n = I * KK;
+    const float* wo = w + (size_t)o * n;
+    float ss = 0.f;
+    for (int j = threadIdx.x; j < n; j += 256) ss += wo[j] * wo[j];
+    ss = block_sum(ss, red);
+    const float sc = rsqrtf(ss / (float)n);
+    if (threadIdx.x == 0) scale[o] = sc;
+    for (int j = threadIdx.x; j < n; j += 256) w_hat[(size_t)o * n + j] = wo[j] * sc;
+    for (int i = threadIdx.x; i < I; i += 256) {
+        float q = 0.f;
+        for (int k = 0; k < KK; k++) { const float v = wo[i * KK + k] * sc; q += v * v; }
+        wsq[(size_t)o * I + i] = q;
+    }
+}
+
+// dw = scale * (G - w_hat * mean(G . w_hat)),  G = g_hat + 2 w_hat g_wsq[o,i]
+__global__ __launch_bounds__(256) void weight_norm_bwd_kernel(float* __restrict__ dw, const float* __restrict__ g_hat, const float* __restrict__ g_wsq,
+                                                              const float* __restrict__ w_hat, const float* __restrict__ scale, int I, int KK) {
+    __shared__ float red[4];
+    const int o = blockIdx.x, n = I * KK;
+    const size_t base = (size_t)o * n;
+    float dot = 0.f;
+    for (int j = threadIdx.x; j < n; j += 256) {
+        const float wh = w_hat[base + j];
+        float g = g_hat ? g_hat[base + j] : 0.f;
+        if (g_wsq) g += 2.f * wh * g_wsq[(size_t)o * I + j / KK];
+        dot += g * wh;
+    }
+    dot = block_sum(dot, red);
+    const float m = dot / (float)n, sc = scale[o];
+    for (int j = threadIdx.x; j < n; j += 256) {
+        const float wh = w_hat[base + j];
+        float g = g_hat ? g_hat[base + j] : 0.f;
+        if (g_wsq) g += 2.f * wh * g_wsq[(size_t)o * I + j / KK];
+        dw[base + j] = sc * (g - wh * m);
+    }
+}
+
+// one workgroup per sample n (every workgroup recomputes the batch-wide mean: N * I <= a few thousand elements)
+__global__ __launch_bounds__(256) void style_coefs_fwd_kernel(float* __restrict__ s_eff, float* __restrict__ d, float* __restrict__ r_out,
+                                                              const float* __restrict__ t, const float* __restrict__ wsq,
+                                                              const float* __restrict__ magnitude, int N, int I, int O, int demod) {
+    __shared__ float red[4];
+    extern __shared__ float s2[];                       // s_hat[n, :]^2
+    const int n = blockIdx.x;
+    float r = 1.f;
+    if (demod) {
+        float ss = 0.f;
+        for (int j = threadIdx.x; j < N * I; j += 256) ss += t[j] * t[j];
+        ss = block_sum(ss, red);
+        r = rsqrtf(ss / (float)(N * I));
+    }
+    if (n == 0 && threadIdx.x == 0) r_out[0] = r;
+    const float g = magnitude ? rsqrtf(magnitude[0]) : 1.f;           // input_gain = magnitude_ema.rsqrt() (NET:346,55-57)
+    for (int i = threadIdx.x; i < I; i += 256) {
+        const float sh = t[(size_t)n * I + i] * r;
+        s_eff[(size_t)n * I + i] = sh * g;
+        s2[i] = sh * sh;
+    }
+    if (!demod) return;
+    __syncthreads();
+    for (int o = threadIdx.x; o < O; o += 256) {
+        const float* wr = wsq + (size_t)o * I;
+        float q = 1e-8f;
+        for (int i = 0; i < I; i++) q += s2[i] * wr[i];
+        d[(size_t)n * O + o] = rsqrtf(q);
+    }
+}
+
+// phase 1, one workgroup per sample: Q[n,o] = -1/2 g_d d^3;  G[n,i] = gain g_s + 2 s_hat[n,i] sum_o Q[n,o] wsq[o,i];
+// partial[n] = sum_i G[n,i] s_hat[n,i]
+__global__ __launch_bounds__(256) void style_coefs_bwd1_kernel(float* __restrict__ G, float* __restrict__ Q, float* __restrict__ partial,
+                                                               const float* __restrict__ g_s, const float* __restrict__ g_d,
+                                                               const float* __restrict__ t, const float* __restrict__ d, const float* __restrict__ wsq,
+                                                               const float* __restrict__ magnitude, const float* __restrict__ r_in, int I, int O, int demod) {
+    __shared__ float red[4];
+    extern __shared__ float q_s[];                      // Q[n, :]
+    const int n = blockIdx.x;
+    const float r = r_in[0], g = magnitude ? rsqrtf(magnitude[0]) : 1.f;
+    if (demod) {
+        for (int o = threadIdx.x; o < O; o += 256) {
+            const float dd = d[(size_t)n * O + o];
+            const float q = g_d ? -0.5f * g_d[(size_t)n * O + o] * dd * dd * dd : 0.f;
+            q_s[o] = q;
+            Q[(size_t)n * O + o] = q;
+        }
+        __syncthreads();
+    }
+    float dot = 0.f;
+    for (int i = threadIdx.x; i < I; i += 256) {
+        const float sh = t[(size_t)n * I + i] * r;
+        float gg = g_s ? g * g_s[(size_t)n * I + i] : 0.f;
+        if (demod) {
+            float u = 0.f;
+            for (int o = 0; o < O; o++) u += q_s[o] * wsq[(size_t)o * I + i];
+            gg += 2.f * sh * u;
+        }
+        G[(size_t)n * I + i] = gg;
+        dot += gg * sh;
+    }
+    dot = block_sum(dot, red);
+    if (threadIdx.x == 0) partial[n] = dot;
+}
+
+// phase 2: workgroups [0, N): dt[n,:] = r (G - s_hat mean(G . s_hat)) (demod) or G (no demod);
+//          workgroups [N, N+O): g_wsq[o,i] = sum_n Q[n,o] s_hat[n,i]^2
+__global__ __launch_bounds__(256) void style_coefs_bwd2_kernel(float* __restrict__ dt, float* __restrict__ g_wsq, const float* __restrict__ G,
+                                                               const float* __restrict__ Q, const float* __restrict__ partial,
+                                                               const float* __restrict__ t, const float* __restrict__ r_in, int N, int I, int O, int demod) {
+    const float r = r_in[0];
+    if ((int)blockIdx.x < N) {
+        const int n = blockIdx.x;
+        float m = 0.f;
+        if (demod) {
+            for (int k = 0; k < N; k++) m += partial[k];
+            m /= (float)(N * I);
+        }
+        for (int i = threadIdx.x; i < I; i += 256) {
+            const float gg = G[(size_t)n * I + i];
+            dt[(size_t)n * I + i] = demod ? r * (gg - t[(size_t)n * I + i] * r * m) : gg;
+        }
+    } else if (demod && g_wsq != nullptr) {
+        const int o = blockIdx.x - N;
+        for (int i = threadIdx.x; i < I; i += 256) {
+            float acc = 0.f;
+            for (int n = 0; n < N; n++) {
+                const float sh = t[(size_t)n * I + i] * r;
+                acc += Q[(size_t)n * O + o] * sh * sh;
+            }
+            g_wsq[(size_t)o * I + i] = acc;
+        }
+    }
+}
+
+}  // namespace afcm
+
+using namespace afcm;
+
+extern "C" int afcm_weight_norm_fwd(float* w_hat, float* wsq, float* scale, const float* w, int32_t cout, int32_t cin, int32_t kk, void* stream) {
+    AFCM_REQUIRE(w_hat && wsq && scale && w && cout > 0 && cin > 0 && kk > 0, "weight_norm_fwd: bad arguments");
+    hipLaunchKernelGGL(weight_norm_fwd_kernel, dim3(cout), dim3(256), 0, (hipStream_t)stream, w_hat, wsq, scale, w, cin, kk);
+    return hip_status(hipGetLastError());
+}
+
+extern "C" int afcm_weight_norm_bwd(float* dw, const float* g_hat, const float* g_wsq, const float* w_hat, const float* scale, int32_t cout,
+                                    int32_t cin, int32_t kk, void* stream) {
+    AFCM_REQUIRE(dw && w_hat && scale && cout > 0 && cin > 0 && kk > 0, "weight_norm_bwd: bad arguments");
+    hipLaunchKernelGGL(weight_norm_bwd_kernel, dim3(cout), dim3(256), 0, (hipStream_t)stream, dw, g_hat, g_wsq, w_hat, scale, cin, kk);
+    return hip_status(hipGetLastError());
+}
+
+extern "C" int afcm_style_coefs_fwd(float* s_eff, float* d, float* r, const float* t, const float* wsq, const float* magnitude, int32_t n, int32_t cin,
+                                    int32_t cout, int32_t demodulate, void* stream) {
+    AFCM_REQUIRE(s_eff && r && t && n > 0 && cin > 0 && (!demodulate || (d && wsq && cout > 0)), "style_coefs_fwd: bad arguments");
+    AFCM_REQUIRE(cin <= 16384, "style_coefs_fwd: %d input channels exceed the LDS row", cin);
+    hipLaunchKernelGGL(style_coefs_fwd_kernel, dim3(n), dim3(256), cin * sizeof(float), (hipStream_t)stream, s_eff, d, r, t, wsq, magnitude, n, cin,
+                       cout, demodulate);
+    return hip_status(hipGetLastError());
+}
+
+extern "C" int afcm_style_coefs_bwd(float* dt, float* g_wsq, float* workspace, const float* g_s, const float* g_d, const float* t, const float* d,
+                                    const float* wsq, const float* magnitude, const float* r, int32_t n, int32_t cin, int32_t cout, int32_t demodulate,
+                                    void* stream) {
+    AFCM_REQUIRE(dt && workspace && t && r && n > 0 && cin > 0 && (!demodulate || (d && wsq && cout > 0)), "style_coefs_bwd: bad arguments");
+    AFCM_REQUIRE(cout <= 16384, "style_coefs_bwd: %d output channels exceed the LDS row", cout);
+    // workspace: G [n, cin] | Q [n, cout] | partial [n]
+    float* G = workspace;
+    float* Q = G + (size_t)n * cin;
+    float* partial = Q + (size_t)n * (demodulate ? cout : 0);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(style_coefs_bwd1_kernel, dim3(n), dim3(256), (demodulate ? cout : 1) * sizeof(float), st, G, Q, partial, g_s, g_d, t, d, wsq,
+                       magnitude, r, cin, cout, demodulate);
+    hipLaunchKernelGGL(style_coefs_bwd2_kernel, dim3(n + ((demodulate && g_wsq) ? cout : 0)), dim3(256), 0, st, dt, g_wsq, G, Q, partial, t, r, n, cin,
+                       cout, demodulate);
+    return hip_status(hipGetLastError());
+}

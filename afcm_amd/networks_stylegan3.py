@@ -17,7 +17,7 @@ import torch.nn.functional as F
 
 from . import layer_schedule as sched
 from .torch_utils.ops import bias_act, conv2d_gradfix, filtered_lrelu, fused_layer
-from .torch_utils.ops.conv2d import modulation_coefficients, scaled_conv2d
+from .torch_utils.ops.conv2d import modulation_coefficients_fused, scaled_conv2d
 from .torch_utils.ops.conv2d import modulated_conv2d  # noqa: F401  (re-exported: NET:25 lives in this module)
 
 
@@ -156,7 +156,7 @@ class SynthesisLayer(torch.nn.Module, _ResampleGeometry):
         styles = self.affine(w)
         if self.is_torgb:
             styles = styles * (1 / np.sqrt(self.in_channels * (self.conv_kernel ** 2)))
-        return modulation_coefficients(self.weight, styles, demodulate=(not self.is_torgb), input_gain=self.magnitude_ema.rsqrt())
+        return modulation_coefficients_fused(self.weight, styles, demodulate=(not self.is_torgb), magnitude=self.magnitude_ema)
 
     def _act_args(self):
         return dict(up=self.up_factor, down=self.down_factor, padding=self.padding, gain=(1 if self.is_torgb else np.sqrt(2)),
@@ -219,6 +219,7 @@ class EncoderLayer(torch.nn.Module, _ResampleGeometry):
         self.magnitude_ema_beta = magnitude_ema_beta
         self.weight = torch.nn.Parameter(torch.randn([self.out_channels, self.in_channels, self.conv_kernel, self.conv_kernel]))
         self.weight_gain = 1 / np.sqrt(in_channels * (conv_kernel ** 2))
+        self._gain_planes = {}
         self.bias = torch.nn.Parameter(torch.zeros([self.out_channels]))
         self.register_buffer('magnitude_ema', torch.ones([]))
         self._setup_resampling(in_size, out_size, in_sampling_rate, out_sampling_rate, in_cutoff, out_cutoff, in_half_width,
@@ -232,13 +233,17 @@ class EncoderLayer(torch.nn.Module, _ResampleGeometry):
                 magnitude_cur = x.detach().to(torch.float32).square().mean()
                 self.magnitude_ema.copy_(magnitude_cur.lerp(self.magnitude_ema, self.magnitude_ema_beta))
         dtype = x.dtype
-        w = self.weight * self.weight_gain
         act = dict(up=self.up_factor, down=self.down_factor, padding=self.padding, gain=np.sqrt(2), slope=0.2, clamp=self.conv_clamp)
         if fused_layer.available(x, self.weight, self.up_filter, self.down_filter, conv_pad=self.conv_kernel - 1, **act):
-            # conv (+ bias in its epilogue) -> filtered_lrelu as one autograd node (16-bit activations)
-            x = fused_layer.conv_filtered_lrelu(x, w, None, None, self.bias, self.up_filter, self.down_filter,
+            # conv (+ bias in its epilogue) -> filtered_lrelu as one autograd node (16-bit activations); the equalised-lr
+            # weight gain (NET:503) rides in the conv epilogue as a constant per-plane factor instead of a pass over w
+            key = (int(x.shape[0]), x.device)
+            if key not in self._gain_planes:
+                self._gain_planes[key] = torch.full([x.shape[0], self.out_channels], float(self.weight_gain), dtype=torch.float32, device=x.device)
+            x = fused_layer.conv_filtered_lrelu(x, self.weight, None, self._gain_planes[key], self.bias, self.up_filter, self.down_filter,
                                                 conv_pad=self.conv_kernel - 1, **act)
         else:
+            w = self.weight * self.weight_gain
             x = conv2d_gradfix.conv2d(input=x, weight=w, padding=self.conv_kernel - 1)
             x = filtered_lrelu.filtered_lrelu(x=x, fu=self.up_filter, fd=self.down_filter, b=self.bias.to(x.dtype), **act)
         _assert_shape(x, [None, self.out_channels, int(self.out_size[1]), int(self.out_size[0])])

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define AFCM_ABI_VERSION 4
+#define AFCM_ABI_VERSION 5
 
 enum { AFCM_F32 = 0, AFCM_F16 = 1, AFCM_BF16 = 2 };
 enum { AFCM_OK = 0, AFCM_E_NOKERNEL = -1, AFCM_E_INVALID = -2 };
@@ -183,6 +183,27 @@ int afcm_scale_planes(void* y, const void* x, const float* scale, int32_t dtype_
 /* out[plane] = sum_i a[plane,i] * b[plane,i]  (b == NULL: plain sum); fp32 accumulation.  Used for the style /
  * demodulation / bias gradients. */
 int afcm_plane_dot(float* out, const void* a, const void* b, int32_t dtype, int64_t planes, int32_t hw, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * The small-tensor half of modulated_conv2d (NET:41-57), fp32, forward and exact backward.  The reference runs it as
+ * ~35 eager elementwise / reduction / matmul launches per layer and step; these are 1 + 1 + 1 + 2 launches.
+ *   weight_norm:  w_hat[o] = w[o] * rsqrt(mean_{i,k} w[o]^2) (NET:42), wsq[o,i] = sum_k w_hat[o,i,k]^2, scale[o] kept for backward.
+ *                 bwd: dw from g_hat (dL/dw_hat, may be NULL) and g_wsq (dL/dwsq, may be NULL).
+ *   style_coefs:  s_hat = t * rsqrt(mean_{n,i} t^2) (NET:43, whole batch; r[0] keeps the factor),
+ *                 d[n,o] = rsqrt(sum_i s_hat[n,i]^2 wsq[o,i] + 1e-8) (NET:50-52 factorised over the shared weights),
+ *                 s_eff = s_hat * rsqrt(magnitude[0]) (input gain, NET:346,55-57; magnitude NULL: 1).
+ *                 demodulate == 0 (ToRGB, NET:362): s_eff = t * gain only, d / wsq unused.
+ *                 bwd: dt from g_s (dL/ds_eff) and g_d (dL/dd); g_wsq (may be NULL) = dL/dwsq.
+ *                 workspace: n*cin + n*cout + n floats.
+ * ---------------------------------------------------------------------------------------- */
+int afcm_weight_norm_fwd(float* w_hat, float* wsq, float* scale, const float* w, int32_t cout, int32_t cin, int32_t kk, void* stream);
+int afcm_weight_norm_bwd(float* dw, const float* g_hat, const float* g_wsq, const float* w_hat, const float* scale, int32_t cout,
+                         int32_t cin, int32_t kk, void* stream);
+int afcm_style_coefs_fwd(float* s_eff, float* d, float* r, const float* t, const float* wsq, const float* magnitude, int32_t n, int32_t cin,
+                         int32_t cout, int32_t demodulate, void* stream);
+int afcm_style_coefs_bwd(float* dt, float* g_wsq, float* workspace, const float* g_s, const float* g_d, const float* t, const float* d,
+                         const float* wsq, const float* magnitude, const float* r, int32_t n, int32_t cin, int32_t cout, int32_t demodulate,
+                         void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Generator update: gradient scale (1/world after the all-reduce), the NaN/Inf scrub of the gradients

@@ -194,3 +194,32 @@ def _close_rel(a, b, tol, what):
     assert a.shape == b.shape, (what, a.shape, b.shape)
     rel = ((a - b).norm() / b.norm().clamp_min(1e-20)).item()
     assert rel <= tol, f'{what}: relative L2 error {rel:.3e} (tol {tol:g})'
+
+
+@pytest.mark.parametrize('demod', [True, False])
+def test_fused_modulation_coefficients_match_eager(demod):
+    """afcm_weight_norm_* / afcm_style_coefs_* (one launch each way) vs the eager torch restatement of NET:41-57:
+    values and gradients w.r.t. the weights and the raw styles, for both outputs."""
+    from afcm_amd.torch_utils.ops.conv2d import modulation_coefficients, modulation_coefficients_fused
+    torch.manual_seed(3)
+    o, i, n = 37, 45, 5
+    w = torch.randn(o, i, 3, 3, device='cuda')
+    t = torch.randn(n, i, device='cuda') + 1.0
+    mag = torch.tensor(1.7, device='cuda')
+    rs, rd, rw = torch.randn(n, i, device='cuda'), torch.randn(n, o, device='cuda'), torch.randn(o, i, 3, 3, device='cuda')
+
+    def run(fn, **kw):
+        wl, tl = w.clone().requires_grad_(True), t.clone().requires_grad_(True)
+        w_hat, s_eff, d = fn(wl, tl, demodulate=demod, **kw)
+        loss = (s_eff * rs).sum() + (w_hat * rw).sum()
+        if d is not None:
+            loss = loss + (d * rd).sum()
+        gw, gt = torch.autograd.grad(loss, [wl, tl])
+        return w_hat, s_eff, d, gw, gt
+    want = run(modulation_coefficients, input_gain=mag.rsqrt())
+    got = run(modulation_coefficients_fused, magnitude=mag)
+    for a, b, nm in zip(got, want, ['w_hat', 's_eff', 'd', 'dw', 'dt']):
+        if b is None:
+            assert a is None
+            continue
+        _close(a, b, 2e-5, f'demod={demod} {nm}')
