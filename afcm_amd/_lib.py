@@ -28,7 +28,7 @@ class FilteredLReluArgs(C.Structure):
         ('gain', C.c_float), ('slope', C.c_float), ('clamp', C.c_float),
         ('flip_filter', C.c_int32), ('sign_mode', C.c_int32),
         ('workspace', C.c_void_p), ('sign_layout', C.c_int32), ('plane_sum_slots', C.c_int32),
-        ('plane_sum', C.c_void_p), ('oscale', C.c_void_p), ('skip', C.c_void_p),
+        ('plane_sum', C.c_void_p), ('oscale', C.c_void_p), ('skip', C.c_void_p), ('oscale2', C.c_void_p),
     ]
 
 
@@ -59,6 +59,7 @@ SIGNATURES = {
     'afcm_weight_norm_bwd': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     'afcm_style_coefs_fwd': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     'afcm_style_coefs_bwd': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    'afcm_layer_bwd_coefs': (C.c_int, [_vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp]),
     'afcm_adam_chunk_elems': (C.c_int32, []),
     'afcm_adam_multi': (C.c_int, [_vp, _i32, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _i32, _f32, _f32, _i32, _vp]),
 }
@@ -77,8 +78,8 @@ def load():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
-        if lib.afcm_abi_version() != 5:
-            raise RuntimeError(f'libafcm_hip.so ABI version {lib.afcm_abi_version()} does not match this package (5); rebuild it')
+        if lib.afcm_abi_version() != 6:
+            raise RuntimeError(f'libafcm_hip.so ABI version {lib.afcm_abi_version()} does not match this package (6); rebuild it')
         _lib = lib
     return _lib
 

@@ -526,7 +526,7 @@ extern "C" int afcm_filtered_lrelu(const afcm_filtered_lrelu_args* a, void* stre
     }
     hipStream_t st = (hipStream_t)stream;
     const bool mfma = a->workspace != nullptr && flrelu_mfma_supported(a);
-    AFCM_REQUIRE(mfma || (a->oscale == nullptr && a->skip == nullptr), "filtered_lrelu: oscale / skip need the matrix-core kernels (16-bit dtype, prepared workspace)");
+    AFCM_REQUIRE(mfma || (a->oscale == nullptr && a->oscale2 == nullptr && a->skip == nullptr), "filtered_lrelu: oscale / skip need the matrix-core kernels (16-bit dtype, prepared workspace)");
     if (a->sign_mode == AFCM_SIGNS_READ)
         AFCM_REQUIRE((a->sign_layout == 1) == mfma, "sign tensor layout %d does not match the kernel family selected for this call", a->sign_layout);
     if (mfma) return flrelu_mfma_launch(a, false, st);

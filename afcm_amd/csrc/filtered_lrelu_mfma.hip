@@ -51,6 +51,7 @@ struct FlreluMfmaParams {
     const void* ws;        // constant fragments + mask table
     float* plane_sum;      // optional fp32 [N*C][tilesX*tilesY]: per-tile sums of this launch's outputs (bias gradient without a second pass)
     const float* oscale;   // optional fp32 [N*C]: per-plane factor of the output
+    const float* oscale2;  // optional second factor (multiplied)
     const void* skip;      // optional [N*C][yh][yw]: added to the output before the factor
     int xw, xh, yw, yh, C;
     int px0, py0;
@@ -556,7 +557,7 @@ __global__ __launch_bounds__((64 * MfmaGeom<UP, DOWN, TOW, TOH>::NG)) void flrel
 #pragma unroll
         for (int t = 0; t < G::NDVK; t++) dh[t] = cfrag(G::NB + UP + 2 * G::NDVK + t);
         const bool inner = (O0x + TOW <= p.yw) && (O0y + TOH <= p.yh);
-        const float osc = p.oscale ? p.oscale[plane] : 1.f;
+        const float osc = (p.oscale ? p.oscale[plane] : 1.f) * (p.oscale2 ? p.oscale2[plane] : 1.f);
         const T* skp = p.skip ? (const T*)p.skip + (size_t)plane * p.yh * p.yw : nullptr;
         float psum = 0.f;
         for (int unit = wave; unit < G::NOB * G::NCB; unit += G::NG) {
@@ -583,7 +584,7 @@ __global__ __launch_bounds__((64 * MfmaGeom<UP, DOWN, TOW, TOH>::NG)) void flrel
                         }
                 }
             }
-            if (p.oscale) acc *= osc;
+            if (p.oscale || p.oscale2) acc *= osc;
             uint2 w;
             w.x = pack2<T>(acc[0], acc[1]);
             w.y = pack2<T>(acc[2], acc[3]);
@@ -657,7 +658,7 @@ static int launch_mfma(const afcm_filtered_lrelu_args* a, hipStream_t st) {
     typedef MfmaGeom<UP, DOWN, TOW, TOH> G;
     FlreluMfmaParams p;
     p.x = a->x; p.y = a->y; p.b = a->b; p.s = a->signs; p.ws = a->workspace; p.plane_sum = a->plane_sum;
-    p.oscale = a->oscale; p.skip = a->skip;
+    p.oscale = a->oscale; p.oscale2 = a->oscale2; p.skip = a->skip;
     p.xw = a->xw; p.xh = a->xh; p.yw = a->yw; p.yh = a->yh; p.C = a->c;
     p.px0 = a->px0; p.py0 = a->py0;
     p.tilesX = cdiv(a->yw, TOW); p.tilesY = cdiv(a->yh, TOH);

@@ -158,9 +158,49 @@ __global__ __launch_bounds__(256) void style_coefs_bwd2_kernel(float* __restrict
     }
 }
 
+// Small-tensor tail of a fused layer's backward (torch_utils/ops/fused_layer.py), one workgroup (one wave) per output channel:
+//   ps[n,o]     = sum over the tile slots of the plane sums the transposed filtered_lrelu emitted (sums of dys)
+//   db[o]       = sum_n ps / d                      (bias gradient: dy = dys / d)
+//   d_next[n,o] = <g, z> / s_next                   (0 where s_next == 0)
+//   d_out[n,o]  = (<dys, y> - b ps) / d^2           (y = d c + b)
+__global__ __launch_bounds__(64) void layer_bwd_coefs_kernel(float* __restrict__ db, float* __restrict__ d_next, float* __restrict__ d_out,
+                                                             const float* __restrict__ psum, int slots, const float* __restrict__ out_scale,
+                                                             const float* __restrict__ next_scale, const float* __restrict__ bias,
+                                                             const float* __restrict__ gz, const float* __restrict__ dysy, int N, int O) {
+    const int o = blockIdx.x;
+    const float b = bias ? bias[o] : 0.f;
+    float acc = 0.f;
+    for (int n = threadIdx.x; n < N; n += 64) {
+        const size_t idx = (size_t)n * O + o;
+        float ps = 0.f;
+        for (int k = 0; k < slots; k++) ps += psum[idx * slots + k];
+        const float d = out_scale ? out_scale[idx] : 1.f;
+        acc += ps / d;
+        if (d_next) {
+            const float ns = next_scale[idx];
+            d_next[idx] = ns != 0.f ? gz[idx] / ns : 0.f;
+        }
+        if (d_out) d_out[idx] = (dysy[idx] - b * ps) / (d * d);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if (db && threadIdx.x == 0) db[o] = acc;
+}
+
 }  // namespace afcm
 
 using namespace afcm;
+
+extern "C" int afcm_layer_bwd_coefs(float* db, float* d_next, float* d_out, const float* psum, int32_t slots, const float* out_scale,
+                                    const float* next_scale, const float* bias, const float* gz, const float* dysy, int32_t n, int32_t cout,
+                                    void* stream) {
+    AFCM_REQUIRE(psum && slots > 0 && n > 0 && cout > 0, "layer_bwd_coefs: bad arguments");
+    AFCM_REQUIRE(!d_next || (next_scale && gz), "layer_bwd_coefs: d_next needs next_scale and <g, z>");
+    AFCM_REQUIRE(!d_out || (out_scale && dysy), "layer_bwd_coefs: d_out needs out_scale and <dys, y>");
+    hipLaunchKernelGGL(layer_bwd_coefs_kernel, dim3(cout), dim3(64), 0, (hipStream_t)stream, db, d_next, d_out, psum, slots, out_scale, next_scale,
+                       bias, gz, dysy, n, cout);
+    return hip_status(hipGetLastError());
+}
 
 extern "C" int afcm_weight_norm_fwd(float* w_hat, float* wsq, float* scale, const float* w, int32_t cout, int32_t cin, int32_t kk, void* stream) {
     AFCM_REQUIRE(w_hat && wsq && scale && w && cout > 0 && cin > 0 && kk > 0, "weight_norm_fwd: bad arguments");

@@ -44,14 +44,15 @@ class FullyConnectedLayer(torch.nn.Module):
         self.bias_gain = lr_multiplier
 
     def forward(self, x):
-        w = self.weight.to(x.dtype) * self.weight_gain
         b = self.bias
         if b is not None:
             b = b.to(x.dtype)
             if self.bias_gain != 1:
                 b = b * self.bias_gain
         if self.activation == 'linear' and b is not None:
-            return torch.addmm(b.unsqueeze(0), x, w.t())
+            # the equalised-lr gain as the GEMM's alpha: same product as x @ (w * gain).t() (NET:97-100) without a pass over w
+            return torch.addmm(b.unsqueeze(0), x, self.weight.to(x.dtype).t(), alpha=float(self.weight_gain))
+        w = self.weight.to(x.dtype) * self.weight_gain
         return bias_act.bias_act(x.matmul(w.t()), b, act=self.activation)
 
     def extra_repr(self):

@@ -96,7 +96,7 @@ def _mfma_workspace(a, fu_t, fd_t, x):
     return None if ent is None else ent[0]
 
 
-def _run(x, fu, fd, b, si, cfg, write_signs, want_plane_sum=False, oscale=None, skip=None):
+def _run(x, fu, fd, b, si, cfg, write_signs, want_plane_sum=False, oscale=None, skip=None, oscale2=None):
     """One launch of the op (C ABI afcm_filtered_lrelu, or the generic GPU path when there is no fused kernel).
     Returns (y, signs written or None, sign layout, per-plane output sums or None)."""
     up, down, px0, px1, py0, py1, gain, slope, clamp, flip_filter, sx, sy, si_layout = cfg
@@ -145,6 +145,8 @@ def _run(x, fu, fd, b, si, cfg, write_signs, want_plane_sum=False, oscale=None, 
         a.sh, a.swb = si.shape[2], si.shape[3]
         a.signs = si.data_ptr()
     a.x, a.y, a.b = x.data_ptr(), y.data_ptr(), _lib.ptr(b)
+    if oscale is None and oscale2 is not None:
+        oscale, oscale2 = oscale2, None
     if oscale is not None or skip is not None:
         # epilogue factors of the fused layer op (matrix-core kernels only; the C side rejects anything else)
         if ws is None:
@@ -155,7 +157,10 @@ def _run(x, fu, fd, b, si, cfg, write_signs, want_plane_sum=False, oscale=None, 
         if skip is not None:
             skip = skip.contiguous()
             assert skip.dtype == x.dtype and tuple(skip.shape) == (a.n, a.c, a.yh, a.yw)
-        a.oscale, a.skip = _lib.ptr(oscale), _lib.ptr(skip)
+        if oscale2 is not None:
+            oscale2 = oscale2.to(torch.float32).contiguous()
+            assert oscale2.numel() == a.n * a.c
+        a.oscale, a.skip, a.oscale2 = _lib.ptr(oscale), _lib.ptr(skip), _lib.ptr(oscale2)
     psum = None
     if ws is not None and want_plane_sum and a.plane_sum_slots > 0:
         psum = torch.empty([a.n, a.c, a.plane_sum_slots], dtype=torch.float32, device=x.device)   # every slot is written

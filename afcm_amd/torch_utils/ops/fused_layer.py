@@ -50,19 +50,30 @@ class _ConvFilteredLRelu(torch.autograd.Function):
         cout, cin, ks, _ = w.shape
         g = g.contiguous()
         f32 = torch.float32
+        assert g.dtype in (torch.bfloat16, torch.float16)
         # dys = d * dL/dy: the transposed filtered_lrelu with both per-plane factors in its epilogue
-        comb = None
-        if out_scale is not None or next_scale is not None:
-            comb = (out_scale.to(f32) if out_scale is not None else 1.0) * (next_scale.to(f32) if next_scale is not None else 1.0)
         bcfg = _flr._backward_cfg(cfg, fu, fd, y_shape, z_shape, layout)
-        dys, _, _, psum = _flr._run(g, fd, fu, None, signs, bcfg, False, want_plane_sum=True, oscale=comb)
-        ps = psum.sum(2) if psum is not None else _conv.plane_dot(dys)           # [N, O] plane sums of dys
+        dys, _, _, psum = _flr._run(g, fd, fu, None, signs, bcfg, False, want_plane_sum=True, oscale=out_scale, oscale2=next_scale)
         dx = dw = d_in = d_out = db = d_skip = d_next = None
-        if ctx.needs_input_grad[4]:
-            db = ((ps / out_scale.to(f32)) if out_scale is not None else ps).sum(0).to(bias.dtype)
-        if ctx.needs_input_grad[8]:
-            ns = next_scale.to(f32)
-            d_next = torch.where(ns != 0, _conv.plane_dot(g, z) / torch.where(ns != 0, ns, torch.ones_like(ns)), torch.zeros_like(ns)).to(next_scale.dtype)
+        # bias / next-styles / demodulation gradients: two plane dot products + ONE small kernel (C ABI afcm_layer_bwd_coefs)
+        n, o = int(g.shape[0]), int(g.shape[1])
+        want_db, want_next, want_out = ctx.needs_input_grad[4], ctx.needs_input_grad[8], ctx.needs_input_grad[3]
+        if want_db or want_next or want_out:
+            lib = _lib.load()
+            gz = _conv.plane_dot(g, z) if want_next else None
+            dysy = _conv.plane_dot(dys, y) if want_out else None
+            db32 = torch.empty([o], dtype=f32, device=g.device) if want_db else None
+            dn32 = torch.empty([n, o], dtype=f32, device=g.device) if want_next else None
+            do32 = torch.empty([n, o], dtype=f32, device=g.device) if want_out else None
+            osc = None if out_scale is None else out_scale.to(f32).contiguous()
+            nsc = None if next_scale is None else next_scale.to(f32).contiguous()
+            b32 = None if bias is None else bias.to(f32).contiguous()
+            _lib.check(lib.afcm_layer_bwd_coefs(_lib.ptr(db32), _lib.ptr(dn32), _lib.ptr(do32), psum.data_ptr(), int(psum.shape[2]), _lib.ptr(osc),
+                                                _lib.ptr(nsc), _lib.ptr(b32), _lib.ptr(gz), _lib.ptr(dysy), n, o, _lib.stream_ptr(g)),
+                       'layer_bwd_coefs')
+            db = None if db32 is None else db32.to(bias.dtype)
+            d_next = None if dn32 is None else dn32.to(next_scale.dtype)
+            d_out = None if do32 is None else do32.to(out_scale.dtype)
         if has_skip and ctx.needs_input_grad[7]:
             d_skip = _conv.scale_planes(g, next_scale) if next_scale is not None else g
         if ctx.needs_input_grad[0] or (ctx.needs_input_grad[2] and not prescaled):
@@ -74,13 +85,6 @@ class _ConvFilteredLRelu(torch.autograd.Function):
                 d_in = torch.where(s2 > 0, _conv.plane_dot(xs, dx) / s2.clamp_min(1e-30), torch.zeros_like(s2)).to(in_scale.dtype)
         if ctx.needs_input_grad[1]:
             dw = _conv._wgrad_raw(dys, xs, cout, cin, ks, conv_pad).to(w.dtype)
-        if ctx.needs_input_grad[3]:
-            # y = d * c + b  =>  dL/dd = <dL/dy, c> = (<dys, y> - b * sum(dys)) / d^2
-            d2 = out_scale.to(f32).square()
-            num = _conv.plane_dot(dys, y)
-            if bias is not None:
-                num = num - bias.to(f32).reshape(1, -1) * ps
-            d_out = (num / d2).to(out_scale.dtype)
         return dx, dw, d_in, d_out, db, None, None, d_skip, d_next, None, None, None
 
 

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define AFCM_ABI_VERSION 5
+#define AFCM_ABI_VERSION 6
 
 enum { AFCM_F32 = 0, AFCM_F16 = 1, AFCM_BF16 = 2 };
 enum { AFCM_OK = 0, AFCM_E_NOKERNEL = -1, AFCM_E_INVALID = -2 };
@@ -93,6 +93,7 @@ typedef struct afcm_filtered_lrelu_args {
                                of the conv that produced x (NET:50-52, backward: the op is linear in dy given the codes). */
     const void*  skip;      /* NULL, or [N, C, yh, yw] of x's dtype: the encoder feature added after the activation
                                (x + x_skip, NET:376-377), added before oscale.  Matrix-core kernels only.                */
+    const float* oscale2;   /* NULL, or a second fp32 [N*C] factor multiplied with oscale (backward: demodulation x styles) */
 } afcm_filtered_lrelu_args;
 
 /* Output / sign-tensor geometry for the arguments above (filtered_lrelu.cpp:61-94). Fills yh, yw
@@ -203,6 +204,14 @@ int afcm_style_coefs_fwd(float* s_eff, float* d, float* r, const float* t, const
                          int32_t cout, int32_t demodulate, void* stream);
 int afcm_style_coefs_bwd(float* dt, float* g_wsq, float* workspace, const float* g_s, const float* g_d, const float* t, const float* d,
                          const float* wsq, const float* magnitude, const float* r, int32_t n, int32_t cin, int32_t cout, int32_t demodulate,
+                         void* stream);
+
+/* Small-tensor tail of a fused layer's backward (afcm_amd/torch_utils/ops/fused_layer.py): from the per-tile plane sums of
+ * dys that the transposed filtered_lrelu emitted (psum [n, cout, slots]) and two plane dot products, the gradients of the
+ * bias (db [cout] = sum_n ps / d), of the next layer's styles (d_next [n, cout] = <g, z> / s_next) and of the demodulation
+ * coefficients (d_out [n, cout] = (<dys, y> - b ps) / d^2).  Any of db / d_next / d_out may be NULL; out_scale, bias may be NULL. */
+int afcm_layer_bwd_coefs(float* db, float* d_next, float* d_out, const float* psum, int32_t slots, const float* out_scale,
+                         const float* next_scale, const float* bias, const float* gz, const float* dysy, int32_t n, int32_t cout,
                          void* stream);
 
 /* ------------------------------------------------------------------------------------------
