@@ -312,6 +312,12 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? 1 : 2)) void conv2d_fwd_kern
 //   * the patch writes are conflict-free: a thread owns 4 consecutive pixels (192 bytes apart from its neighbour's, a
 //     4-way conflict when every lane writes its pixel e at step e), so lane i writes pixel (e + (i >> 2)) & 3 at step e;
 //   * XCD-aware tile order: neighbouring tiles of one image (shared halos, same weights) stay on one XCD's L2.
+// Measured bounds (ablation builds, whole-generator conv bench, baseline 0.92 / 0.96 PF/s fwd / dgrad): weight fragments served
+// from L1 +2 %; no barrier +0 %; B fragments read once per chunk +5 %; patch written later in the chunk +0 %; the four
+// transposing ds_write_b128 removed (loads and permutes kept) +19 %; the whole activation path removed +38 %.  So the
+// register -> LDS transpose that NCHW forces is the limiter; LDS-DMA + ds_read_b64_tr_b16 cannot replace it because the
+// transposing read ignores the low three address bits (tools/ubench/tr_align_probe.hip) and the tap columns shift by
+// 1 and 2 pixels.
 template <typename T, int BM_O>
 __global__ __launch_bounds__(256, 2) void conv2d_fwd16_kernel(ConvParams p) {
     static_assert(sizeof(T) == 2, "16-bit types only");
@@ -319,7 +325,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_fwd16_kernel(ConvParams p) {
     constexpr int KS = 3, KK = 9, BK = C::BK, PITCH = C::PITCH, MI = BM_O / 64, RING = 3;
     typedef typename std::conditional<std::is_same<T, bf16_t>::value, bf16x8, f16x8>::type frag_t;
     typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
-    __shared__ __attribute__((aligned(16))) T lds[2 * kPatchMax * PITCH];
+    __shared__ __attribute__((aligned(16))) T lds[2 * kPatchMax * PITCH + 4 * PITCH];      // + a sink for lanes outside the patch
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -383,50 +389,53 @@ __global__ __launch_bounds__(256, 2) void conv2d_fwd16_kernel(ConvParams p) {
     constexpr unsigned kOob = 0x80000000u;
     const bool d0ok = rowok && (unsigned)ix < (unsigned)p.W, d1ok = rowok && (unsigned)(ix + 2) < (unsigned)p.W;
     const unsigned pmask0 = d0ok ? ~0u : 0u, pmask1 = d1ok ? ~0u : 0u;
-    const bool any_partial = __builtin_amdgcn_ballot_w64(d0ok != d1ok) != 0;          // wave-uniform
     const bool lshift = !d0ok && d1ok;                                                // never touch bytes before a row 0
-    const bool any_lshift = __builtin_amdgcn_ballot_w64(lshift) != 0;
     const unsigned pvoff = (d0ok || d1ok) ? (unsigned)(((long long)cg * 8 * p.H * p.W + pix_off + (lshift ? 2 : 0)) * 2ll) : kOob;
     const long long img_bytes = (long long)p.Cin * p.H * p.W * 2ll;
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)xn, 0, (int)(img_bytes > 0x7fffffffll ? 0x7fffffffll : img_bytes), 0x00020000);
     const int hw2 = p.H * p.W * 2;
-    const int rot = (lane >> 2) & 3;                                                  // write rotation (see header)
 
     unsigned preg[8][2];
+    // Channels past Cin exist only in the last chunk of a layer whose Cin is not a multiple of 16; the chunk's channel offset
+    // rides in the scalar offset, which the descriptor's range check does not cover, so those lanes get the out-of-range
+    // vector offset instead (zeros).  Decided here, at the chunk boundary, to keep the tap loop free of branches.
+    const bool ragged = (p.Cin % BK) != 0;
     auto issue_patch = [&](int kc) __attribute__((always_inline)) {
+        if (ragged && kc == p.nkc - 1) {
 #pragma unroll
-        for (int c = 0; c < 8; c++) {
-            const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(xrs, pvoff, (kc * BK + c) * hw2, 0);
-            preg[c][0] = v.x; preg[c][1] = v.y;
+            for (int c = 0; c < 8; c++) {
+                const unsigned off = (kc * BK + cg * 8 + c < p.Cin) ? pvoff : kOob;
+                const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(xrs, off, (kc * BK + c) * hw2, 0);
+                preg[c][0] = v.x; preg[c][1] = v.y;
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+                const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(xrs, pvoff, (kc * BK + c) * hw2, 0);
+                preg[c][0] = v.x; preg[c][1] = v.y;
+            }
         }
     };
-    auto write_patch = [&](int kc, T* dstbuf) __attribute__((always_inline)) {
-        if ((kc + 1) * BK > p.Cin) {                                                  // channels past Cin: last chunk only
+    // Branch-free on purpose: any branch here (even a wave-uniform one) cuts the tap loop into basic blocks, the ~60
+    // transpose instructions then run as one serial block with no MFMA in flight (measured: the register -> LDS transpose
+    // cost 38 % of the kernel that way).  Channels past Cin are zeroed by issue_patch; lanes outside the patch
+    // write to a sink; edge masks are applied unconditionally.
+    auto write_patch = [&](int kc, T* dstbuf, int bufbase) __attribute__((always_inline)) {
 #pragma unroll
-            for (int c = 0; c < 8; c++)
-                if (kc * BK + cg * 8 + c >= p.Cin) { preg[c][0] = 0u; preg[c][1] = 0u; }
+        for (int c = 0; c < 8; c++) {
+            const unsigned lo = lshift ? 0u : (preg[c][0] & pmask0);
+            const unsigned hi = (lshift ? preg[c][0] : preg[c][1]) & pmask1;
+            preg[c][0] = lo; preg[c][1] = hi;
         }
-        if (pvalid) {
-            if (any_lshift) {
 #pragma unroll
-                for (int c = 0; c < 8; c++) preg[c][1] = lshift ? preg[c][0] : preg[c][1];
-            }
-            if (any_partial) {
-#pragma unroll
-                for (int c = 0; c < 8; c++) { preg[c][0] &= pmask0; preg[c][1] &= pmask1; }
-            }
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const int ei = (e + rot) & 3;
-                const unsigned sel = (ei & 1) ? 0x07060302u : 0x05040100u;
-                const bool hi2 = (ei & 2) != 0;
-                uint4 v;
-                v.x = __builtin_amdgcn_perm(hi2 ? preg[1][1] : preg[1][0], hi2 ? preg[0][1] : preg[0][0], sel);
-                v.y = __builtin_amdgcn_perm(hi2 ? preg[3][1] : preg[3][0], hi2 ? preg[2][1] : preg[2][0], sel);
-                v.z = __builtin_amdgcn_perm(hi2 ? preg[5][1] : preg[5][0], hi2 ? preg[4][1] : preg[4][0], sel);
-                v.w = __builtin_amdgcn_perm(hi2 ? preg[7][1] : preg[7][0], hi2 ? preg[6][1] : preg[6][0], sel);
-                *(uint4*)(dstbuf + pdst + ei * PITCH) = v;
-            }
+        for (int e = 0; e < 4; e++) {
+            const unsigned sel = (e & 1) ? 0x07060302u : 0x05040100u;
+            uint4 v;
+            v.x = __builtin_amdgcn_perm(preg[1][e >> 1], preg[0][e >> 1], sel);
+            v.y = __builtin_amdgcn_perm(preg[3][e >> 1], preg[2][e >> 1], sel);
+            v.z = __builtin_amdgcn_perm(preg[5][e >> 1], preg[4][e >> 1], sel);
+            v.w = __builtin_amdgcn_perm(preg[7][e >> 1], preg[6][e >> 1], sel);
+            *(uint4*)(lds + (pvalid ? bufbase + pdst + e * PITCH : 2 * kPatchMax * PITCH)) = v;
         }
     };
 
@@ -436,7 +445,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_fwd16_kernel(ConvParams p) {
     for (int t = 0; t < RING; t++)
 #pragma unroll
         for (int mi = 0; mi < MI; mi++) ar[t][mi] = load_a(0, t, mi);
-    write_patch(0, lds);
+    write_patch(0, lds, 0);
     __syncthreads();
 
     const int last = p.nkc - 1;
@@ -470,8 +479,19 @@ __global__ __launch_bounds__(256, 2) void conv2d_fwd16_kernel(ConvParams p) {
                     else
                         acc[mi][ti] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mi], b[ti], acc[mi][ti], 0, 0, 0);
                 }
-            if (tap == 5 && more) write_patch(kc + 1, nxt);          // the other buffer: last read one chunk ago
-            else {
+            if (tap == 5) {
+                // the other buffer (last read one chunk ago); on the last chunk this rewrites stale registers into a buffer
+                // nobody reads.  Interleave: one MFMA, then a handful of the transpose's vector instructions.
+                write_patch(kc + 1, nxt, ((kc + 1) & 1) * (kPatchMax * PITCH));
+                __builtin_amdgcn_sched_group_barrier(0x020, MI, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+                for (int i2 = 0; i2 < 4 * MI; i2++) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x200, 4, 0);
+            } else {
                 // pin the issue order of the tap: the ring refill first (left alone, the scheduler sinks the loads next to
                 // their uses and the three-tap prefetch distance collapses), then the B reads, then the MFMAs.
                 // (Also tried: B fragments one tap ahead in a second register set -- +3 % on the 512-channel layers, but
