@@ -11,16 +11,20 @@ Unlike the reference (which dereferences ``netG.module`` and therefore cannot ru
 comodgan_model.py:14), the wrapper owns a bare module and shards by batch across ranks through
 ``afcm_amd.distributed.GradientBuckets``.
 """
+import numpy as np
 import torch
 
 from .distributed import GradientBuckets
+from .torch_utils.ops import upfirdn2d
 from .optim import FusedScrubAdam
 
 
 class StyleGAN3GeneratorStep:
     def __init__(self, netG, lr_G=0.0025, lambda_L1=100.0, distributed=False, bucket_bytes=25 * 1024 * 1024, style_mixing_prob=0,
-                 force_collectives=False):
+                 force_collectives=False, blur_init_sigma=0.0, blur_fade_kimg=0.0):
         self.netG = netG
+        # loss-side blur schedule (models/stylegan3_model.py:80-81,115-116): sigma fades linearly to 0 over blur_fade_kimg
+        self.blur_init_sigma, self.blur_fade_kimg, self.blur_sigma = float(blur_init_sigma), float(blur_fade_kimg), 0.0
         self.G_mapping = netG.mapping
         self.G_synthesis = netG.synthesis
         # nan_to_num of every gradient + Adam(betas=(0, 0.99)) (stylegan3_model.py:132-135, comodgan_model.py:19-20) as one HIP launch
@@ -53,12 +57,25 @@ class StyleGAN3GeneratorStep:
     def forward(self, update_emas=False):
         self.fake_B = self.run_G(self.real_A, update_emas=update_emas)
 
+    def _blur(self, img):
+        """Gaussian blur of the loss inputs while blur_sigma > 0 (models/stylegan3_model.py:97-103): 2*floor(3 sigma)+1 taps,
+        separable, through the HIP upfirdn2d kernel (filter2d)."""
+        blur_size = np.floor(self.blur_sigma * 3)
+        if blur_size <= 0:
+            return img
+        f = torch.arange(-blur_size, blur_size + 1, device=img.device).div(self.blur_sigma).square().neg().exp2()
+        return upfirdn2d.filter2d(img, f / f.sum())
+
     def backward_G(self, extra_loss=None):
-        self.loss_G_L1 = self.criterionL1(self.fake_B, self.real_B) * self.lambda_L1
+        self.loss_G_L1 = self.criterionL1(self._blur(self.fake_B), self._blur(self.real_B)) * self.lambda_L1
         self.loss_G = self.loss_G_L1 if extra_loss is None else self.loss_G_L1 + extra_loss
         self.loss_G.backward()
 
-    def optimize_parameters(self):
+    def optimize_parameters(self, cur_nimg=None):
+        """G half of models/stylegan3_model.py:113-135.  `cur_nimg` drives the blur fade as in the reference (:115-116);
+        None keeps the current blur_sigma."""
+        if cur_nimg is not None:
+            self.blur_sigma = (max(1 - cur_nimg / (self.blur_fade_kimg * 1e3), 0) * self.blur_init_sigma) if self.blur_fade_kimg > 0 else 0.0
         self.optimizer_G.zero_grad(set_to_none=True)
         self.forward(update_emas=False)
         self.backward_G()
@@ -66,3 +83,20 @@ class StyleGAN3GeneratorStep:
         # averaging (1 / world), the NaN/Inf scrub and the Adam update all happen inside the optimizer kernel; with buckets the
         # reduced gradients are read where the all-reduce left them
         self.optimizer_G.step(grads=grads, grad_scale=scale)
+
+
+@torch.no_grad()
+def update_ema(net_ema, net, batch_size, total_iters, ema_kimgs=10.0, ramp=None):
+    """Exponential moving average of the generator as in the reference's train loop (train.py:67-77):
+    beta = 0.5 ** (batch_size / ema_nimg), ema_nimg = min(ema_kimgs * 1000, total_iters * ramp); parameters are lerped,
+    buffers copied.  One multi-tensor lerp instead of a Python loop of copies."""
+    ema_nimg = ema_kimgs * 1000
+    if ramp is not None:
+        ema_nimg = min(ema_nimg, total_iters * ramp)
+    beta = 0.5 ** (batch_size / max(ema_nimg, 1e-8))
+    p_ema, p = list(net_ema.parameters()), list(net.parameters())
+    # p_ema <- p.lerp(p_ema, beta) = p_ema + (1 - beta) * (p - p_ema)
+    torch._foreach_lerp_(p_ema, p, 1.0 - beta)
+    for b_ema, b in zip(net_ema.buffers(), net.buffers()):
+        b_ema.copy_(b)
+    return beta
