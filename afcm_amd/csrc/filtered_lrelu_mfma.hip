@@ -224,7 +224,9 @@ __device__ __forceinline__ unsigned signs_pk(unsigned d) {
 }
 
 template <typename T, int UP, int DOWN, int TOW, int TOH, int SIGN, bool BIAS>
-__global__ __launch_bounds__((64 * MfmaGeom<UP, DOWN, TOW, TOH>::NG)) void flrelu_mfma_kernel(FlreluMfmaParams p) {
+__global__ __launch_bounds__((64 * MfmaGeom<UP, DOWN, TOW, TOH>::NG), (DOWN == 2 ? 6 : 4)) void flrelu_mfma_kernel(FlreluMfmaParams p) {
+    // second bound = waves per SIMD: the 3-wave workgroups (19 KB of LDS) fit 8 to a CU, which needs <= 80 VGPRs -- without
+    // the bound the scheduler spends ~90 on overlapping the tiles' MFMAs and two workgroups per CU are lost
     typedef MfmaGeom<UP, DOWN, TOW, TOH> G;
     typedef MfmaOps<T> M;
     typedef typename M::frag frag;
@@ -444,71 +446,81 @@ __global__ __launch_bounds__((64 * MfmaGeom<UP, DOWN, TOW, TOH>::NG)) void flrel
             frag q[G::NQ];
 #pragma unroll
             for (int m = 0; m < G::NQ; m++) q[m] = pack_pair<T>(x1[m], (m + 1 < G::NMB) ? x1[m + 1] : zero4);
-            // up-y, then the two operands of the down-y pass: X2 itself and relu(X2) (forward) / keep-mask & X2 (backward)
+            // up-y, then the two operands of the down-y pass: X2 itself and relu(X2) (forward) / keep-mask & X2 (backward).
+            // Forward: the whole column block first runs the fast path (no clamp) while the largest |X2| is tracked with two
+            // v_maximum3 per tile; one wave-uniform test per block decides whether it is redone exactly (rare: |v| > clamp).
             u32x4 pv[G::NPAIR], rv[G::NPAIR];
+            auto run_block = [&](auto exact_c) __attribute__((always_inline)) -> float {
+                constexpr bool EXACT = decltype(exact_c)::value;
+                float amax = 0.f;
 #pragma unroll
-            for (int vb = 0; vb < 2 * G::NPAIR; vb++) {
-                unsigned d0 = 0, d1 = 0, r0 = 0, r1 = 0;
-                if (vb < G::NVB) {
-                    f32x4 x2 = M::mma(uv[vb % UP], q[vb / UP], zero4);
-                    if (SIGN == AFCM_SIGNS_READ) {
-                        // codes of rows Y+sy .. Y+sy+3 at column X+sx: two staged quad bytes, funnel-shifted
-                        const unsigned lo = sgr[(4 * vb) * G::SGN_PITCH + 16 * nb];
-                        const unsigned hi = sgr[(4 * vb + 1) * G::SGN_PITCH + 16 * nb];
-                        const unsigned codes = __builtin_amdgcn_ubfe(lo | (hi << 8), 2 * yy, 8);
-                        if (__builtin_expect(!has_clamp, 1)) {
-                            const uint2 keep = lds_tab[codes];
-                            d0 = pack2<T>(x2[0], x2[1]);
-                            d1 = pack2<T>(x2[2], x2[3]);
-                            r0 = d0 & keep.x;
-                            r1 = d1 & keep.y;
-                        } else {
+                for (int vb = 0; vb < 2 * G::NPAIR; vb++) {
+                    unsigned d0 = 0, d1 = 0, r0 = 0, r1 = 0;
+                    if (vb < G::NVB) {
+                        f32x4 x2 = M::mma(uv[vb % UP], q[vb / UP], zero4);
+                        if (SIGN == AFCM_SIGNS_READ) {
+                            // codes of rows Y+sy .. Y+sy+3 at column X+sx: two staged quad bytes, funnel-shifted
+                            const unsigned lo = sgr[(4 * vb) * G::SGN_PITCH + 16 * nb];
+                            const unsigned hi = sgr[(4 * vb + 1) * G::SGN_PITCH + 16 * nb];
+                            const unsigned codes = __builtin_amdgcn_ubfe(lo | (hi << 8), 2 * yy, 8);
+                            if (__builtin_expect(!has_clamp, 1)) {
+                                const uint2 keep = lds_tab[codes];
+                                d0 = pack2<T>(x2[0], x2[1]);
+                                d1 = pack2<T>(x2[2], x2[3]);
+                                r0 = d0 & keep.x;
+                                r1 = d1 & keep.y;
+                            } else {
 #pragma unroll
-                            for (int r = 0; r < 4; r++) {
-                                const unsigned c = codes >> (2 * r);
-                                float v = x2[r];
-                                if (c & 1u) v *= p.slope;
-                                if (c & 2u) v = 0.f;
-                                x2[r] = v;
+                                for (int r = 0; r < 4; r++) {
+                                    const unsigned c = codes >> (2 * r);
+                                    float v = x2[r];
+                                    if (c & 1u) v *= p.slope;
+                                    if (c & 2u) v = 0.f;
+                                    x2[r] = v;
+                                }
+                                d0 = r0 = pack2<T>(x2[0], x2[1]);     // slope*v + (1-slope)*v
+                                d1 = r1 = pack2<T>(x2[2], x2[3]);
                             }
-                            d0 = r0 = pack2<T>(x2[0], x2[1]);     // slope*v + (1-slope)*v
-                            d1 = r1 = pack2<T>(x2[2], x2[3]);
-                        }
-                    } else {
-                        unsigned wcode;
-                        // NaN-propagating maximum: two v_maximum3_f32 (fmaxf would add a canonicalisation per operand)
-                        const float amax = __builtin_elementwise_maximum(
-                            __builtin_elementwise_maximum(__builtin_fabsf(x2[0]), __builtin_fabsf(x2[1])),
-                            __builtin_elementwise_maximum(__builtin_fabsf(x2[2]), __builtin_fabsf(x2[3])));
-                        if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(amax <= cthr)) == 0, 1)) {    // NaN takes the exact path
-                            // common case: nothing in the tile can reach the clamp
-                            d0 = pack2<T>(x2[0], x2[1]);
-                            d1 = pack2<T>(x2[2], x2[3]);
-                            r0 = relu_pk(d0);
-                            r1 = relu_pk(d1);
-                            const unsigned f = (signs_pk(d1) << 4) | signs_pk(d0);       // bits 0 (row 0), 16 (row 1), 4 (row 2), 20 (row 3)
-                            wcode = f | (f >> 14);
                         } else {
-                            wcode = 0;
+                            unsigned wcode;
+                            if (!EXACT) {
+                                // NaN-propagating maximum (fmaxf would add a canonicalisation per operand)
+                                amax = __builtin_elementwise_maximum(amax, __builtin_elementwise_maximum(__builtin_fabsf(x2[0]), __builtin_fabsf(x2[1])));
+                                amax = __builtin_elementwise_maximum(amax, __builtin_elementwise_maximum(__builtin_fabsf(x2[2]), __builtin_fabsf(x2[3])));
+                                d0 = pack2<T>(x2[0], x2[1]);
+                                d1 = pack2<T>(x2[2], x2[3]);
+                                r0 = relu_pk(d0);
+                                r1 = relu_pk(d1);
+                                const unsigned f = (signs_pk(d1) << 4) | signs_pk(d0);       // bits 0 (row 0), 16 (row 1), 4 (row 2), 20 (row 3)
+                                wcode = f | (f >> 14);
+                            } else {
+                                wcode = 0;
 #pragma unroll
-                            for (int r = 0; r < 4; r++) {
-                                float v = x2[r];
-                                unsigned c = __float_as_uint(v) >> 31;
-                                if (c) v *= p.slope;
-                                if (fabsf(v) > p.clamp) { c = 2u; v = (v < 0.f) ? -p.clamp : p.clamp; }
-                                wcode |= c << (2 * r);
-                                x2[r] = v;
+                                for (int r = 0; r < 4; r++) {
+                                    float v = x2[r];
+                                    unsigned c = __float_as_uint(v) >> 31;
+                                    if (c) v *= p.slope;
+                                    if (fabsf(v) > p.clamp) { c = 2u; v = (v < 0.f) ? -p.clamp : p.clamp; }
+                                    wcode |= c << (2 * r);
+                                    x2[r] = v;
+                                }
+                                d0 = r0 = pack2<T>(x2[0], x2[1]);
+                                d1 = r1 = pack2<T>(x2[2], x2[3]);
                             }
-                            d0 = r0 = pack2<T>(x2[0], x2[1]);
-                            d1 = r1 = pack2<T>(x2[2], x2[3]);
+                            if (SIGN == AFCM_SIGNS_WRITE) sgw[(4 * vb) * G::SGW_PITCH + 16 * nb] = (unsigned char)wcode;
                         }
-                        if (SIGN == AFCM_SIGNS_WRITE) sgw[(4 * vb) * G::SGW_PITCH + 16 * nb] = (unsigned char)wcode;
                     }
+                    pv[vb >> 1][2 * (vb & 1)] = d0;
+                    pv[vb >> 1][2 * (vb & 1) + 1] = d1;
+                    rv[vb >> 1][2 * (vb & 1)] = r0;
+                    rv[vb >> 1][2 * (vb & 1) + 1] = r1;
                 }
-                pv[vb >> 1][2 * (vb & 1)] = d0;
-                pv[vb >> 1][2 * (vb & 1) + 1] = d1;
-                rv[vb >> 1][2 * (vb & 1)] = r0;
-                rv[vb >> 1][2 * (vb & 1) + 1] = r1;
+                return amax;
+            };
+            const float amax_nb = run_block(std::false_type{});
+            if (SIGN != AFCM_SIGNS_READ) {
+                if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(amax_nb <= cthr)) != 0, 0))    // NaN takes the exact path
+                    run_block(std::true_type{});
             }
             // down-y, transposed: X3'[ucol][orow] = sum_t P[(DOWN/2)*ob + t]' * DV[t]'  ->  LDS X3[orow][ucol], 4 columns per lane
 #pragma unroll
@@ -560,13 +572,21 @@ __global__ __launch_bounds__((64 * MfmaGeom<UP, DOWN, TOW, TOH>::NG)) void flrel
         const float osc = (p.oscale ? p.oscale[plane] : 1.f) * (p.oscale2 ? p.oscale2[plane] : 1.f);
         const T* skp = p.skip ? (const T*)p.skip + (size_t)plane * p.yh * p.yw : nullptr;
         float psum = 0.f;
-        for (int unit = wave; unit < G::NOB * G::NCB; unit += G::NG) {
+        unsigned x3r_off = l15 * G::PX3 + 8 * g, outw_off = l15 * G::POUT + 4 * g;      // per-lane bases, one register each
+        asm volatile("" : "+v"(x3r_off), "+v"(outw_off));
+        const T* const x3r = lds_x3 + x3r_off;
+        T* const outw = lds_out + outw_off;
+        constexpr int NUNIT = G::NOB * G::NCB, UPW = cdiv(NUNIT, G::NG);
+#pragma unroll
+        for (int ui = 0; ui < UPW; ui++) {
+            const int unit = wave + ui * G::NG;                       // wave-uniform
+            if (NUNIT % G::NG != 0 && unit >= NUNIT) break;
             const int ob = unit / G::NCB, cb = unit - ob * G::NCB;
             f32x4 acc = zero4;
 #pragma unroll
             for (int t = 0; t < G::NDVK; t++) {
                 union { uint4 q; frag f; } b;
-                b.q = *(const uint4*)(lds_x3 + (16 * ob + l15) * G::PX3 + 16 * DOWN * cb + 32 * t + 8 * g);
+                b.q = *(const uint4*)(x3r + (16 * ob) * G::PX3 + 16 * DOWN * cb + 32 * t);
                 acc = M::mma(dh[t], b.f, acc);
             }
             if (skp != nullptr) {
@@ -588,7 +608,7 @@ __global__ __launch_bounds__((64 * MfmaGeom<UP, DOWN, TOW, TOH>::NG)) void flrel
             uint2 w;
             w.x = pack2<T>(acc[0], acc[1]);
             w.y = pack2<T>(acc[2], acc[3]);
-            *(uint2*)(lds_out + (16 * ob + l15) * G::POUT + 16 * cb + 4 * g) = w;
+            *(uint2*)(outw + (16 * ob) * G::POUT + 16 * cb) = w;
             if (p.plane_sum != nullptr) {
                 if (inner) {
                     psum += (acc[0] + acc[1]) + (acc[2] + acc[3]);
@@ -605,6 +625,16 @@ __global__ __launch_bounds__((64 * MfmaGeom<UP, DOWN, TOW, TOH>::NG)) void flrel
         {
             constexpr int SEG = TOW / 8;
             T* yp = (T*)p.y + (size_t)plane * p.yh * p.yw;
+            if (inner) {
+                T* ytile = yp + (size_t)O0y * p.yw + O0x;
+#pragma unroll
+                for (int i = 0; i < cdiv(TOH * SEG, NT); i++) {
+                    const int idx = tid + i * NT;
+                    const int r = idx / SEG, c = idx - r * SEG;
+                    if ((TOH * SEG) % NT == 0 || idx < TOH * SEG)
+                        *(u32x4*)(ytile + (size_t)r * p.yw + 8 * c) = *(const u32x4*)(lds_out + r * G::POUT + 8 * c);
+                }
+            } else
             for (int idx = tid; idx < TOH * SEG; idx += NT) {
                 const int r = idx / SEG, c = idx - r * SEG;
                 const int oy = O0y + r, ox = O0x + 8 * c;
