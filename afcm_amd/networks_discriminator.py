@@ -1,0 +1,216 @@
+"""Drop-in discriminator of the `--model stylegan3` path: ``CoModDiscriminator`` and its blocks with the
+reference's class names, constructor arguments, ``forward()`` signatures and state-dict keys
+(models/networks/CoModGAN/generator.py:613-836; layers of models/networks/CoModGAN/layers.py:81-162).
+
+Resampling FIRs and bias/activation run on the HIP kernels (``upfirdn2d``, ``bias_act``: both arbitrarily differentiable, which
+the R1 penalty's double backward needs); the contraction is the framework convolution, as in the reference (see
+torch_utils/ops/conv2d_resample.py).  fp32 only: the reference's fp16 / channels-last switches are accepted and ignored
+(``num_fp16_res = 0`` in every shipped configuration, models/stylegan3_model.py:69).
+"""
+import numpy as np
+import torch
+
+from .torch_utils.ops import bias_act, conv2d_resample, upfirdn2d
+
+
+class FullyConnectedLayer(torch.nn.Module):
+    """layers.py:81-111."""
+
+    def __init__(self, in_features, out_features, bias=True, activation='linear', lr_multiplier=1, bias_init=0):
+        super().__init__()
+        self.activation = activation
+        self.weight = torch.nn.Parameter(torch.randn([out_features, in_features]) / lr_multiplier)
+        self.bias = torch.nn.Parameter(torch.full([out_features], np.float32(bias_init))) if bias else None
+        self.weight_gain = lr_multiplier / np.sqrt(in_features)
+        self.bias_gain = lr_multiplier
+
+    def forward(self, x):
+        w = self.weight.to(x.dtype) * self.weight_gain
+        b = self.bias
+        if b is not None:
+            b = b.to(x.dtype)
+            if self.bias_gain != 1:
+                b = b * self.bias_gain
+        if self.activation == 'linear' and b is not None:
+            return torch.addmm(b.unsqueeze(0), x, w.t())
+        return bias_act.bias_act(x.matmul(w.t()), b, act=self.activation)
+
+
+class Conv2dLayer(torch.nn.Module):
+    """layers.py:115-162 (with resampling)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, bias=True, activation='linear', up=1, down=1,
+                 resample_filter=[1, 3, 3, 1], conv_clamp=None, channels_last=False, trainable=True):
+        super().__init__()
+        self.activation = activation
+        self.up, self.down = up, down
+        self.conv_clamp = conv_clamp
+        self.register_buffer('resample_filter', upfirdn2d.setup_filter(resample_filter))
+        self.padding = kernel_size // 2
+        self.weight_gain = 1 / np.sqrt(in_channels * (kernel_size ** 2))
+        self.act_gain = bias_act.activation_funcs[activation].def_gain
+        weight = torch.randn([out_channels, in_channels, kernel_size, kernel_size])
+        b = torch.zeros([out_channels]) if bias else None
+        if trainable:
+            self.weight = torch.nn.Parameter(weight)
+            self.bias = torch.nn.Parameter(b) if b is not None else None
+        else:
+            self.register_buffer('weight', weight)
+            if b is not None:
+                self.register_buffer('bias', b)
+            else:
+                self.bias = None
+
+    def forward(self, x, gain=1):
+        w = self.weight * self.weight_gain
+        b = self.bias.to(x.dtype) if self.bias is not None else None
+        flip_weight = (self.up == 1)
+        x = conv2d_resample.conv2d_resample(x=x, w=w.to(x.dtype), f=self.resample_filter, up=self.up, down=self.down,
+                                            padding=self.padding, flip_weight=flip_weight)
+        act_gain = self.act_gain * gain
+        act_clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
+        return bias_act.bias_act(x, b, act=self.activation, gain=act_gain, clamp=act_clamp)
+
+
+class DiscriminatorBlock(torch.nn.Module):
+    """generator.py:613-692."""
+
+    def __init__(self, in_channels, tmp_channels, out_channels, resolution, img_channels, first_layer_idx, architecture='resnet',
+                 activation='lrelu', resample_filter=[1, 3, 3, 1], conv_clamp=None, use_fp16=False, fp16_channels_last=False,
+                 freeze_layers=0):
+        assert architecture in ['orig', 'skip', 'resnet']
+        super().__init__()
+        self.in_channels = in_channels
+        self.resolution = resolution
+        self.img_channels = img_channels
+        self.first_layer_idx = first_layer_idx
+        self.architecture = architecture
+        self.register_buffer('resample_filter', upfirdn2d.setup_filter(resample_filter))
+        self.num_layers = 0
+
+        def trainable_gen():
+            while True:
+                layer_idx = self.first_layer_idx + self.num_layers
+                self.num_layers += 1
+                yield layer_idx >= freeze_layers
+        trainable_iter = trainable_gen()
+        if in_channels == 0 or architecture == 'skip':
+            self.fromrgb = Conv2dLayer(img_channels, tmp_channels, kernel_size=1, activation=activation, trainable=next(trainable_iter),
+                                       conv_clamp=conv_clamp)
+        self.conv0 = Conv2dLayer(tmp_channels, tmp_channels, kernel_size=3, activation=activation, trainable=next(trainable_iter),
+                                 conv_clamp=conv_clamp)
+        self.conv1 = Conv2dLayer(tmp_channels, out_channels, kernel_size=3, activation=activation, down=2, trainable=next(trainable_iter),
+                                 resample_filter=resample_filter, conv_clamp=conv_clamp)
+        if architecture == 'resnet':
+            self.skip = Conv2dLayer(tmp_channels, out_channels, kernel_size=1, bias=False, down=2, trainable=next(trainable_iter),
+                                    resample_filter=resample_filter)
+
+    def forward(self, x, img, force_fp32=False):
+        if x is not None:
+            assert list(x.shape[1:]) == [self.in_channels, self.resolution, self.resolution]
+            x = x.to(torch.float32)
+        if self.in_channels == 0 or self.architecture == 'skip':
+            assert list(img.shape[1:]) == [self.img_channels, self.resolution, self.resolution]
+            img = img.to(torch.float32)
+            y = self.fromrgb(img)
+            x = x + y if x is not None else y
+            img = upfirdn2d.downsample2d(img, self.resample_filter) if self.architecture == 'skip' else None
+        if self.architecture == 'resnet':
+            y = self.skip(x, gain=np.sqrt(0.5))
+            x = self.conv0(x)
+            x = self.conv1(x, gain=np.sqrt(0.5))
+            x = y.add_(x)
+        else:
+            x = self.conv0(x)
+            x = self.conv1(x)
+        return x, img
+
+
+class MinibatchStdLayer(torch.nn.Module):
+    """generator.py:696-718."""
+
+    def __init__(self, group_size, num_channels=1):
+        super().__init__()
+        self.group_size = group_size
+        self.num_channels = num_channels
+
+    def forward(self, x):
+        N, C, H, W = x.shape
+        G = min(self.group_size, N) if self.group_size is not None else N
+        F = self.num_channels
+        c = C // F
+        y = x.reshape(G, -1, F, c, H, W)
+        y = y - y.mean(dim=0)
+        y = y.square().mean(dim=0)
+        y = (y + 1e-8).sqrt()
+        y = y.mean(dim=[2, 3, 4])
+        y = y.reshape(-1, F, 1, 1)
+        y = y.repeat(G, 1, H, W)
+        return torch.cat([x, y], dim=1)
+
+
+class DiscriminatorEpilogue(torch.nn.Module):
+    """generator.py:722-776."""
+
+    def __init__(self, in_channels, cmap_dim, resolution, img_channels, architecture='resnet', mbstd_group_size=4, mbstd_num_channels=1,
+                 activation='lrelu', conv_clamp=None):
+        assert architecture in ['orig', 'skip', 'resnet']
+        super().__init__()
+        self.in_channels = in_channels
+        self.cmap_dim = cmap_dim
+        self.resolution = resolution
+        self.img_channels = img_channels
+        self.architecture = architecture
+        if architecture == 'skip':
+            self.fromrgb = Conv2dLayer(img_channels, in_channels, kernel_size=1, activation=activation)
+        self.mbstd = MinibatchStdLayer(group_size=mbstd_group_size, num_channels=mbstd_num_channels) if mbstd_num_channels > 0 else None
+        self.conv = Conv2dLayer(in_channels + mbstd_num_channels, in_channels, kernel_size=3, activation=activation, conv_clamp=conv_clamp)
+        self.fc = FullyConnectedLayer(in_channels * (resolution ** 2), in_channels, activation=activation)
+        self.out = FullyConnectedLayer(in_channels, 1 if cmap_dim == 0 else cmap_dim)
+
+    def forward(self, x, img, cmap, force_fp32=False):
+        assert list(x.shape[1:]) == [self.in_channels, self.resolution, self.resolution]
+        x = x.to(torch.float32)
+        if self.architecture == 'skip':
+            x = x + self.fromrgb(img.to(torch.float32))
+        if self.mbstd is not None:
+            x = self.mbstd(x)
+        x = self.conv(x)
+        x = self.fc(x.flatten(1))
+        x = self.out(x)
+        if self.cmap_dim > 0:
+            x = (x * cmap).sum(dim=1, keepdim=True) * (1 / np.sqrt(self.cmap_dim))
+        return x
+
+
+class CoModDiscriminator(torch.nn.Module):
+    """generator.py:780-836.  ``c_dim > 0`` (a mapped conditioning label) is not used by any shipped configuration
+    (models/stylegan3_model.py:71: c_dim = 0) and raises."""
+
+    def __init__(self, c_dim, img_resolution, img_channels, architecture='resnet', channel_base=32768, channel_max=512, num_fp16_res=0,
+                 conv_clamp=None, cmap_dim=None, block_kwargs={}, mapping_kwargs={}, epilogue_kwargs={}, **kwargs):
+        super().__init__()
+        if c_dim != 0:
+            raise NotImplementedError('conditional discriminator (c_dim > 0) is outside the built path')
+        self.c_dim = c_dim
+        self.img_resolution = img_resolution
+        self.img_resolution_log2 = int(np.log2(img_resolution))
+        self.img_channels = img_channels
+        self.block_resolutions = [2 ** i for i in range(self.img_resolution_log2, 2, -1)]
+        channels_dict = {res: min(channel_base // res, channel_max) for res in self.block_resolutions + [4]}
+        cmap_dim = 0
+        common_kwargs = dict(img_channels=img_channels, architecture=architecture, conv_clamp=conv_clamp)
+        cur_layer_idx = 0
+        for res in self.block_resolutions:
+            in_channels = channels_dict[res] if res < img_resolution else 0
+            block = DiscriminatorBlock(in_channels, channels_dict[res], channels_dict[res // 2], resolution=res,
+                                       first_layer_idx=cur_layer_idx, use_fp16=False, **block_kwargs, **common_kwargs)
+            setattr(self, f'b{res}', block)
+            cur_layer_idx += block.num_layers
+        self.b4 = DiscriminatorEpilogue(channels_dict[4], cmap_dim=cmap_dim, resolution=4, **epilogue_kwargs, **common_kwargs)
+
+    def forward(self, img, c, **block_kwargs):
+        x = None
+        for res in self.block_resolutions:
+            x, img = getattr(self, f'b{res}')(x, img, **block_kwargs)
+        return self.b4(x, img, None)

@@ -100,3 +100,64 @@ def update_ema(net_ema, net, batch_size, total_iters, ema_kimgs=10.0, ramp=None)
     for b_ema, b in zip(net_ema.buffers(), net.buffers()):
         b_ema.copy_(b)
     return beta
+
+
+class StyleGAN3Step(StyleGAN3GeneratorStep):
+    """The full `--model stylegan3` iteration: discriminator update, then generator update, in the order and
+    with the loss arithmetic of the reference (models/stylegan3_model.py:113-135; backward_D: models/comodgan_model.py:128-149;
+    backward_G: models/stylegan3_model.py:89-111).  D sees cat(real_A, fake_B) (combine_ab) blurred by the same fading Gaussian.
+
+    The D update's generator forward runs without a graph (the reference builds one and detaches the result,
+    comodgan_model.py:131-133: same numbers, less memory).  Both updates use the fused scrub + Adam launch."""
+
+    def __init__(self, netG, netD, lr_G=0.0002, lr_D=0.0002, lambda_L1=100.0, lambda_r1=10.0, combine_ab=True, **kw):
+        super().__init__(netG, lr_G=lr_G, lambda_L1=lambda_L1, **kw)
+        self.netD = netD
+        self.lambda_r1 = float(lambda_r1)
+        self.combine_ab = bool(combine_ab)
+        self.optimizer_D = FusedScrubAdam(netD.parameters(), lr=lr_D, betas=(0.0, 0.99), eps=1e-8, scrub=True, posinf=1e5, neginf=-1e5)
+        self.buckets_D = None
+        if self.buckets is not None:
+            self.buckets_D = GradientBuckets(netD.parameters(), bucket_bytes=kw.get('bucket_bytes', 25 * 1024 * 1024),
+                                             force=kw.get('force_collectives', False))
+            self.buckets_D.broadcast_parameters(netD)
+
+    def run_D(self, img, **kwargs):
+        return self.netD(self._blur(img), **kwargs)                 # models/stylegan3_model.py:24-30
+
+    def _pair(self, b):
+        return torch.cat((self.real_A.to(b.dtype), b), 1) if self.combine_ab else b
+
+    def backward_D(self):
+        gen_logits = self.run_D(self._pair(self.fake_B).detach(), c=self.gen_c)
+        self.loss_D_fake = torch.nn.functional.softplus(gen_logits).mean()
+        self.loss_D_fake.backward()
+        real_img_tmp = self._pair(self.real_B).detach().requires_grad_(True)
+        real_logits = self.run_D(real_img_tmp, c=self.gen_c)
+        self.loss_D_real = torch.nn.functional.softplus(-real_logits).mean()
+        self.loss_D = self.loss_D_real
+        if self.lambda_r1 > 0:
+            r1_grads, = torch.autograd.grad(outputs=[real_logits.sum()], inputs=[real_img_tmp], create_graph=True, only_inputs=True)
+            self.loss_Dr1 = r1_grads.square().sum([1, 2, 3]).mean() * 0.5
+            self.loss_D = self.loss_D + self.loss_Dr1 * self.lambda_r1
+        self.loss_D.backward()
+
+    def backward_G(self, extra_loss=None):
+        gen_logits = self.run_D(self._pair(self.fake_B), c=self.gen_c)
+        self.loss_G_GAN = torch.nn.functional.softplus(-gen_logits).mean()
+        super().backward_G(extra_loss=self.loss_G_GAN if extra_loss is None else self.loss_G_GAN + extra_loss)
+
+    def optimize_parameters(self, cur_nimg=None):
+        if cur_nimg is not None:
+            self.blur_sigma = (max(1 - cur_nimg / (self.blur_fade_kimg * 1e3), 0) * self.blur_init_sigma) if self.blur_fade_kimg > 0 else 0.0
+        # update D
+        self.optimizer_D.zero_grad(set_to_none=True)
+        self.netD.requires_grad_(True)
+        with torch.no_grad():
+            self.forward(update_emas=False)
+        self.backward_D()
+        self.netD.requires_grad_(False)
+        grads, scale = (None, 1.0) if self.buckets_D is None else self.buckets_D.finish_flat()
+        self.optimizer_D.step(grads=grads, grad_scale=scale)
+        # update G
+        super().optimize_parameters(cur_nimg=None)

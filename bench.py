@@ -38,6 +38,9 @@ def parse():
     ap.add_argument('--cpu-baseline-worker', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--no-kernel-timing', action='store_true', help='skip the HIP-event spans around the hot kernels')
     ap.add_argument('--force-dist', action='store_true', help='initialise RCCL and run the gradient buckets even with one rank (path check)')
+    ap.add_argument('--with-discriminator', action='store_true',
+                    help='time the FULL iteration (D update with R1, then G update with the GAN term; SURVEY.md row f1) instead of the '
+                         'generator step that BASELINE.json\'s metric names')
     return ap.parse_args()
 
 
@@ -113,7 +116,15 @@ def main():
     kw = dict(sched.DEFAULT_SYNTHESIS_KWARGS)
     G = Stylegan3Generator(z_dim=512, c_dim=1, w_dim=512, img_resolution=args.res, img_channels_in=4, img_channels_out=1,
                            mapping_kwargs=dict(num_layers=8), synthesis_kwargs=dict(kw, compute_dtype=dtype)).to(dev).train()
-    step = StyleGAN3GeneratorStep(G, lr_G=0.0025, lambda_L1=100.0, distributed=use_dist, force_collectives=args.force_dist)
+    if args.with_discriminator:
+        from afcm_amd.networks_discriminator import CoModDiscriminator
+        from afcm_amd.stylegan3_model import StyleGAN3Step
+        D = CoModDiscriminator(c_dim=0, img_resolution=args.res, img_channels=5, channel_base=int(0.5 * 32768), channel_max=512,
+                               epilogue_kwargs=dict(mbstd_group_size=16)).to(dev)
+        step = StyleGAN3Step(G, D, lr_G=0.0025, lr_D=0.0025, lambda_L1=100.0, lambda_r1=10.0, distributed=use_dist,
+                             force_collectives=args.force_dist)
+    else:
+        step = StyleGAN3GeneratorStep(G, lr_G=0.0025, lambda_L1=100.0, distributed=use_dist, force_collectives=args.force_dist)
     real_A, real_B, z, c = synthetic.generator_inputs(args.batch, size=args.res, seed=rank, device=dev)
 
     def one_step():
@@ -168,7 +179,7 @@ def main():
         cpu = run_cpu_baseline(args.res) if (world == 1 and args.cpu_baseline == 'auto') else None
         images = world * args.batch * args.steps
         out = {
-            'metric': 'generator fwd+bwd images/sec @256^2',
+            'metric': 'generator fwd+bwd images/sec @256^2' if not args.with_discriminator else 'full GAN iteration (D + G update) images/sec @256^2',
             'value': images / elapsed,
             'unit': 'images/sec',
             'n_gpus': world,
@@ -180,7 +191,8 @@ def main():
             'vs_baseline': None,
             'dtype': args.dtype,
             'data': 'synthetic',
-            'config': {'workload': f'AFCM --model stylegan3 generator training step (fwd + L1 loss + bwd + grad all-reduce + Adam), '
+            'config': {'workload': ('AFCM --model stylegan3 FULL iteration (D update with R1 + G update with GAN and L1 terms), ' if args.with_discriminator else '') +
+                                   f'AFCM --model stylegan3 generator training step (fwd + L1 loss + bwd + grad all-reduce + Adam), '
                                    f'IXI T1->T2 shape: {args.res}x{args.res}, 4->1 channels, full-width 58.5M-param generator, random init',
                        'global_batch': world * args.batch, 'per_gpu_batch': args.batch, 'resolution': args.res,
                        'parallelism': f'dp{world}'},

@@ -159,3 +159,34 @@ def test_sign_code_packing():
     assert packed.shape == (1, 2, 5, 12)
     for x in range(37):
         assert np.array_equal((packed[..., x >> 2] >> (2 * (x & 3))) & 3, codes[..., x])
+
+
+@pytest.mark.parametrize('name', ['D1_tiny64', 'D2_tiny128_clamp'])
+def test_discriminator_oracle_matches_reference(name):
+    """Row f1: the functional discriminator restatement (oracle/discriminator.py) vs vectors captured from the reference's
+    CoModDiscriminator -- logits, both D loss gradients (incl. the R1 double backward) and the image gradient of the G term."""
+    import torch
+    from oracle import discriminator as od
+    g = load_golden(name)
+    res, n, _, _, group, clamp = [int(v) for v in g['meta']]
+    kw = dict(mbstd_group_size=group, conv_clamp=None if clamp < 0 else float(clamp))
+    names = [str(k) for k in g['names']]
+    sd = {k[3:]: torch.from_numpy(np.array(v)) for k, v in g.items() if k.startswith('sd/')}
+    for k in names:
+        sd[k] = sd[k].clone().requires_grad_(True)
+    fake, real = torch.from_numpy(g['fake']), torch.from_numpy(g['real'])
+    lf, lr, l1, gen_logits, real_logits, r1 = od.d_losses(sd, fake, real, res, **kw)
+    assert np.allclose(gen_logits.detach().numpy(), g['gen_logits'], atol=1e-5)
+    assert np.allclose(real_logits.detach().numpy(), g['real_logits'], atol=1e-5)
+    assert np.allclose(r1.detach().numpy(), g['r1_grads'], atol=1e-6 + 1e-4 * np.abs(g['r1_grads']).max())
+    assert abs(lf.item() - float(g['loss_fake'])) < 1e-5 and abs(l1.item() - float(g['loss_r1'])) < 1e-6 + 1e-4 * float(g['loss_r1'])
+    gf = torch.autograd.grad(lf, [sd[k] for k in names], retain_graph=True)
+    gr = torch.autograd.grad(lr + l1 * 10.0, [sd[k] for k in names])
+    for k, a, b in zip(names, gf, gr):
+        for got, want, what in ((a, g['gfake/' + k], 'fake'), (b, g['greal/' + k], 'real+r1')):
+            tol = 1e-5 * max(1.0, float(np.abs(want).max()))
+            assert np.abs(got.numpy() - want).max() <= tol, (name, k, what)
+    img = fake.clone().requires_grad_(True)
+    lg = torch.nn.functional.softplus(-od.discriminator(sd, img, res, **kw)).mean()
+    gi, = torch.autograd.grad(lg, img)
+    assert np.abs(gi.numpy() - g['g_img']).max() <= 1e-5 * max(1e-3, float(np.abs(g['g_img']).max()))
