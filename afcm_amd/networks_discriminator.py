@@ -4,8 +4,10 @@ reference's class names, constructor arguments, ``forward()`` signatures and sta
 
 Resampling FIRs and bias/activation run on the HIP kernels (``upfirdn2d``, ``bias_act``: both arbitrarily differentiable, which
 the R1 penalty's double backward needs); the contraction is the framework convolution, as in the reference (see
-torch_utils/ops/conv2d_resample.py).  fp32 only: the reference's fp16 / channels-last switches are accepted and ignored
-(``num_fp16_res = 0`` in every shipped configuration, models/stylegan3_model.py:69).
+torch_utils/ops/conv2d_resample.py).  ``num_fp16_res`` runs the N highest-resolution blocks in 16 bit exactly as the reference
+does (generator.py:808,819: ``use_fp16 = res >= fp16_resolution``; 0 in the shipped configurations,
+models/stylegan3_model.py:69); the 16-bit type is float16 as in the reference unless ``fp16_dtype=torch.bfloat16`` is passed
+(new: bf16 needs no loss scaling).  The channels-last switch is accepted and ignored (contiguous NCHW kernels).
 """
 import numpy as np
 import torch
@@ -77,9 +79,11 @@ class DiscriminatorBlock(torch.nn.Module):
 
     def __init__(self, in_channels, tmp_channels, out_channels, resolution, img_channels, first_layer_idx, architecture='resnet',
                  activation='lrelu', resample_filter=[1, 3, 3, 1], conv_clamp=None, use_fp16=False, fp16_channels_last=False,
-                 freeze_layers=0):
+                 freeze_layers=0, fp16_dtype=torch.float16):
         assert architecture in ['orig', 'skip', 'resnet']
         super().__init__()
+        self.use_fp16 = use_fp16
+        self.fp16_dtype = fp16_dtype
         self.in_channels = in_channels
         self.resolution = resolution
         self.img_channels = img_channels
@@ -106,12 +110,13 @@ class DiscriminatorBlock(torch.nn.Module):
                                     resample_filter=resample_filter)
 
     def forward(self, x, img, force_fp32=False):
+        dtype = self.fp16_dtype if self.use_fp16 and not force_fp32 else torch.float32       # generator.py:662
         if x is not None:
             assert list(x.shape[1:]) == [self.in_channels, self.resolution, self.resolution]
-            x = x.to(torch.float32)
+            x = x.to(dtype)
         if self.in_channels == 0 or self.architecture == 'skip':
             assert list(img.shape[1:]) == [self.img_channels, self.resolution, self.resolution]
-            img = img.to(torch.float32)
+            img = img.to(dtype)
             y = self.fromrgb(img)
             x = x + y if x is not None else y
             img = upfirdn2d.downsample2d(img, self.resample_filter) if self.architecture == 'skip' else None
@@ -123,6 +128,7 @@ class DiscriminatorBlock(torch.nn.Module):
         else:
             x = self.conv0(x)
             x = self.conv1(x)
+        assert x.dtype == dtype
         return x, img
 
 
@@ -199,12 +205,13 @@ class CoModDiscriminator(torch.nn.Module):
         self.block_resolutions = [2 ** i for i in range(self.img_resolution_log2, 2, -1)]
         channels_dict = {res: min(channel_base // res, channel_max) for res in self.block_resolutions + [4]}
         cmap_dim = 0
+        fp16_resolution = max(2 ** (self.img_resolution_log2 + 1 - num_fp16_res), 8)                  # generator.py:808
         common_kwargs = dict(img_channels=img_channels, architecture=architecture, conv_clamp=conv_clamp)
         cur_layer_idx = 0
         for res in self.block_resolutions:
             in_channels = channels_dict[res] if res < img_resolution else 0
             block = DiscriminatorBlock(in_channels, channels_dict[res], channels_dict[res // 2], resolution=res,
-                                       first_layer_idx=cur_layer_idx, use_fp16=False, **block_kwargs, **common_kwargs)
+                                       first_layer_idx=cur_layer_idx, use_fp16=(res >= fp16_resolution), **block_kwargs, **common_kwargs)
             setattr(self, f'b{res}', block)
             cur_layer_idx += block.num_layers
         self.b4 = DiscriminatorEpilogue(channels_dict[4], cmap_dim=cmap_dim, resolution=4, **epilogue_kwargs, **common_kwargs)

@@ -101,3 +101,27 @@ def test_full_training_iteration_runs_and_matches_loss_arithmetic():
     step.optimize_parameters(cur_nimg=800)
     assert abs(step.blur_sigma - 0.4) < 1e-9
     assert all(torch.isfinite(p).all() for p in list(G.parameters()) + list(D.parameters()))
+
+
+@pytest.mark.parametrize('dtype,tol', [(torch.float16, 2e-2), (torch.bfloat16, 8e-2)])
+def test_discriminator_16bit_blocks_track_the_fp32_reference(dtype, tol):
+    """num_fp16_res (generator.py:808,819): the highest-resolution blocks in 16 bit (HIP upfirdn2d / bias_act in that dtype,
+    16-bit framework conv) vs the fp32 golden logits and R1 gradient; looser bound = 16-bit rounding only."""
+    from afcm_amd.networks_discriminator import CoModDiscriminator
+    g = load_golden('D2_tiny128_clamp')
+    res, n, cb, cm, group, clamp = [int(v) for v in g['meta']]
+    D = CoModDiscriminator(c_dim=0, img_resolution=res, img_channels=5, channel_base=cb, channel_max=cm, conv_clamp=clamp, num_fp16_res=3,
+                           block_kwargs=dict(fp16_dtype=dtype), epilogue_kwargs=dict(mbstd_group_size=group))
+    D.load_state_dict({k[3:]: torch.from_numpy(np.array(v)) for k, v in g.items() if k.startswith('sd/')}, strict=True)
+    D = D.cuda()
+    assert [getattr(D, f'b{r}').use_fp16 for r in (128, 64, 32, 16, 8)] == [True, True, True, False, False]
+    real = torch.from_numpy(g['real']).cuda().requires_grad_(True)
+    logits = D(real, None)
+    assert logits.dtype == torch.float32
+    scale = max(1.0, float(np.abs(g['real_logits']).max()))
+    assert np.abs(logits.detach().cpu().numpy() - g['real_logits']).max() <= tol * scale
+    r1, = torch.autograd.grad(logits.sum(), real, create_graph=True)
+    d = r1.detach().cpu().numpy() - g['r1_grads']
+    assert np.sqrt((d ** 2).sum() / (g['r1_grads'] ** 2).sum()) <= 4 * tol
+    (r1.square().sum()).backward()
+    assert all(torch.isfinite(p.grad).all() for p in D.parameters() if p.grad is not None)
