@@ -121,10 +121,22 @@ class _ScaledConv2d(torch.autograd.Function):
         return y
 
     @staticmethod
-    @torch.autograd.function.once_differentiable
     def backward(ctx, dy):
         xs, w, in_scale, out_scale, y = ctx.saved_tensors
         pad = ctx.padding
+        if torch.is_grad_enabled() and (dy.requires_grad or xs.requires_grad or w.requires_grad):
+            # a higher-order graph is being recorded (R1 penalty of the discriminator, models/comodgan_model.py:143-147): the
+            # gradients are themselves convolutions, so express them with the same differentiable nodes
+            if in_scale is not None or out_scale is not None:
+                raise RuntimeError('conv2d: second-order gradients are only built for the unscaled convolution')
+            ks = int(w.shape[2])
+            dx = dw = None
+            if ctx.needs_input_grad[0]:
+                dx = _ScaledConv2d.apply(dy, w.transpose(0, 1).flip([2, 3]), None, None, ks - 1 - pad, False)
+            if ctx.needs_input_grad[1]:
+                dw = _ConvWgrad.apply(dy, xs, ks, pad).to(w.dtype)
+            return dx, dw, None, None, None, None
+        dy = dy.detach()
         if ctx.prescaled:
             in_scale = None
         cout, cin, ks, _ = w.shape
@@ -148,8 +160,34 @@ class _ScaledConv2d(torch.autograd.Function):
         return dx, dw, d_in, d_out, None, None
 
 
+class _ConvWgrad(torch.autograd.Function):
+    """dw[o,i,r,s] = sum_{n,p,q} dy[n,o,p,q] x[n,i,p+r-pad,q+s-pad] as a differentiable node: its own gradients are a forward
+    convolution of x with the incoming tensor (w.r.t. dy) and a data-gradient convolution of dy with it (w.r.t. x)."""
+
+    @staticmethod
+    def forward(ctx, dy, x, ks, pad):
+        dy, x = dy.contiguous(), x.contiguous()
+        cout, cin = int(dy.shape[1]), int(x.shape[1])
+        ctx.save_for_backward(dy, x)
+        ctx.cfg = (ks, pad)
+        return _wgrad_raw(dy, x, cout, cin, ks, pad)
+
+    @staticmethod
+    def backward(ctx, g):
+        dy, x = ctx.saved_tensors
+        ks, pad = ctx.cfg
+        g_dy = g_x = None
+        if ctx.needs_input_grad[0]:
+            g_dy = _ScaledConv2d.apply(x, g, None, None, pad, False)
+        if ctx.needs_input_grad[1]:
+            g_x = _ScaledConv2d.apply(dy, g.transpose(0, 1).flip([2, 3]), None, None, ks - 1 - pad, False)
+        return g_dy, g_x, None, None
+
+
 def scaled_conv2d(x, w, in_scale=None, out_scale=None, padding=0, prescaled=False):
-    return _ScaledConv2d.apply(x, w, in_scale, out_scale, int(padding), bool(prescaled))
+    # contiguity is established out here, under autograd, so that the node saves tensors that are still part of the graph
+    # (a second-order backward differentiates through them)
+    return _ScaledConv2d.apply(x.contiguous(), w.contiguous(), in_scale, out_scale, int(padding), bool(prescaled))
 
 
 def modulation_coefficients(w, s, demodulate=True, input_gain=None):

