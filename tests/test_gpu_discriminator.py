@@ -1,4 +1,4 @@
-"""Row f1 on the GPU: the drop-in CoModDiscriminator (HIP upfirdn2d / bias_act, framework conv) vs vectors captured from the
+"""Row f1 on the GPU: the drop-in CoModDiscriminator (HIP upfirdn2d / bias_act, MFMA or framework conv) vs vectors captured from the
 reference -- logits, the gradients of both discriminator loss terms including the R1 double backward
 (models/comodgan_model.py:128-149), and the gradient the generator receives through D (models/stylegan3_model.py:93-95)."""
 import numpy as np
@@ -115,7 +115,7 @@ def test_full_training_iteration_runs_and_matches_loss_arithmetic():
 @pytest.mark.parametrize('dtype,tol', [(torch.float16, 2e-2), (torch.bfloat16, 8e-2)])
 def test_discriminator_16bit_blocks_track_the_fp32_reference(dtype, tol):
     """num_fp16_res (generator.py:808,819): the highest-resolution blocks in 16 bit (HIP upfirdn2d / bias_act in that dtype,
-    16-bit framework conv) vs the fp32 golden logits and R1 gradient; looser bound = 16-bit rounding only."""
+    16-bit convs on the MFMA kernels) vs the fp32 golden logits and R1 gradient; looser bound = 16-bit rounding only."""
     from afcm_amd.networks_discriminator import CoModDiscriminator
     g = load_golden('D2_tiny128_clamp')
     res, n, cb, cm, group, clamp = [int(v) for v in g['meta']]
