@@ -62,13 +62,14 @@ __global__ __launch_bounds__(256) void weight_norm_bwd_kernel(float* __restrict_
     }
 }
 
-// one workgroup per sample n (every workgroup recomputes the batch-wide mean: N * I <= a few thousand elements)
+// workgroups (n, o-chunk of 32): every workgroup recomputes the batch-wide mean (N * I <= a few thousand elements) and its
+// sample's s_hat^2 row; a wave per output channel reads the wsq row coalesced (lanes over i) and reduces by shuffles
 __global__ __launch_bounds__(256) void style_coefs_fwd_kernel(float* __restrict__ s_eff, float* __restrict__ d, float* __restrict__ r_out,
                                                               const float* __restrict__ t, const float* __restrict__ wsq,
                                                               const float* __restrict__ magnitude, int N, int I, int O, int demod) {
     __shared__ float red[4];
     extern __shared__ float s2[];                       // s_hat[n, :]^2
-    const int n = blockIdx.x;
+    const int n = blockIdx.x, oc = blockIdx.y;
     float r = 1.f;
     if (demod) {
         float ss = 0.f;
@@ -76,69 +77,82 @@ __global__ __launch_bounds__(256) void style_coefs_fwd_kernel(float* __restrict_
         ss = block_sum(ss, red);
         r = rsqrtf(ss / (float)(N * I));
     }
-    if (n == 0 && threadIdx.x == 0) r_out[0] = r;
+    if (n == 0 && oc == 0 && threadIdx.x == 0) r_out[0] = r;
     const float g = magnitude ? rsqrtf(magnitude[0]) : 1.f;           // input_gain = magnitude_ema.rsqrt() (NET:346,55-57)
     for (int i = threadIdx.x; i < I; i += 256) {
         const float sh = t[(size_t)n * I + i] * r;
-        s_eff[(size_t)n * I + i] = sh * g;
+        if (oc == 0) s_eff[(size_t)n * I + i] = sh * g;
         s2[i] = sh * sh;
     }
     if (!demod) return;
     __syncthreads();
-    for (int o = threadIdx.x; o < O; o += 256) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll 2
+    for (int j = 0; j < 8; j++) {
+        const int o = oc * 32 + wave * 8 + j;
+        if (o >= O) break;
         const float* wr = wsq + (size_t)o * I;
-        float q = 1e-8f;
-        for (int i = 0; i < I; i++) q += s2[i] * wr[i];
-        d[(size_t)n * O + o] = rsqrtf(q);
+        float q = 0.f;
+        for (int i = lane; i < I; i += 64) q = fmaf(s2[i], wr[i], q);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) q += __shfl_xor(q, off, 64);
+        if (lane == 0) d[(size_t)n * O + o] = rsqrtf(q + 1e-8f);
     }
 }
 
-// phase 1, one workgroup per sample: Q[n,o] = -1/2 g_d d^3;  G[n,i] = gain g_s + 2 s_hat[n,i] sum_o Q[n,o] wsq[o,i];
-// partial[n] = sum_i G[n,i] s_hat[n,i]
+// phase 1, workgroups (n, i-chunk of 64): Q[n,o] = -1/2 g_d d^3;  G[n,i] = gain g_s + 2 s_hat[n,i] sum_o Q[n,o] wsq[o,i];
+// partial[n, chunk] = sum_{i in chunk} G[n,i] s_hat[n,i].  The sum over o is split four ways over the workgroup's waves.
 __global__ __launch_bounds__(256) void style_coefs_bwd1_kernel(float* __restrict__ G, float* __restrict__ Q, float* __restrict__ partial,
                                                                const float* __restrict__ g_s, const float* __restrict__ g_d,
                                                                const float* __restrict__ t, const float* __restrict__ d, const float* __restrict__ wsq,
                                                                const float* __restrict__ magnitude, const float* __restrict__ r_in, int I, int O, int demod) {
-    __shared__ float red[4];
+    __shared__ float us[4][64];
     extern __shared__ float q_s[];                      // Q[n, :]
-    const int n = blockIdx.x;
+    const int n = blockIdx.x, ib = blockIdx.y, IB = gridDim.y;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int i = ib * 64 + tx;
     const float r = r_in[0], g = magnitude ? rsqrtf(magnitude[0]) : 1.f;
     if (demod) {
         for (int o = threadIdx.x; o < O; o += 256) {
             const float dd = d[(size_t)n * O + o];
             const float q = g_d ? -0.5f * g_d[(size_t)n * O + o] * dd * dd * dd : 0.f;
             q_s[o] = q;
-            Q[(size_t)n * O + o] = q;
+            if (ib == 0) Q[(size_t)n * O + o] = q;
         }
         __syncthreads();
+        float u = 0.f;
+        if (i < I) {
+#pragma unroll 8
+            for (int o = ty; o < O; o += 4) u = fmaf(q_s[o], wsq[(size_t)o * I + i], u);
+        }
+        us[ty][tx] = u;
+        __syncthreads();
     }
+    if (ty != 0) return;
     float dot = 0.f;
-    for (int i = threadIdx.x; i < I; i += 256) {
+    if (i < I) {
         const float sh = t[(size_t)n * I + i] * r;
         float gg = g_s ? g * g_s[(size_t)n * I + i] : 0.f;
-        if (demod) {
-            float u = 0.f;
-            for (int o = 0; o < O; o++) u += q_s[o] * wsq[(size_t)o * I + i];
-            gg += 2.f * sh * u;
-        }
+        if (demod) gg += 2.f * sh * (us[0][tx] + us[1][tx] + us[2][tx] + us[3][tx]);
         G[(size_t)n * I + i] = gg;
-        dot += gg * sh;
+        dot = gg * sh;
     }
-    dot = block_sum(dot, red);
-    if (threadIdx.x == 0) partial[n] = dot;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) dot += __shfl_xor(dot, off, 64);
+    if (tx == 0) partial[(size_t)n * IB + ib] = dot;
 }
 
 // phase 2: workgroups [0, N): dt[n,:] = r (G - s_hat mean(G . s_hat)) (demod) or G (no demod);
 //          workgroups [N, N+O): g_wsq[o,i] = sum_n Q[n,o] s_hat[n,i]^2
 __global__ __launch_bounds__(256) void style_coefs_bwd2_kernel(float* __restrict__ dt, float* __restrict__ g_wsq, const float* __restrict__ G,
                                                                const float* __restrict__ Q, const float* __restrict__ partial,
-                                                               const float* __restrict__ t, const float* __restrict__ r_in, int N, int I, int O, int demod) {
+                                                               const float* __restrict__ t, const float* __restrict__ r_in, int N, int I, int O, int demod, int NP) {
     const float r = r_in[0];
     if ((int)blockIdx.x < N) {
         const int n = blockIdx.x;
         float m = 0.f;
         if (demod) {
-            for (int k = 0; k < N; k++) m += partial[k];
+            for (int k = 0; k < NP; k++) m += partial[k];
             m /= (float)(N * I);
         }
         for (int i = threadIdx.x; i < I; i += 256) {
@@ -219,8 +233,8 @@ extern "C" int afcm_style_coefs_fwd(float* s_eff, float* d, float* r, const floa
                                     int32_t cout, int32_t demodulate, void* stream) {
     AFCM_REQUIRE(s_eff && r && t && n > 0 && cin > 0 && (!demodulate || (d && wsq && cout > 0)), "style_coefs_fwd: bad arguments");
     AFCM_REQUIRE(cin <= 16384, "style_coefs_fwd: %d input channels exceed the LDS row", cin);
-    hipLaunchKernelGGL(style_coefs_fwd_kernel, dim3(n), dim3(256), cin * sizeof(float), (hipStream_t)stream, s_eff, d, r, t, wsq, magnitude, n, cin,
-                       cout, demodulate);
+    hipLaunchKernelGGL(style_coefs_fwd_kernel, dim3(n, demodulate ? (cout + 31) / 32 : 1), dim3(256), cin * sizeof(float), (hipStream_t)stream, s_eff,
+                       d, r, t, wsq, magnitude, n, cin, cout, demodulate);
     return hip_status(hipGetLastError());
 }
 
@@ -229,14 +243,15 @@ extern "C" int afcm_style_coefs_bwd(float* dt, float* g_wsq, float* workspace, c
                                     void* stream) {
     AFCM_REQUIRE(dt && workspace && t && r && n > 0 && cin > 0 && (!demodulate || (d && wsq && cout > 0)), "style_coefs_bwd: bad arguments");
     AFCM_REQUIRE(cout <= 16384, "style_coefs_bwd: %d output channels exceed the LDS row", cout);
-    // workspace: G [n, cin] | Q [n, cout] | partial [n]
+    // workspace: G [n, cin] | Q [n, cout] | partial [n, ceil(cin / 64)]
     float* G = workspace;
     float* Q = G + (size_t)n * cin;
     float* partial = Q + (size_t)n * (demodulate ? cout : 0);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(style_coefs_bwd1_kernel, dim3(n), dim3(256), (demodulate ? cout : 1) * sizeof(float), st, G, Q, partial, g_s, g_d, t, d, wsq,
+    const int ib = (cin + 63) / 64;
+    hipLaunchKernelGGL(style_coefs_bwd1_kernel, dim3(n, ib), dim3(256), (demodulate ? cout : 1) * sizeof(float), st, G, Q, partial, g_s, g_d, t, d, wsq,
                        magnitude, r, cin, cout, demodulate);
     hipLaunchKernelGGL(style_coefs_bwd2_kernel, dim3(n + ((demodulate && g_wsq) ? cout : 0)), dim3(256), 0, st, dt, g_wsq, G, Q, partial, t, r, n, cin,
-                       cout, demodulate);
+                       cout, demodulate, n * ib);
     return hip_status(hipGetLastError());
 }

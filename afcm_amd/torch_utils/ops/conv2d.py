@@ -270,7 +270,7 @@ class _StyleCoefs(torch.autograd.Function):
         g_d = None if (g_d is None or not ctx.demodulate) else g_d.to(torch.float32).contiguous()
         dt = torch.empty_like(t)
         g_wsq = torch.empty_like(wsq) if (ctx.demodulate and ctx.needs_input_grad[1]) else None
-        ws = torch.empty([n * i + n * o + n], dtype=torch.float32, device=t.device)
+        ws = torch.empty([n * i + n * o + n * ((i + 63) // 64)], dtype=torch.float32, device=t.device)
         _lib.check(lib.afcm_style_coefs_bwd(dt.data_ptr(), _lib.ptr(g_wsq), ws.data_ptr(), _lib.ptr(g_s), _lib.ptr(g_d), t.data_ptr(),
                                             d.data_ptr() if ctx.demodulate else None, _lib.ptr(wsq), _lib.ptr(mag), r.data_ptr(), n, i, o,
                                             int(ctx.demodulate), _lib.stream_ptr(t)), 'style_coefs_bwd')

@@ -195,7 +195,7 @@ int afcm_plane_dot(float* out, const void* a, const void* b, int32_t dtype, int6
  *                 s_eff = s_hat * rsqrt(magnitude[0]) (input gain, NET:346,55-57; magnitude NULL: 1).
  *                 demodulate == 0 (ToRGB, NET:362): s_eff = t * gain only, d / wsq unused.
  *                 bwd: dt from g_s (dL/ds_eff) and g_d (dL/dd); g_wsq (may be NULL) = dL/dwsq.
- *                 workspace: n*cin + n*cout + n floats.
+ *                 workspace: n*cin + n*cout + n*ceil(cin/64) floats.
  * ---------------------------------------------------------------------------------------- */
 int afcm_weight_norm_fwd(float* w_hat, float* wsq, float* scale, const float* w, int32_t cout, int32_t cin, int32_t kk, void* stream);
 int afcm_weight_norm_bwd(float* dw, const float* g_hat, const float* g_wsq, const float* w_hat, const float* scale, int32_t cout,

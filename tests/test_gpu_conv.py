@@ -196,13 +196,14 @@ def _close_rel(a, b, tol, what):
     assert rel <= tol, f'{what}: relative L2 error {rel:.3e} (tol {tol:g})'
 
 
+@pytest.mark.parametrize('dims', [(37, 45, 5), (181, 200, 4)])          # second: several 32-o / 64-i chunks, ragged last ones
 @pytest.mark.parametrize('demod', [True, False])
-def test_fused_modulation_coefficients_match_eager(demod):
+def test_fused_modulation_coefficients_match_eager(demod, dims):
     """afcm_weight_norm_* / afcm_style_coefs_* (one launch each way) vs the eager torch restatement of NET:41-57:
     values and gradients w.r.t. the weights and the raw styles, for both outputs."""
     from afcm_amd.torch_utils.ops.conv2d import modulation_coefficients, modulation_coefficients_fused
     torch.manual_seed(3)
-    o, i, n = 37, 45, 5
+    o, i, n = dims
     w = torch.randn(o, i, 3, 3, device='cuda')
     t = torch.randn(n, i, device='cuda') + 1.0
     mag = torch.tensor(1.7, device='cuda')
