@@ -656,34 +656,60 @@ __global__ __launch_bounds__(256) void scale_planes_kernel(TO* __restrict__ y, c
     }
 }
 
-// Per-plane reductions: out[plane] = sum a*b (or sum a when b == null).  One workgroup per plane, fp32 accumulate.
+// Per-plane reductions: out[plane] = sum a*b (or sum a when b == null).  One workgroup per plane, fp32 accumulate, 16-byte
+// loads from the plane's first 16-byte boundary on (both operands share the plane offset; the host checks the base pointers).
 template <typename T>
 __global__ __launch_bounds__(256) void plane_dot_kernel(float* __restrict__ out, const T* __restrict__ a, const T* __restrict__ b,
                                                         long long planes, int hw) {
+    constexpr int E = 16 / (int)sizeof(T);
+    union V16 { uint4 u; T v[E]; };
     __shared__ float part[4];
     const long long plane = blockIdx.x;
     if (plane >= planes) return;
-    const T* ap = a + plane * hw;
-    const T* bp = b ? b + plane * hw : nullptr;
-    float s = 0.f;
-    if ((hw & 3) == 0) {
-        const int nv = hw >> 2;
-        for (int i = threadIdx.x; i < nv; i += 256) {
-            const Vec4<T> va = ((const Vec4<T>*)ap)[i];
-            if (bp) {
-                const Vec4<T> vb = ((const Vec4<T>*)bp)[i];
-#pragma unroll
-                for (int e = 0; e < 4; e++) s = fmaf(to_f32(va.v[e]), to_f32(vb.v[e]), s);
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; e++) s += to_f32(va.v[e]);
-            }
-        }
-    } else {
-        for (int i = threadIdx.x; i < hw; i += 256) s += to_f32(ap[i]) * (bp ? to_f32(bp[i]) : 1.f);
+    const long long off = plane * hw;
+    const T* ap = a + off;
+    const T* bp = b ? b + off : nullptr;
+    int head = (int)((E - (off % E)) % E);
+    if (head > hw) head = hw;
+    const int nv = (hw - head) / E;
+    float s0 = 0.f, s1 = 0.f;
+    {   // ragged ends: fewer than 2E elements in total
+        const int tail0 = head + nv * E;
+        int i = -1;
+        if ((int)threadIdx.x < head) i = threadIdx.x;
+        else if ((int)threadIdx.x - head < hw - tail0) i = tail0 + (int)threadIdx.x - head;
+        if (i >= 0) s0 = to_f32(ap[i]) * (bp ? to_f32(bp[i]) : 1.f);
     }
+    const uint4* av = (const uint4*)(ap + head);
+    const uint4* bv = bp ? (const uint4*)(bp + head) : nullptr;
+    int i = threadIdx.x;
+    for (; i + 256 < nv; i += 512) {
+        V16 a0, a1, b0, b1;
+        a0.u = av[i]; a1.u = av[i + 256];
+        if (bv) {
+            b0.u = bv[i]; b1.u = bv[i + 256];
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+            for (int e = 0; e < E; e++) { s0 = fmaf(to_f32(a0.v[e]), to_f32(b0.v[e]), s0); s1 = fmaf(to_f32(a1.v[e]), to_f32(b1.v[e]), s1); }
+        } else {
+#pragma unroll
+            for (int e = 0; e < E; e++) { s0 += to_f32(a0.v[e]); s1 += to_f32(a1.v[e]); }
+        }
+    }
+    if (i < nv) {
+        V16 a0, b0;
+        a0.u = av[i];
+        if (bv) {
+            b0.u = bv[i];
+#pragma unroll
+            for (int e = 0; e < E; e++) s0 = fmaf(to_f32(a0.v[e]), to_f32(b0.v[e]), s0);
+        } else {
+#pragma unroll
+            for (int e = 0; e < E; e++) s0 += to_f32(a0.v[e]);
+        }
+    }
+    float s = s0 + s1;
+#pragma unroll
+    for (int off2 = 32; off2 > 0; off2 >>= 1) s += __shfl_down(s, off2, 64);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
     __syncthreads();
     if (threadIdx.x == 0) out[plane] = part[0] + part[1] + part[2] + part[3];
@@ -1715,6 +1741,7 @@ extern "C" int afcm_scale_planes(void* y, const void* x, const float* scale, int
 extern "C" int afcm_plane_dot(float* out, const void* a, const void* b, int32_t dtype, int64_t planes, int32_t hw, void* stream) {
     AFCM_REQUIRE(out != nullptr && a != nullptr && planes > 0 && hw > 0, "plane_dot: empty input");
     AFCM_REQUIRE(planes < (1ll << 31), "plane_dot: too many planes");
+    AFCM_REQUIRE((((uintptr_t)a | (uintptr_t)b) & 15) == 0, "plane_dot: operands must be 16-byte aligned");
     dim3 grid((unsigned)planes), block(256);
     hipStream_t st = (hipStream_t)stream;
     switch (dtype) {

@@ -55,10 +55,14 @@ def plane_dot(a, b=None):
     """[N, C] fp32: sum over H, W of a * b (b None: plain sum)."""
     lib = _lib.load()
     a = a.contiguous()
+    if a.data_ptr() % 16:                 # a view at an odd storage offset: the kernel wants 16-byte aligned bases
+        a = a.clone()
     n, c, h, w = a.shape
     if b is not None:
         b = b.contiguous()
         assert b.shape == a.shape and b.dtype == a.dtype
+        if b.data_ptr() % 16:
+            b = b.clone()
     out = torch.empty([n, c], dtype=torch.float32, device=a.device)
     _lib.check(lib.afcm_plane_dot(out.data_ptr(), a.data_ptr(), _lib.ptr(b), _lib.dtype_code(a), n * c, h * w, _lib.stream_ptr(a)),
                'plane_dot')

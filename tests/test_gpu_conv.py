@@ -224,3 +224,20 @@ def test_fused_modulation_coefficients_match_eager(demod, dims):
             assert a is None
             continue
         _close(a, b, 2e-5, f'demod={demod} {nm}')
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('hw', [(7, 7), (1, 3), (38, 38), (278, 278), (5, 64)])
+def test_plane_dot_matches_torch(dtype, hw):
+    """afcm_plane_dot: per-plane <a, b> and plane sums; odd plane sizes put every plane on a different 16-byte phase."""
+    from afcm_amd.torch_utils.ops.conv2d import plane_dot
+    torch.manual_seed(5)
+    a = torch.randn(3, 5, *hw, device='cuda').to(dtype)
+    b = torch.randn(3, 5, *hw, device='cuda').to(dtype)
+    want = (a.double() * b.double()).sum([2, 3])
+    got = plane_dot(a, b)
+    assert got.dtype == torch.float32 and got.shape == (3, 5)
+    scale = (a.double().abs() * b.double().abs()).sum([2, 3])
+    assert ((got.double() - want).abs() <= 1e-5 * scale + 1e-6).all()
+    got1 = plane_dot(a)
+    assert ((got1.double() - a.double().sum([2, 3])).abs() <= 1e-5 * a.double().abs().sum([2, 3]) + 1e-6).all()
