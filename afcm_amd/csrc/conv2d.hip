@@ -1347,6 +1347,7 @@ __global__ __launch_bounds__(512, 1) void conv2d_wgrad16g_kernel(WgradParams p) 
     int ld_rg = (s0 - ld_n * steps_per_img) / p.qchunks;
     int ld_qc = s0 - ld_n * steps_per_img - ld_rg * p.qchunks;
     int ld_buf = 0;
+    int u_qc = ld_qc;                                                            // chunk (of its row pair) of the step being multiplied
 
     // state of the step being loaded (c_*) and of the one before it (f_*: the step whose x edge is fixed up next)
     int c_prow0 = 0, c_q0 = 0, c_live = 0, f_q0 = 0, f_live = 0;
@@ -1422,7 +1423,7 @@ __global__ __launch_bounds__(512, 1) void conv2d_wgrad16g_kernel(WgradParams p) 
     unsigned a_off[2], x0_off[2], x1_off[2][XR];
 #pragma unroll
     for (int kq = 0; kq < 2; kq++) {
-        const int g = th * 4 + kq * 2 + h;
+        const int g = kq * 4 + th * 2 + h;             // 16-pixel groups interleaved over the sibling waves: th 0: 0, 2; th 1: 1, 3
         a_off[kq] = rowA * ROWB + ((g ^ fA) << 4);
         x0_off[kq] = DY_BYTES + rowB * ROWB + ((g ^ fB) << 4);
 #pragma unroll
@@ -1452,8 +1453,17 @@ __global__ __launch_bounds__(512, 1) void conv2d_wgrad16g_kernel(WgradParams p) 
         begin_loads(step + NBUF - 1 < s1);                 // into the buffer everyone left at the last barrier
         const char* buf = lds + cbuf * BUF;
         typedef typename std::conditional<std::is_same<T, bf16_t>::value, bf16x8, f16x8>::type frag_t;
+        // 16-pixel groups of the chunk that lie beyond the row's end would multiply zeros (rows of 86, 150, 278 pixels end
+        // with 22 pixels of a 64-pixel chunk): a wave skips its dead groups and only issues its share of the next loads.  The
+        // groups alternate between the two waves that share a SIMD (th 0 / th 1), so a 22-pixel chunk costs both one group.
+        const int vq = p.Q - u_qc * kWgKQ;
+        if (++u_qc == p.qchunks) u_qc = 0;
         static_for<0, 2>([&](auto kqc) __attribute__((always_inline)) {
             constexpr int kq = decltype(kqc)::value;
+            if ((kq * 2 + th) * 16 >= vq) {
+                issue_range(std::integral_constant<int, (kq * XR * NPIECE) / (2 * XR)>{}, std::integral_constant<int, ((kq + 1) * XR * NPIECE) / (2 * XR)>{});
+                return;
+            }
             frag_t a[R];
 #pragma unroll
             for (int rr = 0; rr < R; rr++) a[rr] = *(const frag_t*)(buf + a_off[kq] + rr * (64 * ROWB));

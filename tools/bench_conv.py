@@ -7,6 +7,7 @@ from afcm_amd import layer_schedule as sched
 from afcm_amd.torch_utils.ops import conv2d as C
 ap = argparse.ArgumentParser()
 ap.add_argument('--batch', type=int, default=16); ap.add_argument('--dtype', default='bf16'); ap.add_argument('--iters', type=int, default=5)
+ap.add_argument('--zeros', action='store_true', help='all-zero operands: same cycles, higher clock where the chip is power-managed')
 a = ap.parse_args()
 dt = {'fp32': torch.float32, 'bf16': torch.bfloat16}[a.dtype]
 pl = sched.plan(256, 4, 1, {})
@@ -24,6 +25,8 @@ for L in pl['enc'] + pl['dec']:
     pad = k - 1
     x = torch.randn(n, ci, h, h, device='cuda', dtype=dt)
     w = torch.randn(co, ci, k, k, device='cuda')
+    if a.zeros:
+        x.zero_(); w.zero_()
     wp, rp = C.pack_weights(w, dt, 0); wpt, rpt = C.pack_weights(w, dt, 1)
     y = C._conv_raw(x, wp, rp, None, co, k, pad)
     fl = 2.0 * n * co * ci * k * k * y.shape[2] * y.shape[3]
