@@ -137,3 +137,38 @@ def test_update_ema_matches_reference_loop():
     for pe, p, r in zip(G_ema.parameters(), G.parameters(), ref):
         want = p.lerp(r, beta)
         assert (pe - want).abs().max().item() <= 1e-6 * max(1.0, want.abs().max().item())
+
+
+def test_forward_ema_and_sliding_window_prediction_on_the_reference_weights(tmp_path):
+    """Row f3 end to end on the GPU: the step's EMA generator (models/comodgan_model.py:114-126) reproduces the golden eval
+    output, survives a '<epoch>_net_<name>.pth' round trip (row f4), and drives the halo-removing sliding-window predictor."""
+    from afcm_amd.stylegan3_model import StyleGAN3GeneratorStep
+    from afcm_amd.predictor import SlidingWindowPredictor
+    g = load_golden('G1_tiny128')
+    G = _build(128)
+    G.load_state_dict({k[3:]: torch.from_numpy(np.array(v)) for k, v in g.items() if k.startswith('sd/')}, strict=True)
+    step = StyleGAN3GeneratorStep(G.cuda(), ema=True)
+    assert step.model_names == ['G', 'G_ema'] and not step.netG_ema.training
+    z, c, x = (torch.from_numpy(g[k]) for k in ('z', 'c', 'x'))
+    step.set_input(x, torch.zeros(x.shape[0], 1, 128, 128), z, c)
+    step.test()
+    assert not step.fake_B.requires_grad
+    assert (step.fake_B.cpu() - torch.from_numpy(g['y'])).abs().max().item() <= 1e-3
+    step.save_networks(7, str(tmp_path))
+    with torch.no_grad():
+        for p in step.netG_ema.parameters():
+            p.zero_()
+    step.load_networks(7, str(tmp_path))
+    step.test()
+    assert (step.fake_B.cpu() - torch.from_numpy(g['y'])).abs().max().item() <= 1e-3
+    # volume of 3 slices, in-plane patches = the whole 128^2 slice (the reference's 2-D configuration: depth-1 patches)
+    vol = np.concatenate([g['x'][:1]] * 3, 0).transpose(1, 0, 2, 3)          # [C_in = 4, D = 3, 128, 128]
+
+    def model_fn(batch):                                                      # [B, 4, 1, 128, 128] -> [B, 1, 1, 128, 128]
+        b = batch[:, :, 0].cuda()
+        step.set_input(b, torch.zeros(b.shape[0], 1, 128, 128), z[:1].expand(b.shape[0], -1), c[:1].expand(b.shape[0], -1))
+        step.test()
+        return step.fake_B.unsqueeze(2)
+    out = SlidingWindowPredictor(out_channels=1, patch_halo=(0, 0, 0)).run(model_fn, vol, (1, 128, 128), (1, 128, 128), batch_size=2)
+    assert out.shape == (1, 3, 128, 128)
+    assert np.abs(out[0, 0] - g['y'][0, 0]).max() <= 1e-3 and np.abs(out[0, 2] - g['y'][0, 0]).max() <= 1e-3
