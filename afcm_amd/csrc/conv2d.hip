@@ -1319,9 +1319,13 @@ __global__ __launch_bounds__(512, 1) void conv2d_wgrad16g_kernel(WgradParams p) 
     int bid = blockIdx.x;
     const int total = tiles * p.splits;
     if ((total & 7) == 0) bid = (bid & 7) * (total >> 3) + (bid >> 3);          // XCD x: contiguous logical ids (split-major)
-    const int split = bid / tiles;
+    // integer division runs on the vector pipe even for uniform operands: pin the results to SGPRs, or every per-step address
+    // and descriptor computation derived from them runs as 64-bit VALU code + v_readfirstlane (measured: ~130 vector
+    // instructions per step beside the 36 MFMAs)
+    const int split = __builtin_amdgcn_readfirstlane(bid / tiles);
     const int tile = bid - split * tiles;
-    const int ib = tile % tiles_i, obk = tile / tiles_i;
+    const int obk = __builtin_amdgcn_readfirstlane(tile / tiles_i);
+    const int ib = tile - obk * tiles_i;
     const int o0 = obk * 64, i0 = ib * 64;
 
     f32x16 acc[KK];
@@ -1334,6 +1338,9 @@ __global__ __launch_bounds__(512, 1) void conv2d_wgrad16g_kernel(WgradParams p) 
     const int prow = 8 * wave + (lane >> 3), pslot = lane & 7;
     const int pg = pslot ^ ((prow >> 1) & 7);                                    // logical granule that lives in this slot
     const int pq = p.P * p.Q, hw = p.H * p.W;
+    // p.W also feeds per-lane offsets, so the compiler keeps it in a VGPR and then evaluates the (uniform) row addresses of the
+    // x pieces on the vector pipe; an explicit scalar copy keeps them on the SALU
+    const int Ws = __builtin_amdgcn_readfirstlane(p.W);
     const unsigned lp_dy = (o0 + prow < p.O) ? (unsigned)(prow * pq * 2 + pg * 16) : kOob;
     const unsigned lp_x = (i0 + prow < p.I) ? (unsigned)(prow * hw * 2 + pg * 16) : kOob;
     const int txr = lane >> 3, trow = 8 * wave + (lane & 7);                     // tail piece: lane = (xr, row), lanes >= 8 XR idle
@@ -1343,8 +1350,8 @@ __global__ __launch_bounds__(512, 1) void conv2d_wgrad16g_kernel(WgradParams p) 
     const int steps_per_img = p.rowgroups * p.qchunks;
     const int s0 = split * p.steps_per_split;
     const int s1 = min(s0 + p.steps_per_split, p.N * steps_per_img);
-    int ld_n = s0 / steps_per_img;
-    int ld_rg = (s0 - ld_n * steps_per_img) / p.qchunks;
+    int ld_n = __builtin_amdgcn_readfirstlane(s0 / steps_per_img);
+    int ld_rg = __builtin_amdgcn_readfirstlane((s0 - ld_n * steps_per_img) / p.qchunks);
     int ld_qc = s0 - ld_n * steps_per_img - ld_rg * p.qchunks;
     int ld_buf = 0;
     int u_qc = ld_qc;                                                            // chunk (of its row pair) of the step being multiplied
@@ -1388,12 +1395,12 @@ __global__ __launch_bounds__(512, 1) void conv2d_wgrad16g_kernel(WgradParams p) 
         } else if constexpr (I < R + XR) {
             constexpr int xr = I - R;
             const int row = c_prow0 - p.pad + xr;
-            const long long off = c_xoff + ((long long)i0 * hw + row * p.W + c_q0 - XLEAD) * 2;
+            const long long off = c_xoff + ((long long)i0 * hw + row * Ws + c_q0 - XLEAD) * 2;
             lds_dma_b128(make_rsrc((const char*)p.x + off, records(x_bytes - off, (unsigned)row < (unsigned)p.H)), v_x,
                          lds0 + c_bufa + DY_BYTES + xr * (64 * ROWB) + wave * 1024);
         } else {
             const int row = c_prow0 - p.pad;                                     // lanes add their xr
-            const long long off = c_xoff + ((long long)i0 * hw + row * p.W + c_q0 - XLEAD) * 2;
+            const long long off = c_xoff + ((long long)i0 * hw + row * Ws + c_q0 - XLEAD) * 2;
             if (lane < 8 * XR)
                 lds_dma_b128(make_rsrc((const char*)p.x + off, records(x_bytes - off, true)), v_t,
                              lds0 + c_bufa + DY_BYTES + XMAIN + wave * (XR * 128));
@@ -1458,50 +1465,93 @@ __global__ __launch_bounds__(512, 1) void conv2d_wgrad16g_kernel(WgradParams p) 
         // groups alternate between the two waves that share a SIMD (th 0 / th 1), so a 22-pixel chunk costs both one group.
         const int vq = p.Q - u_qc * kWgKQ;
         if (++u_qc == p.qchunks) u_qc = 0;
-        static_for<0, 2>([&](auto kqc) __attribute__((always_inline)) {
-            constexpr int kq = decltype(kqc)::value;
-            if ((kq * 2 + th) * 16 >= vq) {
-                issue_range(std::integral_constant<int, (kq * XR * NPIECE) / (2 * XR)>{}, std::integral_constant<int, ((kq + 1) * XR * NPIECE) / (2 * XR)>{});
-                return;
-            }
-            frag_t a[R];
+        // one x row of one 16-pixel group: the next loads' share, the three shifted B fragments, 3 or 6 MFMAs
+        auto row_mfmas = [&](auto kqc, auto xrc, const uint4 lo, const uint4 hi, const frag_t* a) __attribute__((always_inline)) {
+            constexpr int kq = decltype(kqc)::value, xr = decltype(xrc)::value;
+            constexpr int it = kq * XR + xr, NIT = 2 * XR;
+            issue_range(std::integral_constant<int, (it * NPIECE) / NIT>{}, std::integral_constant<int, ((it + 1) * NPIECE) / NIT>{});
+            asm volatile("" : : "v"(lo.x), "v"(lo.y), "v"(lo.z));               // keep the read a full (conflict-free) b128
+            const unsigned d[5] = {lo.w, hi.x, hi.y, hi.z, hi.w};               // pixels 8g+6 .. 8g+15 of the staged row
 #pragma unroll
-            for (int rr = 0; rr < R; rr++) a[rr] = *(const frag_t*)(buf + a_off[kq] + rr * (64 * ROWB));
-            static_for<0, XR>([&](auto xrc) __attribute__((always_inline)) {
-                constexpr int xr = decltype(xrc)::value;
-                constexpr int it = kq * XR + xr, NIT = 2 * XR;
-                issue_range(std::integral_constant<int, (it * NPIECE) / NIT>{}, std::integral_constant<int, ((it + 1) * NPIECE) / NIT>{});
-                if constexpr (!TAIL) {
+            for (int sft = 0; sft < KS; sft++) {
+                union { unsigned u[4]; frag_t f; } b;
+#pragma unroll
+                for (int w = 0; w < 4; w++)
+                    b.u[w] = (sft == 0) ? d[w] : (sft == 1) ? __builtin_amdgcn_alignbyte(d[w + 1], d[w], 2) : d[w + 1];
+#pragma unroll
+                for (int rr = 0; rr < R; rr++) {
+                    const int r = xr - rr;
+                    const int t = r * KS + sft;
+                    if (r >= 0 && r < KS) {
+                        if constexpr (std::is_same<T, bf16_t>::value)
+                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[rr], b.f, acc[t], 0, 0, 0);
+                        else
+                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[rr], b.f, acc[t], 0, 0, 0);
+                    }
+                }
+            }
+        };
+        if constexpr (!TAIL) {
+            static_for<0, 2>([&](auto kqc) __attribute__((always_inline)) {
+                constexpr int kq = decltype(kqc)::value;
+                if ((kq * 2 + th) * 16 >= vq) {
+                    issue_range(std::integral_constant<int, (kq * XR * NPIECE) / (2 * XR)>{}, std::integral_constant<int, ((kq + 1) * XR * NPIECE) / (2 * XR)>{});
+                    return;
+                }
+                frag_t a[R];
+#pragma unroll
+                for (int rr = 0; rr < R; rr++) a[rr] = *(const frag_t*)(buf + a_off[kq] + rr * (64 * ROWB));
+                static_for<0, XR>([&](auto xrc) __attribute__((always_inline)) {
+                    constexpr int xr = decltype(xrc)::value;
+                    constexpr int it = kq * XR + xr, NIT = 2 * XR;
+                    issue_range(std::integral_constant<int, (it * NPIECE) / NIT>{}, std::integral_constant<int, ((it + 1) * NPIECE) / NIT>{});
                     const frag_t b = *(const frag_t*)(buf + x0_off[kq] + xr * (64 * ROWB));
                     constexpr int rr = xr;
                     if constexpr (std::is_same<T, bf16_t>::value) acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[rr], b, acc[0], 0, 0, 0);
                     else acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[rr], b, acc[0], 0, 0, 0);
-                } else {
-                    const uint4 lo = *(const uint4*)(buf + x0_off[kq] + xr * (64 * ROWB));
-                    asm volatile("" : : "v"(lo.x), "v"(lo.y), "v"(lo.z));       // keep the read a full (conflict-free) b128
-                    const uint4 hi = *(const uint4*)(buf + x1_off[kq][xr]);
-                    const unsigned d[5] = {lo.w, hi.x, hi.y, hi.z, hi.w};       // pixels 8g+6 .. 8g+15 of the staged row
-#pragma unroll
-                    for (int sft = 0; sft < KS; sft++) {
-                        union { unsigned u[4]; frag_t f; } b;
-#pragma unroll
-                        for (int w = 0; w < 4; w++)
-                            b.u[w] = (sft == 0) ? d[w] : (sft == 1) ? __builtin_amdgcn_alignbyte(d[w + 1], d[w], 2) : d[w + 1];
-#pragma unroll
-                        for (int rr = 0; rr < R; rr++) {
-                            const int r = xr - rr;
-                            const int t = r * KS + sft;
-                            if (r >= 0 && r < KS) {
-                                if constexpr (std::is_same<T, bf16_t>::value)
-                                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[rr], b.f, acc[t], 0, 0, 0);
-                                else
-                                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[rr], b.f, acc[t], 0, 0, 0);
-                            }
-                        }
-                    }
-                }
+                });
             });
-        });
+        } else {
+            // The x windows are read one row ahead of their MFMAs, also across the two groups (left to itself the scheduler emits
+            // read, wait, multiply for every row: eight exposed LDS round trips per step with only the sibling wave to cover
+            // them).  The reads ahead are unconditional -- a dead group's window is simply not used.
+            frag_t a[2][R];
+#pragma unroll
+            for (int rr = 0; rr < R; rr++) a[0][rr] = *(const frag_t*)(buf + a_off[0] + rr * (64 * ROWB));
+            uint4 lo_n = *(const uint4*)(buf + x0_off[0]);
+            uint4 hi_n = *(const uint4*)(buf + x1_off[0][0]);
+            static_for<0, 2>([&](auto kqc) __attribute__((always_inline)) {
+                constexpr int kq = decltype(kqc)::value;
+                if ((kq * 2 + th) * 16 >= vq) {
+                    issue_range(std::integral_constant<int, (kq * XR * NPIECE) / (2 * XR)>{}, std::integral_constant<int, ((kq + 1) * XR * NPIECE) / (2 * XR)>{});
+                    if constexpr (kq == 0) {
+#pragma unroll
+                        for (int rr = 0; rr < R; rr++) a[1][rr] = *(const frag_t*)(buf + a_off[1] + rr * (64 * ROWB));
+                        lo_n = *(const uint4*)(buf + x0_off[1]);
+                        hi_n = *(const uint4*)(buf + x1_off[1][0]);
+                    }
+                    return;
+                }
+                static_for<0, XR>([&](auto xrc) __attribute__((always_inline)) {
+                    constexpr int xr = decltype(xrc)::value;
+                    const uint4 lo = lo_n, hi = hi_n;
+                    if constexpr (xr + 1 < XR) {
+                        lo_n = *(const uint4*)(buf + x0_off[kq] + (xr + 1) * (64 * ROWB));
+                        hi_n = *(const uint4*)(buf + x1_off[kq][xr + 1 < XR ? xr + 1 : xr]);
+                    } else if constexpr (kq == 0) {
+                        lo_n = *(const uint4*)(buf + x0_off[1]);
+                        hi_n = *(const uint4*)(buf + x1_off[1][0]);
+                    }
+                    if constexpr (kq == 0 && xr == 1) {
+#pragma unroll
+                        for (int rr = 0; rr < R; rr++) a[1][rr] = *(const frag_t*)(buf + a_off[1] + rr * (64 * ROWB));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    row_mfmas(kqc, xrc, lo, hi, a[kq]);
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            });
+        }
         // the next step's loads (issued NBUF-2 iterations ago, or just now when NBUF == 2) must have landed; patch its edge
         if (NBUF == 3) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(NPIECE));
         else { asm volatile("s_waitcnt vmcnt(0)"); f_q0 = c_q0; f_live = c_live; f_bufa = c_bufa; }
