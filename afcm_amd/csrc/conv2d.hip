@@ -399,21 +399,17 @@ __global__ __launch_bounds__(256, 2) void conv2d_fwd16_kernel(ConvParams p) {
     // Channels past Cin exist only in the last chunk of a layer whose Cin is not a multiple of 16; the chunk's channel offset
     // rides in the scalar offset, which the descriptor's range check does not cover, so those lanes get the out-of-range
     // vector offset instead (zeros).  Decided here, at the chunk boundary, to keep the tap loop free of branches.
-    const bool ragged = (p.Cin % BK) != 0;
-    auto issue_patch = [&](int kc) __attribute__((always_inline)) {
-        if (ragged && kc == p.nkc - 1) {
+    // Branch-free, and issued on EVERY chunk (past the last one with the out-of-range offset: zeros, no memory traffic): a
+    // conditional issue makes the compiler's s_waitcnt for the weight ring assume the path without these eight loads, and on
+    // the path with them that count waits for all eight -- a full memory round trip exposed at the top of every chunk.
+    auto issue_patch = [&](int kc, bool live) __attribute__((always_inline)) {
+        const int cbase = kc * BK + cg * 8;
+        const int climit = live ? p.Cin : 0;              // one scalar select; `live && ...` per load comes back as branches
 #pragma unroll
-            for (int c = 0; c < 8; c++) {
-                const unsigned off = (kc * BK + cg * 8 + c < p.Cin) ? pvoff : kOob;
-                const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(xrs, off, (kc * BK + c) * hw2, 0);
-                preg[c][0] = v.x; preg[c][1] = v.y;
-            }
-        } else {
-#pragma unroll
-            for (int c = 0; c < 8; c++) {
-                const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(xrs, pvoff, (kc * BK + c) * hw2, 0);
-                preg[c][0] = v.x; preg[c][1] = v.y;
-            }
+        for (int c = 0; c < 8; c++) {
+            const unsigned off = (cbase + c < climit) ? pvoff : kOob;
+            const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(xrs, off, (kc * BK + c) * hw2, 0);
+            preg[c][0] = v.x; preg[c][1] = v.y;
         }
     };
     // Branch-free on purpose: any branch here (even a wave-uniform one) cuts the tap loop into basic blocks, the ~60
@@ -440,7 +436,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_fwd16_kernel(ConvParams p) {
     };
 
     frag_t ar[RING][MI];
-    issue_patch(0);
+    issue_patch(0, true);
 #pragma unroll
     for (int t = 0; t < RING; t++)
 #pragma unroll
@@ -453,12 +449,20 @@ __global__ __launch_bounds__(256, 2) void conv2d_fwd16_kernel(ConvParams p) {
         const T* cur = lds + (kc & 1) * (kPatchMax * PITCH);
         T* nxt = lds + ((kc + 1) & 1) * (kPatchMax * PITCH);
         const bool more = kc < last;
-        if (more) issue_patch(kc + 1);
+        // B fragments run one tap ahead of their MFMAs in the SAME registers: a tap's MFMAs go pixel-block by pixel-block, and
+        // as soon as block ti's fragment has been consumed the next tap's fragment for that block is read into it.  (Read, wait,
+        // multiply per tap left ~one LDS round trip exposed per 8 MFMAs with only the other workgroup's wave to cover it.)
+        frag_t b[4];
+#pragma unroll
+        for (int ti = 0; ti < 4; ti++) b[ti] = *(const frag_t*)(cur + bbase[ti]);
+        issue_patch(kc + (int)more, more);
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);               // tap 0's fragments first, all four in flight together
+        __builtin_amdgcn_sched_group_barrier(0x020, 8, 0);
 #pragma unroll
         for (int tap = 0; tap < KK; tap++) {
-            const int r = tap / KS, s2 = tap - r * KS;
-            const int tapoff = (r * PWL + s2) * PITCH;
-            frag_t a[MI], b[4];
+            const int nr = (tap + 1) / KS, ns = (tap + 1) - nr * KS;
+            const int tapoff_n = (nr * PWL + ns) * PITCH;                 // next tap's offset (unused on the last tap)
+            frag_t a[MI];
 #pragma unroll
             for (int mi = 0; mi < MI; mi++) a[mi] = ar[tap % RING][mi];
             // refill this ring slot with the fragments three taps ahead (clamped at the end: no branch around a load)
@@ -469,36 +473,40 @@ __global__ __launch_bounds__(256, 2) void conv2d_fwd16_kernel(ConvParams p) {
                 for (int mi = 0; mi < MI; mi++) ar[tap % RING][mi] = load_a(nk, nt, mi);
             }
 #pragma unroll
-            for (int ti = 0; ti < 4; ti++) b[ti] = *(const frag_t*)(cur + bbase[ti] + tapoff);
+            for (int ti = 0; ti < 4; ti++) {
 #pragma unroll
-            for (int mi = 0; mi < MI; mi++)
-#pragma unroll
-                for (int ti = 0; ti < 4; ti++) {
+                for (int mi = 0; mi < MI; mi++) {
                     if constexpr (std::is_same<T, bf16_t>::value)
                         acc[mi][ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ti], acc[mi][ti], 0, 0, 0);
                     else
                         acc[mi][ti] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mi], b[ti], acc[mi][ti], 0, 0, 0);
                 }
+                if (tap + 1 < KK) b[ti] = *(const frag_t*)(cur + bbase[ti] + tapoff_n);
+            }
             if (tap == 5) {
                 // the other buffer (last read one chunk ago); on the last chunk this rewrites stale registers into a buffer
                 // nobody reads.  Interleave: one MFMA, then a handful of the transpose's vector instructions.
                 write_patch(kc + 1, nxt, ((kc + 1) & 1) * (kPatchMax * PITCH));
                 __builtin_amdgcn_sched_group_barrier(0x020, MI, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
 #pragma unroll
-                for (int i2 = 0; i2 < 4 * MI; i2++) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+                for (int ti = 0; ti < 4; ti++) {
+#pragma unroll
+                    for (int mi = 0; mi < MI; mi++) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                 }
                 __builtin_amdgcn_sched_group_barrier(0x200, 4, 0);
             } else {
                 // pin the issue order of the tap: the ring refill first (left alone, the scheduler sinks the loads next to
-                // their uses and the three-tap prefetch distance collapses), then the B reads, then the MFMAs.
-                // (Also tried: B fragments one tap ahead in a second register set -- +3 % on the 512-channel layers, but
-                // the 16 extra VGPRs spill the epilogue state and the short-K layers lose more than that.)
+                // their uses and the three-tap prefetch distance collapses), then per pixel block its MFMAs and the read ahead
                 __builtin_amdgcn_sched_group_barrier(0x020, MI, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 4 * MI, 0);
+#pragma unroll
+                for (int ti = 0; ti < 4; ti++) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, MI, 0);
+                    if (tap + 1 < KK) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
             }
         }
         __syncthreads();
