@@ -270,6 +270,30 @@ __global__ __launch_bounds__((64 * MfmaGeom<UP, DOWN, TOW, TOH>::NG), (DOWN == 2
     constexpr int NSW = (SIGN == AFCM_SIGNS_READ) ? cdiv(G::SGN_ROWS * G::SGN_WORDS, NT) : 1;
     unsigned sv[NSW];                                           // READ: this thread's words of the sign window
     uint4 tabv = make_uint4(0, 0, 0, 0);                        // READ: its piece of the keep-mask table
+    // Constant (Toeplitz) fragments: fetched HERE, ahead of the input tile, so that their L2 round trip overlaps the staging
+    // loads -- the barriers below are fences, and issued behind them every fragment load was waited for on the spot (one
+    // exposed round trip per tile for the up/down-y set, one per column block for UH, one for DH).
+    const frag* wsf = (const frag*)p.ws;
+    auto cfrag = [&](int f) __attribute__((always_inline)) { return wsf[f * 64 + lane]; };
+#ifndef AFCM_FL_PF_TOP
+#define AFCM_FL_PF_TOP (SIGN == AFCM_SIGNS_READ)
+#endif
+    // (the sign-writing forward kernel is register-bound at 80 VGPRs: holding these across the staging phase costs it more
+    // than the round trip it saves, measured 1630 vs 1710 GB/s; the backward kernel gains, 1712 vs 1602)
+    constexpr bool PF_TOP = AFCM_FL_PF_TOP;
+    frag uv[UP], dvs[G::NDVK], dvr[G::NDVK];
+    auto load_const = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int v = 0; v < UP; v++) uv[v] = cfrag(G::NB + v);
+#pragma unroll
+        for (int t = 0; t < G::NDVK; t++) {
+            dvs[t] = cfrag(G::NB + UP + t);
+            dvr[t] = cfrag(G::NB + UP + G::NDVK + t);
+        }
+    };
+    if (PF_TOP) load_const();
+    frag uh_next;
+    if (PF_TOP) uh_next = cfrag(0);
 
     // ---- stage the input tile: zero outside the image (the bias is added before padding).
     // One item = 8 consecutive columns of one row = one 16-byte load from a 4-byte aligned address.  Rows outside the
@@ -409,21 +433,12 @@ __global__ __launch_bounds__((64 * MfmaGeom<UP, DOWN, TOW, TOH>::NG), (DOWN == 2
         __syncthreads();
     }
 
-    const frag* wsf = (const frag*)p.ws;
-    auto cfrag = [&](int f) __attribute__((always_inline)) { return wsf[f * 64 + lane]; };
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
     // ---- phase A: one group of NB ucol blocks per wave: up-x, up-y, activation, down-y, all in registers
     {
         const int Gi = wave;
-        frag uv[UP], dvs[G::NDVK], dvr[G::NDVK];
-#pragma unroll
-        for (int v = 0; v < UP; v++) uv[v] = cfrag(G::NB + v);
-#pragma unroll
-        for (int t = 0; t < G::NDVK; t++) {
-            dvs[t] = cfrag(G::NB + UP + t);
-            dvr[t] = cfrag(G::NB + UP + G::NDVK + t);
-        }
+        if (!PF_TOP) load_const();
         // READ: row offset of the sign window inside its first staged quad / column offset inside its first aligned dword
         const int yy = (U0y + p.sy) & 3, coff = (U0x + p.sx) & 3;
         const float cthr = p.clamp / fmaxf(p.slope, 1.f);      // |lrelu(v)| <= max(1, slope) |v|: below cthr nothing clamps
@@ -438,7 +453,8 @@ __global__ __launch_bounds__((64 * MfmaGeom<UP, DOWN, TOW, TOH>::NG), (DOWN == 2
 
 #pragma unroll
         for (int nb = 0; nb < G::NB; nb++) {
-            const frag uh = cfrag(nb);
+            const frag uh = PF_TOP ? uh_next : cfrag(nb);
+            if (PF_TOP && nb + 1 < G::NB) uh_next = cfrag(nb + 1);                 // one column block ahead
             // up-x: X1[mb] = In[mb] * UH
             f32x4 x1[G::NMB];
 #pragma unroll
@@ -538,6 +554,11 @@ __global__ __launch_bounds__((64 * MfmaGeom<UP, DOWN, TOW, TOH>::NG), (DOWN == 2
             }
         }
     }
+    frag dh[G::NDVK];                                            // phase B's fragments, requested before the barrier
+    if (PF_TOP) {
+#pragma unroll
+        for (int t = 0; t < G::NDVK; t++) dh[t] = cfrag(G::NB + UP + 2 * G::NDVK + t);
+    }
     __syncthreads();
 
     // ---- sign codes of the region this tile owns: LDS -> HBM in 16-byte row segments
@@ -565,9 +586,10 @@ __global__ __launch_bounds__((64 * MfmaGeom<UP, DOWN, TOW, TOH>::NG), (DOWN == 2
 
     // ---- phase B: down-x, transposed (each lane ends up with 4 consecutive output columns of one row)
     {
-        frag dh[G::NDVK];
+        if (!PF_TOP) {
 #pragma unroll
-        for (int t = 0; t < G::NDVK; t++) dh[t] = cfrag(G::NB + UP + 2 * G::NDVK + t);
+            for (int t = 0; t < G::NDVK; t++) dh[t] = cfrag(G::NB + UP + 2 * G::NDVK + t);
+        }
         const bool inner = (O0x + TOW <= p.yw) && (O0y + TOH <= p.yh);
         const float osc = (p.oscale ? p.oscale[plane] : 1.f) * (p.oscale2 ? p.oscale2[plane] : 1.f);
         const T* skp = p.skip ? (const T*)p.skip + (size_t)plane * p.yh * p.yw : nullptr;
