@@ -224,7 +224,7 @@ __device__ __forceinline__ unsigned signs_pk(unsigned d) {
 }
 
 template <typename T, int UP, int DOWN, int TOW, int TOH, int SIGN, bool BIAS>
-__global__ __launch_bounds__((64 * MfmaGeom<UP, DOWN, TOW, TOH>::NG), (DOWN == 2 ? 6 : 4)) void flrelu_mfma_kernel(FlreluMfmaParams p) {
+__global__ __launch_bounds__((64 * MfmaGeom<UP, DOWN, TOW, TOH>::NG), (DOWN == 2 ? (SIGN == AFCM_SIGNS_WRITE ? 5 : 6) : 4)) void flrelu_mfma_kernel(FlreluMfmaParams p) {
     // second bound = waves per SIMD: the 3-wave workgroups (19 KB of LDS) fit 8 to a CU, which needs <= 80 VGPRs -- without
     // the bound the scheduler spends ~90 on overlapping the tiles' MFMAs and two workgroups per CU are lost
     typedef MfmaGeom<UP, DOWN, TOW, TOH> G;
@@ -276,10 +276,11 @@ __global__ __launch_bounds__((64 * MfmaGeom<UP, DOWN, TOW, TOH>::NG), (DOWN == 2
     const frag* wsf = (const frag*)p.ws;
     auto cfrag = [&](int f) __attribute__((always_inline)) { return wsf[f * 64 + lane]; };
 #ifndef AFCM_FL_PF_TOP
-#define AFCM_FL_PF_TOP (SIGN == AFCM_SIGNS_READ)
+#define AFCM_FL_PF_TOP (SIGN != AFCM_SIGNS_NONE)
 #endif
-    // (the sign-writing forward kernel is register-bound at 80 VGPRs: holding these across the staging phase costs it more
-    // than the round trip it saves, measured 1630 vs 1710 GB/s; the backward kernel gains, 1712 vs 1602)
+    // (the sign-writing forward kernel is register-bound: at 6 waves per SIMD / 80 VGPRs holding these across the staging phase
+    // costs more than the round trip saves, 1630 vs 1710 GB/s; bounded to 5 waves / 96 VGPRs it gains, 1750.  The backward
+    // kernel gains at 6 waves, 1712 vs 1602, and loses at 5.)
     constexpr bool PF_TOP = AFCM_FL_PF_TOP;
     frag uv[UP], dvs[G::NDVK], dvr[G::NDVK];
     auto load_const = [&]() __attribute__((always_inline)) {
