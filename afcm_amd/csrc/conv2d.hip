@@ -22,6 +22,23 @@ namespace afcm {
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(2))) float cf32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 cbf16x2;
+typedef __attribute__((ext_vector_type(2))) _Float16 cf16x2;
+
+// two fp32 values -> one dword of two 16-bit floats (one v_cvt_pk of exactly this pair, round to nearest even)
+template <typename T>
+__device__ __forceinline__ unsigned pack2(float lo, float hi) {
+    if constexpr (std::is_same<T, bf16_t>::value) {
+        union { cbf16x2 v; unsigned u; } r;
+        r.v = __builtin_convertvector((cf32x2){lo, hi}, cbf16x2);
+        return r.u;
+    } else {
+        union { cf16x2 v; unsigned u; } r;
+        r.v = __builtin_convertvector((cf32x2){lo, hi}, cf16x2);
+        return r.u;
+    }
+}
 
 template <typename T> struct ConvCfg;
 template <> struct ConvCfg<bf16_t> { static constexpr int BK = 16, PITCH = 24; };   // elements; 48-byte rows: conflict-free b128
@@ -41,6 +58,7 @@ struct ConvParams {
     int pad;
     int TH, TW, PWL, tilesX, tilesY;
     int Opad, nkc;
+    unsigned magicTW;     // ceil(2^32 / TW): j / TW = umulhi(j, magicTW) for the tile-local pixel indices (j < 2^16)
 };
 
 template <typename T, int BM_O, int KS>
@@ -515,21 +533,43 @@ __global__ __launch_bounds__(256, 2) void conv2d_fwd16_kernel(ConvParams p) {
     // ---- epilogue: D[row = channel][col = pixel]; row = (reg&3) + 8*(reg>>2) + 4*h within the 32x32 tile.
     if ((p.TW & 7) == 0) {
         // Tile rows that are multiples of 8 pixels: transpose through LDS (the patch buffers are free after the last barrier)
-        // and store 8 pixels = 16 bytes per lane.  Per thread: 128 conversions + 128 two-byte LDS writes + 16 b128 reads +
-        // 16 stores, instead of 128 predicated two-byte global stores with 64-bit address arithmetic each (~2900
-        // instructions -- more than the whole main loop of a 64-channel layer).
-        constexpr int EP = 264;                                   // bytes per staged channel row: 128 pixels + 8 pad
-        unsigned char* ebuf = (unsigned char*)lds + wave * (32 * EP);
+        // and store 8 pixels = 16 bytes per lane.  A lane holds 16 channels of ONE pixel (4 runs of 4 consecutive channels), so
+        // it stages [pixel][32 channels] rows with four 8-byte writes per 32x32 tile, and the transposing read
+        // (ds_read_b64_tr_b16: a 16-lane group takes a 4-pixel x 16-channel block, lane i receives channel i of the 4 pixels)
+        // hands every lane 4 pixels of one channel.  Per thread and 32-channel pass: 32 packed conversions + 16 ds_write_b64 +
+        // 16 transposing reads + 8 stores (the first version staged [channel][pixel] with 64 two-byte writes per pass: the
+        // epilogue was 12 % of the whole conv time, 35 % on the 64-channel layers).
+        // Row = 64 bytes = eight 8-byte chunks; chunk c of pixel p lives at c ^ ((p >> 1) & 7): conflict-free for the writes
+        // (16 consecutive pixels x one chunk) and for the reads (a 32-lane half = both channel halves of 4 pixels).
+        typedef __attribute__((ext_vector_type(4))) short s16x4;
+        constexpr int EROW = 64;
+        unsigned char* ebuf = (unsigned char*)lds + wave * (128 * EROW);
         T* yn = (T*)p.y + (size_t)n * p.Cout * p.P * p.Q;
         const float* osn = p.oscale ? p.oscale + (size_t)n * p.Cout : nullptr;
         const int pq = p.P * p.Q;
-        // this lane's granule of the read-back: pixels j0 .. j0+7 of the wave's 128, one tile row (TW % 8 == 0)
-        const int gq = lane & 15, j0 = wpx * 128 + gq * 8;
-        const int gpy = j0 / p.TW, gpx = j0 - gpy * p.TW;
-        const int gy = y0 + gpy, gx = x0 + gpx;
-        const bool gok = j0 < p.TH * p.TW && gy < p.P && gx < p.Q;
-        const bool gfull = gx + 8 <= p.Q;
-        const int goff = gy * p.Q + gx;
+        // read side: lane = (half hh: granule parity, chalf: channel half, i16: channel / address role inside the 16-lane group)
+        const int i16 = lane & 15, chalf = (lane >> 4) & 1, hh = lane >> 5;
+        const int q4 = i16 >> 2, p4 = i16 & 3;
+        unsigned rd_off[2];
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            const int prow = 8 * hh + 4 * r + q4;                 // + 16 pixels per iteration: (prow >> 1) & 7 does not change
+            rd_off[r] = prow * EROW + (((chalf * 4 + p4) ^ ((prow >> 1) & 7)) << 3);
+        }
+        // this lane's 8 granules (8 pixels each, one tile row): plane offset, -1 = outside the image; bit it of gfullm = whole
+        int goff[8];
+        unsigned gfullm = 0;
+        int gxv[8];
+#pragma unroll
+        for (int it = 0; it < 8; it++) {
+            const int j0 = wpx * 128 + (2 * it + hh) * 8;
+            const int gpy = (int)__umulhi((unsigned)j0, p.magicTW), gpx = j0 - gpy * p.TW;
+            const int gy = y0 + gpy, gx = x0 + gpx;
+            goff[it] = (j0 < p.TH * p.TW && gy < p.P && gx < p.Q) ? gy * p.Q + gx : -1;
+            gxv[it] = gx;
+            if (gx + 8 <= p.Q) gfullm |= 1u << it;
+        }
+        const int wr_pix = r32;                                    // + 32 ti
 #pragma unroll
         for (int mi = 0; mi < MI; mi++) {
             float sc[16], ob[16];
@@ -545,27 +585,35 @@ __global__ __launch_bounds__(256, 2) void conv2d_fwd16_kernel(ConvParams p) {
                 for (int reg = 0; reg < 16; reg++) ob[reg] = p.obias[min(obase + (reg & 3) + 8 * (reg >> 2), p.Cout - 1)];
             }
 #pragma unroll
-            for (int reg = 0; reg < 16; reg++) {
-                const int row = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+            for (int ti = 0; ti < 4; ti++) {
+                const int pix = ti * 32 + wr_pix;
+                const int sw = (pix >> 1) & 7;
 #pragma unroll
-                for (int ti = 0; ti < 4; ti++)
-                    *(T*)(ebuf + row * EP + (ti * 32 + r32) * 2) = from_f32<T>(acc[mi][ti][reg] * sc[reg] + ob[reg]);
+                for (int k4 = 0; k4 < 4; k4++) {                   // registers 4 k4 .. 4 k4 + 3 = channels 4 h + 8 k4 + 0..3
+                    uint2 w;
+                    w.x = pack2<T>(acc[mi][ti][4 * k4 + 0] * sc[4 * k4 + 0] + ob[4 * k4 + 0], acc[mi][ti][4 * k4 + 1] * sc[4 * k4 + 1] + ob[4 * k4 + 1]);
+                    w.y = pack2<T>(acc[mi][ti][4 * k4 + 2] * sc[4 * k4 + 2] + ob[4 * k4 + 2], acc[mi][ti][4 * k4 + 3] * sc[4 * k4 + 3] + ob[4 * k4 + 3]);
+                    *(uint2*)(ebuf + pix * EROW + (((h + 2 * k4) ^ sw) << 3)) = w;
+                }
             }
             // same wave wrote and reads: LDS operations of a wave complete in order, no barrier needed
+            const int o = o0 + wo * (BM_O / 2) + mi * 32 + chalf * 16 + i16;
+            T* const yo = yn + (size_t)min(o, p.Cout - 1) * pq;
 #pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const int ol = 4 * k + (lane >> 4);
-                const uint4 v = *(const uint4*)(ebuf + ol * EP + gq * 16);
-                const int o = o0 + wo * (BM_O / 2) + mi * 32 + ol;
-                if (gok && o < p.Cout) {
-                    T* dst = yn + (size_t)o * pq + goff;
-                    if (gfull) {
-                        *(uint4*)dst = v;
+            for (int it = 0; it < 8; it++) {
+                union { s16x4 v[2]; uint4 q; } u;
+#pragma unroll
+                for (int r = 0; r < 2; r++)
+                    u.v[r] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ebuf + it * (16 * EROW) + rd_off[r]));
+                if (goff[it] >= 0 && o < p.Cout) {
+                    T* dst = yo + goff[it];
+                    if ((gfullm >> it) & 1) {
+                        *(uint4*)dst = u.q;
                     } else {                                      // the granule straddles the right edge (even width: whole pairs)
-                        const unsigned vv[4] = {v.x, v.y, v.z, v.w};
+                        const unsigned vv[4] = {u.q.x, u.q.y, u.q.z, u.q.w};
 #pragma unroll
                         for (int w2 = 0; w2 < 4; w2++)
-                            if (gx + 2 * w2 < p.Q) ((unsigned*)dst)[w2] = vv[w2];
+                            if (gxv[it] + 2 * w2 < p.Q) ((unsigned*)dst)[w2] = vv[w2];
                     }
                 }
             }
@@ -1703,6 +1751,7 @@ extern "C" int afcm_conv2d(void* y, const void* x, const void* wpacked, const fl
     p.pad = pad;
     choose_tile(p.P, p.Q, ks, &p.TH, &p.TW, &p.PWL);
     p.tilesX = cdiv(p.Q, p.TW); p.tilesY = cdiv(p.P, p.TH);
+    p.magicTW = (unsigned)((0x100000000ull + (unsigned)p.TW - 1) / (unsigned)p.TW);
     p.Opad = rows_pad;
     p.nkc = cdiv(cin, afcm_conv2d_block_k(dtype));
     hipStream_t st = (hipStream_t)stream;
