@@ -103,13 +103,21 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit(f'--gpus {args.gpus} needs a torch.distributed.run launch with {args.gpus} ranks (see the module docstring)')
         raise SystemExit(f'--gpus {args.gpus} does not match WORLD_SIZE {world}')
+    # rehearsal aid for a one-GPU box: AFCM_BENCH_REHEARSE=1 puts every rank on device 0 and exchanges through gloo (RCCL refuses
+    # two ranks on one device) -- exercises the multi-process path (broadcast, bucket hooks, reduced-gradient Adam), not a benchmark
+    rehearse = os.environ.get('AFCM_BENCH_REHEARSE') == '1'
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     use_dist = world > 1 or args.force_dist
     if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29533')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        if rehearse:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+        else:
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
     dtype = {'bf16': torch.bfloat16, 'fp16': torch.float16, 'fp32': torch.float32}[args.dtype]
     torch.manual_seed(0)      # identical init on every rank (the step also broadcasts from rank 0)
