@@ -54,6 +54,14 @@ CASES = [
     (2, 64, 1, 1, 32, 32, 0),        # ToRGB shape
     (2, 72, 72, 3, 36, 36, 1),       # bottleneck conv (pad 1)
     (1, 40, 48, 3, 70, 150, 2),      # wide plane: several q-chunks in the weight gradient
+    # output widths around the weight gradient's 16-pixel K groups and 64-pixel chunks (dead-group skipping, read-ahead across
+    # groups) and the forward kernel's 8-pixel store granules (transposing epilogue, ragged right edge)
+    (1, 64, 64, 3, 6, 14, 2),        # Q = 16: one live group per wave pair
+    (1, 64, 64, 3, 6, 30, 2),        # Q = 32
+    (1, 64, 64, 3, 6, 46, 2),        # Q = 48: three live groups
+    (1, 64, 64, 3, 6, 62, 2),        # Q = 64: exactly one chunk
+    (1, 64, 64, 3, 6, 64, 2),        # Q = 66: second chunk with 2 live pixels
+    (2, 64, 128, 3, 6, 98, 2),       # Q = 100: 36 live pixels in the second chunk, two o-tiles
 ]
 
 
