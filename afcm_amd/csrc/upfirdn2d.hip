@@ -4,6 +4,8 @@
 // sample (polyphase stepping), lanes map to consecutive output columns so reads and writes coalesce.
 // Covers every up/down/tap combination incl. the 61-tap separable Gaussian of the loss blur
 // (stylegan3_model.py:25-28), which arrives as two 1-D calls (SG3OPS/upfirdn2d.py:244-245).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace afcm {
@@ -54,6 +56,112 @@ __global__ __launch_bounds__(256) void upfirdn2d_kernel(UpfirdnParams p, const f
     }
 }
 
+// Small-filter tile kernel: filters of at most 4 x 4 taps with equal factors in x and y, (up, down) in {(1, 1), (1, 2), (2, 1)} --
+// the discriminator's [1, 3, 3, 1] blur, its decimating skip path and their transposes (CoModGAN/layers.py:115-162 through
+// conv2d_resample; the R1 double backward runs the same three shapes).  One workgroup = 64 x 16 outputs: the input tile is
+// staged once into LDS as fp32 (coalesced loads, zero outside the plane), every thread then computes 4 consecutive outputs
+// of one row from 16-byte LDS reads with the taps in scalar registers.  The gather kernel above reads every input 16 times
+// through 2-byte loads (0.9 TB/s on the 256^2 blur); this one is bound by the staging traffic.
+template <int UP, int DOWN> struct UpfTile {
+    static constexpr int TOX = 64, TOY = 16;
+    static constexpr int UW = (TOX - 1) * DOWN + 4, UH = (TOY - 1) * DOWN + 4;       // extent in the zero-inserted domain
+    static constexpr int IW = UP == 1 ? UW : UW / 2 + 2, IH = UP == 1 ? UH : UH / 2 + 2;
+    static constexpr int IWP = (IW + 3) / 4 * 4 + 4;                                 // row pitch in floats (16-byte rows)
+};
+
+template <typename T, int UP, int DOWN>
+__global__ __launch_bounds__(256) void upfirdn2d_tile_kernel(UpfirdnParams p, const float* __restrict__ f) {
+    typedef UpfTile<UP, DOWN> G;
+    __shared__ __attribute__((aligned(16))) float tile[G::IH * G::IWP];
+    // taps[ky][kx] multiplies z[Uy+ky][Ux+kx] (true convolution unless `flip`), zero beyond the filter: uniform -> SGPRs
+    float t[4][4];
+    const int nt = p.fw * p.fh;
+#pragma unroll
+    for (int ky = 0; ky < 4; ky++)
+#pragma unroll
+        for (int kx = 0; kx < 4; kx++) {
+            const int i = ky * p.fw + kx;
+            t[ky][kx] = (ky < p.fh && kx < p.fw) ? (p.flip ? f[i] : f[nt - 1 - i]) * p.gain : 0.f;
+        }
+    const int tilesX = (p.yw + G::TOX - 1) / G::TOX, tilesY = (p.yh + G::TOY - 1) / G::TOY;
+    int bid = blockIdx.x;
+    const int tx = bid % tilesX; bid /= tilesX;
+    const int ty = bid % tilesY;
+    const long long plane = bid / tilesY;
+    const int ox0 = tx * G::TOX, oy0 = ty * G::TOY;
+    const int Ux0 = ox0 * DOWN - p.padx0, Uy0 = oy0 * DOWN - p.pady0;               // tile origin in the zero-inserted domain
+    // first input sample at or after the origin (UP = 2: ceil(U / 2) for negative U too)
+    const int ix0 = UP == 1 ? Ux0 : (Ux0 + (Ux0 & 1)) / 2, iy0 = UP == 1 ? Uy0 : (Uy0 + (Uy0 & 1)) / 2;
+    const T* xp = (const T*)p.x + plane * p.xh * p.xw;
+    for (int idx = threadIdx.x; idx < G::IH * G::IWP; idx += 256) {
+        const int r = idx / G::IWP, c = idx - r * G::IWP;
+        const int iy = iy0 + r, ix = ix0 + c;
+        float v = 0.f;
+        if ((unsigned)iy < (unsigned)p.xh && (unsigned)ix < (unsigned)p.xw) v = to_f32(xp[(size_t)iy * p.xw + ix]);
+        tile[idx] = v;
+    }
+    __syncthreads();
+    const int lx4 = threadIdx.x & 15, ly = threadIdx.x >> 4;
+    const int oy = oy0 + ly, ox = ox0 + 4 * lx4;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (UP == 1) {
+        constexpr int NV = 3 * DOWN + 4, NV4 = (NV + 3) / 4;
+#pragma unroll
+        for (int ky = 0; ky < 4; ky++) {
+            const float4* row = (const float4*)(tile + (ly * DOWN + ky) * G::IWP + 4 * lx4 * DOWN);
+            float v[NV4 * 4];
+#pragma unroll
+            for (int q = 0; q < NV4; q++) { const float4 w = row[q]; v[4 * q] = w.x; v[4 * q + 1] = w.y; v[4 * q + 2] = w.z; v[4 * q + 3] = w.w; }
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int kx = 0; kx < 4; kx++) acc[j] = fmaf(t[ky][kx], v[j * DOWN + kx], acc[j]);
+        }
+    } else {
+        // zero insertion: only taps with (U + k) even meet a sample; two per axis for a 4-tap filter
+        const int Uy = Uy0 + ly;
+#pragma unroll
+        for (int a = 0; a < 2; a++) {
+            const int ky = ((Uy & 1) ? 1 : 0) + 2 * a;
+            const int r = (Uy + ky) / 2 - iy0;                                       // Uy + ky even: exact also below zero
+            const float* row = tile + r * G::IWP;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int Ux = Ux0 + 4 * lx4 + j;
+#pragma unroll
+                for (int b = 0; b < 2; b++) {
+                    const int kx = ((Ux & 1) ? 1 : 0) + 2 * b;
+                    const float tap = ky == 0 ? (kx == 0 ? t[0][0] : kx == 1 ? t[0][1] : kx == 2 ? t[0][2] : t[0][3])
+                                    : ky == 1 ? (kx == 0 ? t[1][0] : kx == 1 ? t[1][1] : kx == 2 ? t[1][2] : t[1][3])
+                                    : ky == 2 ? (kx == 0 ? t[2][0] : kx == 1 ? t[2][1] : kx == 2 ? t[2][2] : t[2][3])
+                                              : (kx == 0 ? t[3][0] : kx == 1 ? t[3][1] : kx == 2 ? t[3][2] : t[3][3]);
+                    acc[j] = fmaf(tap, row[(Ux + kx) / 2 - ix0], acc[j]);
+                }
+            }
+        }
+    }
+    if (oy < p.yh) {
+        T* yp = (T*)p.y + plane * p.yh * p.yw + (size_t)oy * p.yw;
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (ox + j < p.yw) yp[ox + j] = from_f32<T>(acc[j]);
+    }
+}
+
+template <typename T>
+static bool launch_tile(const UpfirdnParams& p, const float* f, hipStream_t st) {
+    const bool sq = p.upx == p.upy && p.downx == p.downy && p.fw <= 4 && p.fh <= 4;
+    if (!sq) return false;
+    const long long nblk = (long long)((p.yw + 63) / 64) * ((p.yh + 15) / 16) * p.planes;
+    if (nblk <= 0 || nblk >= (1ll << 31)) return false;
+    dim3 grid((unsigned)nblk), block(256);
+    if (p.upx == 1 && p.downx == 1) hipLaunchKernelGGL((upfirdn2d_tile_kernel<T, 1, 1>), grid, block, 0, st, p, f);
+    else if (p.upx == 1 && p.downx == 2) hipLaunchKernelGGL((upfirdn2d_tile_kernel<T, 1, 2>), grid, block, 0, st, p, f);
+    else if (p.upx == 2 && p.downx == 1) hipLaunchKernelGGL((upfirdn2d_tile_kernel<T, 2, 1>), grid, block, 0, st, p, f);
+    else return false;
+    return true;
+}
+
 }  // namespace afcm
 
 using namespace afcm;
@@ -76,6 +184,11 @@ extern "C" int afcm_upfirdn2d(void* y, const void* x, const float* f, int32_t dt
     if (nblk > 256 * 64) nblk = 256 * 64;
     dim3 grid((unsigned)nblk), block(256);
     hipStream_t st = (hipStream_t)stream;
+    static const bool no_tile = getenv("AFCM_UPFIRDN_GATHER") != nullptr;       // tuning aid: always the gather kernel
+    if (!no_tile) {
+        const bool done = dtype == AFCM_F32 ? launch_tile<float>(p, f, st) : dtype == AFCM_F16 ? launch_tile<f16_t>(p, f, st) : launch_tile<bf16_t>(p, f, st);
+        if (done) return hip_status(hipGetLastError());
+    }
     switch (dtype) {
         case AFCM_F32: hipLaunchKernelGGL((upfirdn2d_kernel<float>), grid, block, 0, st, p, f); break;
         case AFCM_F16: hipLaunchKernelGGL((upfirdn2d_kernel<f16_t>), grid, block, 0, st, p, f); break;

@@ -325,3 +325,34 @@ def test_filtered_lrelu_16bit_matrix_core_clamp_and_no_bias(lname, dtype, tol):
     for n, c in [(0, 1), (1, 0)]:
         d = (ggot[n, c].float().cpu() - gref[n, c]).norm() / gref[n, c].norm()
         assert d.item() <= 2 * tol, (n, c, d.item())
+
+
+@pytest.mark.parametrize('dtype,tol', [(torch.float32, 2e-6), (torch.bfloat16, 8e-3), (torch.float16, 1e-3)])
+@pytest.mark.parametrize('up,down,pad', [(1, 1, [2, 1, 2, 1]), (1, 1, [1, 2, 2, 2]), (1, 2, [1, 1, 1, 1]), (1, 2, [2, 1, 0, 3]), (2, 1, [2, 1, 2, 1]),
+                                         (2, 1, [1, 2, 3, 0]), (1, 1, [-1, 3, 0, -2]), (2, 1, [-1, 4, 0, 2])])
+@pytest.mark.parametrize('fshape', [(4, 4), (3, 2), (1, 4)])
+def test_upfirdn2d_small_filter_tile_kernel_vs_oracle(fshape, up, down, pad, dtype, tol):
+    """The LDS-tile kernel for filters of at most 4 x 4 taps (the discriminator's [1, 3, 3, 1] blur / decimation and their
+    transposes) against the CPU oracle, forward and input gradient: odd plane sizes that straddle the 64 x 16 tile, uneven and
+    negative paddings, asymmetric filters with and without flip."""
+    from afcm_amd.torch_utils.ops import upfirdn2d as ufd
+    from oracle import aten_ops as ops
+    torch.manual_seed(11)
+    x = torch.randn(2, 3, 37, 71)
+    f = torch.randn(*fshape)
+    if dtype != torch.float32:
+        x = x.to(dtype).float()
+    for flip in (False, True):
+        xr = x.clone().requires_grad_(True)
+        ref = ops.upfirdn2d(xr, f, up=up, down=down, padding=pad, flip_filter=flip, gain=up ** 2)
+        r = torch.randn_like(ref)
+        gref, = torch.autograd.grad((ref * r).sum(), xr)
+        xg = x.cuda().to(dtype).requires_grad_(True)
+        got = ufd.upfirdn2d(xg, f.cuda(), up=up, down=down, padding=pad, flip_filter=flip, gain=up ** 2)
+        assert got.shape == ref.shape and got.dtype == dtype
+        ref = ref.detach()
+        scale = max(1.0, float(ref.abs().max()))
+        assert (got.detach().float().cpu() - ref).abs().max().item() <= tol * scale, (fshape, up, down, pad, flip)
+        ggot, = torch.autograd.grad((got.float() * r.cuda()).sum(), xg)
+        gscale = max(1.0, float(gref.abs().max()))
+        assert (ggot.float().cpu() - gref).abs().max().item() <= tol * gscale, (fshape, up, down, pad, flip, 'grad')
