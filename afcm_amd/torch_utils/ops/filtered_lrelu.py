@@ -96,7 +96,11 @@ def _mfma_workspace(a, fu_t, fd_t, x):
     return None if ent is None else ent[0]
 
 
-def _run(x, fu, fd, b, si, cfg, write_signs, want_plane_sum=False, oscale=None, skip=None, oscale2=None):
+class NoFusedKernel(Exception):
+    """Raised by _run(no_fallback=True) where the reference plugin returns return_code -1 (filtered_lrelu.cpp:52-56)."""
+
+
+def _run(x, fu, fd, b, si, cfg, write_signs, want_plane_sum=False, oscale=None, skip=None, oscale2=None, allow_mfma=True, no_fallback=False):
     """One launch of the op (C ABI afcm_filtered_lrelu, or the generic GPU path when there is no fused kernel).
     Returns (y, signs written or None, sign layout, per-plane output sums or None)."""
     up, down, px0, px1, py0, py1, gain, slope, clamp, flip_filter, sx, sy, si_layout = cfg
@@ -127,7 +131,7 @@ def _run(x, fu, fd, b, si, cfg, write_signs, want_plane_sum=False, oscale=None, 
     a.sign_mode = _lib.SIGNS_WRITE if write_signs else (_lib.SIGNS_READ if si is not None else _lib.SIGNS_NONE)
     # 16-bit activations: matrix-core kernels (signs in the row-quad layout); a given sign tensor fixes the family
     ws = None
-    if si is None or si_layout == 1:
+    if allow_mfma and (si is None or si_layout == 1):
         ws = _mfma_workspace(a, fu_t, fd_t, x)
         if si is not None and ws is None:
             raise RuntimeError('filtered_lrelu: sign tensor was written by the matrix-core kernels but this call has none')
@@ -173,6 +177,8 @@ def _run(x, fu, fd, b, si, cfg, write_signs, want_plane_sum=False, oscale=None, 
         span.end()
     layout = a.sign_layout
 
+    if rc == _lib.E_NOKERNEL and no_fallback:
+        raise NoFusedKernel()
     if rc == _lib.E_NOKERNEL:
         # Generic path, still on the GPU and still keeping only the packed signs for backward.
         warnings.warn('filtered_lrelu called with parameters that have no fused HIP kernel, using generic fallback', RuntimeWarning)

@@ -356,3 +356,61 @@ def test_upfirdn2d_small_filter_tile_kernel_vs_oracle(fshape, up, down, pad, dty
         ggot, = torch.autograd.grad((got.float() * r.cuda()).sum(), xg)
         gscale = max(1.0, float(gref.abs().max()))
         assert (ggot.float().cpu() - gref).abs().max().item() <= tol * gscale, (fshape, up, down, pad, flip, 'grad')
+
+
+@pytest.mark.parametrize('name', ['F1_up2_down2', 'F2_up2_down4', 'F3_up4_down2', 'F4_crop', 'F6_clamp', 'F7_flip_asym'])
+def test_plugin_surface_runs_the_reference_wrapper_call_sequence(name):
+    """custom_ops.get_plugin (the reference's loader signature) returns the pybind-level functions on the C ABI: the forward and
+    the transposed backward call exactly as SG3OPS/filtered_lrelu.py:206-217,252-263 issue them reproduce the golden y and dx."""
+    from afcm_amd.torch_utils import custom_ops
+    plugin = custom_ops.get_plugin(module_name='filtered_lrelu_plugin', sources=['filtered_lrelu.cpp', 'filtered_lrelu_wr.cu'],
+                                   headers=['filtered_lrelu.h', 'filtered_lrelu.cu'], source_dir='.', extra_cuda_cflags=['--use_fast_math'])
+    g = load_golden(name)
+    kw = _flrelu_args(g)
+    up, down, (px0, px1, py0, py1) = kw['up'], kw['down'], kw['padding']
+    gain, slope, flip = kw['gain'], kw['slope'], kw['flip_filter']
+    clamp = float('inf') if kw['clamp'] is None else kw['clamp']
+    x, fu, fd, r = _dev(g['x']), _dev(g['fu']), _dev(g['fd']), _dev(g['r'])
+    b = _dev(g['b']) if 'b' in g else torch.zeros(x.shape[1], device='cuda')
+    empty = torch.empty([0], dtype=torch.uint8, device='cuda')
+    y, so, rc = plugin.filtered_lrelu(x, fu, fd, b, empty, up, down, px0, px1, py0, py1, 0, 0, gain, slope, clamp, flip, True)
+    assert rc == 0 and so.dtype == torch.uint8 and so.ndim == 4
+    _close(y, g['y'], what=name + ' y (plugin)')
+    fuw, fdw = fu.shape[-1], fd.shape[-1]
+    fuh, fdh = (fu.shape[0], fd.shape[0]) if fu.ndim == 2 else (fuw, fdw)
+    pp = [(fuw - 1) + (fdw - 1) - px0, x.shape[3] * up - y.shape[3] * down + px0 - (up - 1),
+          (fuh - 1) + (fdh - 1) - py0, x.shape[2] * up - y.shape[2] * down + py0 - (up - 1)]
+    sx, sy = 0 - (fuw - 1) + px0, 0 - (fuh - 1) + py0
+    dx, so2, rc = plugin.filtered_lrelu(r.contiguous(), fd, fu, torch.zeros_like(b), so, down, up, *pp, sx, sy, gain * (up ** 2) / (down ** 2),
+                                        slope, float('inf'), not flip, False)
+    assert rc == 0 and so2.numel() == 0
+    _close(dx, g['dx'], what=name + ' dx (plugin)')
+
+
+def test_plugin_surface_upfirdn2d_bias_act_and_error_convention():
+    from afcm_amd.torch_utils import custom_ops
+    from afcm_amd.torch_utils.ops.bias_act import activation_funcs
+    torch.manual_seed(2)
+    x = torch.randn(2, 3, 17, 19, device='cuda')
+    f = torch.randn(3, 4, device='cuda')
+    up = custom_ops.get_plugin('upfirdn2d_plugin', sources=[], headers=[], source_dir='.')
+    y = up.upfirdn2d(x, f, 2, 2, 1, 1, 2, 1, 1, 2, False, 4.0)
+    from oracle import aten_ops as ops
+    ref = ops.upfirdn2d(x.cpu(), f.cpu(), up=2, down=1, padding=[2, 1, 1, 2], flip_filter=False, gain=4.0)
+    assert (y.cpu() - ref).abs().max().item() <= 2e-5
+    ba = custom_ops.get_plugin('bias_act_plugin', sources=[], headers=[], source_dir='.')
+    b = torch.randn(3, device='cuda')
+    spec = activation_funcs['lrelu']
+    e = torch.empty([0], device='cuda')
+    got = ba.bias_act(x, b, e, e, e, 0, 1, spec.cuda_idx, 0.2, 2 ** 0.5, 1.5)
+    want = (torch.nn.functional.leaky_relu(x + b.reshape(1, -1, 1, 1), 0.2) * 2 ** 0.5).clamp(-1.5, 1.5)
+    assert (got - want).abs().max().item() <= 1e-6
+    fl = custom_ops.get_plugin('filtered_lrelu_plugin')
+    # no fused kernel (a 40-tap filter pair): return code -1 and empty tensors, not an exception (filtered_lrelu.cpp:52-56)
+    big = torch.randn(40, device='cuda')
+    xs = torch.randn(1, 1, 64, 64, device='cuda')
+    y, so, rc = fl.filtered_lrelu(xs, big, big, torch.zeros(1, device='cuda'), torch.empty([0], dtype=torch.uint8, device='cuda'),
+                                  2, 2, 40, 39, 40, 39, 0, 0, 1.0, 0.2, float('inf'), False, True)
+    assert rc == -1 and y.numel() == 0 and so.numel() == 0
+    with pytest.raises(RuntimeError):
+        custom_ops.get_plugin('conv2d_gradfix_plugin')
