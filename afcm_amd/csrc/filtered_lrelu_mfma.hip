@@ -30,6 +30,7 @@
 // ([N*C][ceil(sh/4)][swq], code of row r at bits 2r..2r+1: bit0 = negative, bit1 = clamped); forward assembles them
 // from the packed X2 words, backward (the same kernel with up/down swapped) reads them with a funnel shift for the
 // row offset.
+#include <cstdlib>
 #include <type_traits>
 
 #include "common.h"
@@ -697,17 +698,24 @@ template <int UP, int DOWN> struct MfmaTile;
 template <> struct MfmaTile<2, 2> { static constexpr int TOW = 64, TOH = 32; };
 template <> struct MfmaTile<2, 4> { static constexpr int TOW = 32, TOH = 32; };
 template <> struct MfmaTile<4, 2> { static constexpr int TOW = 64, TOH = 32; };
+// Tall variant for planes of 33..48 output rows (the 36^2 / 38^2 planes of the 256^2 generator): ONE 48-row tile instead of two
+// 32-row tiles that are 12 % full in their second row.  The constant fragments do not depend on the tile shape (only on up,
+// down and the filters), so both variants share one prepared workspace; the sign layout is tile-independent.
+constexpr int kTallTOH = 48;
+static bool tall_tile(int up, int down, int yh) {
+    static const char* force = getenv("AFCM_FLRELU_TALL");      // tuning aid: 0 = never, 1 = by plane height (default)
+    if (force && atoi(force) == 0) return false;
+    return up == 2 && yh > 32 && yh <= kTallTOH;
+}
 
-template <typename T, int UP, int DOWN, int SIGN>
+template <typename T, int UP, int DOWN, int TOW, int TOH, int SIGN>
 static void launch_one(const FlreluMfmaParams& p, bool bias, dim3 grid, dim3 block, hipStream_t st) {
-    constexpr int TOW = MfmaTile<UP, DOWN>::TOW, TOH = MfmaTile<UP, DOWN>::TOH;
     if (bias) hipLaunchKernelGGL((flrelu_mfma_kernel<T, UP, DOWN, TOW, TOH, SIGN, true>), grid, block, 0, st, p);
     else hipLaunchKernelGGL((flrelu_mfma_kernel<T, UP, DOWN, TOW, TOH, SIGN, false>), grid, block, 0, st, p);
 }
 
-template <typename T, int UP, int DOWN>
-static int launch_mfma(const afcm_filtered_lrelu_args* a, hipStream_t st) {
-    constexpr int TOW = MfmaTile<UP, DOWN>::TOW, TOH = MfmaTile<UP, DOWN>::TOH;
+template <typename T, int UP, int DOWN, int TOW, int TOH>
+static int launch_mfma_tile(const afcm_filtered_lrelu_args* a, hipStream_t st) {
     typedef MfmaGeom<UP, DOWN, TOW, TOH> G;
     FlreluMfmaParams p;
     p.x = a->x; p.y = a->y; p.b = a->b; p.s = a->signs; p.ws = a->workspace; p.plane_sum = a->plane_sum;
@@ -728,11 +736,20 @@ static int launch_mfma(const afcm_filtered_lrelu_args* a, hipStream_t st) {
     dim3 grid((unsigned)blocks), block(64 * G::NG);
     const bool bias = a->b != nullptr;
     switch (a->sign_mode) {
-        case AFCM_SIGNS_NONE: launch_one<T, UP, DOWN, AFCM_SIGNS_NONE>(p, bias, grid, block, st); break;
-        case AFCM_SIGNS_WRITE: launch_one<T, UP, DOWN, AFCM_SIGNS_WRITE>(p, bias, grid, block, st); break;
-        default: launch_one<T, UP, DOWN, AFCM_SIGNS_READ>(p, bias, grid, block, st); break;
+        case AFCM_SIGNS_NONE: launch_one<T, UP, DOWN, TOW, TOH, AFCM_SIGNS_NONE>(p, bias, grid, block, st); break;
+        case AFCM_SIGNS_WRITE: launch_one<T, UP, DOWN, TOW, TOH, AFCM_SIGNS_WRITE>(p, bias, grid, block, st); break;
+        default: launch_one<T, UP, DOWN, TOW, TOH, AFCM_SIGNS_READ>(p, bias, grid, block, st); break;
     }
     return hip_status(hipGetLastError());
+}
+
+template <typename T, int UP, int DOWN>
+static int launch_mfma(const afcm_filtered_lrelu_args* a, hipStream_t st) {
+    constexpr int TOW = MfmaTile<UP, DOWN>::TOW, TOH = MfmaTile<UP, DOWN>::TOH;
+    if constexpr (UP == 2) {
+        if (tall_tile(UP, DOWN, a->yh)) return launch_mfma_tile<T, UP, DOWN, TOW, kTallTOH>(a, st);
+    }
+    return launch_mfma_tile<T, UP, DOWN, TOW, TOH>(a, st);
 }
 
 template <typename T, int UP, int DOWN>
@@ -761,8 +778,8 @@ int flrelu_mfma_supported(const afcm_filtered_lrelu_args* a) { return mfma_case(
 
 int flrelu_mfma_tiles(const afcm_filtered_lrelu_args* a) {
     switch (mfma_case(a)) {
-        case 22: return cdiv(a->yw, MfmaTile<2, 2>::TOW) * cdiv(a->yh, MfmaTile<2, 2>::TOH);
-        case 24: return cdiv(a->yw, MfmaTile<2, 4>::TOW) * cdiv(a->yh, MfmaTile<2, 4>::TOH);
+        case 22: return cdiv(a->yw, MfmaTile<2, 2>::TOW) * cdiv(a->yh, tall_tile(2, 2, a->yh) ? kTallTOH : MfmaTile<2, 2>::TOH);
+        case 24: return cdiv(a->yw, MfmaTile<2, 4>::TOW) * cdiv(a->yh, tall_tile(2, 4, a->yh) ? kTallTOH : MfmaTile<2, 4>::TOH);
         case 42: return cdiv(a->yw, MfmaTile<4, 2>::TOW) * cdiv(a->yh, MfmaTile<4, 2>::TOH);
         default: return 0;
     }

@@ -236,7 +236,8 @@ def test_bias_act_second_order(act):
 
 
 @pytest.mark.parametrize('dtype,tol', [(torch.float16, 6e-3), (torch.bfloat16, 4e-2)])
-@pytest.mark.parametrize('lname', ['encoder_1', 'encoder_4', 'L10_276_128', 'L13_256_64'])
+@pytest.mark.parametrize('lname', ['encoder_1', 'encoder_4', 'L10_276_128', 'L13_256_64',
+                                   'encoder_11', 'encoder_12', 'L3_52_512'])   # 36^2 / 38^2 planes: the one-tile 48-row variant, forward and transposed
 def test_filtered_lrelu_16bit_matrix_core_path(lname, dtype, tol):
     """16-bit activations run the matrix-core kernels (banded-Toeplitz MFMA): multi-tile planes, several (n, c) planes,
     forward and backward (sign codes in the row-quad layout) vs the fp32 CPU oracle on the same 16-bit inputs.
@@ -293,7 +294,7 @@ def test_filtered_lrelu_16bit_odd_width_uses_exact_kernels():
 
 
 @pytest.mark.parametrize('dtype,tol', [(torch.float16, 6e-3), (torch.bfloat16, 4e-2)])
-@pytest.mark.parametrize('lname', ['encoder_1', 'encoder_4', 'L10_276_128'])
+@pytest.mark.parametrize('lname', ['encoder_1', 'encoder_4', 'L10_276_128', 'encoder_11', 'encoder_12', 'L3_52_512'])
 def test_filtered_lrelu_16bit_matrix_core_clamp_and_no_bias(lname, dtype, tol):
     """Matrix-core kernels, the paths the generator-shaped test does not reach: (a) no bias (the generator's convs add it
     in their epilogue), (b) inputs scaled so the clamp fires in some tiles and not in others -- the wave-uniform exact path
