@@ -29,6 +29,37 @@ def _assert_shape(t, ref):
             raise AssertionError(f'Wrong size for dimension {idx}: got {size}, expected {want}')
 
 
+class _ScaledLinear(torch.autograd.Function):
+    """y = alpha * x @ w.t() (+ beta_b * b): the equalised-lr gains ride as the GEMMs' alpha in the forward AND in both
+    gradients (the framework's addmm backward multiplies each gradient by alpha in a separate launch; the reference's
+    ``w * weight_gain`` costs a pass over w each way, NET:97-100).  backward is made of differentiable ops (no
+    once_differentiable), so higher-order gradients still work."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, alpha, bias_gain):
+        ctx.save_for_backward(x, w)
+        ctx.gains = (float(alpha), float(bias_gain), b is not None)
+        wt = w.t()
+        if b is None:
+            return torch.addmm(x.new_empty([w.shape[0]]), x, wt, beta=0.0, alpha=float(alpha))
+        return torch.addmm(b.unsqueeze(0), x, wt, beta=float(bias_gain), alpha=float(alpha))
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        alpha, bias_gain, has_b = ctx.gains
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.addmm(g.new_empty([w.shape[1]]), g, w, beta=0.0, alpha=alpha)
+        if ctx.needs_input_grad[1]:
+            dw = torch.addmm(g.new_empty([w.shape[1]]), g.t(), x, beta=0.0, alpha=alpha)
+        if has_b and ctx.needs_input_grad[2]:
+            db = g.sum(0)
+            if bias_gain != 1:
+                db = db * bias_gain
+        return dx, dw, db, None, None
+
+
 class FullyConnectedLayer(torch.nn.Module):
     """Equalised-learning-rate dense layer (NET:69-104)."""
 
@@ -47,12 +78,19 @@ class FullyConnectedLayer(torch.nn.Module):
         b = self.bias
         if b is not None:
             b = b.to(x.dtype)
-            if self.bias_gain != 1:
+        w = self.weight.to(x.dtype)
+        if x.ndim == 2:
+            # the equalised-lr gains as GEMM alpha / beta: same values as x @ (w * gain).t() + b * bias_gain (NET:97-100)
+            if self.activation == 'linear':
+                return _ScaledLinear.apply(x, w, b, self.weight_gain, self.bias_gain)
+            if b is not None and self.bias_gain != 1:
                 b = b * self.bias_gain
+            return bias_act.bias_act(_ScaledLinear.apply(x, w, None, self.weight_gain, 1.0), b, act=self.activation)
+        if b is not None and self.bias_gain != 1:
+            b = b * self.bias_gain
+        w = w * self.weight_gain
         if self.activation == 'linear' and b is not None:
-            # the equalised-lr gain as the GEMM's alpha: same product as x @ (w * gain).t() (NET:97-100) without a pass over w
-            return torch.addmm(b.unsqueeze(0), x, self.weight.to(x.dtype).t(), alpha=float(self.weight_gain))
-        w = self.weight.to(x.dtype) * self.weight_gain
+            return torch.addmm(b.unsqueeze(0), x, w.t())
         return bias_act.bias_act(x.matmul(w.t()), b, act=self.activation)
 
     def extra_repr(self):

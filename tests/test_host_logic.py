@@ -70,3 +70,19 @@ def test_psnr_matches_oracle_definition():
     a = torch.rand(2, 1, 32, 32) * 2 - 1
     b = (a + 0.05 * torch.randn_like(a)).clamp(-1, 1)
     assert abs(synthetic.psnr(a, b) - ops.psnr(a, b)) < 1e-3
+
+
+def test_scaled_linear_matches_the_reference_dense_layer_arithmetic():
+    """FullyConnectedLayer's GEMM-alpha form (afcm_amd.networks_stylegan3._ScaledLinear) against the reference's
+    x @ (w * weight_gain).t() + b * bias_gain (NET:97-100), first- and second-order gradients."""
+    import torch
+    from afcm_amd.networks_stylegan3 import _ScaledLinear
+    torch.manual_seed(0)
+    x = torch.randn(5, 7, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(3, 7, dtype=torch.float64, requires_grad=True)
+    b = torch.randn(3, dtype=torch.float64, requires_grad=True)
+    y = _ScaledLinear.apply(x, w, b, 0.3, 0.01)
+    assert (y - (x @ (w * 0.3).t() + b * 0.01)).abs().max().item() < 1e-14
+    assert torch.autograd.gradcheck(lambda x, w, b: _ScaledLinear.apply(x, w, b, 0.3, 0.01), (x, w, b))
+    assert torch.autograd.gradgradcheck(lambda x, w, b: _ScaledLinear.apply(x, w, b, 0.3, 0.01), (x, w, b))
+    assert torch.autograd.gradcheck(lambda x, w: _ScaledLinear.apply(x, w, None, 0.3, 1.0), (x, w))
