@@ -14,3 +14,5 @@ HIP library is not built.  The CPU restatement used for parity checks lives in t
 ``oracle/`` package and is test infrastructure only.
 """
 __version__ = '0.1.0'
+
+from .torch_utils import op_registry as _op_registry  # noqa: E402,F401  (registers torch.ops.afcm.*; loads no native code)

@@ -739,6 +739,19 @@ __global__ __launch_bounds__(256) void plane_dot_kernel(float* __restrict__ out,
     const uint4* av = (const uint4*)(ap + head);
     const uint4* bv = bp ? (const uint4*)(bp + head) : nullptr;
     int i = threadIdx.x;
+    if (bv) {
+        // four 16-byte loads per operand in flight (128 B per lane) before the first use
+        for (; i + 768 < nv; i += 1024) {
+            V16 a0, a1, a2, a3, b0, b1, b2, b3;
+            a0.u = av[i]; a1.u = av[i + 256]; a2.u = av[i + 512]; a3.u = av[i + 768];
+            b0.u = bv[i]; b1.u = bv[i + 256]; b2.u = bv[i + 512]; b3.u = bv[i + 768];
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                s0 = fmaf(to_f32(a0.v[e]), to_f32(b0.v[e]), s0); s1 = fmaf(to_f32(a1.v[e]), to_f32(b1.v[e]), s1);
+                s0 = fmaf(to_f32(a2.v[e]), to_f32(b2.v[e]), s0); s1 = fmaf(to_f32(a3.v[e]), to_f32(b3.v[e]), s1);
+            }
+        }
+    }
     for (; i + 256 < nv; i += 512) {
         V16 a0, a1, b0, b1;
         a0.u = av[i]; a1.u = av[i + 256];
@@ -769,6 +782,63 @@ __global__ __launch_bounds__(256) void plane_dot_kernel(float* __restrict__ out,
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
     __syncthreads();
     if (threadIdx.x == 0) out[plane] = part[0] + part[1] + part[2] + part[3];
+}
+
+// Small planes (<= 16 KB): one WAVE per plane, four planes per workgroup -- a 36^2 plane is 180 16-byte pieces, so a
+// 256-thread workgroup per plane leaves most lanes without a load and the launch is bound by workgroup turnover.
+template <typename T>
+__global__ __launch_bounds__(256) void plane_dot_wave_kernel(float* __restrict__ out, const T* __restrict__ a, const T* __restrict__ b,
+                                                             long long planes, int hw) {
+    constexpr int E = 16 / (int)sizeof(T);
+    union V16 { uint4 u; T v[E]; };
+    const int lane = threadIdx.x & 63;
+    const long long plane = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (plane >= planes) return;
+    const long long off = plane * hw;
+    const T* ap = a + off;
+    const T* bp = b ? b + off : nullptr;
+    int head = (int)((E - (off % E)) % E);
+    if (head > hw) head = hw;
+    const int nv = (hw - head) / E;
+    float s0 = 0.f, s1 = 0.f;
+    {   // ragged ends: fewer than 2E <= 16 elements in total
+        const int tail0 = head + nv * E;
+        int i = -1;
+        if (lane < head) i = lane;
+        else if (lane - head < hw - tail0) i = tail0 + lane - head;
+        if (i >= 0) s0 = to_f32(ap[i]) * (bp ? to_f32(bp[i]) : 1.f);
+    }
+    const uint4* av = (const uint4*)(ap + head);
+    const uint4* bv = bp ? (const uint4*)(bp + head) : nullptr;
+    int i = lane;
+    for (; i + 64 < nv; i += 128) {
+        V16 a0, a1, b0, b1;
+        a0.u = av[i]; a1.u = av[i + 64];
+        if (bv) {
+            b0.u = bv[i]; b1.u = bv[i + 64];
+#pragma unroll
+            for (int e = 0; e < E; e++) { s0 = fmaf(to_f32(a0.v[e]), to_f32(b0.v[e]), s0); s1 = fmaf(to_f32(a1.v[e]), to_f32(b1.v[e]), s1); }
+        } else {
+#pragma unroll
+            for (int e = 0; e < E; e++) { s0 += to_f32(a0.v[e]); s1 += to_f32(a1.v[e]); }
+        }
+    }
+    if (i < nv) {
+        V16 a0, b0;
+        a0.u = av[i];
+        if (bv) {
+            b0.u = bv[i];
+#pragma unroll
+            for (int e = 0; e < E; e++) s0 = fmaf(to_f32(a0.v[e]), to_f32(b0.v[e]), s0);
+        } else {
+#pragma unroll
+            for (int e = 0; e < E; e++) s0 += to_f32(a0.v[e]);
+        }
+    }
+    float s = s0 + s1;
+#pragma unroll
+    for (int off2 = 32; off2 > 0; off2 >>= 1) s += __shfl_down(s, off2, 64);
+    if (lane == 0) out[plane] = s;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1859,13 +1929,20 @@ extern "C" int afcm_plane_dot(float* out, const void* a, const void* b, int32_t 
     AFCM_REQUIRE(out != nullptr && a != nullptr && planes > 0 && hw > 0, "plane_dot: empty input");
     AFCM_REQUIRE(planes < (1ll << 31), "plane_dot: too many planes");
     AFCM_REQUIRE((((uintptr_t)a | (uintptr_t)b) & 15) == 0, "plane_dot: operands must be 16-byte aligned");
-    dim3 grid((unsigned)planes), block(256);
     hipStream_t st = (hipStream_t)stream;
+    const int esize = dtype == AFCM_F32 ? 4 : 2;
+    static const char* force = getenv("AFCM_PLANE_DOT_WAVE");     // tuning aid: 0 = always one workgroup per plane
+    const bool per_wave = (long long)hw * esize <= 16384 && !(force && atoi(force) == 0);
+    dim3 grid((unsigned)(per_wave ? (planes + 3) / 4 : planes)), block(256);
+#define AFCM_PD(T) do { \
+        if (per_wave) hipLaunchKernelGGL((plane_dot_wave_kernel<T>), grid, block, 0, st, out, (const T*)a, (const T*)b, (long long)planes, hw); \
+        else hipLaunchKernelGGL((plane_dot_kernel<T>), grid, block, 0, st, out, (const T*)a, (const T*)b, (long long)planes, hw); } while (0)
     switch (dtype) {
-        case AFCM_F32: hipLaunchKernelGGL((plane_dot_kernel<float>), grid, block, 0, st, out, (const float*)a, (const float*)b, (long long)planes, hw); break;
-        case AFCM_F16: hipLaunchKernelGGL((plane_dot_kernel<f16_t>), grid, block, 0, st, out, (const f16_t*)a, (const f16_t*)b, (long long)planes, hw); break;
-        case AFCM_BF16: hipLaunchKernelGGL((plane_dot_kernel<bf16_t>), grid, block, 0, st, out, (const bf16_t*)a, (const bf16_t*)b, (long long)planes, hw); break;
+        case AFCM_F32: AFCM_PD(float); break;
+        case AFCM_F16: AFCM_PD(f16_t); break;
+        case AFCM_BF16: AFCM_PD(bf16_t); break;
         default: set_error("plane_dot: bad dtype"); return AFCM_E_INVALID;
     }
+#undef AFCM_PD
     return hip_status(hipGetLastError());
 }

@@ -86,3 +86,21 @@ def test_ops_refuse_cpu_tensors():
                lambda: upfirdn2d.upfirdn2d(x, None)):
         with pytest.raises(RuntimeError, match='no CPU'):
             fn()
+
+
+def test_operator_library_is_registered_with_the_plugin_schemas():
+    """torch.ops.afcm.* exist after `import afcm_amd` (no native code needed to register), carry the plugins' argument lists
+    (filtered_lrelu.cpp:16-18,213; upfirdn2d.cpp:16; bias_act.cpp:32) and have no CPU kernel."""
+    import pytest
+    import torch
+    import afcm_amd  # noqa: F401
+    from afcm_amd.torch_utils import op_registry
+    for name in op_registry.OPS:
+        assert hasattr(torch.ops.afcm, name), name
+    s = str(torch.ops.afcm.filtered_lrelu.default._schema)
+    assert 'Tensor si, int up, int down, int px0, int px1, int py0, int py1, int sx, int sy, float gain, float slope, float clamp, bool flip_filter, bool writeSigns' in s
+    assert '-> (Tensor, Tensor, int)' in s
+    assert 'Tensor(a!) x' in str(torch.ops.afcm.filtered_lrelu_act_.default._schema)      # the in-place mutation is declared
+    assert 'int grad, int dim, int act, float alpha, float gain, float clamp' in str(torch.ops.afcm.bias_act.default._schema)
+    with pytest.raises(NotImplementedError):
+        torch.ops.afcm.upfirdn2d(torch.zeros(1, 1, 4, 4), torch.ones(1, 1), 1, 1, 1, 1, 0, 0, 0, 0, False, 1.0)

@@ -235,7 +235,7 @@ def test_fused_modulation_coefficients_match_eager(demod, dims):
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16])
-@pytest.mark.parametrize('hw', [(7, 7), (1, 3), (38, 38), (278, 278), (5, 64)])
+@pytest.mark.parametrize('hw', [(7, 7), (1, 3), (38, 38), (278, 278), (5, 64), (86, 86), (150, 150)])
 def test_plane_dot_matches_torch(dtype, hw):
     """afcm_plane_dot: per-plane <a, b> and plane sums; odd plane sizes put every plane on a different 16-byte phase."""
     from afcm_amd.torch_utils.ops.conv2d import plane_dot

@@ -415,3 +415,72 @@ def test_plugin_surface_upfirdn2d_bias_act_and_error_convention():
     assert rc == -1 and y.numel() == 0 and so.numel() == 0
     with pytest.raises(RuntimeError):
         custom_ops.get_plugin('conv2d_gradfix_plugin')
+
+
+@pytest.mark.parametrize('name', ['F1_up2_down2', 'F3_up4_down2', 'F6_clamp'])
+def test_registered_custom_ops_filtered_lrelu(name):
+    """torch.ops.afcm.filtered_lrelu (dispatcher-registered, plugin argument list of filtered_lrelu.cpp:16-18): forward with sign
+    write and the transposed backward with sign read reproduce the golden y and dx."""
+    import afcm_amd  # noqa: F401  (registers the operator library)
+    g = load_golden(name)
+    kw = _flrelu_args(g)
+    up, down, (px0, px1, py0, py1) = kw['up'], kw['down'], kw['padding']
+    gain, slope, flip = kw['gain'], kw['slope'], kw['flip_filter']
+    clamp = float('inf') if kw['clamp'] is None else kw['clamp']
+    x, fu, fd, r = _dev(g['x']), _dev(g['fu']), _dev(g['fd']), _dev(g['r'])
+    b = _dev(g['b']) if 'b' in g else torch.zeros(x.shape[1], device='cuda')
+    empty = torch.empty([0], dtype=torch.uint8, device='cuda')
+    y, so, rc = torch.ops.afcm.filtered_lrelu(x, fu, fd, b, empty, up, down, px0, px1, py0, py1, 0, 0, gain, slope, clamp, flip, True)
+    assert rc == 0
+    _close(y, g['y'], what=name + ' y (torch.ops.afcm)')
+    fuw, fdw = fu.shape[-1], fd.shape[-1]
+    pp = [(fuw - 1) + (fdw - 1) - px0, x.shape[3] * up - y.shape[3] * down + px0 - (up - 1),
+          (fuw - 1) + (fdw - 1) - py0, x.shape[2] * up - y.shape[2] * down + py0 - (up - 1)]
+    dx, _, rc = torch.ops.afcm.filtered_lrelu(r.contiguous(), fd, fu, torch.zeros_like(b), so, down, up, *pp, px0 - (fuw - 1), py0 - (fuw - 1),
+                                              gain * (up ** 2) / (down ** 2), slope, float('inf'), not flip, False)
+    assert rc == 0
+    _close(dx, g['dx'], what=name + ' dx (torch.ops.afcm)')
+
+
+def test_registered_custom_ops_upfirdn2d_bias_act_conv():
+    """torch.ops.afcm.{upfirdn2d, bias_act, conv2d_pack_weights, conv2d, conv2d_wgrad} against the CPU oracle / aten; CPU tensors
+    are refused by the dispatcher (no CPU kernel is registered)."""
+    import afcm_amd  # noqa: F401
+    from afcm_amd.torch_utils.ops.bias_act import activation_funcs
+    from oracle import aten_ops as ops
+    torch.manual_seed(4)
+    x = torch.randn(2, 3, 17, 19, device='cuda')
+    f = torch.randn(3, 4, device='cuda')
+    y = torch.ops.afcm.upfirdn2d(x, f, 2, 2, 1, 1, 2, 1, 1, 2, False, 4.0)
+    ref = ops.upfirdn2d(x.cpu(), f.cpu(), up=2, down=1, padding=[2, 1, 1, 2], flip_filter=False, gain=4.0)
+    assert (y.cpu() - ref).abs().max().item() <= 2e-5
+    b = torch.randn(3, device='cuda')
+    e = torch.empty([0], device='cuda')
+    got = torch.ops.afcm.bias_act(x, b, e, e, e, 0, 1, activation_funcs['lrelu'].cuda_idx, 0.2, 2 ** 0.5, 1.5)
+    want = (torch.nn.functional.leaky_relu(x + b.reshape(1, -1, 1, 1), 0.2) * 2 ** 0.5).clamp(-1.5, 1.5)
+    assert (got - want).abs().max().item() <= 1e-6
+    # in-place activation with sign write (filtered_lrelu.cpp:213): x is mutated, the schema declares it
+    xa = torch.randn(1, 2, 8, 20, device='cuda')
+    want_a = (torch.nn.functional.leaky_relu(xa, 0.2) * 1.5).clamp(-1.0, 1.0)
+    so = torch.ops.afcm.filtered_lrelu_act_(xa, torch.empty([0], dtype=torch.uint8, device='cuda'), 0, 0, 1.5, 0.2, 1.0, True)
+    assert so.dtype == torch.uint8 and (xa - want_a).abs().max().item() <= 1e-6
+    # convolution triple, fp32 (exact MFMA path)
+    xc = torch.randn(2, 5, 12, 14, device='cuda')
+    w = torch.randn(7, 5, 3, 3, device='cuda')
+    osc = torch.rand(2, 7, device='cuda') + 0.5
+    ob = torch.randn(7, device='cuda')
+    wp, rows_pad = torch.ops.afcm.conv2d_pack_weights(w, torch.float32, 0)
+    yc = torch.ops.afcm.conv2d(xc, wp, osc, ob, 7, 3, 2, rows_pad)
+    refc = torch.nn.functional.conv2d(xc.cpu().double(), w.cpu().double(), padding=2) * osc.cpu().double()[:, :, None, None] + ob.cpu().double()[None, :, None, None]
+    _close(yc, refc.float(), tol=1e-5, what='afcm::conv2d')
+    dy = torch.randn_like(yc)
+    wpt, rows_pad_t = torch.ops.afcm.conv2d_pack_weights(w, torch.float32, 1)
+    dxc = torch.ops.afcm.conv2d(dy, wpt, None, None, 5, 3, 0, rows_pad_t)
+    xr = xc.cpu().double().requires_grad_(True)
+    wr = w.cpu().double().requires_grad_(True)
+    torch.nn.functional.conv2d(xr, wr, padding=2).backward(dy.cpu().double())
+    _close(dxc, xr.grad.float(), tol=1e-5, what='afcm::conv2d (data gradient)')
+    dw = torch.ops.afcm.conv2d_wgrad(dy, xc, 7, 5, 3, 2)
+    _close(dw, wr.grad.float(), tol=1e-5, what='afcm::conv2d_wgrad')
+    with pytest.raises(NotImplementedError):
+        torch.ops.afcm.upfirdn2d(x.cpu(), f.cpu(), 1, 1, 1, 1, 0, 0, 0, 0, False, 1.0)
