@@ -237,7 +237,7 @@ def test_bias_act_second_order(act):
 
 @pytest.mark.parametrize('dtype,tol', [(torch.float16, 6e-3), (torch.bfloat16, 4e-2)])
 @pytest.mark.parametrize('lname', ['encoder_1', 'encoder_4', 'L10_276_128', 'L13_256_64',
-                                   'encoder_11', 'encoder_12', 'L3_52_512'])   # 36^2 / 38^2 planes: the one-tile 48-row variant, forward and transposed
+                                   'encoder_11', 'encoder_12', 'L3_52_512', 'encoder_9', 'L5_84_512'])   # 52 / 54-column down-4 planes; 36^2 / 38^2 planes: the one-tile 48-row variant, forward and transposed
 def test_filtered_lrelu_16bit_matrix_core_path(lname, dtype, tol):
     """16-bit activations run the matrix-core kernels (banded-Toeplitz MFMA): multi-tile planes, several (n, c) planes,
     forward and backward (sign codes in the row-quad layout) vs the fp32 CPU oracle on the same 16-bit inputs.
