@@ -16,11 +16,12 @@ TINY = dict(channel_base=256, channel_max=8, num_layers=14, num_critical=2, marg
 
 def _build(res, dtype=torch.float32):
     from afcm_amd.networks_stylegan3 import Stylegan3Generator
+    tiny = dict(TINY, channel_base=1024) if res == 512 else TINY         # G3_tiny512 (tools/gen_golden_512.py)
     return Stylegan3Generator(z_dim=32, c_dim=1, w_dim=32, img_resolution=res, img_channels_in=4, img_channels_out=1,
-                              mapping_kwargs=dict(num_layers=2), synthesis_kwargs=dict(TINY, compute_dtype=dtype))
+                              mapping_kwargs=dict(num_layers=2), synthesis_kwargs=dict(tiny, compute_dtype=dtype))
 
 
-@pytest.mark.parametrize('name,res', [('G1_tiny128', 128), ('G2_tiny256', 256)])
+@pytest.mark.parametrize('name,res', [('G1_tiny128', 128), ('G2_tiny256', 256), ('G3_tiny512', 512)])
 def test_generator_matches_reference_golden(name, res):
     g = load_golden(name)
     G = _build(res).eval()
@@ -74,15 +75,16 @@ def test_state_dict_keys_match_reference_full_width():
     assert sum(p.numel() for p in G.parameters()) == int(g['nparams'])
 
 
-@pytest.mark.parametrize('dtype,tol_db', [(torch.bfloat16, 30.0), (torch.float16, 40.0)])
-def test_generator_16bit_vs_fp32_oracle(dtype, tol_db):
-    """bf16/f16 activation stream vs the fp32 CPU oracle on the same weights: report max-abs and PSNR.
-    (bf16 is new capability; the stated bound is PSNR >= 30 dB / 40 dB between the two outputs.)"""
+@pytest.mark.parametrize('name,res,dtype,tol_db', [('G1_tiny128', 128, torch.bfloat16, 30.0), ('G1_tiny128', 128, torch.float16, 40.0),
+                                                   ('G3_tiny512', 512, torch.float16, 40.0), ('G3_tiny512', 512, torch.bfloat16, 30.0)])
+def test_generator_16bit_vs_fp32_oracle(name, res, dtype, tol_db):
+    """bf16/f16 activation stream vs the reference's fp32 output on the same weights: report max-abs and PSNR.
+    (bf16 is new capability; the stated bound is PSNR >= 30 dB / 40 dB between the two outputs.)  The 512^2 rows are BASELINE
+    config 5's shape (fp16, planes up to 532^2) on the matrix-core kernels."""
     from afcm_amd import synthetic
-    from oracle import generator as ogen
-    g = load_golden('G1_tiny128')
+    g = load_golden(name)
     sd = {k[3:]: torch.from_numpy(np.array(v)) for k, v in g.items() if k.startswith('sd/')}
-    G = _build(128, dtype).eval()
+    G = _build(res, dtype).eval()
     G.load_state_dict(sd)
     G = G.cuda()
     z, c, x = (torch.from_numpy(g[k]).cuda() for k in ('z', 'c', 'x'))

@@ -103,11 +103,11 @@ def test_modulated_conv2d(name):
 TINY = dict(channel_base=256, channel_max=8)
 
 
-@pytest.mark.parametrize('name,res', [('G1_tiny128', 128), ('G2_tiny256', 256)])
+@pytest.mark.parametrize('name,res', [('G1_tiny128', 128), ('G2_tiny256', 256), ('G3_tiny512', 512)])
 def test_generator(name, res):
     g = load_golden(name)
     sd = {k[3:]: _t(v) for k, v in g.items() if k.startswith('sd/')}
-    pl = ogen.plan(res, 4, 1, TINY)
+    pl = ogen.plan(res, 4, 1, dict(TINY, channel_base=1024) if res == 512 else TINY)
     # the plan must reproduce the reference's layer names and the filters stored in its state dict
     names = [L['name'] for L in pl['enc'] + pl['dec']]
     assert names == [str(n) for n in g['layer_names']]
