@@ -1,6 +1,8 @@
 """End-to-end generator parity on the GPU: the drop-in Stylegan3Generator on the HIP kernels vs golden
 outputs/gradients captured from the real reference (G1: 128^2 batch 2 -- BASELINE config 1's network shape at
 reduced width; G2: 256^2), and vs the CPU oracle on a fresh random network.  fp32 bar: <= 1e-3 max-abs."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -174,3 +176,55 @@ def test_forward_ema_and_sliding_window_prediction_on_the_reference_weights(tmp_
     out = SlidingWindowPredictor(out_channels=1, patch_halo=(0, 0, 0)).run(model_fn, vol, (1, 128, 128), (1, 128, 128), batch_size=2)
     assert out.shape == (1, 3, 128, 128)
     assert np.abs(out[0, 0] - g['y'][0, 0]).max() <= 1e-3 and np.abs(out[0, 2] - g['y'][0, 0]).max() <= 1e-3
+
+
+def test_full_width_generator_fp32_matches_oracle():
+    """BASELINE's full-width 256^2 generator (58.5 M parameters, the bench configuration's network), fp32, eval mode, one
+    MR-like slice: the HIP forward against the CPU oracle (itself pinned to the reference's golden vectors) on the SAME
+    state dict -- the north-star bar, <= 1e-3 max-abs, at full channel width (every layer of the SURVEY section 8 table at
+    its real Cin / Cout).  Also bf16 on the same weights: PSNR against the fp32 oracle output."""
+    from afcm_amd import synthetic
+    from afcm_amd.layer_schedule import DEFAULT_SYNTHESIS_KWARGS
+    from afcm_amd.networks_stylegan3 import Stylegan3Generator
+    from oracle import generator as ogen
+    torch.manual_seed(0)
+    with torch.device('cpu'):
+        G = Stylegan3Generator(z_dim=512, c_dim=1, w_dim=512, img_resolution=256, img_channels_in=4, img_channels_out=1,
+                               mapping_kwargs=dict(num_layers=8), synthesis_kwargs=dict(DEFAULT_SYNTHESIS_KWARGS)).eval()
+    sd = {k: v.detach().clone() for k, v in G.state_dict().items()}
+    real_A, _, z, c = synthetic.generator_inputs(1, size=256, seed=3)
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    # gradients of a fixed random cotangent w.r.t. one parameter of every kind (relative L2: leaky-ReLU kinks, see above)
+    names = ['synthesis.encoder_0.weight', 'synthesis.encoder_7.weight', 'synthesis.encoder_7.bias', 'synthesis.L3_52_512.weight',
+             'synthesis.L3_52_512.affine.weight', 'synthesis.L10_276_128.bias', 'synthesis.L14_256_1.weight', 'mapping.fc3.weight',
+             'synthesis.fc_in.weight']
+    osd = dict(sd)
+    oparams = {k: sd[k].clone().requires_grad_(True) for k in names}
+    osd.update(oparams)
+    r = torch.randn(1, 1, 256, 256)
+    ref = ogen.generator(osd, ogen.plan(256, 4, 1, {}), z, c, real_A, mapping_layers=8)
+    gref = torch.autograd.grad((ref * r).sum(), [oparams[k] for k in names])
+    ref = ref.detach()
+    G = G.cuda()
+    yg = G(z.cuda(), c.cuda(), real_A.cuda())
+    gparams = dict(G.named_parameters())
+    ggot = torch.autograd.grad((yg * r.cuda()).sum(), [gparams[k] for k in names])
+    y = yg.detach().cpu()
+    assert y.shape == ref.shape == (1, 1, 256, 256)
+    err = (y - ref).abs().max().item()
+    scale = ref.abs().max().item()
+    print(f'full-width fp32: max-abs {err:.3e} (output scale {scale:.3g})')
+    assert err <= 1e-3, f'full-width forward max-abs {err:.3e}'
+    for k, a, b in zip(names, ggot, gref):
+        rel = ((a.cpu().double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
+        print(f'  grad {k}: relative L2 {rel:.2e}')
+        assert rel <= 1e-2, f'full-width gradient {k}: relative L2 {rel:.3e}'
+    G16 = Stylegan3Generator(z_dim=512, c_dim=1, w_dim=512, img_resolution=256, img_channels_in=4, img_channels_out=1,
+                             mapping_kwargs=dict(num_layers=8),
+                             synthesis_kwargs=dict(DEFAULT_SYNTHESIS_KWARGS, compute_dtype=torch.bfloat16)).eval()
+    G16.load_state_dict(sd)
+    with torch.no_grad():
+        y16 = G16.cuda()(z.cuda(), c.cuda(), real_A.cuda()).float().cpu()
+    ps = synthetic.psnr(y16, ref)
+    print(f'full-width bf16: max-abs {(y16 - ref).abs().max().item():.3e}, PSNR vs fp32 oracle {ps:.1f} dB')
+    assert ps >= 30.0
