@@ -1736,6 +1736,41 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(float* __restrict__ d
     }
 }
 
+// Same reduction for numel % 4 == 0 with 16-byte loads and the split index spread over the workgroup: 256 threads =
+// COLS float4 columns x (256 / COLS) split groups, group partials summed through LDS.  A 64 -> 64 layer has 36,864 outputs and 256
+// splits (151 MB of partials): one thread per output is 144 workgroups of serial 4-byte loads on a 256-CU chip.
+template <int COLS>
+__global__ __launch_bounds__(256) void wgrad_reduce4_kernel(float* __restrict__ dw, const float* __restrict__ part, long long numel4, int splits) {
+    constexpr int GROUPS = 256 / COLS;
+    typedef __attribute__((ext_vector_type(4))) float f32x4v;
+    __shared__ f32x4v red[GROUPS][COLS];
+    const int col = threadIdx.x % COLS, grp = threadIdx.x / COLS;
+    const long long c4 = (long long)blockIdx.x * COLS + col;
+    f32x4v s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+    if (c4 < numel4) {
+        const f32x4v* src = (const f32x4v*)part + c4;
+        int k = grp;
+        for (; k + 3 * GROUPS < splits; k += 4 * GROUPS) {
+            const f32x4v v0 = src[(size_t)k * numel4], v1 = src[(size_t)(k + GROUPS) * numel4];
+            const f32x4v v2 = src[(size_t)(k + 2 * GROUPS) * numel4], v3 = src[(size_t)(k + 3 * GROUPS) * numel4];
+            s0 += v0; s1 += v1; s0 += v2; s1 += v3;
+        }
+        for (; k < splits; k += GROUPS) s0 += src[(size_t)k * numel4];
+    }
+    s0 += s1;
+    if (GROUPS > 1) {
+        red[grp][col] = s0;
+        __syncthreads();
+        if (grp == 0 && c4 < numel4) {
+#pragma unroll
+            for (int g = 1; g < GROUPS; g++) s0 += red[g][col];
+            ((f32x4v*)dw)[c4] = s0;
+        }
+    } else if (c4 < numel4) {
+        ((f32x4v*)dw)[c4] = s0;
+    }
+}
+
 static void choose_tile(int P, int Q, int KS, int* TH, int* TW, int* PWL) {
     // Tile of TH x TW output pixels with TH*TW <= 256 slots and an LDS patch (TH+KS-1) x round4(TW+KS) <= kPatchMax,
     // chosen to maximise the fraction of useful slots.
@@ -1901,7 +1936,14 @@ extern "C" int afcm_conv2d_wgrad(float* dw, float* workspace, const void* dy, co
     long long rb = (numel + 255) / 256;
     if (rb > 2048) rb = 2048;
     // splits beyond the last populated one were never launched with work: they still wrote zeros (acc = 0)
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)rb), dim3(256), 0, st, dw, (const float*)workspace, numel, p.splits);
+    if ((numel & 3) == 0 && (((uintptr_t)dw | (uintptr_t)workspace) & 15) == 0) {
+        const long long n4 = numel / 4;
+        if (p.splits >= 64) hipLaunchKernelGGL(wgrad_reduce4_kernel<16>, dim3((unsigned)cdiv(n4, 16)), dim3(256), 0, st, dw, (const float*)workspace, n4, p.splits);
+        else if (p.splits >= 8) hipLaunchKernelGGL(wgrad_reduce4_kernel<64>, dim3((unsigned)cdiv(n4, 64)), dim3(256), 0, st, dw, (const float*)workspace, n4, p.splits);
+        else hipLaunchKernelGGL(wgrad_reduce4_kernel<256>, dim3((unsigned)cdiv(n4, 256)), dim3(256), 0, st, dw, (const float*)workspace, n4, p.splits);
+    } else {
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)rb), dim3(256), 0, st, dw, (const float*)workspace, numel, p.splits);
+    }
     return hip_status(hipGetLastError());
 }
 
