@@ -682,6 +682,43 @@ __global__ __launch_bounds__(256) void conv2d_pack_kernel(T* __restrict__ dst, c
     }
 }
 
+// Same layout, one work item = (row, 8 consecutive columns) x ALL taps: the 8 x k*k source values of the forward mode are one
+// contiguous run of w (8 runs of k*k in the transposed mode), every tap leaves as one 8-element store, and the index
+// arithmetic is paid once per 72 elements instead of once per element.  blockIdx.y selects the mode, so the forward and the
+// data-gradient images of a layer come out of ONE launch (dst of a mode may be null).
+template <typename T, int KK>
+__global__ __launch_bounds__(256) void conv2d_pack8_kernel(T* __restrict__ dst0, T* __restrict__ dst1, const float* __restrict__ w, int O,
+                                                           int I, int rows_pad0, int rows_pad1, int BK) {
+    const int mode = blockIdx.y;
+    T* __restrict__ dst = mode == 0 ? dst0 : dst1;
+    if (dst == nullptr) return;
+    const int rows = mode == 0 ? O : I, cols = mode == 0 ? I : O, rows_pad = mode == 0 ? rows_pad0 : rows_pad1;
+    const int G = BK / 8, nkc = cdiv(cols, BK);
+    const int total = nkc * rows_pad * G;
+    struct alignas(8 * sizeof(T)) Out { T v[8]; };
+    for (int item = blockIdx.x * blockDim.x + threadIdx.x; item < total; item += gridDim.x * blockDim.x) {
+        const int half = item % G;
+        const int t = item / G;
+        const int row = t % rows_pad, kc = t / rows_pad;
+        const int col0 = kc * BK + half * 8;
+        float v[8][KK];
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            const bool ok = row < rows && col0 + c < cols;
+            const float* src = mode == 0 ? w + ((size_t)row * I + (col0 + c)) * KK : w + ((size_t)(col0 + c) * I + row) * KK;
+#pragma unroll
+            for (int tp = 0; tp < KK; tp++) v[c][tp] = ok ? src[tp] : 0.f;
+        }
+#pragma unroll
+        for (int tap = 0; tap < KK; tap++) {
+            Out o;
+#pragma unroll
+            for (int c = 0; c < 8; c++) o.v[c] = from_f32<T>(v[c][mode == 0 ? tap : KK - 1 - tap]);
+            *(Out*)(dst + (((size_t)kc * KK + tap) * rows_pad + row) * BK + half * 8) = o;
+        }
+    }
+}
+
 // 4 consecutive elements as one vector access (8 B for 16-bit types, 16 B for fp32); planes are 4-element aligned when hw % 4 == 0
 template <typename T> struct Vec4 { T v[4]; } __attribute__((aligned(sizeof(T) * 4)));
 
@@ -1816,27 +1853,42 @@ using namespace afcm;
 
 extern "C" int afcm_conv2d_block_k(int32_t dtype) { return dtype == AFCM_F32 ? ConvCfg<float>::BK : ConvCfg<bf16_t>::BK; }
 
+template <typename T>
+static void launch_pack8(void* dst0, void* dst1, const float* w, int cout, int cin, int ks, int rows_pad0, int rows_pad1, int BK, hipStream_t st) {
+    const int G = BK / 8;
+    const int items0 = dst0 ? cdiv(cin, BK) * rows_pad0 * G : 0, items1 = dst1 ? cdiv(cout, BK) * rows_pad1 * G : 0;
+    int blocks = cdiv(items0 > items1 ? items0 : items1, 256);
+    if (blocks > 2048) blocks = 2048;
+    dim3 grid((unsigned)blocks, 2), block(256);
+    if (ks == 3) hipLaunchKernelGGL((conv2d_pack8_kernel<T, 9>), grid, block, 0, st, (T*)dst0, (T*)dst1, w, cout, cin, rows_pad0, rows_pad1, BK);
+    else hipLaunchKernelGGL((conv2d_pack8_kernel<T, 1>), grid, block, 0, st, (T*)dst0, (T*)dst1, w, cout, cin, rows_pad0, rows_pad1, BK);
+}
+
+extern "C" int afcm_conv2d_pack_weights2(void* dst_fwd, void* dst_dgrad, const float* w, int32_t dtype, int32_t cout, int32_t cin, int32_t ks,
+                                         int32_t rows_pad_fwd, int32_t rows_pad_dgrad, void* stream) {
+    AFCM_REQUIRE(w != nullptr && (dst_fwd != nullptr || dst_dgrad != nullptr), "conv2d_pack_weights: null pointer");
+    AFCM_REQUIRE(dtype == AFCM_F32 || dtype == AFCM_F16 || dtype == AFCM_BF16, "dtype must be float32, float16 or bfloat16");
+    AFCM_REQUIRE(ks == 1 || ks == 3, "only 1x1 and 3x3 kernels are supported");
+    AFCM_REQUIRE(cout > 0 && cin > 0, "conv2d_pack_weights: empty weights");
+    AFCM_REQUIRE(dst_fwd == nullptr || (rows_pad_fwd >= cout && rows_pad_fwd % 64 == 0), "rows_pad must be a multiple of 64 covering the rows");
+    AFCM_REQUIRE(dst_dgrad == nullptr || (rows_pad_dgrad >= cin && rows_pad_dgrad % 64 == 0), "rows_pad must be a multiple of 64 covering the rows");
+    AFCM_REQUIRE((((uintptr_t)dst_fwd | (uintptr_t)dst_dgrad) & 31) == 0, "conv2d_pack_weights: destinations must be 32-byte aligned");
+    const int BK = afcm_conv2d_block_k(dtype);
+    hipStream_t st = (hipStream_t)stream;
+    switch (dtype) {
+        case AFCM_F32: launch_pack8<float>(dst_fwd, dst_dgrad, w, cout, cin, ks, rows_pad_fwd, rows_pad_dgrad, BK, st); break;
+        case AFCM_F16: launch_pack8<f16_t>(dst_fwd, dst_dgrad, w, cout, cin, ks, rows_pad_fwd, rows_pad_dgrad, BK, st); break;
+        default: launch_pack8<bf16_t>(dst_fwd, dst_dgrad, w, cout, cin, ks, rows_pad_fwd, rows_pad_dgrad, BK, st); break;
+    }
+    return hip_status(hipGetLastError());
+}
+
 extern "C" int afcm_conv2d_pack_weights(void* dst, const float* w, int32_t dtype, int32_t cout, int32_t cin, int32_t ks,
                                         int32_t mode, int32_t rows_pad, void* stream) {
     AFCM_REQUIRE(dst != nullptr && w != nullptr, "conv2d_pack_weights: null pointer");
-    AFCM_REQUIRE(dtype == AFCM_F32 || dtype == AFCM_F16 || dtype == AFCM_BF16, "dtype must be float32, float16 or bfloat16");
-    AFCM_REQUIRE(ks == 1 || ks == 3, "only 1x1 and 3x3 kernels are supported");
     AFCM_REQUIRE(mode == 0 || mode == 1, "mode must be 0 (forward) or 1 (data gradient)");
-    const int rows = mode == 0 ? cout : cin, cols = mode == 0 ? cin : cout;
-    AFCM_REQUIRE(rows_pad >= rows && rows_pad % 64 == 0, "rows_pad must be a multiple of 64 covering the rows");
-    const int BK = afcm_conv2d_block_k(dtype);
-    const int nkc = cdiv(cols, BK);
-    const long long total = (long long)nkc * ks * ks * rows_pad * BK;
-    long long blocks = (total + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
-    dim3 grid((unsigned)blocks), block(256);
-    hipStream_t st = (hipStream_t)stream;
-    switch (dtype) {
-        case AFCM_F32: hipLaunchKernelGGL((conv2d_pack_kernel<float>), grid, block, 0, st, (float*)dst, w, cout, cin, ks, rows, cols, rows_pad, BK, nkc, mode); break;
-        case AFCM_F16: hipLaunchKernelGGL((conv2d_pack_kernel<f16_t>), grid, block, 0, st, (f16_t*)dst, w, cout, cin, ks, rows, cols, rows_pad, BK, nkc, mode); break;
-        default: hipLaunchKernelGGL((conv2d_pack_kernel<bf16_t>), grid, block, 0, st, (bf16_t*)dst, w, cout, cin, ks, rows, cols, rows_pad, BK, nkc, mode); break;
-    }
-    return hip_status(hipGetLastError());
+    return mode == 0 ? afcm_conv2d_pack_weights2(dst, nullptr, w, dtype, cout, cin, ks, rows_pad, 0, stream)
+                     : afcm_conv2d_pack_weights2(nullptr, dst, w, dtype, cout, cin, ks, 0, rows_pad, stream);
 }
 
 extern "C" int afcm_conv2d(void* y, const void* x, const void* wpacked, const float* oscale, const float* obias, int32_t dtype, int32_t n,

@@ -36,6 +36,23 @@ def pack_weights(w, dtype, mode):
     return dst, rows_pad
 
 
+def pack_weights_both(w, dtype):
+    """Forward AND data-gradient images of one layer's weights in one launch (C ABI afcm_conv2d_pack_weights2):
+    ((packed, rows_pad), (packed_t, rows_pad_t)) -- what pack_weights(w, dtype, 0) and pack_weights(w, dtype, 1) return."""
+    lib = _lib.load()
+    o, i, kh, kw = w.shape
+    assert kh == kw and kh in (1, 3), 'only 1x1 and 3x3 kernels are supported'
+    w = w.detach().to(torch.float32).contiguous()
+    code = _lib._DTYPES[dtype]
+    bk = lib.afcm_conv2d_block_k(code)
+    rp0, rp1 = _pad64(o), _pad64(i)
+    d0 = torch.empty([(i + bk - 1) // bk, kh * kw, rp0, bk], dtype=dtype, device=w.device)
+    d1 = torch.empty([(o + bk - 1) // bk, kh * kw, rp1, bk], dtype=dtype, device=w.device)
+    _lib.check(lib.afcm_conv2d_pack_weights2(d0.data_ptr(), d1.data_ptr(), w.data_ptr(), code, o, i, kh, rp0, rp1, _lib.stream_ptr(w)),
+               'conv2d_pack_weights2')
+    return (d0, rp0), (d1, rp1)
+
+
 def scale_planes(x, scale, out_dtype=None):
     """y[n, c] = x[n, c] * scale[n, c] (scale None: cast only)."""
     lib = _lib.load()
@@ -117,7 +134,12 @@ class _ScaledConv2d(torch.autograd.Function):
         x = x.contiguous()
         # prescaled: the producer of x already applied in_scale (fused into its epilogue) and owns the gradient of in_scale
         xs = scale_planes(x, in_scale) if (in_scale is not None and not prescaled) else x
-        wp, rows_pad = pack_weights(w, x.dtype, 0)
+        # a backward that will need the data gradient gets its (transposed, flipped) weight image from the same launch
+        ctx.wpt = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[2]:
+            (wp, rows_pad), ctx.wpt = pack_weights_both(w, x.dtype)
+        else:
+            wp, rows_pad = pack_weights(w, x.dtype, 0)
         y = _conv_raw(xs, wp, rows_pad, out_scale, cout, ks, padding)
         ctx.save_for_backward(xs, w, in_scale, out_scale, y if (out_scale is not None and ctx.needs_input_grad[3]) else None)
         ctx.padding = padding
@@ -148,7 +170,7 @@ class _ScaledConv2d(torch.autograd.Function):
         dx = dw = d_in = d_out = None
         dys = scale_planes(dy, out_scale) if out_scale is not None else dy
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[2]:
-            wpt, rows_pad = pack_weights(w, dy.dtype, 1)
+            wpt, rows_pad = ctx.wpt if (ctx.wpt is not None and ctx.wpt[0].dtype == dy.dtype) else pack_weights(w, dy.dtype, 1)
             # data gradient of a pad-p correlation = correlation of dy with the flipped kernel at pad k-1-p;
             # the style factor of dx rides in the epilogue scale.
             dx = _conv_raw(dys, wpt, rows_pad, in_scale, cin, ks, ks - 1 - pad)

@@ -32,7 +32,11 @@ class _ConvFilteredLRelu(torch.autograd.Function):
         cout, cin, ks, _ = w.shape
         x = x.contiguous()
         xs = _conv.scale_planes(x, in_scale) if (in_scale is not None and not prescaled) else x
-        wp, rows_pad = _conv.pack_weights(w, x.dtype, 0)
+        ctx.wpt = None
+        if ctx.needs_input_grad[0] or (ctx.needs_input_grad[2] and not prescaled):
+            (wp, rows_pad), ctx.wpt = _conv.pack_weights_both(w, x.dtype)      # the backward's weight image from the same launch
+        else:
+            wp, rows_pad = _conv.pack_weights(w, x.dtype, 0)
         y = _conv._conv_raw(xs, wp, rows_pad, out_scale, cout, ks, conv_pad, obias=bias)
         need_grad = any(ctx.needs_input_grad[:5]) or ctx.needs_input_grad[7] or ctx.needs_input_grad[8]
         z, signs, layout, _ = _flr._run(y, fu, fd, None, None, cfg, need_grad, oscale=next_scale, skip=skip)
@@ -77,7 +81,7 @@ class _ConvFilteredLRelu(torch.autograd.Function):
         if has_skip and ctx.needs_input_grad[7]:
             d_skip = _conv.scale_planes(g, next_scale) if next_scale is not None else g
         if ctx.needs_input_grad[0] or (ctx.needs_input_grad[2] and not prescaled):
-            wpt, rows_pad = _conv.pack_weights(w, g.dtype, 1)
+            wpt, rows_pad = ctx.wpt if (ctx.wpt is not None and ctx.wpt[0].dtype == g.dtype) else _conv.pack_weights(w, g.dtype, 1)
             eff_in = None if prescaled else in_scale
             dx = _conv._conv_raw(dys, wpt, rows_pad, eff_in, cin, ks, ks - 1 - conv_pad)
             if ctx.needs_input_grad[2] and eff_in is not None:

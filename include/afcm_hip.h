@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define AFCM_ABI_VERSION 6
+#define AFCM_ABI_VERSION 7
 
 enum { AFCM_F32 = 0, AFCM_F16 = 1, AFCM_BF16 = 2 };
 enum { AFCM_OK = 0, AFCM_E_NOKERNEL = -1, AFCM_E_INVALID = -2 };
@@ -161,6 +161,11 @@ int afcm_conv2d_block_k(int32_t dtype);
  * (rows = cin, cols = cout, taps flipped).  rows_pad: multiple of 64, >= rows. */
 int afcm_conv2d_pack_weights(void* dst, const float* w, int32_t dtype, int32_t cout, int32_t cin, int32_t ks,
                              int32_t mode, int32_t rows_pad, void* stream);
+
+/* Both images of one layer in ONE launch (training: the forward packs what its backward will need): dst_fwd as mode 0,
+ * dst_dgrad as mode 1 of afcm_conv2d_pack_weights; either may be NULL.  Destinations 32-byte aligned. */
+int afcm_conv2d_pack_weights2(void* dst_fwd, void* dst_dgrad, const float* w, int32_t dtype, int32_t cout, int32_t cin, int32_t ks,
+                              int32_t rows_pad_fwd, int32_t rows_pad_dgrad, void* stream);
 
 /* y[n, cout, h+2*pad-k+1, w+2*pad-k+1] = oscale[n*cout+o] * sum W * x + obias[o].   oscale / obias (fp32) may be NULL.
  * obias is the layer bias the reference adds at the head of filtered_lrelu (x + b before the padding, NET:371 ->

@@ -249,3 +249,32 @@ def test_plane_dot_matches_torch(dtype, hw):
     assert ((got.double() - want).abs() <= 1e-5 * scale + 1e-6).all()
     got1 = plane_dot(a)
     assert ((got1.double() - a.double().sum([2, 3])).abs() <= 1e-5 * a.double().abs().sum([2, 3]) + 1e-6).all()
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('cout,cin,ks', [(7, 5, 3), (91, 128, 3), (64, 4, 3), (1, 64, 1), (181, 70, 3)])
+def test_pack_weights_layout(dtype, cout, cin, ks):
+    """afcm_conv2d_pack_weights / _pack_weights2: [ceil(cols / BK)][k*k][rows_pad][BK], zero padded; mode 0 rows = cout, mode 1
+    rows = cin with the taps flipped (include/afcm_hip.h) -- both images of the one-launch form equal the single-mode calls and
+    a definition-level restatement, bit for bit."""
+    from afcm_amd import _lib
+    from afcm_amd.torch_utils.ops.conv2d import pack_weights, pack_weights_both
+    torch.manual_seed(3)
+    w = torch.randn(cout, cin, ks, ks, device='cuda')
+    bk = _lib.load().afcm_conv2d_block_k(_lib._DTYPES[dtype])
+
+    def restate(mode):
+        src = w if mode == 0 else w.transpose(0, 1).flip([2, 3])
+        rows, cols = src.shape[:2]
+        rows_pad, nkc = (rows + 63) // 64 * 64, (cols + bk - 1) // bk
+        full = torch.zeros(rows_pad, nkc * bk, ks * ks, device='cuda')
+        full[:rows, :cols] = src.reshape(rows, cols, ks * ks)
+        return full.reshape(rows_pad, nkc, bk, ks * ks).permute(1, 3, 0, 2).contiguous().to(dtype), rows_pad
+
+    (p0, r0), (p1, r1) = pack_weights_both(w, dtype)
+    for mode, (got, rp) in enumerate([(p0, r0), (p1, r1)]):
+        want, rows_pad = restate(mode)
+        single, rp_single = pack_weights(w, dtype, mode)
+        assert rp == rows_pad == rp_single and got.shape == want.shape == single.shape
+        assert torch.equal(got, want), f'mode {mode}: one-launch image differs from the layout definition'
+        assert torch.equal(single, want), f'mode {mode}: single-mode image differs from the layout definition'
