@@ -682,39 +682,79 @@ __global__ __launch_bounds__(256) void conv2d_pack_kernel(T* __restrict__ dst, c
     }
 }
 
-// Same layout, one work item = (row, 8 consecutive columns) x ALL taps: the 8 x k*k source values of the forward mode are one
-// contiguous run of w (8 runs of k*k in the transposed mode), every tap leaves as one 8-element store, and the index
-// arithmetic is paid once per 72 elements instead of once per element.  blockIdx.y selects the mode, so the forward and the
-// data-gradient images of a layer come out of ONE launch (dst of a mode may be null).
-template <typename T, int KK>
-__global__ __launch_bounds__(256) void conv2d_pack8_kernel(T* __restrict__ dst0, T* __restrict__ dst1, const float* __restrict__ w, int O,
-                                                           int I, int rows_pad0, int rows_pad1, int BK) {
-    const int mode = blockIdx.y;
-    T* __restrict__ dst = mode == 0 ? dst0 : dst1;
-    if (dst == nullptr) return;
-    const int rows = mode == 0 ? O : I, cols = mode == 0 ? I : O, rows_pad = mode == 0 ? rows_pad0 : rows_pad1;
-    const int G = BK / 8, nkc = cdiv(cols, BK);
-    const int total = nkc * rows_pad * G;
+// Same layout from an LDS tile: a workgroup stages w[o0 .. o0+16)[i0 .. i0+64)[all taps] with coalesced loads (every o is one
+// contiguous run of 64 * k*k floats) and emits BOTH images from it as 8-element (16-byte for 16-bit types) stores --
+//   forward       dst0[kc = i / BK][tap][row = o][i % BK]            16 rows x BK contiguous per (kc, tap)
+//   data gradient dst1[kc = o / BK][k*k-1-tap][row = i][o % BK]      64 rows x BK contiguous per (kc, tap)
+// -- so the weights are read once for the two images, the index arithmetic is per 8 elements, and the forward and the backward
+// image of a layer come out of ONE launch (a null destination skips that image).  The per-element gather kernel above is kept
+// as the definition the layout test checks against.
+template <typename T, int KK, int BK>
+__global__ __launch_bounds__(256) void conv2d_pack_tile_kernel(T* __restrict__ dst0, T* __restrict__ dst1, const float* __restrict__ w, int O,
+                                                               int I, int rows_pad0, int rows_pad1) {
+    constexpr int TO = 16, TI = 64, ROW = TI * KK + 1;             // + 1: the 8 channel runs of a store start 9 floats apart
+    __shared__ float tile[TO * ROW];
     struct alignas(8 * sizeof(T)) Out { T v[8]; };
-    for (int item = blockIdx.x * blockDim.x + threadIdx.x; item < total; item += gridDim.x * blockDim.x) {
-        const int half = item % G;
-        const int t = item / G;
-        const int row = t % rows_pad, kc = t / rows_pad;
-        const int col0 = kc * BK + half * 8;
-        float v[8][KK];
+    const int i0 = blockIdx.x * TI, o0 = blockIdx.y * TO;
+    {
+        // all of a thread's loads in flight before the first LDS write (left as a loop, each load waited for its predecessor:
+        // 36 serial round trips = 10 us for any layer size)
+        constexpr int NL = TO * TI * KK / 256;
+        static_assert(TO * TI * KK % 256 == 0, "tile size");
+        float v[NL];
 #pragma unroll
-        for (int c = 0; c < 8; c++) {
-            const bool ok = row < rows && col0 + c < cols;
-            const float* src = mode == 0 ? w + ((size_t)row * I + (col0 + c)) * KK : w + ((size_t)(col0 + c) * I + row) * KK;
-#pragma unroll
-            for (int tp = 0; tp < KK; tp++) v[c][tp] = ok ? src[tp] : 0.f;
+        for (int k = 0; k < NL; k++) {
+            const int e = threadIdx.x + 256 * k;
+            const int o = e / (TI * KK), r = e - o * (TI * KK);
+            const int i = r / KK;
+            v[k] = (o0 + o < O && i0 + i < I) ? w[((size_t)(o0 + o) * I + i0) * KK + r] : 0.f;
         }
 #pragma unroll
-        for (int tap = 0; tap < KK; tap++) {
-            Out o;
+        for (int k = 0; k < NL; k++) {
+            const int e = threadIdx.x + 256 * k;
+            const int o = e / (TI * KK), r = e - o * (TI * KK);
+            tile[o * ROW + r] = v[k];
+        }
+    }
+    __syncthreads();
+    constexpr int G = BK / 8;
+    if (dst0 != nullptr && o0 < rows_pad0) {
+        // items: (kc_local, tap, o, half); cols (i) are written up to the last started K-chunk only
+        const int nkc = cdiv(I, BK);
+        constexpr int kcl = TI / BK, NIT = kcl * KK * TO * G;
 #pragma unroll
-            for (int c = 0; c < 8; c++) o.v[c] = from_f32<T>(v[c][mode == 0 ? tap : KK - 1 - tap]);
-            *(Out*)(dst + (((size_t)kc * KK + tap) * rows_pad + row) * BK + half * 8) = o;
+        for (int it0 = 0; it0 < NIT; it0 += 256) {
+            const int it = it0 + threadIdx.x;
+            if (NIT % 256 != 0 && it >= NIT) break;
+            const int half = it % G;
+            int t = it / G;
+            const int o = t % TO; t /= TO;
+            const int tap = t % KK, kc = t / KK;
+            const int kcg = i0 / BK + kc;
+            if (kcg >= nkc) continue;
+            Out v;
+#pragma unroll
+            for (int c = 0; c < 8; c++) v.v[c] = from_f32<T>(tile[o * ROW + (kc * BK + half * 8 + c) * KK + tap]);
+            *(Out*)(dst0 + (((size_t)kcg * KK + tap) * rows_pad0 + o0 + o) * BK + half * 8) = v;
+        }
+    }
+    if (dst1 != nullptr && i0 < rows_pad1) {
+        const int nkc = cdiv(O, BK);
+        constexpr int kcl = TO / BK, NIT = kcl * KK * TI * G;
+#pragma unroll
+        for (int it0 = 0; it0 < NIT; it0 += 256) {
+            const int it = it0 + threadIdx.x;
+            if (NIT % 256 != 0 && it >= NIT) break;
+            const int half = it % G;
+            int t = it / G;
+            const int i = t % TI; t /= TI;
+            const int tap = t % KK, kc = t / KK;
+            const int kcg = o0 / BK + kc;
+            if (kcg >= nkc) continue;
+            Out v;
+#pragma unroll
+            for (int c = 0; c < 8; c++) v.v[c] = from_f32<T>(tile[(kc * BK + half * 8 + c) * ROW + i * KK + (KK - 1 - tap)]);
+            *(Out*)(dst1 + (((size_t)kcg * KK + tap) * rows_pad1 + i0 + i) * BK + half * 8) = v;
         }
     }
 }
@@ -1855,13 +1895,13 @@ extern "C" int afcm_conv2d_block_k(int32_t dtype) { return dtype == AFCM_F32 ? C
 
 template <typename T>
 static void launch_pack8(void* dst0, void* dst1, const float* w, int cout, int cin, int ks, int rows_pad0, int rows_pad1, int BK, hipStream_t st) {
-    const int G = BK / 8;
-    const int items0 = dst0 ? cdiv(cin, BK) * rows_pad0 * G : 0, items1 = dst1 ? cdiv(cout, BK) * rows_pad1 * G : 0;
-    int blocks = cdiv(items0 > items1 ? items0 : items1, 256);
-    if (blocks > 2048) blocks = 2048;
-    dim3 grid((unsigned)blocks, 2), block(256);
-    if (ks == 3) hipLaunchKernelGGL((conv2d_pack8_kernel<T, 9>), grid, block, 0, st, (T*)dst0, (T*)dst1, w, cout, cin, rows_pad0, rows_pad1, BK);
-    else hipLaunchKernelGGL((conv2d_pack8_kernel<T, 1>), grid, block, 0, st, (T*)dst0, (T*)dst1, w, cout, cin, rows_pad0, rows_pad1, BK);
+    // tiles cover the padded row ranges of both images: o up to rows_pad0 (forward rows) and the last started K-chunk of the
+    // data-gradient image, i up to rows_pad1 and the forward image's last K-chunk (rows_pad are multiples of 64 >= the extents)
+    const int omax = dst0 ? rows_pad0 : round_up(cout, BK), imax = dst1 ? rows_pad1 : round_up(cin, BK);
+    dim3 grid((unsigned)cdiv(imax > cin ? imax : cin, 64), (unsigned)cdiv(omax > cout ? omax : cout, 16)), block(256);
+    constexpr int BKT = ConvCfg<T>::BK;
+    if (ks == 3) hipLaunchKernelGGL((conv2d_pack_tile_kernel<T, 9, BKT>), grid, block, 0, st, (T*)dst0, (T*)dst1, w, cout, cin, rows_pad0, rows_pad1);
+    else hipLaunchKernelGGL((conv2d_pack_tile_kernel<T, 1, BKT>), grid, block, 0, st, (T*)dst0, (T*)dst1, w, cout, cin, rows_pad0, rows_pad1);
 }
 
 extern "C" int afcm_conv2d_pack_weights2(void* dst_fwd, void* dst_dgrad, const float* w, int32_t dtype, int32_t cout, int32_t cin, int32_t ks,
