@@ -20,45 +20,94 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
     return red[0] + red[1] + red[2] + red[3];
 }
 
-// one workgroup per output channel o
+// one workgroup per output channel o.  PT > 0: the row (I * KK <= 256 * PT elements) is read ONCE, all loads in flight, and
+// stays in registers for the three uses (sum of squares, w_hat, wsq through an LDS copy); PT == 0: any row length, three passes.
+template <int PT>
 __global__ __launch_bounds__(256) void weight_norm_fwd_kernel(float* __restrict__ w_hat, float* __restrict__ wsq, float* __restrict__ scale,
                                                               const float* __restrict__ w, int I, int KK) {
     __shared__ float red[4];
+    __shared__ float row[PT > 0 ? 256 * PT : 1];
     const int o = blockIdx.x, n = I * KK;
     const float* wo = w + (size_t)o * n;
     float ss = 0.f;
-    for (int j = threadIdx.x; j < n; j += 256) ss += wo[j] * wo[j];
-    ss = block_sum(ss, red);
-    const float sc = rsqrtf(ss / (float)n);
-    if (threadIdx.x == 0) scale[o] = sc;
-    for (int j = threadIdx.x; j < n; j += 256) w_hat[(size_t)o * n + j] = wo[j] * sc;
-    for (int i = threadIdx.x; i < I; i += 256) {
-        float q = 0.f;
-        for (int k = 0; k < KK; k++) { const float v = wo[i * KK + k] * sc; q += v * v; }
-        wsq[(size_t)o * I + i] = q;
+    if constexpr (PT > 0) {
+        float v[PT];
+#pragma unroll
+        for (int k = 0; k < PT; k++) { const int j = threadIdx.x + 256 * k; v[k] = j < n ? wo[j] : 0.f; }
+#pragma unroll
+        for (int k = 0; k < PT; k++) ss += v[k] * v[k];
+        ss = block_sum(ss, red);
+        const float sc = rsqrtf(ss / (float)n);
+        if (threadIdx.x == 0) scale[o] = sc;
+#pragma unroll
+        for (int k = 0; k < PT; k++) {
+            const int j = threadIdx.x + 256 * k;
+            const float wh = v[k] * sc;
+            row[j] = wh;
+            if (j < n) w_hat[(size_t)o * n + j] = wh;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < I; i += 256) {
+            float q = 0.f;
+            for (int k = 0; k < KK; k++) { const float t = row[i * KK + k]; q += t * t; }
+            wsq[(size_t)o * I + i] = q;
+        }
+    } else {
+        for (int j = threadIdx.x; j < n; j += 256) ss += wo[j] * wo[j];
+        ss = block_sum(ss, red);
+        const float sc = rsqrtf(ss / (float)n);
+        if (threadIdx.x == 0) scale[o] = sc;
+        for (int j = threadIdx.x; j < n; j += 256) w_hat[(size_t)o * n + j] = wo[j] * sc;
+        for (int i = threadIdx.x; i < I; i += 256) {
+            float q = 0.f;
+            for (int k = 0; k < KK; k++) { const float t = wo[i * KK + k] * sc; q += t * t; }
+            wsq[(size_t)o * I + i] = q;
+        }
     }
 }
 
-// dw = scale * (G - w_hat * mean(G . w_hat)),  G = g_hat + 2 w_hat g_wsq[o,i]
+// dw = scale * (G - w_hat * mean(G . w_hat)),  G = g_hat + 2 w_hat g_wsq[o,i].  PT as above: operands read once, kept in registers.
+template <int PT>
 __global__ __launch_bounds__(256) void weight_norm_bwd_kernel(float* __restrict__ dw, const float* __restrict__ g_hat, const float* __restrict__ g_wsq,
                                                               const float* __restrict__ w_hat, const float* __restrict__ scale, int I, int KK) {
     __shared__ float red[4];
     const int o = blockIdx.x, n = I * KK;
     const size_t base = (size_t)o * n;
     float dot = 0.f;
-    for (int j = threadIdx.x; j < n; j += 256) {
-        const float wh = w_hat[base + j];
-        float g = g_hat ? g_hat[base + j] : 0.f;
-        if (g_wsq) g += 2.f * wh * g_wsq[(size_t)o * I + j / KK];
-        dot += g * wh;
-    }
-    dot = block_sum(dot, red);
-    const float m = dot / (float)n, sc = scale[o];
-    for (int j = threadIdx.x; j < n; j += 256) {
-        const float wh = w_hat[base + j];
-        float g = g_hat ? g_hat[base + j] : 0.f;
-        if (g_wsq) g += 2.f * wh * g_wsq[(size_t)o * I + j / KK];
-        dw[base + j] = sc * (g - wh * m);
+    if constexpr (PT > 0) {
+        float wh[PT], g[PT];
+#pragma unroll
+        for (int k = 0; k < PT; k++) {
+            const int j = threadIdx.x + 256 * k;
+            const bool ok = j < n;
+            wh[k] = ok ? w_hat[base + j] : 0.f;
+            g[k] = (ok && g_hat) ? g_hat[base + j] : 0.f;
+            if (ok && g_wsq) g[k] += 2.f * wh[k] * g_wsq[(size_t)o * I + j / KK];
+        }
+#pragma unroll
+        for (int k = 0; k < PT; k++) dot += g[k] * wh[k];
+        dot = block_sum(dot, red);
+        const float m = dot / (float)n, sc = scale[o];
+#pragma unroll
+        for (int k = 0; k < PT; k++) {
+            const int j = threadIdx.x + 256 * k;
+            if (j < n) dw[base + j] = sc * (g[k] - wh[k] * m);
+        }
+    } else {
+        for (int j = threadIdx.x; j < n; j += 256) {
+            const float wh = w_hat[base + j];
+            float g = g_hat ? g_hat[base + j] : 0.f;
+            if (g_wsq) g += 2.f * wh * g_wsq[(size_t)o * I + j / KK];
+            dot += g * wh;
+        }
+        dot = block_sum(dot, red);
+        const float m = dot / (float)n, sc = scale[o];
+        for (int j = threadIdx.x; j < n; j += 256) {
+            const float wh = w_hat[base + j];
+            float g = g_hat ? g_hat[base + j] : 0.f;
+            if (g_wsq) g += 2.f * wh * g_wsq[(size_t)o * I + j / KK];
+            dw[base + j] = sc * (g - wh * m);
+        }
     }
 }
 
@@ -73,8 +122,14 @@ __global__ __launch_bounds__(256) void style_coefs_fwd_kernel(float* __restrict_
     float r = 1.f;
     if (demod) {
         float ss = 0.f;
-        for (int j = threadIdx.x; j < N * I; j += 256) ss += t[j] * t[j];
-        ss = block_sum(ss, red);
+        float s4[4] = {0.f, 0.f, 0.f, 0.f};
+        int j = threadIdx.x;
+        for (; j + 768 < N * I; j += 1024) {                       // four independent loads per trip
+            const float a0 = t[j], a1 = t[j + 256], a2 = t[j + 512], a3 = t[j + 768];
+            s4[0] += a0 * a0; s4[1] += a1 * a1; s4[2] += a2 * a2; s4[3] += a3 * a3;
+        }
+        for (; j < N * I; j += 256) s4[0] += t[j] * t[j];
+        ss = block_sum((s4[0] + s4[1]) + (s4[2] + s4[3]), red);
         r = rsqrtf(ss / (float)(N * I));
     }
     if (n == 0 && oc == 0 && threadIdx.x == 0) r_out[0] = r;
@@ -87,16 +142,25 @@ __global__ __launch_bounds__(256) void style_coefs_fwd_kernel(float* __restrict_
     if (!demod) return;
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-#pragma unroll 2
-    for (int j = 0; j < 8; j++) {
-        const int o = oc * 32 + wave * 8 + j;
-        if (o >= O) break;
-        const float* wr = wsq + (size_t)o * I;
-        float q = 0.f;
-        for (int i = lane; i < I; i += 64) q = fmaf(s2[i], wr[i], q);
+    // the wave's 8 output channels together: 8 independent row loads per i step (one row at a time left each load waiting
+    // for the previous row's reduction)
+    const int ob = oc * 32 + wave * 8;
+    float q[8];
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) q += __shfl_xor(q, off, 64);
-        if (lane == 0) d[(size_t)n * O + o] = rsqrtf(q + 1e-8f);
+    for (int j = 0; j < 8; j++) q[j] = 0.f;
+    for (int i = lane; i < I; i += 64) {
+        const float sv = s2[i];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int o = ob + j < O ? ob + j : O - 1;            // clamped: rows past O are computed and dropped
+            q[j] = fmaf(sv, wsq[(size_t)o * I + i], q[j]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) q[j] += __shfl_xor(q[j], off, 64);
+        if (lane == 0 && ob + j < O) d[(size_t)n * O + ob + j] = rsqrtf(q[j] + 1e-8f);
     }
 }
 
@@ -218,14 +282,20 @@ extern "C" int afcm_layer_bwd_coefs(float* db, float* d_next, float* d_out, cons
 
 extern "C" int afcm_weight_norm_fwd(float* w_hat, float* wsq, float* scale, const float* w, int32_t cout, int32_t cin, int32_t kk, void* stream) {
     AFCM_REQUIRE(w_hat && wsq && scale && w && cout > 0 && cin > 0 && kk > 0, "weight_norm_fwd: bad arguments");
-    hipLaunchKernelGGL(weight_norm_fwd_kernel, dim3(cout), dim3(256), 0, (hipStream_t)stream, w_hat, wsq, scale, w, cin, kk);
+    const int n = cin * kk;
+    if (n <= 256 * 4) hipLaunchKernelGGL(weight_norm_fwd_kernel<4>, dim3(cout), dim3(256), 0, (hipStream_t)stream, w_hat, wsq, scale, w, cin, kk);
+    else if (n <= 256 * 18) hipLaunchKernelGGL(weight_norm_fwd_kernel<18>, dim3(cout), dim3(256), 0, (hipStream_t)stream, w_hat, wsq, scale, w, cin, kk);
+    else hipLaunchKernelGGL(weight_norm_fwd_kernel<0>, dim3(cout), dim3(256), 0, (hipStream_t)stream, w_hat, wsq, scale, w, cin, kk);
     return hip_status(hipGetLastError());
 }
 
 extern "C" int afcm_weight_norm_bwd(float* dw, const float* g_hat, const float* g_wsq, const float* w_hat, const float* scale, int32_t cout,
                                     int32_t cin, int32_t kk, void* stream) {
     AFCM_REQUIRE(dw && w_hat && scale && cout > 0 && cin > 0 && kk > 0, "weight_norm_bwd: bad arguments");
-    hipLaunchKernelGGL(weight_norm_bwd_kernel, dim3(cout), dim3(256), 0, (hipStream_t)stream, dw, g_hat, g_wsq, w_hat, scale, cin, kk);
+    const int n = cin * kk;
+    if (n <= 256 * 4) hipLaunchKernelGGL(weight_norm_bwd_kernel<4>, dim3(cout), dim3(256), 0, (hipStream_t)stream, dw, g_hat, g_wsq, w_hat, scale, cin, kk);
+    else if (n <= 256 * 18) hipLaunchKernelGGL(weight_norm_bwd_kernel<18>, dim3(cout), dim3(256), 0, (hipStream_t)stream, dw, g_hat, g_wsq, w_hat, scale, cin, kk);
+    else hipLaunchKernelGGL(weight_norm_bwd_kernel<0>, dim3(cout), dim3(256), 0, (hipStream_t)stream, dw, g_hat, g_wsq, w_hat, scale, cin, kk);
     return hip_status(hipGetLastError());
 }
 

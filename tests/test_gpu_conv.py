@@ -204,7 +204,7 @@ def _close_rel(a, b, tol, what):
     assert rel <= tol, f'{what}: relative L2 error {rel:.3e} (tol {tol:g})'
 
 
-@pytest.mark.parametrize('dims', [(37, 45, 5), (181, 200, 4)])          # second: several 32-o / 64-i chunks, ragged last ones
+@pytest.mark.parametrize('dims', [(37, 45, 5), (181, 200, 4), (8, 600, 2), (40, 512, 16)])   # several 32-o / 64-i chunks with ragged last ones; rows beyond / exactly at the register-resident weight-norm limit (512 x 9)
 @pytest.mark.parametrize('demod', [True, False])
 def test_fused_modulation_coefficients_match_eager(demod, dims):
     """afcm_weight_norm_* / afcm_style_coefs_* (one launch each way) vs the eager torch restatement of NET:41-57:
