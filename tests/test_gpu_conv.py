@@ -53,6 +53,7 @@ CASES = [
     (2, 96, 200, 3, 38, 38, 2),      # 38^2 plane, two o-blocks
     (2, 64, 1, 1, 32, 32, 0),        # ToRGB shape
     (2, 72, 72, 3, 36, 36, 1),       # bottleneck conv (pad 1)
+    (2, 64, 96, 3, 20, 34, 1),       # pad 1, non-square
     (1, 40, 48, 3, 70, 150, 2),      # wide plane: several q-chunks in the weight gradient
     # output widths around the weight gradient's 16-pixel K groups and 64-pixel chunks (dead-group skipping, read-ahead across
     # groups) and the forward kernel's 8-pixel store granules (transposing epilogue, ragged right edge)
