@@ -125,13 +125,48 @@ __global__ __launch_bounds__(256) void bias_act_kernel(BiasActParams p) {
     }
 }
 
+// 16-byte path: V = 16 / sizeof(T) consecutive elements per lane and trip, ONE 64-bit bias-index division per vector (the
+// host takes this path only when inner % V == 0, so a vector never straddles two bias entries, numel % V == 0 and every
+// operand is 16-byte aligned).  The element kernel above pays a 64-bit division and a 2-byte access per element: 2.3 TB/s on
+// the discriminator's 134 MB bf16 activations.
+template <typename T, int A>
+__global__ __launch_bounds__(256) void bias_act_vec_kernel(BiasActParams p) {
+    constexpr int V = 16 / (int)sizeof(T);
+    union Vec { uint4 u; T v[V]; };
+    const uint4* x = (const uint4*)p.x;
+    const uint4* xr = (const uint4*)p.xref;
+    const uint4* yr = (const uint4*)p.yref;
+    const uint4* dy = (const uint4*)p.dy;
+    const T* b = (const T*)p.b;
+    uint4* y = (uint4*)p.y;
+    const long long nvec = p.numel / V;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += stride) {
+        Vec xv, xrv, yrv, dyv, out;
+        xv.u = x[v];
+        if (xr) xrv.u = xr[v];
+        if (yr) yrv.u = yr[v];
+        if (dy) dyv.u = dy[v];
+        const float bb = b ? to_f32(b[((v * V) / p.inner) % p.nb]) : 0.f;
+#pragma unroll
+        for (int e = 0; e < V; e++)
+            out.v[e] = from_f32<T>(bias_act_elem<A>(p, to_f32(xv.v[e]), bb, xr ? to_f32(xrv.v[e]) : 0.f, yr ? to_f32(yrv.v[e]) : 0.f,
+                                                    dy ? to_f32(dyv.v[e]) : 1.f));
+        y[v] = out.u;
+    }
+}
+
 template <typename T>
 static int launch_bias_act(const BiasActParams& p, int act, hipStream_t st) {
-    long long blocks = ((p.numel >> 2) + 255) / 256;
+    constexpr int V = 16 / (int)sizeof(T);
+    const uintptr_t ptrs = (uintptr_t)p.y | (uintptr_t)p.x | (uintptr_t)p.xref | (uintptr_t)p.yref | (uintptr_t)p.dy;
+    const bool vec = (p.numel % V == 0) && (ptrs & 15) == 0 && (p.b == nullptr || p.inner % V == 0);
+    long long blocks = ((vec ? p.numel / V : (p.numel >> 2)) + 255) / 256;
     if (blocks < 1) blocks = 1;
     if (blocks > 2048) blocks = 2048;
     dim3 grid((unsigned)blocks), block(256);
-#define AFCM_BA_CASE(A) case A: hipLaunchKernelGGL((bias_act_kernel<T, A>), grid, block, 0, st, p); break;
+#define AFCM_BA_CASE(A) case A: if (vec) hipLaunchKernelGGL((bias_act_vec_kernel<T, A>), grid, block, 0, st, p); \
+                                else hipLaunchKernelGGL((bias_act_kernel<T, A>), grid, block, 0, st, p); break;
     switch (act) {
         AFCM_BA_CASE(1) AFCM_BA_CASE(2) AFCM_BA_CASE(3) AFCM_BA_CASE(4) AFCM_BA_CASE(5)
         AFCM_BA_CASE(6) AFCM_BA_CASE(7) AFCM_BA_CASE(8) AFCM_BA_CASE(9)

@@ -484,3 +484,37 @@ def test_registered_custom_ops_upfirdn2d_bias_act_conv():
     _close(dw, wr.grad.float(), tol=1e-5, what='afcm::conv2d_wgrad')
     with pytest.raises(NotImplementedError):
         torch.ops.afcm.upfirdn2d(x.cpu(), f.cpu(), 1, 1, 1, 1, 0, 0, 0, 0, False, 1.0)
+
+
+@pytest.mark.parametrize('dtype,tol', [(torch.float32, 2e-5), (torch.bfloat16, 2e-2), (torch.float16, 3e-3)])
+@pytest.mark.parametrize('shape', [(2, 5, 8, 12), (3, 7, 4, 4), (2, 5, 7, 9), (4, 24)])
+@pytest.mark.parametrize('act', ['lrelu', 'swish', 'linear'])
+def test_bias_act_vector_and_element_paths(act, shape, dtype, tol):
+    """The 16-byte kernel (plane size a multiple of 8 / 4 elements: one bias per vector) and the element kernel (ragged
+    planes) against the CPU oracle on the same rounded inputs: value, first- and second-order gradients, several bias channels."""
+    from afcm_amd.torch_utils.ops import bias_act as ba
+    from oracle import aten_ops as ops
+    torch.manual_seed(9)
+    dim = 1
+    xc = torch.randn(*shape).to(dtype).float().requires_grad_(True)
+    bc = torch.randn(shape[dim]).to(dtype).float().requires_grad_(True)
+    rc, qc = torch.randn(*shape).to(dtype).float(), torch.randn(*shape).to(dtype).float()
+    # clamp only in fp32: the backward masks on the SAVED output, and a 16-bit output that rounds onto the clamp value flips the mask
+    kw = dict(dim=dim, act=act, gain=1.3, clamp=(2.0 if (act != 'linear' and dtype == torch.float32) else None))
+
+    def run(x, b, r, q, fn):
+        y = fn(x, b, **kw)
+        dx, = torch.autograd.grad((y.float() * r.float()).sum(), x, create_graph=True)
+        d2 = torch.autograd.grad((dx.float() * q.float()).sum(), [x, b], allow_unused=True) if dx.requires_grad else (None, None)
+        return y, dx, d2
+    yw, dxw, d2w = run(xc, bc, rc, qc, ops.bias_act)
+    xg = xc.detach().to(dtype).cuda().requires_grad_(True)
+    bg = bc.detach().to(dtype).cuda().requires_grad_(True)
+    yg, dxg, d2g = run(xg, bg, rc.to(dtype).cuda(), qc.to(dtype).cuda(), ba.bias_act)
+    _close(yg, yw, tol=tol, what=f'{act} {shape} y')
+    _close(dxg, dxw, tol=tol, what=f'{act} {shape} dx')
+    for a, b_, nm in zip(d2g, d2w, ['d2x', 'd2b']):
+        if b_ is None:
+            assert a is None or a.abs().max().item() == 0
+        elif a is not None:
+            _close(a, b_, tol=8 * tol, what=f'{act} {shape} {nm}')
