@@ -54,12 +54,14 @@ def _conv2d_wrapper(x, w, stride=1, padding=0, groups=1, transpose=False, flip_w
             y = y[:, :, ::stride, ::stride]
         return y
     op = F.conv_transpose2d if transpose else F.conv2d
-    return op(x, w, stride=stride, padding=padding, groups=groups)
+    return op(x, w.to(x.dtype), stride=stride, padding=padding, groups=groups)
 
 
 def conv2d_resample(x, w, f=None, up=1, down=1, padding=0, groups=1, flip_weight=True, flip_filter=False):
     assert isinstance(x, torch.Tensor) and x.ndim == 4
-    assert isinstance(w, torch.Tensor) and w.ndim == 4 and w.dtype == x.dtype
+    # fp32 master weights are accepted next to 16-bit activations: the MFMA path packs them to the activation dtype itself (the same
+    # single rounding as the reference's w.to(x.dtype)), the framework path casts at the call -- no conversion pass each way per layer
+    assert isinstance(w, torch.Tensor) and w.ndim == 4 and (w.dtype == x.dtype or w.dtype == torch.float32)
     assert f is None or (isinstance(f, torch.Tensor) and f.ndim in [1, 2] and f.dtype == torch.float32)
     assert isinstance(up, int) and up >= 1 and isinstance(down, int) and down >= 1 and isinstance(groups, int) and groups >= 1
     out_channels, in_channels_per_group, kh, kw = [int(v) for v in w.shape]
