@@ -1,3 +1,7 @@
+#!/usr/bin/env python3
+"""plane_dot bandwidth probe: (a) does the offset between the two operands matter (HBM channel aliasing)? -- no; (b) cold
+(after a 512 MB fill that leaves dirty lines in front of it) vs back-to-back launches: 2.7 vs 6.2 TB/s -- the isolated figure
+measures the eviction fill's write-back, not the kernel."""
 import os, sys
 sys.path.insert(0, '/root/repo')
 import torch
