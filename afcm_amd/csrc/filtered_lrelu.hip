@@ -13,6 +13,7 @@
 //   d = U0 - px0,  I0 = ceil(d / up),  ph = up*I0 - d  in [0, up)
 //   u[U0 + up*m + a] = sum_j F[kmin(a) + up*j] * x[I0 + m + o(a) + j]
 //   o(a) = (a > ph),  kmin(a) = o(a) ? up - (a - ph) : ph - a,   F = flip ? fu : reversed(fu)
+#include <stdlib.h>
 #include "common.h"
 
 namespace afcm {
@@ -460,7 +461,15 @@ template <typename T>
 static int dispatch(const afcm_filtered_lrelu_args* a, const FlreluParams& p, hipStream_t st) {
     const bool sep = (a->fuh == 0 && a->fdh == 0);
     if (sep && a->up == 2 && a->down == 2 && a->fuw == 12 && a->fdw == 12)
+    {
+        // Tile height by mode (measured, fp32, batch 16): the sign-writing forward runs 10 % faster on 20-row tiles (53 KB of LDS:
+        // three workgroups per CU instead of two cover its five LDS stages), the sign-reading backward 12 % slower (its staged sign
+        // window grows with the halo); planes of <= 40 rows take the 20-row tile both ways (36 rows: 40 computed instead of 70).
+        static const char* force = getenv("AFCM_FLRELU_SEP_TOH");       // tuning aid: 20 or 35 for every launch
+        const int toh = force ? atoi(force) : ((a->sign_mode != AFCM_SIGNS_READ || a->yh <= 40) ? 20 : 35);
+        if (toh == 20) return launch_sep<T, 2, 2, 6, 12, 64, 20, 5, 384>(a, p, st);
         return launch_sep<T, 2, 2, 6, 12, 64, 35, 5, 384>(a, p, st);
+    }
     if (sep && a->up == 2 && a->down == 4 && a->fuw == 12 && a->fdw == 24)
         return launch_sep<T, 2, 4, 6, 24, 32, 12, 4, 384>(a, p, st);
     if (sep && a->up == 4 && a->down == 2 && a->fuw == 24 && a->fdw == 12)
