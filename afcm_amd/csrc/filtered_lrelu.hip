@@ -470,10 +470,20 @@ static int dispatch(const afcm_filtered_lrelu_args* a, const FlreluParams& p, hi
         if (toh == 20) return launch_sep<T, 2, 2, 6, 12, 64, 20, 5, 384>(a, p, st);
         return launch_sep<T, 2, 2, 6, 12, 64, 35, 5, 384>(a, p, st);
     }
-    if (sep && a->up == 2 && a->down == 4 && a->fuw == 12 && a->fdw == 24)
+    if (sep && a->up == 2 && a->down == 4 && a->fuw == 12 && a->fdw == 24) {
+        // 16-column tiles (46 KB of LDS) only where they also cut the padded columns: planes of <= 40 columns (36 / 38: 48 computed
+        // instead of 64).  On the larger planes the 1.31x halo of a 16-column tile costs more than the third workgroup per CU wins.
+        static const char* force = getenv("AFCM_FLRELU_SEP_TOW24");     // tuning aid: 16 or 32 output columns per tile
+        const int tow = force ? atoi(force) : (a->yw <= 40 ? 16 : 32);
+        if (tow == 16) return launch_sep<T, 2, 4, 6, 24, 16, 12, 4, 384>(a, p, st);
         return launch_sep<T, 2, 4, 6, 24, 32, 12, 4, 384>(a, p, st);
-    if (sep && a->up == 4 && a->down == 2 && a->fuw == 24 && a->fdw == 12)
+    }
+    if (sep && a->up == 4 && a->down == 2 && a->fuw == 24 && a->fdw == 12) {
+        static const char* force = getenv("AFCM_FLRELU_SEP_TOH42");     // tuning aid: 20 or 35 (20 is faster in every mode: 47 KB of LDS)
+        const int toh = force ? atoi(force) : 20;
+        if (toh == 20) return launch_sep<T, 4, 2, 6, 12, 64, 20, 5, 384>(a, p, st);
         return launch_sep<T, 4, 2, 6, 12, 64, 35, 5, 384>(a, p, st);
+    }
     return AFCM_E_NOKERNEL;
 }
 
