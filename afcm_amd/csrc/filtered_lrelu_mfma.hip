@@ -702,10 +702,17 @@ template <> struct MfmaTile<4, 2> { static constexpr int TOW = 64, TOH = 32; };
 // 32-row tiles that are 12 % full in their second row.  The constant fragments do not depend on the tile shape (only on up,
 // down and the filters), so both variants share one prepared workspace; the sign layout is tile-independent.
 constexpr int kTallTOH = 48;
-static bool tall_tile(int up, int down, int yh) {
-    static const char* force = getenv("AFCM_FLRELU_TALL");      // tuning aid: 0 = never, 1 = by plane height (default)
-    if (force && atoi(force) == 0) return false;
-    return up == 2 && yh > 32 && yh <= kTallTOH;
+static bool tall_tile(int up, int down, int yh, int sign_mode) {
+    static const char* force = getenv("AFCM_FLRELU_TALL");      // tuning aid: 0 = never, 1 = rules below (default), 2 = 33..48-row planes only
+    const int mode = force ? atoi(force) : 1;
+    if (mode == 0 || up != 2) return false;
+    if (yh > 32 && yh <= kTallTOH) return true;
+    // The sign-WRITING kernels (forward) also gain on larger planes whenever 48-row tiles cover the plane with no more padded rows
+    // than 32-row tiles (276 rows: 6 x 48 = 9 x 32; 84 rows: 2 x 48 = 3 x 32): 7 % fewer halo rows, a third fewer workgroups --
+    // enc0..3 forward 0.207 / 0.277 / 0.383 -> 0.181 / 0.250 / 0.337 ms.  The sign-READING kernels lose 5-20 % on the same tiles
+    // (their staged sign window and keep-mask table scale with the tile), so the transposed op keeps 32 rows.
+    if (mode == 1 && sign_mode != AFCM_SIGNS_READ && cdiv(yh, kTallTOH) * kTallTOH <= cdiv(yh, 32) * 32) return true;
+    return false;
 }
 
 template <typename T, int UP, int DOWN, int TOW, int TOH, int SIGN>
@@ -747,7 +754,7 @@ template <typename T, int UP, int DOWN>
 static int launch_mfma(const afcm_filtered_lrelu_args* a, hipStream_t st) {
     constexpr int TOW = MfmaTile<UP, DOWN>::TOW, TOH = MfmaTile<UP, DOWN>::TOH;
     if constexpr (UP == 2) {
-        if (tall_tile(UP, DOWN, a->yh)) return launch_mfma_tile<T, UP, DOWN, TOW, kTallTOH>(a, st);
+        if (tall_tile(UP, DOWN, a->yh, a->sign_mode)) return launch_mfma_tile<T, UP, DOWN, TOW, kTallTOH>(a, st);
     }
     return launch_mfma_tile<T, UP, DOWN, TOW, TOH>(a, st);
 }
@@ -778,8 +785,8 @@ int flrelu_mfma_supported(const afcm_filtered_lrelu_args* a) { return mfma_case(
 
 int flrelu_mfma_tiles(const afcm_filtered_lrelu_args* a) {
     switch (mfma_case(a)) {
-        case 22: return cdiv(a->yw, MfmaTile<2, 2>::TOW) * cdiv(a->yh, tall_tile(2, 2, a->yh) ? kTallTOH : MfmaTile<2, 2>::TOH);
-        case 24: return cdiv(a->yw, MfmaTile<2, 4>::TOW) * cdiv(a->yh, tall_tile(2, 4, a->yh) ? kTallTOH : MfmaTile<2, 4>::TOH);
+        case 22: return cdiv(a->yw, MfmaTile<2, 2>::TOW) * cdiv(a->yh, tall_tile(2, 2, a->yh, a->sign_mode) ? kTallTOH : MfmaTile<2, 2>::TOH);
+        case 24: return cdiv(a->yw, MfmaTile<2, 4>::TOW) * cdiv(a->yh, tall_tile(2, 4, a->yh, a->sign_mode) ? kTallTOH : MfmaTile<2, 4>::TOH);
         case 42: return cdiv(a->yw, MfmaTile<4, 2>::TOW) * cdiv(a->yh, MfmaTile<4, 2>::TOH);
         default: return 0;
     }
