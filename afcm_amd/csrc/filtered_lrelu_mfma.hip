@@ -711,7 +711,11 @@ static bool tall_tile(int up, int down, int yh, int sign_mode) {
     // than 32-row tiles (276 rows: 6 x 48 = 9 x 32; 84 rows: 2 x 48 = 3 x 32): 7 % fewer halo rows, a third fewer workgroups --
     // enc0..3 forward 0.207 / 0.277 / 0.383 -> 0.181 / 0.250 / 0.337 ms.  The sign-READING kernels lose 5-20 % on the same tiles
     // (their staged sign window and keep-mask table scale with the tile), so the transposed op keeps 32 rows.
-    if (mode == 1 && sign_mode != AFCM_SIGNS_READ && cdiv(yh, kTallTOH) * kTallTOH <= cdiv(yh, 32) * 32) return true;
+    // up to 7 % more padded rows still pay (the 532- and 512-row planes of the 512^2 generator: 576 vs 544, 528 vs 512 rows --
+    // filtered_lrelu 10.0 -> 9.8 ms per step there); at 12.5 % (256 rows) the gain is gone
+    static const char* slack_s = getenv("AFCM_FLRELU_TALL_SLACK");        // tuning aid: extra padded rows tolerated, in percent
+    const int slack = slack_s ? atoi(slack_s) : 7;
+    if (mode == 1 && sign_mode != AFCM_SIGNS_READ && 100 * cdiv(yh, kTallTOH) * kTallTOH <= (100 + slack) * cdiv(yh, 32) * 32) return true;
     return false;
 }
 
