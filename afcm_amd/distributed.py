@@ -10,20 +10,51 @@ gradients (58.5 M params = 234 MB fp32), averaged over ranks.
 Buckets are filled in reverse parameter order (the order backward produces gradients), ~25 MB each:
 on xGMI (7 point-to-point links per GPU) a few large ring collectives beat many small ones, and the
 last-layer buckets are in flight while the encoder's backward still runs.
+
+Gradient accumulation.  The reference's D update calls ``backward()`` twice per iteration
+(models/comodgan_model.py:136,149: the fake term, then the real term + R1).  A bucket may only be reduced
+once every one of its gradients is final, so:
+
+* ``with buckets.no_sync(): loss_a.backward()`` disarms the hooks for all but the last pass (the
+  gradients accumulate in ``.grad`` as usual and the LAST pass copies the running totals), or
+* ``passes=k`` declares k accumulations per parameter and iteration; a bucket is launched when every
+  parameter has been accumulated k times;
+* an accumulation that arrives after its bucket was launched anyway (undeclared extra pass) never
+  touches the buffer of a collective in flight: the bucket is marked and ``finish*()`` reduces it again
+  from the final ``.grad`` values -- slower (one more collective, a warning says so) but never wrong.
+
+Collectives are always issued in bucket order (a ready bucket waits for its predecessors), so the call
+sequence is the same on every rank whatever order the hooks fire in.
+
+Parameters without a gradient.  ``finish*()`` treat a parameter as unused only if NO rank produced a
+gradient for it (a per-parameter flag vector is sum-reduced next to the buckets): such parameters keep
+``.grad = None`` / are left out of ``finish_flat()``'s views, exactly as the single-process path and
+``torch.optim.Adam`` skip them; a parameter used on some ranks only gets the reduced gradient on all of
+them.  With ``static_graph=True`` the flag vector is read on the host (one sync) in the first iteration
+only and verified one iteration late afterwards (no sync in steady state; a change updates the mask for
+the following iterations with a warning); ``static_graph=False`` reads it every iteration.
 """
+import contextlib
+import warnings
+
 import torch
 import torch.distributed as dist
 
 
 class GradientBuckets:
-    def __init__(self, params, bucket_bytes=25 * 1024 * 1024, process_group=None, comm_dtype=None, force=False):
+    def __init__(self, params, bucket_bytes=25 * 1024 * 1024, process_group=None, comm_dtype=None, force=False, passes=1,
+                 static_graph=True):
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.active = self.world > 1 or (force and dist.is_initialized())   # force: exercise the hooks/collectives on one rank
         self.params = [p for p in params if p.requires_grad]
         self.comm_dtype = comm_dtype
-        self._buckets = []          # list of dict(params, flat, pending, handle)
-        self._where = {}
+        self.passes = int(passes)
+        if self.passes < 1:
+            raise ValueError('passes must be >= 1')
+        self.static_graph = bool(static_graph)
+        self._buckets = []          # dicts: params, flat, comm, offs, count, pending, launched, handle, redo
+        self._where = {}            # parameter -> (bucket index, position inside the bucket)
         cur, cur_bytes = [], 0
         for p in reversed(self.params):
             nbytes = p.numel() * p.element_size()
@@ -35,21 +66,31 @@ class GradientBuckets:
         if cur:
             self._add_bucket(cur)
         self._hooks = []
+        self._armed = True
+        self._next = 0              # first bucket whose collective has not been issued yet (collectives go out in bucket order)
+        self._warned = False
+        self._used = None           # per parameter (bucket order): some rank produced a gradient
+        self._flag_check = None     # (pinned host flags, event) of the previous iteration, verified lazily
         if self.active:
             for p in self.params:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
-        self._inflight = []
+            self._order = [p for b in self._buckets for p in b['params']]
+            self._flags = torch.zeros(len(self._order), dtype=torch.float32, device=self.params[0].device)
+            self._flags_local = torch.zeros_like(self._flags)
+            self._local = None
 
     def _add_bucket(self, plist):
         idx = len(self._buckets)
-        total = sum(p.numel() for p in plist)
-        dev = plist[0].device
-        dtype = self.comm_dtype or plist[0].dtype
-        self._buckets.append(dict(params=list(plist), flat=torch.zeros(total, dtype=dtype, device=dev), pending=len(plist), n=len(plist)))
-        off = 0
-        for p in plist:
-            self._where[p] = (idx, off)
+        offs, off = [], 0
+        for k, p in enumerate(plist):
+            self._where[p] = (idx, k)
+            offs.append(off)
             off += p.numel()
+        dev, dtype = plist[0].device, plist[0].dtype
+        flat = torch.zeros(off, dtype=dtype, device=dev)
+        comm = torch.zeros(off, dtype=self.comm_dtype, device=dev) if (self.comm_dtype is not None and self.comm_dtype != dtype) else None
+        self._buckets.append(dict(params=list(plist), flat=flat, comm=comm, offs=offs, count=[0] * len(plist), pending=len(plist),
+                                  launched=False, handle=None, redo=False))
 
     @property
     def num_buckets(self):
@@ -62,69 +103,158 @@ class GradientBuckets:
         for t in list(module.parameters()) + list(module.buffers()):
             dist.broadcast(t.data, src=src, group=self.group)
 
+    @contextlib.contextmanager
+    def no_sync(self):
+        """Backward passes inside this context only accumulate into ``.grad`` (no bucket copy, no collective): wrap every
+        backward of an iteration except the last one, as with DistributedDataParallel.no_sync()."""
+        old, self._armed = self._armed, False
+        try:
+            yield
+        finally:
+            self._armed = old
+
+    # ---------------------------------------------------------------- hook side
+    def _slice(self, b, k):
+        p = b['params'][k]
+        return b['flat'][b['offs'][k]:b['offs'][k] + p.numel()]
+
     def _on_grad(self, p):
-        idx, off = self._where[p]
+        if not self._armed:
+            return
+        idx, k = self._where[p]
         b = self._buckets[idx]
-        b['flat'][off:off + p.numel()].copy_(p.grad.reshape(-1))
-        b['pending'] -= 1
+        b['count'][k] += 1
+        c = b['count'][k]
+        if b['launched']:
+            # an accumulation after the bucket went out: the buffer belongs to the collective -- leave it alone and
+            # reduce the bucket again from the final .grad values in finish*()
+            b['redo'] = True
+            if not self._warned:
+                self._warned = True
+                warnings.warn('GradientBuckets: a gradient was accumulated after its bucket had been reduced (more backward passes per '
+                              'iteration than declared); the bucket is reduced again in finish(). Wrap the earlier passes in no_sync() '
+                              'or pass passes=<count>.', RuntimeWarning)
+            return
+        if c < self.passes:
+            return                      # an earlier pass of a declared multi-pass iteration: .grad is still accumulating
+        self._slice(b, k).copy_(p.grad.reshape(-1))      # .grad holds the running total of all passes so far
+        if c == self.passes:
+            b['pending'] -= 1
         if b['pending'] == 0:
-            # every gradient of this bucket is final: launch its all-reduce now, while backward continues
-            h = dist.all_reduce(b['flat'], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-            self._inflight.append((idx, h))
+            self._launch_ready()
+
+    def _launch_ready(self):
+        while self._next < len(self._buckets):
+            b = self._buckets[self._next]
+            if b['pending'] != 0 or b['launched']:
+                break
+            self._launch(b)
+            self._next += 1
+
+    def _launch(self, b):
+        buf = b['flat']
+        if b['comm'] is not None:
+            b['comm'].copy_(b['flat'])
+            buf = b['comm']
+        b['handle'] = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        b['launched'] = True
+
+    # ---------------------------------------------------------------- finish side
+    def _fill_from_grads(self, b, everything):
+        for k, p in enumerate(b['params']):
+            if p.grad is None:
+                self._slice(b, k).zero_()
+            elif everything or b['count'][k] < self.passes:
+                self._slice(b, k).copy_(p.grad.reshape(-1))
+
+    def _complete(self):
+        """Issue what the hooks did not (in bucket order), re-reduce marked buckets, wait, and resolve the used-parameter mask."""
+        for idx in range(self._next, len(self._buckets)):
+            b = self._buckets[idx]
+            self._fill_from_grads(b, everything=False)
+            self._launch(b)
+        self._next = len(self._buckets)
+        for b in self._buckets:
+            if b['redo']:
+                b['handle'].wait()
+                self._fill_from_grads(b, everything=True)
+                self._launch(b)
+        local = [p.grad is not None for p in self._order]
+        if local != self._local:
+            # upload only when this rank's pattern changes (pinned + non-blocking: no host stall behind the queued backward)
+            self._local = local
+            host = torch.tensor(local, dtype=torch.float32)
+            if self._flags.is_cuda:
+                host = host.pin_memory()
+                self._local_host = host                    # stays alive until the copy has run
+            self._flags_local.copy_(host, non_blocking=True)
+        self._flags.copy_(self._flags_local)
+        fh = dist.all_reduce(self._flags, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        for b in self._buckets:
+            b['handle'].wait()
+            if b['comm'] is not None:
+                b['flat'].copy_(b['comm'])
+        fh.wait()
+        self._resolve_used()
+        for b in self._buckets:
+            b.update(count=[0] * len(b['params']), pending=len(b['params']), launched=False, handle=None, redo=False)
+        self._next = 0
+
+    def _resolve_used(self):
+        if self._used is None or not self.static_graph:
+            self._used = (self._flags > 0).cpu().tolist()          # host sync: first iteration (or every one without static_graph)
+            return
+        # steady state: verify the PREVIOUS iteration's flags (their copy finished long ago) and queue this iteration's
+        if self._flag_check is not None:
+            host, ev = self._flag_check
+            if ev is not None:
+                ev.synchronize()
+            seen = (host > 0).tolist()
+            if seen != self._used:
+                warnings.warn('GradientBuckets: the set of parameters receiving gradients changed between iterations; the new set '
+                              'applies from this iteration on (construct with static_graph=False to follow it exactly).', RuntimeWarning)
+                self._used = seen
+        if self._flags.is_cuda:
+            host = torch.empty(self._flags.shape, dtype=torch.float32).pin_memory()
+            host.copy_(self._flags, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._flag_check = (host, ev)
+        else:
+            self._flag_check = (self._flags.clone(), None)
 
     def finish(self):
-        """Wait for the collectives, average, and scatter the reduced values back into .grad.
-        Parameters that received no gradient this iteration are reduced as zeros."""
+        """Wait for the collectives, average, and put the reduced values into .grad (on every rank, also where this rank had
+        produced none).  Parameters for which no rank produced a gradient keep .grad = None."""
         if not self.active:
             return
-        launched = {i for i, _ in self._inflight}
-        for idx, b in enumerate(self._buckets):
-            if idx not in launched:
-                for p in b['params']:
-                    i, off = self._where[p]
-                    if p.grad is None:
-                        b['flat'][off:off + p.numel()].zero_()
-                    elif b['pending'] > 0:
-                        b['flat'][off:off + p.numel()].copy_(p.grad.reshape(-1))
-                self._inflight.append((idx, dist.all_reduce(b['flat'], op=dist.ReduceOp.SUM, group=self.group, async_op=True)))
-        for idx, h in self._inflight:
-            h.wait()
-            b = self._buckets[idx]
+        self._complete()
+        i = 0
+        for b in self._buckets:
             b['flat'].div_(self.world)
-            off = 0
-            for p in b['params']:
-                if p.grad is not None:
-                    p.grad.copy_(b['flat'][off:off + p.numel()].view_as(p.grad))
-                off += p.numel()
-            b['pending'] = b['n']
-        self._inflight = []
+            for k, p in enumerate(b['params']):
+                if self._used[i]:
+                    red = self._slice(b, k).view(p.shape)
+                    if p.grad is None:
+                        p.grad = red.clone()
+                    else:
+                        p.grad.copy_(red)
+                i += 1
 
     def finish_flat(self):
         """Like finish(), but leaves the SUMMED gradients in the buckets and returns ({parameter: bucket slice}, 1 / world)
         for an optimizer that consumes them in place (afcm_amd.optim.FusedScrubAdam): no averaging pass and no copy back
-        into .grad -- the scale rides in the optimizer kernel."""
+        into .grad -- the scale rides in the optimizer kernel.  Parameters unused on every rank are left out."""
         if not self.active:
             return None, 1.0
-        launched = {i for i, _ in self._inflight}
-        for idx, b in enumerate(self._buckets):
-            if idx not in launched:
-                for p in b['params']:
-                    i, off = self._where[p]
-                    if p.grad is None:
-                        b['flat'][off:off + p.numel()].zero_()
-                    elif b['pending'] > 0:
-                        b['flat'][off:off + p.numel()].copy_(p.grad.reshape(-1))
-                self._inflight.append((idx, dist.all_reduce(b['flat'], op=dist.ReduceOp.SUM, group=self.group, async_op=True)))
+        self._complete()
         views = {}
-        for idx, h in self._inflight:
-            h.wait()
-            b = self._buckets[idx]
-            off = 0
-            for p in b['params']:
-                views[p] = b['flat'][off:off + p.numel()].view(p.shape)
-                off += p.numel()
-            b['pending'] = b['n']
-        self._inflight = []
+        i = 0
+        for b in self._buckets:
+            for k, p in enumerate(b['params']):
+                if self._used[i]:
+                    views[p] = self._slice(b, k).view(p.shape)
+                i += 1
         return views, 1.0 / self.world
 
     def remove_hooks(self):

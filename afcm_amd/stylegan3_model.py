@@ -1,16 +1,18 @@
-"""Generator half of the `--model stylegan3` training step.
+"""The `--model stylegan3` training step: generator-only step and the full D + G iteration.
 
 Mirrors the reference's model wrapper for the path SURVEY.md section 8 scopes in: ``set_input``
 (models/pix2pix_model.py:111-113 + models/comodgan_model.py:93-99), ``run_G`` / ``forward``
 (models/stylegan3_model.py:13-22,85-87), the G update of ``optimize_parameters`` (:127-135: zero_grad,
 forward, backward_G, NaN/Inf scrub of the gradients, Adam(beta=(0, 0.99)) step -- comodgan_model.py:19-20).
-The adversarial term of ``backward_G`` needs the discriminator (not built yet); the loss
-here is the lambda_L1-weighted L1 term of models/stylegan3_model.py:107 (+ a caller-supplied extra term).
+``StyleGAN3GeneratorStep`` is the generator-only step the headline metric times: its loss is the lambda_L1-weighted L1
+term of models/stylegan3_model.py:107 (+ a caller-supplied extra term).  ``StyleGAN3Step`` adds the
+discriminator update and the adversarial term of ``backward_G``: the full iteration of the reference.
 
 Unlike the reference (which dereferences ``netG.module`` and therefore cannot run without DataParallel,
 comodgan_model.py:14), the wrapper owns a bare module and shards by batch across ranks through
 ``afcm_amd.distributed.GradientBuckets``.
 """
+import contextlib
 import copy
 import os
 
@@ -24,7 +26,7 @@ from .optim import FusedScrubAdam
 
 class StyleGAN3GeneratorStep:
     def __init__(self, netG, lr_G=0.0025, lambda_L1=100.0, distributed=False, bucket_bytes=25 * 1024 * 1024, style_mixing_prob=0,
-                 force_collectives=False, blur_init_sigma=0.0, blur_fade_kimg=0.0, ema=False):
+                 force_collectives=False, blur_init_sigma=0.0, blur_fade_kimg=0.0, ema=False, comm_dtype=None):
         self.netG = netG
         # `ema`: keep the evaluation copy the reference creates unconditionally (models/comodgan_model.py:16-17); off by default
         # because the throughput path never reads it (234 MB)
@@ -44,7 +46,7 @@ class StyleGAN3GeneratorStep:
         self.style_mixing_prob = style_mixing_prob
         self.real_A = self.real_B = self.fake_B = None
         self.gen_z = self.gen_c = None
-        self.buckets = GradientBuckets(netG.parameters(), bucket_bytes=bucket_bytes, force=force_collectives) if distributed else None
+        self.buckets = GradientBuckets(netG.parameters(), bucket_bytes=bucket_bytes, force=force_collectives, comm_dtype=comm_dtype) if distributed else None
         if self.buckets is not None:
             self.buckets.broadcast_parameters(netG)
 
@@ -166,7 +168,7 @@ class StyleGAN3Step(StyleGAN3GeneratorStep):
         self.buckets_D = None
         if self.buckets is not None:
             self.buckets_D = GradientBuckets(netD.parameters(), bucket_bytes=kw.get('bucket_bytes', 25 * 1024 * 1024),
-                                             force=kw.get('force_collectives', False))
+                                             force=kw.get('force_collectives', False), comm_dtype=kw.get('comm_dtype'))
             self.buckets_D.broadcast_parameters(netD)
 
     def run_D(self, img, **kwargs):
@@ -178,7 +180,10 @@ class StyleGAN3Step(StyleGAN3GeneratorStep):
     def backward_D(self):
         gen_logits = self.run_D(self._pair(self.fake_B).detach(), c=self.gen_c)
         self.loss_D_fake = torch.nn.functional.softplus(gen_logits).mean()
-        self.loss_D_fake.backward()
+        # two backward passes per D update, as in the reference (comodgan_model.py:136,149): the first only accumulates into
+        # .grad; the bucket all-reduces go out during the second (the longer one: it carries the R1 double backward)
+        with (self.buckets_D.no_sync() if self.buckets_D is not None else contextlib.nullcontext()):
+            self.loss_D_fake.backward()
         real_img_tmp = self._pair(self.real_B).detach().requires_grad_(True)
         real_logits = self.run_D(real_img_tmp, c=self.gen_c)
         self.loss_D_real = torch.nn.functional.softplus(-real_logits).mean()
