@@ -26,7 +26,7 @@ from .optim import FusedScrubAdam
 
 class StyleGAN3GeneratorStep:
     def __init__(self, netG, lr_G=0.0025, lambda_L1=100.0, distributed=False, bucket_bytes=25 * 1024 * 1024, style_mixing_prob=0,
-                 force_collectives=False, blur_init_sigma=0.0, blur_fade_kimg=0.0, ema=False, comm_dtype=None):
+                 force_collectives=False, blur_init_sigma=0.0, blur_fade_kimg=0.0, ema=False, comm_dtype=None, eval_dtype='auto'):
         self.netG = netG
         # `ema`: keep the evaluation copy the reference creates unconditionally (models/comodgan_model.py:16-17); off by default
         # because the throughput path never reads it (234 MB)
@@ -35,6 +35,16 @@ class StyleGAN3GeneratorStep:
         if ema:
             self.netG_ema = copy.deepcopy(netG).eval()
             self.model_names.append('G_ema')
+            # Accuracy budget of the evaluation path (north star: PSNR within 0.05 dB of the reference).  With uncorrelated
+            # errors a 16-bit forward of PSNR P_e against the fp32 forward costs 10 log10(1 + 10^((P_t - P_e) / 10)) dB at a task
+            # PSNR P_t: <= 0.05 dB needs P_e >= P_t + 19.4 dB, i.e. >= 52 dB for tasks up to 32.6 dB.  Full-width bf16 is
+            # 44 dB (8 mantissa bits): fine for training throughput, over budget for reported metrics.  So `test()` /
+            # `forward_ema()` run the EMA copy in fp16 when training runs in bf16 (11 mantissa bits, same kernels, same speed;
+            # measured PSNR in tests/test_gpu_generator.py::test_full_width_16bit_accuracy_budget), else in the training dtype;
+            # eval_dtype=torch.float32 selects the exact kernels.  The weights are fp32 masters either way.
+            if eval_dtype == 'auto':
+                eval_dtype = torch.float16 if netG.synthesis.compute_dtype == torch.bfloat16 else netG.synthesis.compute_dtype
+            self.netG_ema.synthesis.compute_dtype = eval_dtype
         # loss-side blur schedule (models/stylegan3_model.py:80-81,115-116): sigma fades linearly to 0 over blur_fade_kimg
         self.blur_init_sigma, self.blur_fade_kimg, self.blur_sigma = float(blur_init_sigma), float(blur_fade_kimg), 0.0
         self.G_mapping = netG.mapping

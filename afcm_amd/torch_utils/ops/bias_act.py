@@ -136,8 +136,8 @@ def bias_act(x, b=None, dim=1, act='linear', alpha=None, gain=None, clamp=None, 
     """Fused bias + activation.  Same signature and defaults as SG3OPS/bias_act.py:52."""
     assert isinstance(x, torch.Tensor)
     assert impl in ['ref', 'cuda']
-    if impl == 'ref':
-        raise NotImplementedError("afcm_amd ships no aten fallback; impl='ref' lives in oracle/aten_ops.py (test-only)")
+    # impl='ref' on a GPU tensor runs the same HIP kernel (one device implementation; the reference's 'ref' twin is the aten
+    # composition of SG3OPS/bias_act.py:91-120).  CPU tensors raise below for either value: no CPU path in this package.
     assert clamp is None or clamp >= 0
     spec = activation_funcs[act]
     alpha = float(alpha if alpha is not None else spec.def_alpha)

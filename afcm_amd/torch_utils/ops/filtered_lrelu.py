@@ -245,6 +245,19 @@ class _FilteredLRelu(torch.autograd.Function):
         return dx, None, None, db, None, None
 
 
+def _filtered_lrelu_generic(x, fu, fd, b, up, down, padding, gain, slope, clamp, flip_filter):
+    """impl='ref' on a GPU tensor: the op as its definition composes it -- bias, upsampling FIR with gain up^2, leaky ReLU with
+    gain / clamp, downsampling FIR (SG3OPS/filtered_lrelu.py:121-153) -- on the HIP upfirdn2d and bias_act kernels.  Unfused and
+    memory-hungry like the reference's 'ref' twin (it keeps the up^2-times larger intermediate), arbitrarily differentiable;
+    nothing here touches the CPU or oracle/."""
+    from . import bias_act as _ba
+    px0, px1, py0, py1 = _parse_padding(padding)
+    y = _ba.bias_act(x=x, b=b)
+    y = _ufd.upfirdn2d(x=y, f=fu, up=up, padding=[px0, px1, py0, py1], gain=up ** 2, flip_filter=flip_filter)
+    y = _ba.bias_act(x=y, act='lrelu', alpha=slope, gain=gain, clamp=clamp)
+    return _ufd.upfirdn2d(x=y, f=fd, down=down, flip_filter=flip_filter)
+
+
 def filtered_lrelu(x, fu=None, fd=None, b=None, up=1, down=1, padding=0, gain=np.sqrt(2), slope=0.2, clamp=None,
                    flip_filter=False, impl='cuda'):
     r"""Filtered leaky ReLU for a batch of 2-D images; see the module docstring.
@@ -258,7 +271,8 @@ def filtered_lrelu(x, fu=None, fd=None, b=None, up=1, down=1, padding=0, gain=np
     assert isinstance(x, torch.Tensor)
     assert impl in ['ref', 'cuda']
     if impl == 'ref':
-        raise NotImplementedError("afcm_amd ships no aten fallback; impl='ref' lives in oracle/aten_ops.py (test-only)")
+        _lib.require_gpu(x, fu, fd, b)
+        return _filtered_lrelu_generic(x, fu, fd, b, up, down, padding, gain, slope, clamp, flip_filter)
     assert isinstance(up, (int, np.integer)) and up >= 1
     assert isinstance(down, (int, np.integer)) and down >= 1
     px0, px1, py0, py1 = _parse_padding(padding)

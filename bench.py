@@ -38,15 +38,27 @@ def parse():
     ap.add_argument('--cpu-baseline-worker', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--no-kernel-timing', action='store_true', help='skip the HIP-event spans around the hot kernels')
     ap.add_argument('--force-dist', action='store_true', help='initialise RCCL and run the gradient buckets even with one rank (path check)')
+    ap.add_argument('--comm-dtype', default='fp32', choices=['fp32', 'bf16'], help='dtype of the gradient buckets on the wire')
     ap.add_argument('--with-discriminator', action='store_true',
                     help='time the FULL iteration (D update with R1, then G update with the GAN term; SURVEY.md row f1) instead of the '
                          'generator step that BASELINE.json\'s metric names')
     return ap.parse_args()
 
 
-def cpu_baseline_worker(res):
-    """Child process: time the CPU oracle (pure-aten restatement of the reference's impl='ref' path) on a bounded
-    sample -- full-width generator, batch 1, ONE fwd+bwd, all host cores."""
+def _cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown CPU'
+
+
+def cpu_baseline_worker(res, batch=2, timed=2):
+    """Child process: time the CPU oracle (pure-aten restatement of the reference's impl='ref' path, oracle/) as SURVEY.md
+    section 8(d) / BASELINE.md section 4 plan it: full-width generator, batch 2, fwd + L1 loss + bwd on the same synthetic tensors
+    the GPU run uses (afcm_amd.synthetic, seed 0), all host cores, 1 warm-up + 2 timed iterations."""
     import torch
     from oracle import generator as ogen
     threads = min(os.cpu_count() or 1, 32)      # the oracle's small aten ops stop scaling (and thrash) beyond a few dozen threads
@@ -54,34 +66,47 @@ def cpu_baseline_worker(res):
     from afcm_amd import synthetic
     pl = ogen.plan(res, 4, 1, {})
     sd = ogen.random_state_dict(pl, 512, 1, 512, 8, seed=0)
-    params = {k: v.requires_grad_(True) for k, v in sd.items() if not k.endswith(('magnitude_ema', 'w_avg'))}
-    real_A, real_B, z, c = synthetic.generator_inputs(1, size=res, seed=0)
-    t0 = time.time()
-    y = ogen.generator(sd, pl, z, c, real_A, mapping_layers=8, dropout_mask=(torch.rand(1, 1024) > 0.5).float() * 2)
-    loss = (y - real_B).abs().mean() * 100.0
-    loss.backward()
-    dt = time.time() - t0
-    del params
-    print(json.dumps(dict(seconds=dt, images=1, cores=threads)))
+    params = [v.requires_grad_(True) for k, v in sd.items() if not k.endswith(('magnitude_ema', 'w_avg', 'up_filter', 'down_filter'))]
+    real_A, real_B, z, c = synthetic.generator_inputs(batch, size=res, seed=0)
+    mask = (torch.rand(batch, 1024, generator=torch.Generator().manual_seed(0)) > 0.5).float() * 2
+    times = []
+    for it in range(1 + timed):
+        for p in params:
+            p.grad = None
+        t0 = time.time()
+        y = ogen.generator(sd, pl, z, c, real_A, mapping_layers=8, dropout_mask=mask)
+        loss = (y - real_B).abs().mean() * 100.0
+        loss.backward()
+        times.append(time.time() - t0)
+        print(json.dumps(dict(progress=it, seconds=times[-1])), flush=True)
+    print(json.dumps(dict(seconds=sum(times[1:]) / timed, warmup_seconds=times[0], images=batch, batch=batch, timed=timed, cores=threads,
+                          cpu=_cpu_model(), res=res)))
 
 
-def run_cpu_baseline(res, timeout=100):
-    """Bounded CPU sample: the 256^2 workload first; if the host cannot finish it inside the budget, the reference's own
-    CPU-runnable configuration (BASELINE.json configs[0] resolution, 128^2).  Never blocks the GPU number."""
-    tried = []
-    for r in ([res, 128] if res > 128 else [res]):
+def run_cpu_baseline(res, budget=(120, 200)):
+    """Bounded CPU samples, config-1 shape first (128^2, BASELINE.json configs[0]: the reference's own CPU-runnable case), then the
+    bench resolution; each in a child process under its own time limit so the GPU number is never blocked.  `value` is the point
+    at the bench resolution when it finished inside its limit, else the 128^2 point (said in `sample`)."""
+    points, notes = [], []
+    for r, limit in zip(sorted({128, res}), budget):
         try:
             out = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-baseline-worker', '--res', str(r)],
-                                 capture_output=True, text=True, timeout=timeout, cwd=ROOT)
-            line = [l for l in out.stdout.splitlines() if l.startswith('{')][-1]
-            d = json.loads(line)
-            note = '' if r == res else f' (the {res}x{res} sample exceeded {timeout} s on this host; 128^2 is BASELINE.json configs[0], 4x fewer pixels per image)'
-            return dict(value=d['images'] / d['seconds'], unit='images/sec', cores=d['cores'], kind='port',
-                        sample=f'oracle/ (aten restatement of the reference impl=ref path), full-width {r}x{r} generator, batch 1, '
-                               f'one fwd+bwd incl. first-call overheads, {d["seconds"]:.1f} s on {d["cores"]} threads' + note)
-        except Exception as e:  # timeout or failure: try the smaller sample, then give up
-            tried.append(f'{r}: {type(e).__name__}')
-    return dict(value=None, unit='images/sec', cores=min(os.cpu_count() or 1, 32), kind='port', sample='not measured: ' + '; '.join(tried))
+                                 capture_output=True, text=True, timeout=limit, cwd=ROOT)
+            d = json.loads([l for l in out.stdout.splitlines() if l.startswith('{"seconds"')][-1])
+            points.append(dict(resolution=r, batch=d['batch'], images_per_sec=d['images'] / d['seconds'], s_per_iteration=d['seconds'],
+                               warmup_s=d['warmup_seconds'], timed_iterations=d['timed'], cores=d['cores'], cpu=d['cpu']))
+        except Exception as e:  # timeout or failure: say so, keep what was measured
+            notes.append(f'{r}x{r}: {type(e).__name__} (limit {limit} s)')
+    if not points:
+        return dict(value=None, unit='images/sec', cores=min(os.cpu_count() or 1, 32), kind='port', sample='not measured: ' + '; '.join(notes))
+    head = [p for p in points if p['resolution'] == res] or points[-1:]
+    h = head[0]
+    return dict(value=h['images_per_sec'], unit='images/sec', cores=h['cores'], kind='port',
+                sample=f'oracle/ (aten restatement of the reference impl=ref path), full-width {h["resolution"]}x{h["resolution"]} generator, '
+                       f'batch {h["batch"]}, fwd + L1 + bwd on the GPU run\'s synthetic tensors, 1 warm-up ({h["warmup_s"]:.1f} s) + '
+                       f'{h["timed_iterations"]} timed iterations ({h["s_per_iteration"]:.1f} s each) on {h["cores"]} threads of {h["cpu"]}'
+                       + ('' if not notes else '; not finished: ' + '; '.join(notes)),
+                points=points)
 
 
 def main():
@@ -120,6 +145,7 @@ def main():
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
     dtype = {'bf16': torch.bfloat16, 'fp16': torch.float16, 'fp32': torch.float32}[args.dtype]
+    comm_dtype = torch.bfloat16 if args.comm_dtype == 'bf16' else None
     torch.manual_seed(0)      # identical init on every rank (the step also broadcasts from rank 0)
     kw = dict(sched.DEFAULT_SYNTHESIS_KWARGS)
     G = Stylegan3Generator(z_dim=512, c_dim=1, w_dim=512, img_resolution=args.res, img_channels_in=4, img_channels_out=1,
@@ -134,9 +160,10 @@ def main():
                                num_fp16_res=n16, conv_clamp=(256 if n16 else None), block_kwargs=dict(fp16_dtype=dtype if n16 else torch.float16),
                                epilogue_kwargs=dict(mbstd_group_size=16)).to(dev)
         step = StyleGAN3Step(G, D, lr_G=0.0025, lr_D=0.0025, lambda_L1=100.0, lambda_r1=10.0, distributed=use_dist,
-                             force_collectives=args.force_dist)
+                             force_collectives=args.force_dist, comm_dtype=comm_dtype)
     else:
-        step = StyleGAN3GeneratorStep(G, lr_G=0.0025, lambda_L1=100.0, distributed=use_dist, force_collectives=args.force_dist)
+        step = StyleGAN3GeneratorStep(G, lr_G=0.0025, lambda_L1=100.0, distributed=use_dist, force_collectives=args.force_dist,
+                                      comm_dtype=comm_dtype)
     real_A, real_B, z, c = synthetic.generator_inputs(args.batch, size=args.res, seed=rank, device=dev)
 
     def one_step():
@@ -191,7 +218,7 @@ def main():
         cpu = run_cpu_baseline(args.res) if (world == 1 and args.cpu_baseline == 'auto') else None
         images = world * args.batch * args.steps
         out = {
-            'metric': 'generator fwd+bwd images/sec @256^2' if not args.with_discriminator else 'full GAN iteration (D + G update) images/sec @256^2',
+            'metric': f'generator fwd+bwd images/sec @{args.res}^2' if not args.with_discriminator else f'full GAN iteration (D + G update) images/sec @{args.res}^2',
             'value': images / elapsed,
             'unit': 'images/sec',
             'n_gpus': world,
@@ -207,7 +234,12 @@ def main():
                                    f'AFCM --model stylegan3 generator training step (fwd + L1 loss + bwd + grad all-reduce + Adam), '
                                    f'IXI T1->T2 shape: {args.res}x{args.res}, 4->1 channels, full-width 58.5M-param generator, random init',
                        'global_batch': world * args.batch, 'per_gpu_batch': args.batch, 'resolution': args.res,
-                       'parallelism': f'dp{world}'},
+                       'parallelism': f'dp{world}',
+                       # what the process group itself reports (a SCALE record can check that RCCL saw N ranks)
+                       'world_size': dist.get_world_size() if use_dist else 1,
+                       'backend': dist.get_backend() if use_dist else None,
+                       'gradient_buckets': step.buckets.num_buckets if step.buckets is not None else 0,
+                       'comm_dtype': args.comm_dtype},
             'roofline': roofline,
             'kernels': kernels,
             'cpu_baseline': cpu,

@@ -131,10 +131,15 @@ def downsample2d(x, f, down=2, padding=0, flip_filter=False, gain=1):
 
 
 def filtered_lrelu(x, fu=None, fd=None, b=None, up=1, down=1, padding=0, gain=SQRT2, slope=0.2, clamp=None,
-                   flip_filter=False):
+                   flip_filter=False, codes=None, record=None):
     """bias -> upfirdn(up, gain up^2) -> leaky-ReLU * gain -> clamp -> upfirdn(down).
 
     Follows _filtered_lrelu_ref, SG3OPS/filtered_lrelu.py:121-153.
+
+    Test instrumentation (not part of the reference signature): ``record`` (a list) receives the pre-activation tensor on the
+    upsampled grid; ``codes`` (uint8 [N, C, >= rows used, >= cols], bit 0 = negative branch, bit 1 = clamped -- the meaning of the
+    plugin's 2-bit codes, SG3OPS/filtered_lrelu.cu:494-505) imposes the branch decisions of another implementation, so that a
+    gradient comparison can separate "a pre-activation within rounding distance of 0 took the other branch" from real errors.
     """
     px0, px1, py0, py1 = _pad4(padding)
     fuw, fuh = _fsize(fu)
@@ -144,7 +149,22 @@ def filtered_lrelu(x, fu=None, fd=None, b=None, up=1, down=1, padding=0, gain=SQ
     oh = (h * up + py0 + py1 - (fuh - 1) - (fdh - 1) + (down - 1)) // down        # [line 142]
     y = bias_act(x, b)
     y = upfirdn2d(y, fu, up=up, padding=[px0, px1, py0, py1], gain=up ** 2, flip_filter=flip_filter)
-    y = bias_act(y, act='lrelu', alpha=slope, gain=gain, clamp=clamp)
+    if record is not None:
+        record.append(y.detach())
+    if codes is None:
+        y = bias_act(y, act='lrelu', alpha=slope, gain=gain, clamp=clamp)
+    else:
+        full = torch.zeros(y.shape, dtype=torch.uint8)
+        hh, ww = min(y.shape[2], codes.shape[2]), min(y.shape[3], codes.shape[3])
+        full[:, :, :hh, :ww] = codes[:, :, :hh, :ww]
+        if hh < y.shape[2] or ww < y.shape[3]:      # rows / columns the other implementation never stored: own decision
+            own = (y.detach() < 0).to(torch.uint8)
+            own[:, :, :hh, :ww] = full[:, :, :hh, :ww]
+            full = own
+        v = y * torch.where((full & 1) != 0, torch.full_like(y, slope), torch.ones_like(y)) * gain
+        if clamp is not None and clamp >= 0:
+            v = torch.where((full & 2) != 0, v.detach().clamp(-clamp, clamp), v)
+        y = v
     y = upfirdn2d(y, fd, down=down, flip_filter=flip_filter)
     assert tuple(y.shape) == (n, c, oh, ow), (y.shape, (n, c, oh, ow))
     return y

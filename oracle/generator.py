@@ -123,11 +123,22 @@ def mapping(sd, z, c, num_ws, num_layers, lr_mul=0.01, prefix='mapping.'):
     return x[:, None].repeat(1, num_ws, 1)
 
 
-def synthesis(sd, pl, ws, img_in, dropout_mask=None, prefix='synthesis.', taps=None):
+def _instr(name, codes, preact):
+    kw = {}
+    if codes is not None and name in codes:
+        kw['codes'] = codes[name]
+    if preact is not None:
+        kw['record'] = preact.setdefault(name, [])
+    return kw
+
+
+def synthesis(sd, pl, ws, img_in, dropout_mask=None, prefix='synthesis.', taps=None, codes=None, preact=None):
     """SynthesisNetwork.forward (NET:666-705) with update_emas=False.
 
     ``dropout_mask`` (already scaled by 1/(1-p)) stands in for torch's Dropout in training mode;
-    ``None`` is eval mode.  ``taps`` optionally receives every resampling layer's output.
+    ``None`` is eval mode.  ``taps`` optionally receives every resampling layer's output; ``preact`` (dict) every layer's
+    pre-activation tensor and ``codes`` (dict name -> uint8 codes) imposes another implementation's leaky-ReLU branch decisions
+    (see oracle.aten_ops.filtered_lrelu).
     """
     dt = sd[prefix + 'fc_in.weight'].dtype
     ws = ws.to(dt).unbind(1)
@@ -140,7 +151,7 @@ def synthesis(sd, pl, ws, img_in, dropout_mask=None, prefix='synthesis.', taps=N
         w = sd[p + 'weight'] * (1 / math.sqrt(L['cin'] * L['k'] ** 2))
         x = ops.conv2d(x, w, padding=L['k'] - 1)
         x = ops.filtered_lrelu(x, fu=L['fu'], fd=L['fd'], b=sd[p + 'bias'], up=L['up'], down=L['down'], padding=L['padding'],
-                               gain=math.sqrt(2), slope=0.2, clamp=clamp)
+                               gain=math.sqrt(2), slope=0.2, clamp=clamp, **_instr(L['name'], codes, preact))
         if taps is not None:
             taps[L['name']] = x
         if L['store']:
@@ -166,7 +177,8 @@ def synthesis(sd, pl, ws, img_in, dropout_mask=None, prefix='synthesis.', taps=N
         x = ops.modulated_conv2d(x, sd[p + 'weight'], styles, demodulate=not L['torgb'], padding=L['k'] - 1,
                                  input_gain=input_gain)
         x = ops.filtered_lrelu(x, fu=L['fu'], fd=L['fd'], b=sd[p + 'bias'], up=L['up'], down=L['down'], padding=L['padding'],
-                               gain=1.0 if L['torgb'] else math.sqrt(2), slope=1.0 if L['torgb'] else 0.2, clamp=clamp)
+                               gain=1.0 if L['torgb'] else math.sqrt(2), slope=1.0 if L['torgb'] else 0.2, clamp=clamp,
+                               **_instr(L['name'], codes, preact))
         if L['skip']:
             x = x + feats[L['skip_key']]
         if taps is not None:
@@ -176,10 +188,10 @@ def synthesis(sd, pl, ws, img_in, dropout_mask=None, prefix='synthesis.', taps=N
     return x.to(dt)
 
 
-def generator(sd, pl, z, c, cond_img, mapping_layers, dropout_mask=None, taps=None):
+def generator(sd, pl, z, c, cond_img, mapping_layers, dropout_mask=None, taps=None, codes=None, preact=None):
     """Stylegan3Generator.forward (NET:737-740)."""
     ws = mapping(sd, z, c, pl['num_ws'], mapping_layers)
-    return synthesis(sd, pl, ws, cond_img, dropout_mask=dropout_mask, taps=taps)
+    return synthesis(sd, pl, ws, cond_img, dropout_mask=dropout_mask, taps=taps, codes=codes, preact=preact)
 
 
 def random_state_dict(pl, z_dim, c_dim, w_dim, mapping_layers, seed=0, lr_mul=0.01):

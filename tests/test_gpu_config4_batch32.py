@@ -1,0 +1,121 @@
+"""BASELINE.json configs[3] -- ADNI CMSR 256x256, batch 32 per GPU -- per-GPU workload on ONE MI355X (the 8-GPU leg is the same
+program on every rank plus the gradient all-reduce, covered on CPU by tests/test_distributed_cpu.py).
+
+Full BASELINE sizes admit no CPU oracle for the whole tensor, so these are the size-independent checks the batch-16 tests use,
+at batch 32: linearity of the (given-the-codes) linear backward, spot planes against the CPU oracle, the matrix-core kernels
+against the exact fp32 kernels on the same planes, and the data-parallel identity itself -- one batch-32 step's gradient equals
+the mean of the gradients of its two batch-16 halves (what sharding the batch over two ranks computes)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _plan():
+    from oracle import generator as ogen
+    return ogen.plan(256, 4, 1, {})
+
+
+@pytest.mark.parametrize('layer,channels', [('enc1', 64), ('enc4', 181)])
+def test_filtered_lrelu_batch32_full_size(layer, channels):
+    """enc1 (up2/down2, 64 x 278^2 planes) and enc4 (up2/down4, 181 x 278^2) at batch 32, bf16 matrix-core kernels: backward
+    linear in dy; spot planes vs the fp32 CPU oracle on the same 16-bit-rounded inputs (y and dx)."""
+    from afcm_amd.torch_utils.ops import filtered_lrelu as flr
+    from oracle import aten_ops as ops
+    pl = _plan()
+    L = pl['enc'][int(layer[3:])]
+    torch.manual_seed(1)
+    h = L['in_size'] + 2
+    x = torch.randn(32, channels, h, h, device='cuda', dtype=torch.bfloat16).requires_grad_(True)
+    b = (torch.randn(channels, device='cuda') * 0.1).to(torch.bfloat16)
+    kw = dict(up=L['up'], down=L['down'], padding=L['padding'], gain=float(np.sqrt(2)), slope=0.2, clamp=256.0)
+    fu, fd = L['fu'].cuda(), L['fd'].cuda()
+    y = flr.filtered_lrelu(x, fu=fu, fd=fd, b=b, **kw)
+    assert y.shape == (32, channels, L['out_size'], L['out_size'])
+    assert y.grad_fn is not None
+    r1, r2 = torch.randn_like(y), torch.randn_like(y)
+    g1, = torch.autograd.grad(y, x, r1, retain_graph=True)
+    g2, = torch.autograd.grad(y, x, r2, retain_graph=True)
+    g12, = torch.autograd.grad(y, x, (r1.float() + 2 * r2.float()).to(torch.bfloat16), retain_graph=True)
+    lin = (g12.float() - (g1.float() + 2 * g2.float())).abs().max().item()
+    assert lin <= 4e-2 * g12.float().abs().max().item(), lin          # bf16 rounding of three separately rounded results
+    for (n, c) in [(0, 0), (17, channels // 2), (31, channels - 1)]:
+        xs = x[n:n + 1, c:c + 1].detach().float().cpu().requires_grad_(True)
+        ref = ops.filtered_lrelu(xs, fu=L['fu'], fd=L['fd'], b=b[c:c + 1].float().cpu(), **kw)
+        scale = max(1.0, ref.abs().max().item())
+        assert (y[n, c].float().cpu() - ref[0, 0]).abs().max().item() <= 3e-2 * scale, (layer, n, c)
+        gref, = torch.autograd.grad(ref, xs, r1[n:n + 1, c:c + 1].float().cpu())
+        assert (g1[n, c].float().cpu() - gref[0, 0]).abs().max().item() <= 3e-2 * max(1.0, gref.abs().max().item()), (layer, n, c, 'dx')
+
+
+def test_modulated_conv_batch32_enc7_shape():
+    """The largest contraction of the network, 362 -> 512 @ 148^2 (enc7's shape, run modulated), batch 32, bf16: linear in x,
+    three output planes vs the fp32 CPU oracle, and the weight gradient's batch-32 value = sum of its two batch-16 halves."""
+    from afcm_amd.torch_utils.ops.conv2d import modulated_conv2d
+    from oracle import aten_ops as ops
+    torch.manual_seed(2)
+    n, ci, co, h = 32, 362, 512, 148
+    x = torch.randn(n, ci, h, h, device='cuda', dtype=torch.bfloat16)
+    w = torch.randn(co, ci, 3, 3, device='cuda').requires_grad_(True)
+    s = torch.randn(n, ci, device='cuda') * 0.2 + 1
+    y = modulated_conv2d(x, w, s, padding=2)
+    assert y.shape == (n, co, h + 2, h + 2)
+    y2 = modulated_conv2d(x * 2, w, s, padding=2)
+    assert ((y2.float() - 2 * y.float()).abs().max() <= 2e-2 * y.float().abs().max()).item()
+    for (ni, oi) in [(0, 0), (19, 300), (31, 511)]:
+        ref = ops.modulated_conv2d(x[ni:ni + 1].float().cpu(), w.detach().cpu(), s[ni:ni + 1].cpu(), padding=2)
+        err = (y[ni, oi].float().cpu() - ref[0, oi]).abs().max().item()
+        assert err <= 2e-2 * max(1.0, ref[0, oi].abs().max().item()), (ni, oi, err)
+    r = torch.randn_like(y)
+    gw, = torch.autograd.grad(y, w, r)
+    # the style normaliser (NET:43) spans the batch; it cancels under demodulation, so the halves are comparable at 16-bit noise
+    gh = 0
+    for sl in (slice(0, 16), slice(16, 32)):
+        yh = modulated_conv2d(x[sl], w, s[sl], padding=2)
+        gh = gh + torch.autograd.grad(yh, w, r[sl])[0]
+    rel = ((gw - gh).norm() / gh.norm()).item()
+    assert rel <= 1e-2, rel
+
+
+@pytest.mark.parametrize('dtype,rel_tol', [(torch.float32, 2e-3), (torch.bfloat16, 5e-2)])
+def test_generator_step_batch32_equals_mean_of_two_batch16_halves(dtype, rel_tol):
+    """One StyleGAN3GeneratorStep gradient evaluation of the full-width 256^2 generator at batch 32 (eval mode: no dropout draw)
+    vs the mean of the gradients of its two batch-16 halves -- the identity batch sharding over ranks rests on (SURVEY section
+    8e: the only cross-sample coupling, NET:43, cancels under demodulation up to 1e-8).  fp32 on the exact kernels: 2e-3
+    relative L2 (kink flips from summation order); bf16 on the matrix-core kernels: 5e-2 (16-bit activation rounding differs
+    between the two evaluations where the batch-wide normaliser differs in its last bits)."""
+    from afcm_amd import synthetic
+    from afcm_amd.layer_schedule import DEFAULT_SYNTHESIS_KWARGS
+    from afcm_amd.networks_stylegan3 import Stylegan3Generator
+    from afcm_amd.stylegan3_model import StyleGAN3GeneratorStep
+    torch.manual_seed(0)
+    G = Stylegan3Generator(z_dim=512, c_dim=1, w_dim=512, img_resolution=256, img_channels_in=4, img_channels_out=1,
+                           mapping_kwargs=dict(num_layers=8), synthesis_kwargs=dict(DEFAULT_SYNTHESIS_KWARGS, compute_dtype=dtype)).cuda().eval()
+    step = StyleGAN3GeneratorStep(G, lambda_L1=100.0)
+    a, b, z, c = synthetic.generator_inputs(32, size=256, seed=4, device='cuda')
+
+    def grads(sl):
+        step.optimizer_G.zero_grad(set_to_none=True)
+        step.set_input(a[sl], b[sl], z[sl], c[sl])
+        step.forward()
+        step.backward_G()
+        assert step.fake_B.shape == (a[sl].shape[0], 1, 256, 256)
+        return {n: p.grad.detach().float().clone() for n, p in G.named_parameters() if p.grad is not None}, step.loss_G.item()
+    g32, l32 = grads(slice(0, 32))
+    ga, la = grads(slice(0, 16))
+    gb, lb = grads(slice(16, 32))
+    assert abs(l32 - 0.5 * (la + lb)) <= (1e-5 if dtype == torch.float32 else 5e-3) * abs(l32)
+    assert set(g32) == set(ga) == set(gb)
+    num = den = 0.0
+    worst = ('', 0.0)
+    for n in g32:
+        m = 0.5 * (ga[n] + gb[n])
+        e, s = (g32[n] - m).double().norm().item(), m.double().norm().item()
+        num, den = num + e * e, den + s * s
+        if s > 0 and e / s > worst[1]:
+            worst = (n, e / s)
+    rel = (num / den) ** 0.5
+    print(f'{dtype}: batch 32 vs mean of halves: relative L2 over all parameters {rel:.2e}; worst tensor {worst[0]} {worst[1]:.2e}')
+    assert rel <= rel_tol
+    assert worst[1] <= 10 * rel_tol, worst

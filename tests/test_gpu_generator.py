@@ -65,6 +65,78 @@ def test_generator_matches_reference_golden(name, res):
         assert abs(norms[str(n)] - v) <= 5e-3 * max(1.0, v), (n, norms[str(n)], v)
 
 
+@pytest.mark.parametrize('name,res', [('G1_tiny128', 128), ('G2_tiny256', 256)])
+def test_generator_gradients_with_the_kernels_branch_decisions_imposed(name, res, monkeypatch):
+    """the end-to-end gradient bound above is loose (relative L2 1e-2) on the argument that pre-activations
+    within rounding distance of 0 take the other leaky-ReLU branch.  Verified here instead of argued: the 2-bit codes every HIP
+    filtered_lrelu launch wrote are decoded and (a) compared with the oracle's own decisions -- they may differ only where the
+    oracle's pre-activation is within 1e-5 x scale of 0 (or of the clamp), (b) imposed on the oracle, after which EVERY parameter
+    gradient agrees to 1e-4 (relative L2 and max-abs over the tensor's scale)."""
+    from afcm_amd.torch_utils.ops import filtered_lrelu as flr
+    from oracle import generator as ogen
+    g = load_golden(name)
+    G = _build(res).eval()
+    sd = {k[3:]: torch.from_numpy(np.array(v)) for k, v in g.items() if k.startswith('sd/')}
+    G.load_state_dict(sd, strict=True)
+    G = G.cuda()
+    written = []
+    run = flr._run
+
+    def recording_run(x, fu, fd, b, si, cfg, write_signs, *a, **k):
+        out = run(x, fu, fd, b, si, cfg, write_signs, *a, **k)
+        if write_signs:
+            assert out[2] == 0                                     # fp32: the reference's row-major 2-bit packing
+            written.append(out[1])
+        return out
+    monkeypatch.setattr(flr, '_run', recording_run)
+    z, c, x, r = (torch.from_numpy(g[k]) for k in ('z', 'c', 'x', 'r'))
+    y = G(z.cuda(), c.cuda(), x.cuda())
+    names = [n for n, _ in G.named_parameters()]
+    grads = torch.autograd.grad((y * r.cuda()).sum(), list(G.parameters()), allow_unused=True)
+    pl = ogen.plan(res, 4, 1, dict(TINY))
+    layers = [L['name'] for L in pl['enc']] + [L['name'] for L in pl['dec']]
+    assert len(written) == len(layers)
+    codes = {}
+    for lname, s in zip(layers, written):
+        s = s.cpu().numpy()
+        codes[lname] = torch.from_numpy(np.stack([(s >> (2 * k)) & 3 for k in range(4)], axis=-1).reshape(*s.shape[:3], s.shape[3] * 4))
+    # (a) the oracle's own decisions
+    pre = {}
+    osd = {k: v.clone() for k, v in sd.items()}
+    ogen.generator(osd, pl, z, c, x, mapping_layers=2, preact=pre)
+    flips = 0
+    for L in pl['enc'] + pl['dec']:
+        u = pre[L['name']][0]
+        cd = codes[L['name']]
+        hh, ww = min(u.shape[2], cd.shape[2]), min(u.shape[3], cd.shape[3])
+        u, cd = u[:, :, :hh, :ww], cd[:, :, :hh, :ww]
+        slope, gain = (1.0, 1.0) if L['torgb'] else (0.2, float(np.sqrt(2)))
+        own_neg = u < 0
+        v = (u * torch.where(own_neg, slope, 1.0) * gain).abs()
+        diff = ((cd & 1) != 0) != own_neg
+        if slope == 1.0:
+            diff = torch.zeros_like(diff)                          # ToRGB: both branches are the same function
+        diff |= ((cd & 2) != 0) != (v > pl['conv_clamp'])
+        flips += int(diff.sum())
+        scale = max(1.0, float(u.abs().max()))
+        near = (u.abs() <= 1e-5 * scale) | ((v - pl['conv_clamp']).abs() <= 1e-5 * pl['conv_clamp'])
+        assert not (diff & ~near).any(), f'{L["name"]}: a branch decision differs away from the kink'
+    print(f'{name}: {flips} branch decisions differ from the oracle over {len(layers)} layers (all within rounding distance of a kink)')
+    # (b) same decisions -> same gradients
+    oparams = {k: osd[k].requires_grad_(True) for k in names}
+    yo = ogen.generator(osd, pl, z, c, x, mapping_layers=2, codes=codes)
+    assert (y.detach().cpu() - yo.detach()).abs().max().item() <= 5e-5 * max(1.0, float(yo.abs().max()))
+    gref = torch.autograd.grad((yo * r).sum(), [oparams[k] for k in names], allow_unused=True)
+    for k, a, b in zip(names, grads, gref):
+        assert (a is None) == (b is None), k
+        if a is None:
+            continue
+        d = a.cpu().double() - b.double()
+        scale = max(1e-6, float(b.abs().max()))
+        assert float(d.abs().max()) <= 1e-4 * scale, f'{name} grad {k}: max-abs {float(d.abs().max()):.3e} of scale {scale:.3g}'
+        assert float(d.norm() / b.double().norm().clamp_min(1e-30)) <= 1e-4, f'{name} grad {k}: relative L2'
+
+
 def test_state_dict_keys_match_reference_full_width():
     """Key-for-key state-dict compatibility with the reference's shipped 256^2 configuration."""
     from afcm_amd.networks_stylegan3 import Stylegan3Generator
@@ -228,3 +300,39 @@ def test_full_width_generator_fp32_matches_oracle():
     ps = synthetic.psnr(y16, ref)
     print(f'full-width bf16: max-abs {(y16 - ref).abs().max().item():.3e}, PSNR vs fp32 oracle {ps:.1f} dB')
     assert ps >= 30.0
+
+
+def test_full_width_16bit_accuracy_budget():
+    """North star: "PSNR within 0.05 dB of reference".  A 16-bit forward whose output has PSNR P_e against the fp32 forward
+    (errors uncorrelated with the task error) lowers a task PSNR P_t by 10 log10(1 + 10^((P_t - P_e)/10)) dB; <= 0.05 dB at
+    P_t <= 32.6 dB needs P_e >= 52 dB.  Measured on the full-width 256^2 generator (the fp32 GPU forward is itself within 2e-6
+    of the CPU oracle, test_full_width_generator_fp32_matches_oracle): fp16 must meet the budget -- it is what `test()` /
+    `forward_ema()` use when training runs in bf16 (StyleGAN3GeneratorStep(eval_dtype='auto')); bf16 is reported, bounded below
+    at 40 dB, and is a training-throughput dtype only."""
+    import copy
+    import math
+    from afcm_amd import synthetic
+    from afcm_amd.layer_schedule import DEFAULT_SYNTHESIS_KWARGS
+    from afcm_amd.networks_stylegan3 import Stylegan3Generator
+    from afcm_amd.stylegan3_model import StyleGAN3GeneratorStep
+    torch.manual_seed(0)
+    G = Stylegan3Generator(z_dim=512, c_dim=1, w_dim=512, img_resolution=256, img_channels_in=4, img_channels_out=1,
+                           mapping_kwargs=dict(num_layers=8), synthesis_kwargs=dict(DEFAULT_SYNTHESIS_KWARGS)).cuda().eval()
+    a, _, z, c = synthetic.generator_inputs(4, size=256, seed=5, device='cuda')
+    out = {}
+    with torch.no_grad():
+        for dt in (torch.float32, torch.float16, torch.bfloat16):
+            G.synthesis.compute_dtype = dt
+            out[dt] = G(z, c, a).float().cpu()
+    G.synthesis.compute_dtype = torch.bfloat16
+    ps16, psb = synthetic.psnr(out[torch.float16], out[torch.float32]), synthetic.psnr(out[torch.bfloat16], out[torch.float32])
+    cost = lambda pe, pt: 10 * math.log10(1 + 10 ** ((pt - pe) / 10))
+    print(f'full-width vs fp32: fp16 {ps16:.1f} dB (costs {cost(ps16, 32.6):.3f} dB at a 32.6 dB task), bf16 {psb:.1f} dB ({cost(psb, 32.6):.3f} dB)')
+    assert ps16 >= 52.0, ps16
+    assert psb >= 40.0, psb
+    step = StyleGAN3GeneratorStep(G, ema=True)                               # training dtype bf16 -> evaluation copy in fp16
+    assert step.netG_ema.synthesis.compute_dtype == torch.float16 and G.synthesis.compute_dtype == torch.bfloat16
+    step.set_input(a, torch.zeros(4, 1, 256, 256), z, c)
+    step.test()
+    assert synthetic.psnr(step.fake_B.float().cpu(), out[torch.float32]) >= 52.0
+    assert StyleGAN3GeneratorStep(G, ema=True, eval_dtype=torch.float32).netG_ema.synthesis.compute_dtype == torch.float32

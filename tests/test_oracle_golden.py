@@ -190,3 +190,28 @@ def test_discriminator_oracle_matches_reference(name):
     lg = torch.nn.functional.softplus(-od.discriminator(sd, img, res, **kw)).mean()
     gi, = torch.autograd.grad(lg, img)
     assert np.abs(gi.numpy() - g['g_img']).max() <= 1e-5 * max(1e-3, float(np.abs(g['g_img']).max()))
+
+
+def test_filtered_lrelu_branch_override_is_self_consistent():
+    """oracle.aten_ops.filtered_lrelu(codes=...) with the oracle's OWN branch decisions reproduces value and gradient of the plain
+    call (the instrumentation the GPU gradient-attribution test relies on)."""
+    import torch
+    from oracle import aten_ops as ops
+    g = load_golden('F6_clamp')
+    up, down, *pad = [int(v) for v in g['meta']]
+    gain, slope, clamp, flip = [float(v) for v in g['fmeta']]
+    kw = dict(fu=torch.from_numpy(g['fu']), fd=torch.from_numpy(g['fd']), b=torch.from_numpy(g['b']), up=up, down=down, padding=pad,
+              gain=gain, slope=slope, clamp=clamp, flip_filter=bool(flip))
+    x = torch.from_numpy(g['x']).requires_grad_(True)
+    rec = []
+    y = ops.filtered_lrelu(x, record=rec, **kw)
+    u = rec[0]
+    v = u * torch.where(u < 0, slope, 1.0) * gain
+    codes = (u < 0).to(torch.uint8) | ((v.abs() > clamp).to(torch.uint8) << 1)
+    assert int((codes & 2).ne(0).sum()) > 0
+    y2 = ops.filtered_lrelu(x, codes=codes, **kw)
+    r = torch.from_numpy(g['r'])
+    g1, = torch.autograd.grad((y * r).sum(), x)
+    g2, = torch.autograd.grad((y2 * r).sum(), x)
+    assert torch.allclose(y, y2, atol=1e-6) and torch.allclose(g1, g2, atol=1e-6)
+    assert np.abs(g2.numpy() - g['dx']).max() <= 1e-5 * max(1.0, np.abs(g['dx']).max())
