@@ -80,12 +80,12 @@ def test_modulated_conv_batch32_enc7_shape():
     assert rel <= 1e-2, rel
 
 
-@pytest.mark.parametrize('dtype,rel_tol', [(torch.float32, 2e-3), (torch.bfloat16, 5e-2)])
+@pytest.mark.parametrize('dtype,rel_tol', [(torch.float32, 1e-4), (torch.bfloat16, 1e-2)])
 def test_generator_step_batch32_equals_mean_of_two_batch16_halves(dtype, rel_tol):
     """One StyleGAN3GeneratorStep gradient evaluation of the full-width 256^2 generator at batch 32 (eval mode: no dropout draw)
     vs the mean of the gradients of its two batch-16 halves -- the identity batch sharding over ranks rests on (SURVEY section
-    8e: the only cross-sample coupling, NET:43, cancels under demodulation up to 1e-8).  fp32 on the exact kernels: 2e-3
-    relative L2 (kink flips from summation order); bf16 on the matrix-core kernels: 5e-2 (16-bit activation rounding differs
+    8e: the only cross-sample coupling, NET:43, cancels under demodulation up to 1e-8).  fp32 on the exact kernels: 1e-4 (measured 1e-5)
+    relative L2 (kink flips from summation order); bf16 on the matrix-core kernels: 1e-2 (measured 1.4e-3; 16-bit activation rounding differs
     between the two evaluations where the batch-wide normaliser differs in its last bits)."""
     from afcm_amd import synthetic
     from afcm_amd.layer_schedule import DEFAULT_SYNTHESIS_KWARGS
