@@ -489,6 +489,7 @@ static int dispatch(const afcm_filtered_lrelu_args* a, const FlreluParams& p, hi
 
 int flrelu_mfma_supported(const afcm_filtered_lrelu_args* a);
 int flrelu_mfma_tiles(const afcm_filtered_lrelu_args* a);
+int flrelu_mfma_sign_layout(const afcm_filtered_lrelu_args* a);
 int flrelu_mfma_launch(const afcm_filtered_lrelu_args* a, bool prepare, hipStream_t st);
 
 }  // namespace afcm
@@ -514,8 +515,9 @@ extern "C" int afcm_filtered_lrelu_shapes(afcm_filtered_lrelu_args* a) {
         const long long sw_active = yw * a->down - (a->down - 1) + fdt_w;
         const long long sh = yh * a->down - (a->down - 1) + fdt_h;
         if (a->workspace != nullptr && flrelu_mfma_supported(a)) {
-            a->sign_layout = 1;                                   // row-quad bytes: one byte = 4 rows of one column
+            a->sign_layout = flrelu_mfma_sign_layout(a);         // row-quad bytes (one byte = 4 rows of one column), 2: column-blocked
             a->sh = (int)((sh + 3) >> 2);
+            if (a->sign_layout == 2) a->sh = (a->sh + 15) & ~15;   // whole dwords: 4 row blocks of 4 quad-rows (filtered_lrelu_wave.hip)
             a->swb = (int)((sw_active + 15) & ~15ll);
         } else {
             a->sign_layout = 0;
@@ -547,7 +549,7 @@ extern "C" int afcm_filtered_lrelu(const afcm_filtered_lrelu_args* a, void* stre
     const bool mfma = a->workspace != nullptr && flrelu_mfma_supported(a);
     AFCM_REQUIRE(mfma || (a->oscale == nullptr && a->oscale2 == nullptr && a->skip == nullptr), "filtered_lrelu: oscale / skip need the matrix-core kernels (16-bit dtype, prepared workspace)");
     if (a->sign_mode == AFCM_SIGNS_READ)
-        AFCM_REQUIRE((a->sign_layout == 1) == mfma, "sign tensor layout %d does not match the kernel family selected for this call", a->sign_layout);
+        AFCM_REQUIRE((a->sign_layout != 0) == mfma, "sign tensor layout %d does not match the kernel family selected for this call", a->sign_layout);
     if (mfma) return flrelu_mfma_launch(a, false, st);
 
     FlreluParams p;

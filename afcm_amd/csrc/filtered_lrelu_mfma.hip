@@ -30,41 +30,9 @@
 // ([N*C][ceil(sh/4)][swq], code of row r at bits 2r..2r+1: bit0 = negative, bit1 = clamped); forward assembles them
 // from the packed X2 words, backward (the same kernel with up/down swapped) reads them with a funnel shift for the
 // row offset.
-#include <cstdlib>
-#include <type_traits>
-
-#include "common.h"
+#include "flrelu_mfma_common.h"
 
 namespace afcm {
-
-typedef __attribute__((ext_vector_type(4))) float f32x4;
-typedef __attribute__((ext_vector_type(8))) __bf16 mbf16x8;
-typedef __attribute__((ext_vector_type(8))) _Float16 mf16x8;
-typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-typedef __attribute__((ext_vector_type(2))) short s16x2;
-typedef __attribute__((ext_vector_type(2))) unsigned short u16x2;
-
-struct FlreluMfmaParams {
-    const void* x;
-    void* y;
-    const void* b;
-    unsigned char* s;
-    const void* ws;        // constant fragments + mask table
-    float* plane_sum;      // optional fp32 [N*C][tilesX*tilesY]: per-tile sums of this launch's outputs (bias gradient without a second pass)
-    const float* oscale;   // optional fp32 [N*C]: per-plane factor of the output
-    const float* oscale2;  // optional second factor (multiplied)
-    const void* skip;      // optional [N*C][yh][yw]: added to the output before the factor
-    int xw, xh, yw, yh, C;
-    int px0, py0;
-    int tilesX, tilesY;
-    unsigned magicT, magicP;   // ceil(2^32 / tilesX), ceil(2^32 / (tilesX * tilesY)): block id -> (plane, tile) on the scalar unit
-    float slope, clamp;
-    int sx, sy, shq, swq;  // sign tensor: rows of quads, bytes per row
-};
-
-constexpr int kFUT = 6;            // taps per polyphase branch of the up filter (filter_size of the model)
-constexpr int kWsTable = 16384;    // byte offset of the 256-entry sign-code -> keep-mask table inside the workspace
-constexpr int kWsBytes = kWsTable + 256 * 8;
 
 // Geometry shared by the kernel, the prepare kernel and the host.
 template <int UP, int DOWN, int TOW, int TOH>
@@ -99,9 +67,6 @@ struct MfmaGeom {
     static_assert(NFRAG * 1024 <= kWsTable, "workspace");
     static_assert((POUT / 8) % 2 == 1 && (PX3 / 8) % 2 == 1, "LDS pitches");
 };
-
-// row index inside a 32-row K window carried by fragment element (g, j): two stacked accumulator tiles
-__host__ __device__ __forceinline__ int krow(int g, int j) { return 16 * (j >> 2) + 4 * g + (j & 3); }
 
 // ---------------------------------------------------------------------------------------------
 // Constant fragments.  Layout: [frag][lane][8] elements of T, then (byte kWsTable) the keep-mask table.
@@ -159,69 +124,6 @@ __global__ void flrelu_mfma_prepare_kernel(T* __restrict__ ws, const float* __re
         tab[2 * c] = m[0];
         tab[2 * c + 1] = m[1];
     }
-}
-
-template <typename T> struct MfmaOps;
-template <> struct MfmaOps<bf16_t> {
-    typedef mbf16x8 frag;
-    static __device__ __forceinline__ f32x4 mma(frag a, frag b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
-};
-template <> struct MfmaOps<f16_t> {
-    typedef mf16x8 frag;
-    static __device__ __forceinline__ f32x4 mma(frag a, frag b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
-};
-
-typedef __attribute__((ext_vector_type(2))) float f32x2;
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
-
-template <typename T>
-__device__ __forceinline__ unsigned pack2(float lo, float hi) {
-    // an explicit two-element conversion: one v_cvt_pk_bf16_f32 of exactly this pair.  (Scalar casts left to the
-    // vectoriser get paired across dwords and re-shuffled with four extra instructions per pair; inline asm is not an
-    // option on accumulator values -- the hazard recogniser does not see MFMA -> asm dependencies.)
-    if constexpr (std::is_same<T, bf16_t>::value) {
-        union { bf16x2 v; unsigned u; } r;
-        r.v = __builtin_convertvector((f32x2){lo, hi}, bf16x2);
-        return r.u;
-    } else {
-        union { f16x2 v; unsigned u; } r;
-        r.v = __builtin_convertvector((f32x2){lo, hi}, f16x2);
-        return r.u;
-    }
-}
-
-template <typename F>
-__device__ __forceinline__ F as_frag(const u32x4& v) {
-    union { u32x4 u; F f; } r;
-    r.u = v;
-    return r.f;
-}
-
-// Two accumulator tiles -> one 8-element fragment: elements 0-3 from `lo`, 4-7 from `hi` (K order = krow()).
-template <typename T>
-__device__ __forceinline__ typename MfmaOps<T>::frag pack_pair(const f32x4& lo, const f32x4& hi) {
-    u32x4 r;
-    r[0] = pack2<T>(lo[0], lo[1]);
-    r[1] = pack2<T>(lo[2], lo[3]);
-    r[2] = pack2<T>(hi[0], hi[1]);
-    r[3] = pack2<T>(hi[2], hi[3]);
-    return as_frag<typename MfmaOps<T>::frag>(r);
-}
-
-// relu of two packed 16-bit floats: as signed 16-bit integers every negative float (sign bit set) is below zero
-__device__ __forceinline__ unsigned relu_pk(unsigned d) {
-    union { unsigned u; s16x2 s; } a, r;
-    a.u = d;
-    r.s = __builtin_elementwise_max(a.s, (s16x2){0, 0});
-    return r.u;
-}
-// sign bits of two packed 16-bit floats -> bit 0 and bit 16
-__device__ __forceinline__ unsigned signs_pk(unsigned d) {
-    union { unsigned u; u16x2 s; } a, r;
-    a.u = d;
-    r.s = a.s >> (u16x2){15, 15};
-    return r.u;
 }
 
 template <typename T, int UP, int DOWN, int TOW, int TOH, int SIGN, bool BIAS>
@@ -702,9 +604,27 @@ template <> struct MfmaTile<4, 2> { static constexpr int TOW = 64, TOH = 32; };
 // 32-row tiles that are 12 % full in their second row.  The constant fragments do not depend on the tile shape (only on up,
 // down and the filters), so both variants share one prepared workspace; the sign layout is tile-independent.
 constexpr int kTallTOH = 48;
-static bool tall_tile(int up, int down, int yh, int sign_mode) {
+
+// Kernel family of a call.  The wave-autonomous kernels (filtered_lrelu_wave.hip) take every matrix-core case without a bias
+// operand; they write / read sign layout 2, the LDS-tile kernels below layout 1, so a READ call follows the layout of its tensor.
+template <typename T, int UP, int DOWN, int TOW, int TOH>
+int launch_wave_tile(const afcm_filtered_lrelu_args* a, FlreluMfmaParams p, hipStream_t st);
+template <typename T, int UP, int DOWN>
+int prepare_wave(const afcm_filtered_lrelu_args* a, hipStream_t st);
+
+static bool wave_family(const afcm_filtered_lrelu_args* a) {
+    static const char* e = getenv("AFCM_FLRELU_WAVE");          // tuning aid: 0 = LDS-tile kernels only
+    if (e != nullptr && atoi(e) == 0) return false;
+    if (a->sign_mode == AFCM_SIGNS_READ) return a->sign_layout == 2;
+    // no bias operand; offsets + out-of-range markers stay below 2^31
+    return a->b == nullptr && (long long)a->xh * a->xw < (1ll << 28) && (long long)a->yh * a->yw < (1ll << 28);
+}
+
+static bool tall_tile(int up, int down, int yh, int sign_mode, bool wave) {
+    if (wave) return up == 2 && down == 2 && yh > 32 && yh <= kTallTOH;    // one 48-row tile for the 36^2 / 38^2 planes
     static const char* force = getenv("AFCM_FLRELU_TALL");      // tuning aid: 0 = never, 1 = rules below (default), 2 = 33..48-row planes only
     const int mode = force ? atoi(force) : 1;
+    (void)down;
     if (mode == 0 || up != 2) return false;
     if (yh > 32 && yh <= kTallTOH) return true;
     // The sign-WRITING kernels (forward) also gain on larger planes whenever 48-row tiles cover the plane with no more padded rows
@@ -733,7 +653,8 @@ static int launch_mfma_tile(const afcm_filtered_lrelu_args* a, hipStream_t st) {
     p.oscale = a->oscale; p.oscale2 = a->oscale2; p.skip = a->skip;
     p.xw = a->xw; p.xh = a->xh; p.yw = a->yw; p.yh = a->yh; p.C = a->c;
     p.px0 = a->px0; p.py0 = a->py0;
-    p.tilesX = cdiv(a->yw, TOW); p.tilesY = cdiv(a->yh, TOH);
+    const bool wave = wave_family(a);
+    p.tilesX = wave ? 1 : cdiv(a->yw, TOW); p.tilesY = cdiv(a->yh, TOH);      // wave kernels: one strip spans the plane's width
     p.slope = a->slope; p.clamp = a->clamp;
     p.sx = a->sx; p.sy = a->sy; p.shq = a->sh; p.swq = a->swb;
     const long long blocks = (long long)p.tilesX * p.tilesY * a->n * a->c;
@@ -744,6 +665,10 @@ static int launch_mfma_tile(const afcm_filtered_lrelu_args* a, hipStream_t st) {
     p.magicT = p.tilesX == 1 ? 0u : (unsigned)(((1ull << 32) + p.tilesX - 1) / p.tilesX);
     p.magicP = tpp == 1 ? 0u : (unsigned)(((1ull << 32) + tpp - 1) / tpp);
     AFCM_REQUIRE((long long)a->xh * a->xw < (1ll << 30), "filtered_lrelu: plane of %d x %d elements is out of range", a->xh, a->xw);
+    if constexpr (!(DOWN == 4 && TOH == kTallTOH)) if (wave) {      // (the wave family has no tall down-4 tile: tall_tile())
+        AFCM_REQUIRE(a->b == nullptr, "filtered_lrelu: sign layout 2 (wave kernels) takes no bias operand");
+        return launch_wave_tile<T, UP, DOWN, TOW, TOH>(a, p, st);
+    }
     dim3 grid((unsigned)blocks), block(64 * G::NG);
     const bool bias = a->b != nullptr;
     switch (a->sign_mode) {
@@ -758,7 +683,7 @@ template <typename T, int UP, int DOWN>
 static int launch_mfma(const afcm_filtered_lrelu_args* a, hipStream_t st) {
     constexpr int TOW = MfmaTile<UP, DOWN>::TOW, TOH = MfmaTile<UP, DOWN>::TOH;
     if constexpr (UP == 2) {
-        if (tall_tile(UP, DOWN, a->yh, a->sign_mode)) return launch_mfma_tile<T, UP, DOWN, TOW, kTallTOH>(a, st);
+        if (tall_tile(UP, DOWN, a->yh, a->sign_mode, wave_family(a))) return launch_mfma_tile<T, UP, DOWN, TOW, kTallTOH>(a, st);
     }
     return launch_mfma_tile<T, UP, DOWN, TOW, TOH>(a, st);
 }
@@ -770,7 +695,8 @@ static int prepare_mfma(const afcm_filtered_lrelu_args* a, hipStream_t st) {
     const float gain_total = (float)a->up * (float)a->up * a->gain;
     hipLaunchKernelGGL((flrelu_mfma_prepare_kernel<T, UP, DOWN, TOW, TOH>), dim3(cdiv(G::NFRAG * 512, 256)), dim3(256), 0, st,
                        (T*)a->workspace, a->fu, a->fd, a->px0, a->py0, a->flip_filter, gain_total, a->slope);
-    return hip_status(hipGetLastError());
+    const int rc = hip_status(hipGetLastError());
+    return rc != AFCM_OK ? rc : prepare_wave<T, UP, DOWN>(a, st);
 }
 
 static int mfma_case(const afcm_filtered_lrelu_args* a) {
@@ -787,11 +713,14 @@ static int mfma_case(const afcm_filtered_lrelu_args* a) {
 
 int flrelu_mfma_supported(const afcm_filtered_lrelu_args* a) { return mfma_case(a) != 0; }
 
+// sign layout a WRITE call of this configuration produces (1: row-quad bytes, 2: column-blocked row-quad bytes)
+int flrelu_mfma_sign_layout(const afcm_filtered_lrelu_args* a) { return wave_family(a) ? 2 : 1; }
+
 int flrelu_mfma_tiles(const afcm_filtered_lrelu_args* a) {
     switch (mfma_case(a)) {
-        case 22: return cdiv(a->yw, MfmaTile<2, 2>::TOW) * cdiv(a->yh, tall_tile(2, 2, a->yh, a->sign_mode) ? kTallTOH : MfmaTile<2, 2>::TOH);
-        case 24: return cdiv(a->yw, MfmaTile<2, 4>::TOW) * cdiv(a->yh, tall_tile(2, 4, a->yh, a->sign_mode) ? kTallTOH : MfmaTile<2, 4>::TOH);
-        case 42: return cdiv(a->yw, MfmaTile<4, 2>::TOW) * cdiv(a->yh, MfmaTile<4, 2>::TOH);
+        case 22: return (wave_family(a) ? 1 : cdiv(a->yw, MfmaTile<2, 2>::TOW)) * cdiv(a->yh, tall_tile(2, 2, a->yh, a->sign_mode, wave_family(a)) ? kTallTOH : MfmaTile<2, 2>::TOH);
+        case 24: return (wave_family(a) ? 1 : cdiv(a->yw, MfmaTile<2, 4>::TOW)) * cdiv(a->yh, tall_tile(2, 4, a->yh, a->sign_mode, wave_family(a)) ? kTallTOH : MfmaTile<2, 4>::TOH);
+        case 42: return (wave_family(a) ? 1 : cdiv(a->yw, MfmaTile<4, 2>::TOW)) * cdiv(a->yh, MfmaTile<4, 2>::TOH);
         default: return 0;
     }
 }

@@ -1,0 +1,640 @@
+// filtered_lrelu on the matrix cores, wave-autonomous form (16-bit activations, no bias operand).
+//
+// The workgroup-tile kernels of filtered_lrelu_mfma.hip are bound by vector-instruction issue (PMC r01e: VALU 72-81 % of the
+// slots, MFMA pipe 30 %, HBM traffic = algorithmic): three waves share a 64x32-output tile through LDS, and more than half of
+// each wave's ~490 vector instructions are not arithmetic on the tile at all -- staging index math, LDS round trips of the input
+// tile / X3 / the staged output / the staged sign codes, copy-out loops, barriers.  Here ONE wave owns a whole output tile and
+// nothing is exchanged between waves:
+//   * the input rows are loaded from global memory straight into MFMA A fragments (a lane's 8 consecutive columns of one row are
+//     one 16-byte load; rows outside the plane fall outside the buffer descriptor and read as zero) -- no LDS staging, no barrier;
+//   * X1 (up-x), X2 (up-y), X3 (down-y) never leave the register file: each accumulator tile is the next MFMA's operand with the
+//     K order the accumulator layout dictates (krow()), also for the down-x pass (the LDS-tile kernels transposed X3 through LDS);
+//   * the linear part of the leaky ReLU is folded into ONE composite operator: lrelu(v) = slope v + (1 - slope) relu(v), and
+//         X3 = DV lrelu(X2) = (slope DV UV) X1 + ((1 - slope) DV) relu(X2)
+//     -- the first term is a single banded product from X1 (already packed as an operand), so the down-y pass needs NDVK + NLT
+//     instead of 2 NDVK MFMAs per block and X2 itself is never an operand;
+//   * the clamp (|v| > 256: rare) is excluded per column block from max |X1| and the L1 norm of the up-y operator (two
+//     v_maximum3 per X1 tile instead of two per X2 tile); only a flagged block recomputes its X2 tiles on the exact path;
+//   * sign codes are written only for the region the tile OWNS (the halo blocks are the neighbours'), as bytes straight from the
+//     registers, into a column-blocked row-quad layout (sign_layout 2: [plane][col / 16][quad-row][col % 16], one byte = the codes
+//     of 4 rows of one column) in which a tile's stores are 256 contiguous bytes per column block and the transposed op's reads
+//     need one address register: quad-row and column-block strides are compile-time offsets;
+//   * outputs leave as 8-byte stores from the accumulators (4 consecutive columns per lane).
+// Per 64x32-output tile: ~600 vector + 142 matrix instructions on one wave instead of 3 x (~490 + 53).
+#include "flrelu_mfma_common.h"
+
+// waves per SIMD the register allocation targets (tuning aids)
+#ifndef AFCM_WAVE_OCC_D2
+#define AFCM_WAVE_OCC_D2 3
+#endif
+#ifndef AFCM_WAVE_OCC_D4
+#define AFCM_WAVE_OCC_D4 2
+#endif
+
+namespace afcm {
+
+template <int UP, int DOWN, int TOW, int TOH>
+struct WaveGeom {
+    static constexpr int FU = kFUT * UP, FD = kFUT * DOWN;
+    static constexpr int TUW = (TOW - 1) * DOWN + FD, TUH = (TOH - 1) * DOWN + FD;
+    static constexpr int NBG = 2;                               // ucol blocks per group: one 32-wide input window, one packed X3 pair
+    static constexpr int NVB = cdiv(TUH, 16);                   // urow blocks
+    static constexpr int NOB = TOH / 16, NCB = TOW / 16;
+    static constexpr int NDVK = DOWN == 2 ? 2 : 3;              // 32-wide K windows of a down pass
+    static constexpr int NPAIR = (DOWN / 2) * (NOB - 1) + NDVK; // packed X2 tile pairs the down-y pass touches
+    static constexpr int NMB = cdiv((16 / UP) * (NVB - 1) + 16 / UP + kFUT, 16);   // input row blocks
+    static constexpr int NQ = ((NVB - 1) / UP) + 1;             // packed X1 tile pairs
+    static constexpr int IWSTEP = 16 * NBG / UP;                // input-window advance per group
+    static constexpr int NHIST = NDVK - 1;                      // earlier X3 pairs the down-x pass of a column block reads
+    static constexpr int OWN_VB = TOH * DOWN / 16;             // urow blocks whose codes this strip writes
+    // composite linear operator (slope DV UV): in-row offsets of an orow block inside its packed X1 pair, K windows
+    static constexpr int NLV = (16 * DOWN / UP) % 16 == 0 ? 1 : 2;                  // distinct offsets (0, 8)
+    static constexpr int LIN_DI = (15 * DOWN + FD - 1) / UP + 1 + kFUT;            // in-rows (from the block's first) that contribute
+    static constexpr int NLT = cdiv(LIN_DI + 8 * (NLV - 1), 32);
+    static constexpr int NLIN = NLV * NLT;
+    static __host__ __device__ constexpr int lin_q(int ob, int t) { return (16 * DOWN * ob / UP) / 16 + 2 * t; }
+    static __host__ __device__ constexpr int lin_f(int ob, int t) { return (((16 * DOWN * ob / UP) % 16) / 8) * NLT + t; }
+    static_assert(TOW % 16 == 0 && TOH % 16 == 0 && (TOH * DOWN) % 16 == 0 && (TOW * DOWN) % 16 == 0, "tile shape");
+    static_assert((16 * NBG - 1) / UP + 1 + kFUT + 1 <= 32, "shifted input window must fit the 32-wide K window");
+    static_assert(lin_q(NOB - 1, NLT - 1) < NQ, "composite operator reaches beyond the packed X1 pairs");
+    static_assert(NLIN + NDVK <= kWsWaveFrags, "workspace");
+    static_assert((16 * DOWN) % UP == 0, "orow blocks start on input rows");
+
+};
+
+// ---------------------------------------------------------------------------------------------
+// Filter coefficient of the polyphase operators, tile-relative indices (the tile's first upsampled row / column is a multiple of
+// UP away from phase `ph`, as in flrelu_mfma_prepare_kernel).
+__device__ __forceinline__ float up_coef(const float* fu, int FU, int UP, int ph, int flip, int u, int i) {
+    const int a = u % UP, o = (a > ph) ? 1 : 0;
+    const int kmin = o ? UP - (a - ph) : ph - a;
+    const int jj = i - u / UP - o;
+    if (jj < 0 || jj >= kFUT) return 0.f;
+    const int tap = kmin + UP * jj;
+    return flip ? fu[tap] : fu[FU - 1 - tap];
+}
+__device__ __forceinline__ float down_coef(const float* fd, int FD, int DOWN, int flip, int n, int urel) {
+    const int kk = urel - DOWN * n;
+    if (kk < 0 || kk >= FD) return 0.f;
+    return flip ? fd[kk] : fd[FD - 1 - kk];
+}
+
+// Extra constant fragments of the wave kernels, appended to the workspace of flrelu_mfma_prepare_kernel:
+//   LIN[v][t]  B operand [k][n]: n = l15 (orow of the block), k = krow(g, j) -> in-row 32 t + k - 8 v counted from the block's first
+//              contributing input row; value = slope * sum_u DV[n][u] * UV[u][in-row]   (UV carries up^2 * gain)
+//   DH2[t]     A operand [m][k]: m = l15 (ocol of the block), k = krow(g, j) -> ucol 32 t + k of the window starting at 16 DOWN cb
+// and one scalar: an upper bound of the L1 norm of the rows of UV (|X2| <= bound * max |X1|).
+template <typename T, int UP, int DOWN>
+__global__ void flrelu_wave_prepare_kernel(char* __restrict__ wsb, const float* __restrict__ fu, const float* __restrict__ fd,
+                                           int py0, int flip, float gain_total, float slope) {
+    typedef WaveGeom<UP, DOWN, 32, 32> G;                      // fragment contents do not depend on the tile shape
+    constexpr int FU = kFUT * UP, FD = kFUT * DOWN;
+    const int phy = pos_mod(py0, UP);
+    T* ws = (T*)(wsb + kWsWave);
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < (G::NLIN + G::NDVK) * 512; idx += gridDim.x * blockDim.x) {
+        const int j = idx & 7, lane = (idx >> 3) & 63, frag = idx >> 9;
+        const int l15 = lane & 15, g = lane >> 4;
+        float v = 0.f;
+        if (frag < G::NLIN) {
+            const int var = frag / G::NLT, t = frag % G::NLT;
+            const int di = 32 * t + krow(g, j) - 8 * var;
+            if (di >= 0) {
+                float acc = 0.f;
+                for (int kk = 0; kk < FD; kk++) {
+                    const int u = DOWN * l15 + kk;             // upsampled row, from the block's first
+                    acc += down_coef(fd, FD, DOWN, flip, l15, u) * up_coef(fu, FU, UP, phy, flip, u, di);
+                }
+                v = acc * gain_total * slope;
+            }
+        } else {
+            const int t = frag - G::NLIN;
+            v = down_coef(fd, FD, DOWN, flip, l15, 32 * t + krow(g, j));
+        }
+        ws[idx] = from_f32<T>(v);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        float best = 0.f;
+        for (int a = 0; a < UP; a++) {
+            float s = 0.f;
+            for (int i = 0; i < kFUT + 2; i++) s += fabsf(up_coef(fu, FU, UP, phy, flip, a, i));
+            best = fmaxf(best, s);
+        }
+        // + 2 %: the bound is applied to fp32 X1 while X2 is formed from its 16-bit rounding and 16-bit coefficients
+        ((float*)(wsb + kWsScalars))[0] = best * fabsf(gain_total) * 1.02f;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Sign codes, layout 2 (private to this kernel family): one byte = the 2-bit codes of 4 consecutive rows ("quad-row" q) of one
+// column c.  With V = q >> 2 (the 16-row block) and gq = q & 3, the byte lives at
+//     ((((c >> 4) * nV4 + (V >> 2)) * 4 + gq) * 16 + (c & 15)) * 4 + (V & 3)          nV4 = quad-rows / 16
+// i.e. [plane][column block][V / 4][gq][column in block][V % 4]: lane (g, l15) of the X2 tiles (vb, nb) of a strip owns whole
+// dwords -- its codes of 4 consecutive row blocks.
+//   forward: one dword store per lane and 4 row blocks: 256 contiguous bytes per store instruction; bounds (plane bottom, row
+//            blocks of the next strip) ride in the buffer descriptor of the column block, so no store is predicated;
+//   backward: the window starts at an arbitrary (row, column) offset: a lane fetches the dwords of ITS column that cover quad-rows
+//            r0 + 4 vb (and r0 + 4 vb + 1 when the window starts inside a quad) -- compile-time offsets from two address registers --
+//            and extracts the bytes with v_alignbyte / v_perm.
+// The tensor keeps the [N, C, sh, swb] shape of the ABI with sh rounded up to 16 quad-rows.
+//
+// Loop structure: ONE rolled loop over groups of two column blocks.  An iteration loads its 32-column input window, produces
+// the packed X3 pair of its two blocks and runs the down-x pass of the output column block that pair completes; the earlier
+// pairs that pass reads are loop-carried registers.  (Fully unrolled, the compiler's latency-driven scheduling stretched live
+// ranges over the tile -- 210-240 VGPRs, two waves per SIMD, or spills; a wave spends most of its residency waiting on its own
+// MFMA -> convert -> MFMA chains, so the SIMD only fills up with 3-4 of them.)
+//
+// EPI: 0 = plain store; 1 = + encoder skip, per-plane factors and per-tile output sums (fused layer node, backward bias gradient).
+template <typename T, int UP, int DOWN, int TOW, int TOH, int SIGN, int EPI>
+__global__ __launch_bounds__(256, (DOWN == 2 ? AFCM_WAVE_OCC_D2 : AFCM_WAVE_OCC_D4)) void flrelu_wave_kernel(FlreluMfmaParams p) {
+    typedef WaveGeom<UP, DOWN, TOW, TOH> G;
+    typedef MfmaOps<T> M;
+    typedef typename M::frag frag;
+    __shared__ uint2 lds_tab[SIGN == AFCM_SIGNS_READ ? 256 : 1];          // READ: sign byte -> keep masks of its 4 rows
+    // Output staging, private to each wave: 64 output columns (4 column blocks) x TOH rows, flushed as full 128-byte row segments.
+    // (Stored straight from the accumulators a column block is 32 bytes per row: those reach HBM as partial lines -- measured
+    // 1.9x / 2.5x the algorithmic write traffic in forward / backward.)
+    constexpr int OPITCH = 144;                                            // bytes per staged row: 128 + 16 (16-byte aligned, spreads banks)
+    __shared__ __attribute__((aligned(16))) unsigned char lds_o[4][TOH * OPITCH];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, g = lane >> 4;
+    if (SIGN == AFCM_SIGNS_READ) {
+        if (tid < 128) ((uint4*)lds_tab)[tid] = ((const uint4*)((const char*)p.ws + kWsTable))[tid];
+        __syncthreads();
+    }
+    // XCD-aware order: consecutive logical blocks (neighbouring tiles, shared halos) stay on one XCD / one L2
+    int bid = blockIdx.x;
+    {
+        const int total = gridDim.x;
+        if ((total & 7) == 0) bid = (bid & 7) * (total >> 3) + (bid >> 3);
+    }
+    const int wt = bid * 4 + wave;                                       // this wave's strip: TOH output rows x the plane's width
+    if (wt >= p.total_tiles) return;
+    const int plane = p.magicP ? (int)__umulhi((unsigned)wt, p.magicP) : wt;
+    const int tile = wt - plane * (p.tilesX * p.tilesY);
+    const int ty = p.magicT ? (int)__umulhi((unsigned)tile, p.magicT) : tile;
+    const int tx = tile - ty * p.tilesX;
+    const int O0x = 0, O0y = ty * TOH;                                    // (tilesX = 1: a strip spans the plane)
+    const int U0x = 0, U0y = O0y * DOWN;
+    (void)tx;
+    // column groups: the last output column block, cdiv(yw, 16) - 1, ends on X3 pair (DOWN / 2) cb + NDVK - 1
+    const int ncb = (p.yw + 15) >> 4;
+    const int ng = (DOWN / 2) * (ncb - 1) + G::NDVK;
+    const int I0x = -floor_div(p.px0 - U0x, UP), I0y = -floor_div(p.py0 - U0y, UP);
+    const int S0x = I0x - (I0x & 1);                                      // first input column touched (even: aligned dword pairs)
+    const bool lastY = (ty == p.tilesY - 1);
+
+    // constant fragments (registers): UH[NBG] UV[UP] DVr[NDVK] from the LDS-tile kernels' workspace, LIN[NLIN] DH2[NDVK] from ours
+    const frag* wsf = (const frag*)p.ws;                                  // UH[3] UV[UP] DVs[NDVK] DVr[NDVK] (DH[NDVK])
+    const frag* wsw = (const frag*)((const char*)p.ws + kWsWave);         // LIN[NLIN] DH2[NDVK]
+    constexpr int F_UV = 3, F_DVS = 3 + UP, F_DVR = 3 + UP + G::NDVK;
+    frag uh[G::NBG], uv[UP], dvr[G::NDVK], lin[G::NLIN], dh[G::NDVK];
+#pragma unroll
+    for (int v = 0; v < G::NBG; v++) uh[v] = wsf[v * 64 + lane];
+#pragma unroll
+    for (int v = 0; v < UP; v++) uv[v] = wsf[(F_UV + v) * 64 + lane];
+#pragma unroll
+    for (int t = 0; t < G::NDVK; t++) dvr[t] = wsf[(F_DVR + t) * 64 + lane];
+#pragma unroll
+    for (int f = 0; f < G::NLIN; f++) lin[f] = wsw[f * 64 + lane];
+#pragma unroll
+    for (int t = 0; t < G::NDVK; t++) dh[t] = wsw[(G::NLIN + t) * 64 + lane];
+    // no element of the tile can reach the clamp while max |X1| stays below this
+    const float cthr1 = p.clamp / (fmaxf(p.slope, 1.f) * ((const float*)((const char*)p.ws + kWsScalars))[0]);
+
+    // ---- input: rows [I0y, +16 NMB) x columns [S0x + IWSTEP gi, +32) per group, straight into A fragments
+    const T* xp = (const T*)p.x + (size_t)plane * p.xh * p.xw;
+#ifdef AFCM_WAVE_EXPERIMENT_NOLOAD    // timing experiment only: every input load falls outside the descriptor
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)xp, 0, 0, 0x00020000);
+#else
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)xp, 0, p.xh * p.xw * 2, 0x00020000);
+#endif
+    // Lane map of the global accesses: an MFMA fragment puts 16 different ROWS on consecutive lanes (lane = 16 g + l15), which the
+    // memory pipeline sees as 64 separate 16-byte requests per instruction (measured: the two output stores of a group cost more
+    // than all of its arithmetic).  So loads and stores use lane = 4 row + chunk -- 4 consecutive lanes cover 64 (stores: 32)
+    // contiguous bytes -- and ds_bpermute moves the dwords between that map and the fragment map: no LDS allocation, no VALU.
+    const int lrow = lane >> 2, lchk = lane & 3;
+    const int to_frag = (4 * l15 + g) * 4;                                // fragment lane (g, l15) reads from access lane 4 l15 + g
+    // byte offset of (row I0y + lrow, column S0x + 8 lchk); rows above the plane give a negative offset = beyond the descriptor's
+    // range as an unsigned number, rows below it exceed the record count: both read as zero without a predicate
+    const int xoff0 = ((I0y + lrow) * p.xw + S0x + 8 * lchk) * 2;
+    const int xrow16 = 32 * p.xw;                                         // 16 rows, bytes
+    constexpr unsigned kOut = 0x40000000u;                               // out-of-range marker (planes stay below 2^29 bytes)
+    auto load_group = [&](int gi, frag (&a)[G::NMB]) __attribute__((always_inline)) {
+        const int c0 = S0x + G::IWSTEP * gi;                              // wave-uniform
+        if (__builtin_expect(c0 >= 0 && c0 + 32 <= p.xw, 1)) {
+#pragma unroll
+            for (int mb = 0; mb < G::NMB; mb++) {
+                union { u32x4 u; frag f; } r;
+                r.u = __builtin_amdgcn_raw_buffer_load_b128(rsx, (unsigned)(xoff0 + 2 * G::IWSTEP * gi + mb * xrow16), 0, 0);
+#pragma unroll
+                for (int w = 0; w < 4; w++) r.u[w] = (unsigned)__builtin_amdgcn_ds_bpermute(to_frag, (int)r.u[w]);
+                a[mb] = r.f;
+            }
+        } else {
+            // the window crosses the left or right edge of the plane: dword by dword, columns outside it read as zero
+            // (even plane widths: the two elements of a dword are in or out together; rows outside: as above, except that a
+            // negative row offset plus the marker must not wrap back into range)
+            const int col = c0 + 8 * lchk;
+            unsigned cofs[4];
+#pragma unroll
+            for (int w = 0; w < 4; w++) cofs[w] = (unsigned)(col + 2 * w) < (unsigned)p.xw ? (unsigned)(2 * G::IWSTEP * gi + 4 * w) : kOut;
+#pragma unroll
+            for (int mb = 0; mb < G::NMB; mb++) {
+                const unsigned ro = (I0y + 16 * mb + lrow < 0) ? kOut : (unsigned)(xoff0 + mb * xrow16);
+                union { u32x4 u; frag f; } r;
+#pragma unroll
+                for (int w = 0; w < 4; w++) r.u[w] = __builtin_amdgcn_raw_buffer_load_b32(rsx, ro + cofs[w], 0, 0);
+#pragma unroll
+                for (int w = 0; w < 4; w++) r.u[w] = (unsigned)__builtin_amdgcn_ds_bpermute(to_frag, (int)r.u[w]);
+                a[mb] = r.f;
+            }
+        }
+    };
+
+    // ---- sign codes (layout 2, see above)
+    const int nblk = p.swq >> 4, nV4 = p.shq >> 4;                         // column blocks, groups of 4 row blocks (shq is a multiple of 16)
+    const int blkbytes = nV4 * 256;
+    unsigned char* const splane = p.s + (size_t)plane * p.shq * p.swq;
+    constexpr int NA = cdiv(G::NVB, 4);                                    // dwords of codes per lane and column block
+    // WRITE: this strip's row blocks are V = ty * OWN_VB + vb (a multiple of 4 at vb = 0; the tall single-strip tile starts at 0):
+    // offset of this lane's first dword inside a column block; dword groups this strip may write (the rest is the next strip's, or
+    // below the plane)
+    const unsigned sgw_off = (unsigned)((((U0y >> 4) >> 2) * 4 + g) * 64 + l15 * 4);
+    const int v4_end = lastY ? nV4 : min(nV4, ((U0y >> 4) + G::OWN_VB) >> 2);
+    // READ: lane (g, l15) follows column U0x + sx + l15 and quad-rows r0 + 4 vb (lo) and r0 + 4 vb + 1 (hi), r0 = Q0 + g
+    const int yy = p.sy & 3;                                               // row offset inside a quad (U0y is a multiple of 4)
+    const int Q0 = (U0y + p.sy) >> 2;
+    int sgr_lo = 0, sgr_hi = 0, sgr_dl = 0, sgr_dh = 0;
+    unsigned sgr_sl = 0, sgr_sh = 0;
+    __amdgpu_buffer_rsrc_t rss = rsx;
+    if (SIGN == AFCM_SIGNS_READ) {
+        rss = __builtin_amdgcn_make_buffer_rsrc((void*)splane, 0, p.shq * p.swq, 0x00020000);
+        const int c = U0x + p.sx + l15, r0 = Q0 + g, r1 = r0 + 1;
+        // columns left of the tensor give a negative block = a negative offset, columns right of it a block beyond the last:
+        // both fall outside the descriptor and read code 0 ("unchanged", filtered_lrelu.cu:564-571)
+        const int cbase = (c >> 4) * nV4 * 256 + (c & 15) * 4;
+        sgr_dl = (r0 >> 2) >> 2; sgr_sl = (unsigned)((r0 >> 2) & 3);
+        sgr_dh = (r1 >> 2) >> 2; sgr_sh = (unsigned)((r1 >> 2) & 3);
+        sgr_lo = cbase + (sgr_dl * 4 + (r0 & 3)) * 64;
+        sgr_hi = cbase + (sgr_dh * 4 + (r1 & 3)) * 64;
+    }
+    // dword groups outside the tensor would alias a neighbouring column block: select them out (wave-uniform fast case)
+    const bool rows_inside = Q0 >= 0 && (((Q0 + 4) >> 2) >> 2) + NA + 1 <= nV4;
+
+    // ---- output
+    T* const yp = (T*)p.y + (size_t)plane * p.yh * p.yw;
+#ifdef AFCM_WAVE_EXPERIMENT_NOSTORE   // timing experiment only: every output store falls outside the descriptor
+    const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc((void*)yp, 0, 0, 0x00020000);
+#else
+    const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc((void*)yp, 0, p.yh * p.yw * 2, 0x00020000);
+#endif
+    const bool has_skip = EPI && p.skip != nullptr;
+    const __amdgpu_buffer_rsrc_t rsk = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(has_skip ? (const T*)p.skip + (size_t)plane * p.yh * p.yw : (const T*)p.x), 0, has_skip ? p.yh * p.yw * 2 : 0, 0x00020000);
+    // skip operand: byte offset of (row O0y + lrow, column 4 lchk) (access lane map); rows below the plane exceed the record count
+    // and read as zero, columns right of it are selected out per output column block
+    const int koff0 = ((O0y + lrow) * p.yw + 4 * lchk) * 2;
+    const int yrow16 = 32 * p.yw;
+    const float osc = EPI ? (p.oscale ? p.oscale[plane] : 1.f) * (p.oscale2 ? p.oscale2[plane] : 1.f) : 1.f;
+    float psum = 0.f;
+    unsigned char* const stage = lds_o[wave];
+    const unsigned st_w = (unsigned)(l15 * OPITCH + g * 8);                // fragment lane (g, l15): 4 columns of row l15 (+ 16 ob rows, + 32 B per column block)
+    const unsigned st_r = (unsigned)((lane >> 3) * OPITCH + (lane & 7) * 16);   // flush lane: 8 columns (16 B) of row lane / 8 (+ 8 rows per instruction)
+    const int fl_row = lane >> 3, fl_chk = lane & 7;
+
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+    // down-x of output column block cb, transposed: Y'[ocol][orow] = DH2 * X3'; a lane holds 4 consecutive output columns of
+    // one row.  xw[t] = the X3 pairs of its K windows.  The packed result goes to the staging buffer.
+    auto phase_b = [&](int cb, const u32x4 (&xw)[G::NOB][G::NDVK]) __attribute__((always_inline)) {
+        const int slot = cb & 3;
+#pragma unroll
+        for (int ob = 0; ob < G::NOB; ob++) {
+            f32x4 acc = zero4;
+#pragma unroll
+            for (int t = 0; t < G::NDVK; t++) acc = M::mma(dh[t], as_frag<frag>(xw[ob][t]), acc);
+            if (EPI) {
+                // encoder feature of this lane's 4 columns (x + x_skip, NET:376-377): zero-record descriptor when there is none;
+                // fetched in the access lane map (columns / rows outside the plane read as zero), moved to the fragment map
+                const int ox = 16 * cb + 4 * lchk;
+                const unsigned off = (unsigned)(koff0 + ob * yrow16 + 32 * cb);
+                union { unsigned u; T t[2]; } e0, e1;
+                e0.u = __builtin_amdgcn_raw_buffer_load_b32(rsk, (ox + 2 <= p.yw) ? off : kOut, 0, 0);
+                e1.u = __builtin_amdgcn_raw_buffer_load_b32(rsk, (ox + 4 <= p.yw) ? off + 4u : kOut, 0, 0);
+                e0.u = (unsigned)__builtin_amdgcn_ds_bpermute(to_frag, (int)e0.u);
+                e1.u = (unsigned)__builtin_amdgcn_ds_bpermute(to_frag, (int)e1.u);
+                acc[0] += to_f32(e0.t[0]);
+                acc[1] += to_f32(e0.t[1]);
+                acc[2] += to_f32(e1.t[0]);
+                acc[3] += to_f32(e1.t[1]);
+                acc *= osc;
+                const int fx = 16 * cb + 4 * g;                                                // fragment lane map
+                const bool rin = O0y + 16 * ob + l15 < p.yh;
+                psum += (rin && fx + 2 <= p.yw ? acc[0] + acc[1] : 0.f) + (rin && fx + 4 <= p.yw ? acc[2] + acc[3] : 0.f);
+            }
+            uint2 w;
+            w.x = pack2<T>(acc[0], acc[1]);
+            w.y = pack2<T>(acc[2], acc[3]);
+            *(uint2*)(stage + st_w + (unsigned)(ob * 16 * OPITCH + slot * 32)) = w;
+        }
+        // flush after every fourth column block (and after the last one): 8 rows x 128 bytes per store instruction
+        if (slot == 3 || cb == ncb - 1) {
+            const int c0 = 64 * (cb >> 2) + 8 * fl_chk;                                         // this lane's first output column
+            const bool full = 64 * (cb >> 2) + 64 <= p.yw;                                      // wave-uniform: the whole 64-column group is inside
+            const unsigned gofs = (unsigned)(((O0y + fl_row) * p.yw + c0) * 2);
+#pragma unroll
+            for (int j = 0; j < TOH / 8; j++) {
+                const u32x4 v = *(const u32x4*)(stage + st_r + (unsigned)(j * 8 * OPITCH));
+                const unsigned off = gofs + (unsigned)(j * 16 * p.yw);
+                if (full) {
+                    __builtin_amdgcn_raw_buffer_store_b128(v, rsy, off, 0, 0);
+                } else {
+                    // the group crosses the right edge (or is only partly produced): pair by pair (even plane widths)
+#pragma unroll
+                    for (int w2 = 0; w2 < 4; w2++)
+                        __builtin_amdgcn_raw_buffer_store_b32(v[w2], rsy, (c0 + 2 * w2 + 2 <= p.yw && 8 * fl_chk + 2 * w2 < 16 * (slot + 1)) ? off + 4u * w2 : kOut, 0, 0);
+                }
+            }
+        }
+    };
+
+    // ---- the tile: groups of two column blocks: up-x, up-y, activation (+ codes), down-y, then the down-x pass the new X3 pair
+    // completes.  The rare exact path (clamp reached somewhere in the tile) is a second pass over the tile.
+    auto run_tile = [&](auto exact_c) __attribute__((always_inline)) -> bool {
+        constexpr bool EXACT = decltype(exact_c)::value;
+        float amax = 0.f;
+        unsigned anyc = 0;
+        if (EXACT) psum = 0.f;
+        u32x4 hist[G::NOB][G::NHIST];                                      // the NHIST latest complete X3 pairs, oldest first
+#pragma unroll
+        for (int ob = 0; ob < G::NOB; ob++)
+#pragma unroll
+            for (int h = 0; h < G::NHIST; h++) hist[ob][h] = (u32x4){0u, 0u, 0u, 0u};
+#ifndef AFCM_WAVE_PREFETCH
+#define AFCM_WAVE_PREFETCH 1
+#endif
+        frag a_nxt[G::NMB];
+        if (AFCM_WAVE_PREFETCH) load_group(0, a_nxt);
+        // READ: the sign dwords of a group's two column blocks, fetched one group ahead like the input window (consumed right
+        // after the up-y products: fetched in place, every column block exposed a full memory round trip)
+        unsigned sg_nxt[G::NBG][2][NA + 1];
+        auto load_signs = [&](int gi2, unsigned (&sg)[G::NBG][2][NA + 1]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int nbl = 0; nbl < G::NBG; nbl++) {
+                const int nb = gi2 * G::NBG + nbl;
+                const int blo = sgr_lo + nb * blkbytes, bhi = sgr_hi + nb * blkbytes;
+#pragma unroll
+                for (int i = 0; i <= NA; i++) {
+                    unsigned ol = (unsigned)(blo + 256 * i), oh = (unsigned)(bhi + 256 * i);
+                    if (!rows_inside) {
+                        ol = ((unsigned)(sgr_dl + i) < (unsigned)nV4) ? ol : 0x80000000u;
+                        oh = ((unsigned)(sgr_dh + i) < (unsigned)nV4) ? oh : 0x80000000u;
+                    }
+                    sg[nbl][0][i] = __builtin_amdgcn_raw_buffer_load_b32(rss, ol, 0, 0);
+                    sg[nbl][1][i] = (yy != 0) ? __builtin_amdgcn_raw_buffer_load_b32(rss, oh, 0, 0) : 0u;
+                }
+            }
+        };
+        if (SIGN == AFCM_SIGNS_READ) load_signs(0, sg_nxt);
+#pragma unroll 1
+        for (int gi = 0; gi < ng; gi++) {
+            frag a_in[G::NMB];
+            if (AFCM_WAVE_PREFETCH) {
+#pragma unroll
+                for (int mb = 0; mb < G::NMB; mb++) a_in[mb] = a_nxt[mb];
+                // one group ahead, issued before this group's stores: vmcnt counts in order, so waiting for these loads at the
+                // top of the next iteration does not wait for the (younger) stores
+                if (gi + 1 < ng) load_group(gi + 1, a_nxt);
+            } else {
+                load_group(gi, a_in);
+            }
+            unsigned sg[G::NBG][2][NA + 1];
+            if (SIGN == AFCM_SIGNS_READ) {
+#pragma unroll
+                for (int nbl = 0; nbl < G::NBG; nbl++)
+#pragma unroll
+                    for (int i = 0; i <= NA; i++) { sg[nbl][0][i] = sg_nxt[nbl][0][i]; sg[nbl][1][i] = sg_nxt[nbl][1][i]; }
+                if (gi + 1 < ng) load_signs(gi + 1, sg_nxt);
+            }
+            u32x4 cur[G::NOB];                                             // this group's packed X3 pair
+#pragma unroll
+            for (int nbl = 0; nbl < G::NBG; nbl++) {
+                const int nb = gi * G::NBG + nbl;
+                // up-x: X1[mb] = In[mb] * UH, packed in pairs as the B operand of up-y / the A operand of the composite operator
+                f32x4 x1[G::NMB];
+#pragma unroll
+                for (int mb = 0; mb < G::NMB; mb++) x1[mb] = M::mma(a_in[mb], uh[nbl], zero4);
+                frag q[G::NQ];
+#pragma unroll
+                for (int m = 0; m < G::NQ; m++) q[m] = pack_pair<T>(x1[m], (m + 1 < G::NMB) ? x1[m + 1] : zero4);
+                if (SIGN != AFCM_SIGNS_READ && !EXACT) {
+#pragma unroll
+                    for (int mb = 0; mb < G::NMB; mb++) {
+                        amax = __builtin_elementwise_maximum(__builtin_elementwise_maximum(amax, __builtin_fabsf(x1[mb][0])), __builtin_fabsf(x1[mb][1]));
+                        amax = __builtin_elementwise_maximum(__builtin_elementwise_maximum(amax, __builtin_fabsf(x1[mb][2])), __builtin_fabsf(x1[mb][3]));
+                    }
+                }
+                // READ: the codes of this block's X2 tiles
+                unsigned codes[G::NVB];
+                if (SIGN == AFCM_SIGNS_READ) {
+                    unsigned dl[NA + 1], dq[NA + 1];
+#pragma unroll
+                    for (int i = 0; i <= NA; i++) {
+                        dl[i] = sg[nbl][0][i];
+                        dq[i] = sg[nbl][1][i];
+                        anyc |= dl[i] | dq[i];
+                    }
+#pragma unroll
+                    for (int k = 0; k < NA; k++) {
+                        // the 4 codes of row blocks 4 k .. 4 k + 3: bytes sl .. sl + 3 of the dword pair (k, k + 1)
+                        const unsigned al = __builtin_amdgcn_alignbyte(dl[k + 1], dl[k], sgr_sl);
+                        const unsigned ah = yy != 0 ? __builtin_amdgcn_alignbyte(dq[k + 1], dq[k], sgr_sh) : 0u;
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            if (4 * k + j < G::NVB) {
+                                // quad-rows r0 + 4 vb (low byte) and r0 + 4 vb + 1 (high byte), shifted to the window's first row
+                                const unsigned two = __builtin_amdgcn_perm(ah, al, 0x0c0c0000u | ((4u + j) << 8) | (unsigned)j);
+                                codes[4 * k + j] = __builtin_amdgcn_ubfe(two, 2 * yy, 8);
+                            }
+                        }
+                    }
+                }
+                // WRITE: this block's descriptor: rows below the plane / not owned and blocks not owned or beyond the tensor
+                // fall outside it and are dropped by the memory pipeline
+                __amdgpu_buffer_rsrc_t rsw = rsx;
+                if (SIGN == AFCM_SIGNS_WRITE) {
+                    const int blk = (U0x >> 4) + nb;
+                    const bool own = blk < nblk;
+                    rsw = __builtin_amdgcn_make_buffer_rsrc((void*)(splane + (size_t)blk * blkbytes), 0, own ? v4_end * 256 : 0, 0x00020000);
+                }
+
+                // up-y + activation.  Fast path: relu(X2) (forward) / keep-mask & X2 (backward) is the only operand kept; the
+                // linear part comes from X1 through the composite operator.  Exact path: the activated value itself.
+                u32x4 rv[G::NPAIR];
+                unsigned wc[4 * NA];                                       // WRITE: the code bytes of this lane's tiles
+#pragma unroll
+                for (int i = 0; i < 4 * NA; i++) wc[i] = 0;
+#pragma unroll
+                for (int vb = 0; vb < 2 * G::NPAIR; vb++) {
+                    unsigned r0 = 0, r1 = 0;
+                    if (vb < G::NVB) {
+                        f32x4 x2 = M::mma(uv[vb % UP], q[vb / UP], zero4);
+                        if (SIGN == AFCM_SIGNS_READ) {
+                            if (!EXACT) {
+                                const uint2 keep = lds_tab[codes[vb]];
+                                r0 = pack2<T>(x2[0], x2[1]) & keep.x;
+                                r1 = pack2<T>(x2[2], x2[3]) & keep.y;
+                            } else {
+#pragma unroll
+                                for (int r = 0; r < 4; r++) {
+                                    const unsigned c = codes[vb] >> (2 * r);
+                                    float v = x2[r];
+                                    if (c & 1u) v *= p.slope;
+                                    if (c & 2u) v = 0.f;
+                                    x2[r] = v;
+                                }
+                                r0 = pack2<T>(x2[0], x2[1]);
+                                r1 = pack2<T>(x2[2], x2[3]);
+                            }
+                        } else {
+                            unsigned wcode = 0;
+                            if (!EXACT) {
+                                const unsigned d0 = pack2<T>(x2[0], x2[1]), d1 = pack2<T>(x2[2], x2[3]);
+                                r0 = relu_pk(d0);
+                                r1 = relu_pk(d1);
+                                if (SIGN == AFCM_SIGNS_WRITE) {
+                                    const unsigned f = (signs_pk(d1) << 4) | signs_pk(d0);   // bits 0 (row 0), 16 (row 1), 4 (row 2), 20 (row 3)
+                                    wcode = f | (f >> 14);
+                                }
+                            } else {
+#pragma unroll
+                                for (int r = 0; r < 4; r++) {
+                                    float v = x2[r];
+                                    unsigned c = __float_as_uint(v) >> 31;
+                                    if (c) v *= p.slope;
+                                    if (fabsf(v) > p.clamp) { c = 2u; v = (v < 0.f) ? -p.clamp : p.clamp; }
+                                    wcode |= c << (2 * r);
+                                    x2[r] = v;
+                                }
+                                r0 = pack2<T>(x2[0], x2[1]);
+                                r1 = pack2<T>(x2[2], x2[3]);
+                            }
+                            wc[vb] = wcode;
+                        }
+                    }
+                    rv[vb >> 1][2 * (vb & 1)] = r0;
+                    rv[vb >> 1][2 * (vb & 1) + 1] = r1;
+                }
+                if (SIGN == AFCM_SIGNS_WRITE) {
+                    // byte 0 of each code register -> one dword per 4 row blocks, 256 contiguous bytes per store
+#pragma unroll
+                    for (int d = 0; d < NA; d++) {
+                        unsigned dw;
+                        if (4 * d + 1 >= G::NVB) {
+                            dw = wc[4 * d] & 0xffu;
+                        } else {
+                            const unsigned p01 = __builtin_amdgcn_perm(wc[4 * d + 1], wc[4 * d], 0x0c0c0400u);
+                            const unsigned p23 = (4 * d + 2 < G::NVB) ? __builtin_amdgcn_perm(wc[4 * d + 3], wc[4 * d + 2], 0x0c0c0400u) : 0u;
+                            dw = __builtin_amdgcn_perm(p23, p01, 0x05040100u);
+                        }
+                        __builtin_amdgcn_raw_buffer_store_b32(dw, rsw, sgw_off + 256u * d, 0, 0);
+                    }
+                }
+
+                // down-y, transposed: X3'[ucol][orow]; a lane ends up with 4 consecutive ucols of one orow = its share of the
+                // down-x B operand (K order krow())
+#pragma unroll
+                for (int ob = 0; ob < G::NOB; ob++) {
+                    f32x4 x3 = zero4;
+                    if (!EXACT) {
+#pragma unroll
+                        for (int t = 0; t < G::NLT; t++) x3 = M::mma(q[G::lin_q(ob, t)], lin[G::lin_f(ob, t)], x3);
+#pragma unroll
+                        for (int t = 0; t < G::NDVK; t++) x3 = M::mma(as_frag<frag>(rv[(DOWN / 2) * ob + t]), dvr[t], x3);
+                    } else {
+                        // rv holds the activated values: (slope DV + (1 - slope) DV) rv = DV rv
+#pragma unroll
+                        for (int t = 0; t < G::NDVK; t++) {
+                            x3 = M::mma(as_frag<frag>(rv[(DOWN / 2) * ob + t]), wsf[(F_DVS + t) * 64 + lane], x3);
+                            x3 = M::mma(as_frag<frag>(rv[(DOWN / 2) * ob + t]), dvr[t], x3);
+                        }
+                    }
+                    cur[ob][2 * nbl] = pack2<T>(x3[0], x3[1]);
+                    cur[ob][2 * nbl + 1] = pack2<T>(x3[2], x3[3]);
+                }
+            }
+            // the output column block whose last K window is this pair: pairs (DOWN / 2) cb ... + NDVK - 1 = gi
+            if (gi >= G::NDVK - 1 && (gi - (G::NDVK - 1)) % (DOWN / 2) == 0) {
+                u32x4 xw[G::NOB][G::NDVK];
+#pragma unroll
+                for (int ob = 0; ob < G::NOB; ob++) {
+#pragma unroll
+                    for (int h = 0; h < G::NHIST; h++) xw[ob][h] = hist[ob][h];
+                    xw[ob][G::NDVK - 1] = cur[ob];
+                }
+                phase_b((gi - (G::NDVK - 1)) / (DOWN / 2), xw);
+            }
+#pragma unroll
+            for (int ob = 0; ob < G::NOB; ob++) {
+#pragma unroll
+                for (int h = 0; h + 1 < G::NHIST; h++) hist[ob][h] = hist[ob][h + 1];
+                hist[ob][G::NHIST - 1] = cur[ob];
+            }
+        }
+        if (SIGN == AFCM_SIGNS_READ) return __builtin_amdgcn_ballot_w64((anyc & 0xaaaaaaaau) != 0) != 0;   // a clamped element in reach
+        return __builtin_amdgcn_ballot_w64(!(amax <= cthr1)) != 0;                                        // NaN takes the exact path
+    };
+    if (__builtin_expect(run_tile(std::false_type{}), 0)) run_tile(std::true_type{});
+
+    if (EPI && p.plane_sum != nullptr) {
+        // one plain store into this tile's slot (no atomics: deterministic)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) psum += __shfl_down(psum, off, 64);
+        if (lane == 0) p.plane_sum[(size_t)plane * (p.tilesX * p.tilesY) + ty * p.tilesX + tx] = psum;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+template <typename T, int UP, int DOWN, int TOW, int TOH>
+int launch_wave_tile(const afcm_filtered_lrelu_args* a, FlreluMfmaParams p, hipStream_t st) {
+    const long long tiles = (long long)p.tilesX * p.tilesY * a->n * a->c;
+    p.total_tiles = (int)tiles;
+    dim3 grid((unsigned)((tiles + 3) / 4)), block(256);
+    const bool epi = p.skip != nullptr || p.oscale != nullptr || p.oscale2 != nullptr || p.plane_sum != nullptr;
+#define AFCM_WAVE_LAUNCH(SIGN) do { \
+        if (epi) hipLaunchKernelGGL((flrelu_wave_kernel<T, UP, DOWN, TOW, TOH, SIGN, 1>), grid, block, 0, st, p); \
+        else hipLaunchKernelGGL((flrelu_wave_kernel<T, UP, DOWN, TOW, TOH, SIGN, 0>), grid, block, 0, st, p); } while (0)
+    switch (a->sign_mode) {
+        case AFCM_SIGNS_NONE: AFCM_WAVE_LAUNCH(AFCM_SIGNS_NONE); break;
+        case AFCM_SIGNS_WRITE: AFCM_WAVE_LAUNCH(AFCM_SIGNS_WRITE); break;
+        default: AFCM_WAVE_LAUNCH(AFCM_SIGNS_READ); break;
+    }
+#undef AFCM_WAVE_LAUNCH
+    return hip_status(hipGetLastError());
+}
+
+template <typename T, int UP, int DOWN>
+int prepare_wave(const afcm_filtered_lrelu_args* a, hipStream_t st) {
+    typedef WaveGeom<UP, DOWN, 32, 32> G;
+    const float gain_total = (float)a->up * (float)a->up * a->gain;
+    hipLaunchKernelGGL((flrelu_wave_prepare_kernel<T, UP, DOWN>), dim3(cdiv((G::NLIN + G::NDVK) * 512, 256)), dim3(256), 0, st,
+                       (char*)a->workspace, a->fu, a->fd, a->py0, a->flip_filter, gain_total, a->slope);
+    return hip_status(hipGetLastError());
+}
+
+#define AFCM_WAVE_INST(T, UP, DOWN, TOW, TOH) \
+    template int launch_wave_tile<T, UP, DOWN, TOW, TOH>(const afcm_filtered_lrelu_args*, FlreluMfmaParams, hipStream_t);
+#define AFCM_WAVE_INST_T(T)           \
+    AFCM_WAVE_INST(T, 2, 2, 64, 32)   \
+    AFCM_WAVE_INST(T, 2, 2, 64, 48)   \
+    AFCM_WAVE_INST(T, 2, 4, 32, 32)   \
+    AFCM_WAVE_INST(T, 4, 2, 64, 32)   \
+    template int prepare_wave<T, 2, 2>(const afcm_filtered_lrelu_args*, hipStream_t); \
+    template int prepare_wave<T, 2, 4>(const afcm_filtered_lrelu_args*, hipStream_t); \
+    template int prepare_wave<T, 4, 2>(const afcm_filtered_lrelu_args*, hipStream_t);
+AFCM_WAVE_INST_T(bf16_t)
+AFCM_WAVE_INST_T(f16_t)
+
+}  // namespace afcm

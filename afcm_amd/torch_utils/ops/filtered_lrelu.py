@@ -131,12 +131,13 @@ def _run(x, fu, fd, b, si, cfg, write_signs, want_plane_sum=False, oscale=None, 
     a.sign_mode = _lib.SIGNS_WRITE if write_signs else (_lib.SIGNS_READ if si is not None else _lib.SIGNS_NONE)
     # 16-bit activations: matrix-core kernels (signs in the row-quad layout); a given sign tensor fixes the family
     ws = None
-    if allow_mfma and (si is None or si_layout == 1):
+    if allow_mfma and (si is None or si_layout in (1, 2)):
         ws = _mfma_workspace(a, fu_t, fd_t, x)
         if si is not None and ws is None:
             raise RuntimeError('filtered_lrelu: sign tensor was written by the matrix-core kernels but this call has none')
     a.workspace = _lib.ptr(ws)
     a.sign_layout = si_layout if si is not None else 0
+    a.b = _lib.ptr(b)                     # the kernel family (and with it the sign layout a WRITE call produces) depends on it
     _lib.check(lib.afcm_filtered_lrelu_shapes(a), 'filtered_lrelu')
     y = torch.empty([a.n, a.c, a.yh, a.yw], dtype=x.dtype, device=x.device)
     so = None

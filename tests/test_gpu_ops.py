@@ -341,7 +341,7 @@ def test_filtered_lrelu_16bit_matrix_core_clamp_and_no_bias(lname, dtype, tol):
     gref, = torch.autograd.grad((ref * r.float()).sum(), xr)
     xg = x.cuda().requires_grad_(True)
     got = flr.filtered_lrelu(xg, fu=L['fu'].cuda(), fd=L['fd'].cuda(), b=None, **kw)
-    assert got.grad_fn.sign_layout == 1, 'expected the matrix-core kernel family'
+    assert got.grad_fn.sign_layout == 2, 'expected the wave-autonomous matrix-core kernels (no bias operand)'
     _close(got, ref, tol=tol, what=f'{lname} {dtype} clamp y')
     ggot, = torch.autograd.grad((got.float() * r.cuda().float()).sum(), xg)
     rel = ((ggot.float().cpu() - gref).norm() / gref.norm()).item()

@@ -20,13 +20,17 @@ def main():
     ap.add_argument('--res', type=int, default=256)
     ap.add_argument('--dtype', default='fp32')
     ap.add_argument('--iters', type=int, default=10)
+    ap.add_argument('--layers', default='', help='comma-separated layer names (default: all)')
     ap.add_argument('--no-bias', action='store_true', help='b=None: the generator path (the convs add the bias)')
     args = ap.parse_args()
     dt = {'fp32': torch.float32, 'bf16': torch.bfloat16, 'fp16': torch.float16}[args.dtype]
     pl = sched.plan(args.res, 4, 1, {})
     tot_b = tot_t = tot_bb = tot_tb = 0.0
     seen = {}
+    only = set(args.layers.split(',')) if args.layers else None
     for L in pl['enc'] + pl['dec']:
+        if only is not None and L['name'] not in only:
+            continue
         h = L['in_size'] + L['k'] - 1
         key = (L['cout'], h, L['up'], L['down'], tuple(L['padding']))
         x = torch.randn(args.batch, L['cout'], h, h, device='cuda', dtype=dt).requires_grad_(True)
