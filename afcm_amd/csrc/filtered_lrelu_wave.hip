@@ -30,6 +30,16 @@
 #ifndef AFCM_WAVE_OCC_D4
 #define AFCM_WAVE_OCC_D4 2
 #endif
+// cache-policy bits of the output / sign stores (buffer aux: 1 = sc0, 2 = nt, 16 = sc1).  nt: the outputs and codes are written
+// once and read by a later kernel; as plain (write-back allocating) stores they slowed the loads queued behind them --
+// encoder_1 forward 0.190 -> 0.145 ms with nt
+#ifndef AFCM_WAVE_STORE_AUX
+#define AFCM_WAVE_STORE_AUX 2
+#endif
+// ... of the sign-code loads of the transposed op (read once)
+#ifndef AFCM_WAVE_SIGNLOAD_AUX
+#define AFCM_WAVE_SIGNLOAD_AUX 0
+#endif
 
 namespace afcm {
 
@@ -143,7 +153,7 @@ __global__ void flrelu_wave_prepare_kernel(char* __restrict__ wsb, const float* 
 // ranges over the tile -- 210-240 VGPRs, two waves per SIMD, or spills; a wave spends most of its residency waiting on its own
 // MFMA -> convert -> MFMA chains, so the SIMD only fills up with 3-4 of them.)
 //
-// EPI: 0 = plain store; 1 = + encoder skip, per-plane factors and per-tile output sums (fused layer node, backward bias gradient).
+// EPI bits: 1 = per-plane factors and per-strip output sums (fused layer node; backward bias gradient), 2 = + encoder skip operand.
 template <typename T, int UP, int DOWN, int TOW, int TOH, int SIGN, int EPI>
 __global__ __launch_bounds__(256, (DOWN == 2 ? AFCM_WAVE_OCC_D2 : AFCM_WAVE_OCC_D4)) void flrelu_wave_kernel(FlreluMfmaParams p) {
     typedef WaveGeom<UP, DOWN, TOW, TOH> G;
@@ -282,6 +292,21 @@ __global__ __launch_bounds__(256, (DOWN == 2 ? AFCM_WAVE_OCC_D2 : AFCM_WAVE_OCC_
     }
     // dword groups outside the tensor would alias a neighbouring column block: select them out (wave-uniform fast case)
     const bool rows_inside = Q0 >= 0 && (((Q0 + 4) >> 2) >> 2) + NA + 1 <= nV4;
+    // READ: the sign dwords of a group's two column blocks, fetched one group ahead like the input window (consumed right after
+    // the up-y products: fetched in place, every column block exposed a full memory round trip)
+    auto load_signs = [&](int nb, unsigned (&sg)[2][NA + 1]) __attribute__((always_inline)) {
+        const int blo = sgr_lo + nb * blkbytes, bhi = sgr_hi + nb * blkbytes;
+#pragma unroll
+        for (int i = 0; i <= NA; i++) {
+            unsigned ol = (unsigned)(blo + 256 * i), oh = (unsigned)(bhi + 256 * i);
+            if (!rows_inside) {
+                ol = ((unsigned)(sgr_dl + i) < (unsigned)nV4) ? ol : 0x80000000u;
+                oh = ((unsigned)(sgr_dh + i) < (unsigned)nV4) ? oh : 0x80000000u;
+            }
+            sg[0][i] = __builtin_amdgcn_raw_buffer_load_b32(rss, ol, 0, AFCM_WAVE_SIGNLOAD_AUX);
+            sg[1][i] = (yy != 0) ? __builtin_amdgcn_raw_buffer_load_b32(rss, oh, 0, AFCM_WAVE_SIGNLOAD_AUX) : 0u;
+        }
+    };
 
     // ---- output
     T* const yp = (T*)p.y + (size_t)plane * p.yh * p.yw;
@@ -290,14 +315,14 @@ __global__ __launch_bounds__(256, (DOWN == 2 ? AFCM_WAVE_OCC_D2 : AFCM_WAVE_OCC_
 #else
     const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc((void*)yp, 0, p.yh * p.yw * 2, 0x00020000);
 #endif
-    const bool has_skip = EPI && p.skip != nullptr;
+    const bool has_skip = (EPI & 2) && p.skip != nullptr;
     const __amdgpu_buffer_rsrc_t rsk = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(has_skip ? (const T*)p.skip + (size_t)plane * p.yh * p.yw : (const T*)p.x), 0, has_skip ? p.yh * p.yw * 2 : 0, 0x00020000);
     // skip operand: byte offset of (row O0y + lrow, column 4 lchk) (access lane map); rows below the plane exceed the record count
     // and read as zero, columns right of it are selected out per output column block
     const int koff0 = ((O0y + lrow) * p.yw + 4 * lchk) * 2;
     const int yrow16 = 32 * p.yw;
-    const float osc = EPI ? (p.oscale ? p.oscale[plane] : 1.f) * (p.oscale2 ? p.oscale2[plane] : 1.f) : 1.f;
+    const float osc = (EPI & 1) ? (p.oscale ? p.oscale[plane] : 1.f) * (p.oscale2 ? p.oscale2[plane] : 1.f) : 1.f;
     float psum = 0.f;
     unsigned char* const stage = lds_o[wave];
     const unsigned st_w = (unsigned)(l15 * OPITCH + g * 8);                // fragment lane (g, l15): 4 columns of row l15 (+ 16 ob rows, + 32 B per column block)
@@ -315,9 +340,9 @@ __global__ __launch_bounds__(256, (DOWN == 2 ? AFCM_WAVE_OCC_D2 : AFCM_WAVE_OCC_
             f32x4 acc = zero4;
 #pragma unroll
             for (int t = 0; t < G::NDVK; t++) acc = M::mma(dh[t], as_frag<frag>(xw[ob][t]), acc);
-            if (EPI) {
-                // encoder feature of this lane's 4 columns (x + x_skip, NET:376-377): zero-record descriptor when there is none;
-                // fetched in the access lane map (columns / rows outside the plane read as zero), moved to the fragment map
+            if (EPI & 2) {
+                // encoder feature of this lane's 4 columns (x + x_skip, NET:376-377), fetched in the access lane map (columns /
+                // rows outside the plane read as zero), moved to the fragment map
                 const int ox = 16 * cb + 4 * lchk;
                 const unsigned off = (unsigned)(koff0 + ob * yrow16 + 32 * cb);
                 union { unsigned u; T t[2]; } e0, e1;
@@ -329,10 +354,16 @@ __global__ __launch_bounds__(256, (DOWN == 2 ? AFCM_WAVE_OCC_D2 : AFCM_WAVE_OCC_
                 acc[1] += to_f32(e0.t[1]);
                 acc[2] += to_f32(e1.t[0]);
                 acc[3] += to_f32(e1.t[1]);
+            }
+            if (EPI & 1) {
                 acc *= osc;
-                const int fx = 16 * cb + 4 * g;                                                // fragment lane map
-                const bool rin = O0y + 16 * ob + l15 < p.yh;
-                psum += (rin && fx + 2 <= p.yw ? acc[0] + acc[1] : 0.f) + (rin && fx + 4 <= p.yw ? acc[2] + acc[3] : 0.f);
+                if (!(lastY || cb == ncb - 1)) {                                              // wave-uniform: every element is inside the plane
+                    psum += (acc[0] + acc[1]) + (acc[2] + acc[3]);
+                } else {
+                    const int fx = 16 * cb + 4 * g;                                            // fragment lane map
+                    const bool rin = O0y + 16 * ob + l15 < p.yh;
+                    psum += (rin && fx + 2 <= p.yw ? acc[0] + acc[1] : 0.f) + (rin && fx + 4 <= p.yw ? acc[2] + acc[3] : 0.f);
+                }
             }
             uint2 w;
             w.x = pack2<T>(acc[0], acc[1]);
@@ -347,248 +378,251 @@ __global__ __launch_bounds__(256, (DOWN == 2 ? AFCM_WAVE_OCC_D2 : AFCM_WAVE_OCC_
 #pragma unroll
             for (int j = 0; j < TOH / 8; j++) {
                 const u32x4 v = *(const u32x4*)(stage + st_r + (unsigned)(j * 8 * OPITCH));
-                const unsigned off = gofs + (unsigned)(j * 16 * p.yw);
+                unsigned off = gofs + (unsigned)(j * 16 * p.yw);
+#ifdef AFCM_WAVE_EXPERIMENT_STORE_ALIAS  // timing experiment only: all output stores land in one 64 KB window (no HBM write traffic)
+                off &= 0xfff0u;
+#endif
                 if (full) {
-                    __builtin_amdgcn_raw_buffer_store_b128(v, rsy, off, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(v, rsy, off, 0, AFCM_WAVE_STORE_AUX);
                 } else {
                     // the group crosses the right edge (or is only partly produced): pair by pair (even plane widths)
 #pragma unroll
                     for (int w2 = 0; w2 < 4; w2++)
-                        __builtin_amdgcn_raw_buffer_store_b32(v[w2], rsy, (c0 + 2 * w2 + 2 <= p.yw && 8 * fl_chk + 2 * w2 < 16 * (slot + 1)) ? off + 4u * w2 : kOut, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(v[w2], rsy, (c0 + 2 * w2 + 2 <= p.yw && 8 * fl_chk + 2 * w2 < 16 * (slot + 1)) ? off + 4u * w2 : kOut, 0, AFCM_WAVE_STORE_AUX);
                 }
             }
         }
     };
 
-    // ---- the tile: groups of two column blocks: up-x, up-y, activation (+ codes), down-y, then the down-x pass the new X3 pair
-    // completes.  The rare exact path (clamp reached somewhere in the tile) is a second pass over the tile.
-    auto run_tile = [&](auto exact_c) __attribute__((always_inline)) -> bool {
-        constexpr bool EXACT = decltype(exact_c)::value;
+    // ---- the strip: groups of two column blocks: up-x, up-y, activation (+ codes), down-y, then the down-x pass the new X3 pair
+    // completes.  EXACT: the rare second pass over a strip in which the clamp was reached.  LASTY: the strip also writes the codes of
+    // its halo row blocks (every other strip leaves them to the strip below and skips their extraction).
+    // One group; the caller alternates two register sets for everything that is carried from one group to the next.
+    auto group = [&](int gi, auto exact_c, auto lasty_c, frag (&a_in)[G::NMB], frag (&a_nxt)[G::NMB], unsigned (&sg)[G::NBG][2][NA + 1],
+                     u32x4 (&hist)[G::NOB][G::NHIST], u32x4 (&cur)[G::NOB], float& amax, unsigned& anyc) __attribute__((always_inline)) {
+        constexpr bool EXACT = decltype(exact_c)::value, LASTY = decltype(lasty_c)::value;
+        constexpr int NVW = LASTY ? G::NVB : G::OWN_VB;                  // row blocks whose codes this strip writes
+        // one group ahead, issued before this group's stores: vmcnt counts in order, so waiting for these loads at the top of
+        // the next group does not wait for the (younger) stores
+        if (gi + 1 < ng) load_group(gi + 1, a_nxt);
+#pragma unroll
+        for (int nbl = 0; nbl < G::NBG; nbl++) {
+            const int nb = gi * G::NBG + nbl;
+            // READ: the next column block's sign dwords (sg[0] holds block nb0 on entry, loaded by the previous group; block nb1
+            // goes to sg[1] while nb0 runs, the next group's nb0 back to sg[0] while nb1 runs)
+            if (SIGN == AFCM_SIGNS_READ) {
+                if (nbl == 0) load_signs(nb + 1, sg[1]);
+                else if (gi + 1 < ng) load_signs(nb + 1, sg[0]);
+            }
+            // up-x: X1[mb] = In[mb] * UH, packed in pairs as the B operand of up-y / the A operand of the composite operator
+            f32x4 x1[G::NMB];
+#pragma unroll
+            for (int mb = 0; mb < G::NMB; mb++) x1[mb] = M::mma(a_in[mb], uh[nbl], zero4);
+            frag q[G::NQ];
+#pragma unroll
+            for (int m = 0; m < G::NQ; m++) q[m] = pack_pair<T>(x1[m], (m + 1 < G::NMB) ? x1[m + 1] : zero4);
+            if (SIGN != AFCM_SIGNS_READ && !EXACT) {
+#pragma unroll
+                for (int mb = 0; mb < G::NMB; mb++) {
+                    amax = __builtin_elementwise_maximum(__builtin_elementwise_maximum(amax, __builtin_fabsf(x1[mb][0])), __builtin_fabsf(x1[mb][1]));
+                    amax = __builtin_elementwise_maximum(__builtin_elementwise_maximum(amax, __builtin_fabsf(x1[mb][2])), __builtin_fabsf(x1[mb][3]));
+                }
+            }
+            // READ: the codes of this block's X2 tiles
+            unsigned codes[G::NVB];
+            if (SIGN == AFCM_SIGNS_READ) {
+#pragma unroll
+                for (int i = 0; i <= NA; i++) anyc |= sg[nbl][0][i] | sg[nbl][1][i];
+#pragma unroll
+                for (int k = 0; k < NA; k++) {
+                    // the 4 codes of row blocks 4 k .. 4 k + 3: bytes sl .. sl + 3 of the dword pair (k, k + 1)
+                    const unsigned al = __builtin_amdgcn_alignbyte(sg[nbl][0][k + 1], sg[nbl][0][k], sgr_sl);
+                    const unsigned ah = yy != 0 ? __builtin_amdgcn_alignbyte(sg[nbl][1][k + 1], sg[nbl][1][k], sgr_sh) : 0u;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        if (4 * k + j < G::NVB) {
+                            // quad-rows r0 + 4 vb (low byte) and r0 + 4 vb + 1 (high byte), shifted to the window's first row
+                            const unsigned two = __builtin_amdgcn_perm(ah, al, 0x0c0c0000u | ((4u + j) << 8) | (unsigned)j);
+                            codes[4 * k + j] = __builtin_amdgcn_ubfe(two, 2 * yy, 8);
+                        }
+                    }
+                }
+            }
+            // WRITE: this block's descriptor: rows below the plane / not owned and blocks beyond the tensor fall outside it and
+            // are dropped by the memory pipeline
+            __amdgpu_buffer_rsrc_t rsw = rsx;
+            if (SIGN == AFCM_SIGNS_WRITE) {
+                const int blk = (U0x >> 4) + nb;
+                rsw = __builtin_amdgcn_make_buffer_rsrc((void*)(splane + (size_t)blk * blkbytes), 0, blk < nblk ? v4_end * 256 : 0, 0x00020000);
+            }
+
+            // up-y + activation.  Fast path: relu(X2) (forward) / keep-mask & X2 (backward) is the only operand kept; the linear
+            // part comes from X1 through the composite operator.  Exact path: the activated value itself.
+            u32x4 rv[G::NPAIR];
+            unsigned wc[4 * NA];          // WRITE: per tile the sign bits (fast path: bits 0, 4, 16, 20 = rows 0, 2, 1, 3) / the code byte (exact)
+#pragma unroll
+            for (int i = 0; i < 4 * NA; i++) wc[i] = 0;
+#pragma unroll
+            for (int vb = 0; vb < 2 * G::NPAIR; vb++) {
+                unsigned r0 = 0, r1 = 0;
+                if (vb < G::NVB) {
+                    f32x4 x2 = M::mma(uv[vb % UP], q[vb / UP], zero4);
+                    if (SIGN == AFCM_SIGNS_READ) {
+                        if (!EXACT) {
+                            const uint2 keep = lds_tab[codes[vb]];
+                            r0 = pack2<T>(x2[0], x2[1]) & keep.x;
+                            r1 = pack2<T>(x2[2], x2[3]) & keep.y;
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 4; r++) {
+                                const unsigned c = codes[vb] >> (2 * r);
+                                float v = x2[r];
+                                if (c & 1u) v *= p.slope;
+                                if (c & 2u) v = 0.f;
+                                x2[r] = v;
+                            }
+                            r0 = pack2<T>(x2[0], x2[1]);
+                            r1 = pack2<T>(x2[2], x2[3]);
+                        }
+                    } else if (!EXACT) {
+                        const unsigned d0 = pack2<T>(x2[0], x2[1]), d1 = pack2<T>(x2[2], x2[3]);
+                        r0 = relu_pk(d0);
+                        r1 = relu_pk(d1);
+                        if (SIGN == AFCM_SIGNS_WRITE && vb < NVW) wc[vb] = (signs_pk(d1) << 4) | signs_pk(d0);
+                    } else {
+                        unsigned wcode = 0;
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            float v = x2[r];
+                            unsigned c = __float_as_uint(v) >> 31;
+                            if (c) v *= p.slope;
+                            if (fabsf(v) > p.clamp) { c = 2u; v = (v < 0.f) ? -p.clamp : p.clamp; }
+                            wcode |= c << (2 * r);
+                            x2[r] = v;
+                        }
+                        r0 = pack2<T>(x2[0], x2[1]);
+                        r1 = pack2<T>(x2[2], x2[3]);
+                        if (vb < NVW) wc[vb] = wcode;
+                    }
+                }
+                rv[vb >> 1][2 * (vb & 1)] = r0;
+                rv[vb >> 1][2 * (vb & 1) + 1] = r1;
+            }
+            if (SIGN == AFCM_SIGNS_WRITE) {
+                // one dword of 4 code bytes per 4 row blocks: 256 contiguous bytes per store instruction
+#pragma unroll
+                for (int d = 0; d < cdiv(NVW, 4); d++) {
+                    unsigned dw;
+                    if (!EXACT) {
+                        // sign bits -> code bytes, two tiles at a time: bytes (b0, b2) of a tile hold rows (0, 2) and (1, 3) at bits
+                        // (0, 4); gathered pairwise, x | x >> 6 drops rows (1, 3) onto bits (2, 6) of the bytes of rows (0, 2)
+                        const unsigned p01 = __builtin_amdgcn_perm(wc[4 * d + 1], wc[4 * d], 0x06040200u);
+                        const unsigned q01 = p01 | (p01 >> 6);
+                        if (4 * d + 2 < NVW) {
+                            const unsigned p23 = __builtin_amdgcn_perm(wc[4 * d + 3], wc[4 * d + 2], 0x06040200u);
+                            const unsigned q23 = p23 | (p23 >> 6);
+                            dw = __builtin_amdgcn_perm(q23, q01, 0x06040200u);
+                        } else {
+                            dw = __builtin_amdgcn_perm(0u, q01, 0x0c0c0200u);
+                        }
+                    } else {
+                        const unsigned p01 = __builtin_amdgcn_perm(wc[4 * d + 1], wc[4 * d], 0x0c0c0400u);
+                        const unsigned p23 = __builtin_amdgcn_perm(wc[4 * d + 3], wc[4 * d + 2], 0x0c0c0400u);
+                        dw = __builtin_amdgcn_perm(p23, p01, 0x05040100u);
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b32(dw, rsw, sgw_off + 256u * d, 0, AFCM_WAVE_STORE_AUX);
+                }
+            }
+
+            // down-y, transposed: X3'[ucol][orow]; a lane ends up with 4 consecutive ucols of one orow = its share of the
+            // down-x B operand (K order krow())
+#pragma unroll
+            for (int ob = 0; ob < G::NOB; ob++) {
+                f32x4 x3 = zero4;
+                if (!EXACT) {
+#pragma unroll
+                    for (int t = 0; t < G::NLT; t++) x3 = M::mma(q[G::lin_q(ob, t)], lin[G::lin_f(ob, t)], x3);
+#pragma unroll
+                    for (int t = 0; t < G::NDVK; t++) x3 = M::mma(as_frag<frag>(rv[(DOWN / 2) * ob + t]), dvr[t], x3);
+                } else {
+                    // rv holds the activated values: (slope DV + (1 - slope) DV) rv = DV rv
+#pragma unroll
+                    for (int t = 0; t < G::NDVK; t++) {
+                        x3 = M::mma(as_frag<frag>(rv[(DOWN / 2) * ob + t]), wsf[(F_DVS + t) * 64 + lane], x3);
+                        x3 = M::mma(as_frag<frag>(rv[(DOWN / 2) * ob + t]), dvr[t], x3);
+                    }
+                }
+                cur[ob][2 * nbl] = pack2<T>(x3[0], x3[1]);
+                cur[ob][2 * nbl + 1] = pack2<T>(x3[2], x3[3]);
+            }
+        }
+        // the output column block whose last K window is this pair: pairs (DOWN / 2) cb ... + NDVK - 1 = gi
+        if (gi >= G::NDVK - 1 && (gi - (G::NDVK - 1)) % (DOWN / 2) == 0) {
+            u32x4 xw[G::NOB][G::NDVK];
+#pragma unroll
+            for (int ob = 0; ob < G::NOB; ob++) {
+#pragma unroll
+                for (int h = 0; h < G::NHIST; h++) xw[ob][h] = hist[ob][h];
+                xw[ob][G::NDVK - 1] = cur[ob];
+            }
+            phase_b((gi - (G::NDVK - 1)) / (DOWN / 2), xw);
+        }
+    };
+
+    auto run_strip = [&](auto exact_c, auto lasty_c) __attribute__((always_inline)) -> bool {
         float amax = 0.f;
         unsigned anyc = 0;
-        if (EXACT) psum = 0.f;
-        u32x4 hist[G::NOB][G::NHIST];                                      // the NHIST latest complete X3 pairs, oldest first
+        if (decltype(exact_c)::value) psum = 0.f;
+        frag a0[G::NMB], a1[G::NMB];
+        unsigned sg[G::NBG][2][NA + 1];
+        load_group(0, a0);
+        if (SIGN == AFCM_SIGNS_READ) load_signs(0, sg[0]);
+        u32x4 hist[G::NOB][G::NHIST], cur[G::NOB];
 #pragma unroll
         for (int ob = 0; ob < G::NOB; ob++)
 #pragma unroll
             for (int h = 0; h < G::NHIST; h++) hist[ob][h] = (u32x4){0u, 0u, 0u, 0u};
-#ifndef AFCM_WAVE_PREFETCH
-#define AFCM_WAVE_PREFETCH 1
-#endif
-        frag a_nxt[G::NMB];
-        if (AFCM_WAVE_PREFETCH) load_group(0, a_nxt);
-        // READ: the sign dwords of a group's two column blocks, fetched one group ahead like the input window (consumed right
-        // after the up-y products: fetched in place, every column block exposed a full memory round trip)
-        unsigned sg_nxt[G::NBG][2][NA + 1];
-        auto load_signs = [&](int gi2, unsigned (&sg)[G::NBG][2][NA + 1]) __attribute__((always_inline)) {
-#pragma unroll
-            for (int nbl = 0; nbl < G::NBG; nbl++) {
-                const int nb = gi2 * G::NBG + nbl;
-                const int blo = sgr_lo + nb * blkbytes, bhi = sgr_hi + nb * blkbytes;
-#pragma unroll
-                for (int i = 0; i <= NA; i++) {
-                    unsigned ol = (unsigned)(blo + 256 * i), oh = (unsigned)(bhi + 256 * i);
-                    if (!rows_inside) {
-                        ol = ((unsigned)(sgr_dl + i) < (unsigned)nV4) ? ol : 0x80000000u;
-                        oh = ((unsigned)(sgr_dh + i) < (unsigned)nV4) ? oh : 0x80000000u;
-                    }
-                    sg[nbl][0][i] = __builtin_amdgcn_raw_buffer_load_b32(rss, ol, 0, 0);
-                    sg[nbl][1][i] = (yy != 0) ? __builtin_amdgcn_raw_buffer_load_b32(rss, oh, 0, 0) : 0u;
-                }
-            }
-        };
-        if (SIGN == AFCM_SIGNS_READ) load_signs(0, sg_nxt);
-#pragma unroll 1
-        for (int gi = 0; gi < ng; gi++) {
-            frag a_in[G::NMB];
-            if (AFCM_WAVE_PREFETCH) {
-#pragma unroll
-                for (int mb = 0; mb < G::NMB; mb++) a_in[mb] = a_nxt[mb];
-                // one group ahead, issued before this group's stores: vmcnt counts in order, so waiting for these loads at the
-                // top of the next iteration does not wait for the (younger) stores
-                if (gi + 1 < ng) load_group(gi + 1, a_nxt);
-            } else {
-                load_group(gi, a_in);
-            }
-            unsigned sg[G::NBG][2][NA + 1];
-            if (SIGN == AFCM_SIGNS_READ) {
-#pragma unroll
-                for (int nbl = 0; nbl < G::NBG; nbl++)
-#pragma unroll
-                    for (int i = 0; i <= NA; i++) { sg[nbl][0][i] = sg_nxt[nbl][0][i]; sg[nbl][1][i] = sg_nxt[nbl][1][i]; }
-                if (gi + 1 < ng) load_signs(gi + 1, sg_nxt);
-            }
-            u32x4 cur[G::NOB];                                             // this group's packed X3 pair
-#pragma unroll
-            for (int nbl = 0; nbl < G::NBG; nbl++) {
-                const int nb = gi * G::NBG + nbl;
-                // up-x: X1[mb] = In[mb] * UH, packed in pairs as the B operand of up-y / the A operand of the composite operator
-                f32x4 x1[G::NMB];
-#pragma unroll
-                for (int mb = 0; mb < G::NMB; mb++) x1[mb] = M::mma(a_in[mb], uh[nbl], zero4);
-                frag q[G::NQ];
-#pragma unroll
-                for (int m = 0; m < G::NQ; m++) q[m] = pack_pair<T>(x1[m], (m + 1 < G::NMB) ? x1[m + 1] : zero4);
-                if (SIGN != AFCM_SIGNS_READ && !EXACT) {
-#pragma unroll
-                    for (int mb = 0; mb < G::NMB; mb++) {
-                        amax = __builtin_elementwise_maximum(__builtin_elementwise_maximum(amax, __builtin_fabsf(x1[mb][0])), __builtin_fabsf(x1[mb][1]));
-                        amax = __builtin_elementwise_maximum(__builtin_elementwise_maximum(amax, __builtin_fabsf(x1[mb][2])), __builtin_fabsf(x1[mb][3]));
-                    }
-                }
-                // READ: the codes of this block's X2 tiles
-                unsigned codes[G::NVB];
-                if (SIGN == AFCM_SIGNS_READ) {
-                    unsigned dl[NA + 1], dq[NA + 1];
-#pragma unroll
-                    for (int i = 0; i <= NA; i++) {
-                        dl[i] = sg[nbl][0][i];
-                        dq[i] = sg[nbl][1][i];
-                        anyc |= dl[i] | dq[i];
-                    }
-#pragma unroll
-                    for (int k = 0; k < NA; k++) {
-                        // the 4 codes of row blocks 4 k .. 4 k + 3: bytes sl .. sl + 3 of the dword pair (k, k + 1)
-                        const unsigned al = __builtin_amdgcn_alignbyte(dl[k + 1], dl[k], sgr_sl);
-                        const unsigned ah = yy != 0 ? __builtin_amdgcn_alignbyte(dq[k + 1], dq[k], sgr_sh) : 0u;
-#pragma unroll
-                        for (int j = 0; j < 4; j++) {
-                            if (4 * k + j < G::NVB) {
-                                // quad-rows r0 + 4 vb (low byte) and r0 + 4 vb + 1 (high byte), shifted to the window's first row
-                                const unsigned two = __builtin_amdgcn_perm(ah, al, 0x0c0c0000u | ((4u + j) << 8) | (unsigned)j);
-                                codes[4 * k + j] = __builtin_amdgcn_ubfe(two, 2 * yy, 8);
-                            }
-                        }
-                    }
-                }
-                // WRITE: this block's descriptor: rows below the plane / not owned and blocks not owned or beyond the tensor
-                // fall outside it and are dropped by the memory pipeline
-                __amdgpu_buffer_rsrc_t rsw = rsx;
-                if (SIGN == AFCM_SIGNS_WRITE) {
-                    const int blk = (U0x >> 4) + nb;
-                    const bool own = blk < nblk;
-                    rsw = __builtin_amdgcn_make_buffer_rsrc((void*)(splane + (size_t)blk * blkbytes), 0, own ? v4_end * 256 : 0, 0x00020000);
-                }
-
-                // up-y + activation.  Fast path: relu(X2) (forward) / keep-mask & X2 (backward) is the only operand kept; the
-                // linear part comes from X1 through the composite operator.  Exact path: the activated value itself.
-                u32x4 rv[G::NPAIR];
-                unsigned wc[4 * NA];                                       // WRITE: the code bytes of this lane's tiles
-#pragma unroll
-                for (int i = 0; i < 4 * NA; i++) wc[i] = 0;
-#pragma unroll
-                for (int vb = 0; vb < 2 * G::NPAIR; vb++) {
-                    unsigned r0 = 0, r1 = 0;
-                    if (vb < G::NVB) {
-                        f32x4 x2 = M::mma(uv[vb % UP], q[vb / UP], zero4);
-                        if (SIGN == AFCM_SIGNS_READ) {
-                            if (!EXACT) {
-                                const uint2 keep = lds_tab[codes[vb]];
-                                r0 = pack2<T>(x2[0], x2[1]) & keep.x;
-                                r1 = pack2<T>(x2[2], x2[3]) & keep.y;
-                            } else {
-#pragma unroll
-                                for (int r = 0; r < 4; r++) {
-                                    const unsigned c = codes[vb] >> (2 * r);
-                                    float v = x2[r];
-                                    if (c & 1u) v *= p.slope;
-                                    if (c & 2u) v = 0.f;
-                                    x2[r] = v;
-                                }
-                                r0 = pack2<T>(x2[0], x2[1]);
-                                r1 = pack2<T>(x2[2], x2[3]);
-                            }
-                        } else {
-                            unsigned wcode = 0;
-                            if (!EXACT) {
-                                const unsigned d0 = pack2<T>(x2[0], x2[1]), d1 = pack2<T>(x2[2], x2[3]);
-                                r0 = relu_pk(d0);
-                                r1 = relu_pk(d1);
-                                if (SIGN == AFCM_SIGNS_WRITE) {
-                                    const unsigned f = (signs_pk(d1) << 4) | signs_pk(d0);   // bits 0 (row 0), 16 (row 1), 4 (row 2), 20 (row 3)
-                                    wcode = f | (f >> 14);
-                                }
-                            } else {
-#pragma unroll
-                                for (int r = 0; r < 4; r++) {
-                                    float v = x2[r];
-                                    unsigned c = __float_as_uint(v) >> 31;
-                                    if (c) v *= p.slope;
-                                    if (fabsf(v) > p.clamp) { c = 2u; v = (v < 0.f) ? -p.clamp : p.clamp; }
-                                    wcode |= c << (2 * r);
-                                    x2[r] = v;
-                                }
-                                r0 = pack2<T>(x2[0], x2[1]);
-                                r1 = pack2<T>(x2[2], x2[3]);
-                            }
-                            wc[vb] = wcode;
-                        }
-                    }
-                    rv[vb >> 1][2 * (vb & 1)] = r0;
-                    rv[vb >> 1][2 * (vb & 1) + 1] = r1;
-                }
-                if (SIGN == AFCM_SIGNS_WRITE) {
-                    // byte 0 of each code register -> one dword per 4 row blocks, 256 contiguous bytes per store
-#pragma unroll
-                    for (int d = 0; d < NA; d++) {
-                        unsigned dw;
-                        if (4 * d + 1 >= G::NVB) {
-                            dw = wc[4 * d] & 0xffu;
-                        } else {
-                            const unsigned p01 = __builtin_amdgcn_perm(wc[4 * d + 1], wc[4 * d], 0x0c0c0400u);
-                            const unsigned p23 = (4 * d + 2 < G::NVB) ? __builtin_amdgcn_perm(wc[4 * d + 3], wc[4 * d + 2], 0x0c0c0400u) : 0u;
-                            dw = __builtin_amdgcn_perm(p23, p01, 0x05040100u);
-                        }
-                        __builtin_amdgcn_raw_buffer_store_b32(dw, rsw, sgw_off + 256u * d, 0, 0);
-                    }
-                }
-
-                // down-y, transposed: X3'[ucol][orow]; a lane ends up with 4 consecutive ucols of one orow = its share of the
-                // down-x B operand (K order krow())
-#pragma unroll
-                for (int ob = 0; ob < G::NOB; ob++) {
-                    f32x4 x3 = zero4;
-                    if (!EXACT) {
-#pragma unroll
-                        for (int t = 0; t < G::NLT; t++) x3 = M::mma(q[G::lin_q(ob, t)], lin[G::lin_f(ob, t)], x3);
-#pragma unroll
-                        for (int t = 0; t < G::NDVK; t++) x3 = M::mma(as_frag<frag>(rv[(DOWN / 2) * ob + t]), dvr[t], x3);
-                    } else {
-                        // rv holds the activated values: (slope DV + (1 - slope) DV) rv = DV rv
-#pragma unroll
-                        for (int t = 0; t < G::NDVK; t++) {
-                            x3 = M::mma(as_frag<frag>(rv[(DOWN / 2) * ob + t]), wsf[(F_DVS + t) * 64 + lane], x3);
-                            x3 = M::mma(as_frag<frag>(rv[(DOWN / 2) * ob + t]), dvr[t], x3);
-                        }
-                    }
-                    cur[ob][2 * nbl] = pack2<T>(x3[0], x3[1]);
-                    cur[ob][2 * nbl + 1] = pack2<T>(x3[2], x3[3]);
-                }
-            }
-            // the output column block whose last K window is this pair: pairs (DOWN / 2) cb ... + NDVK - 1 = gi
-            if (gi >= G::NDVK - 1 && (gi - (G::NDVK - 1)) % (DOWN / 2) == 0) {
-                u32x4 xw[G::NOB][G::NDVK];
-#pragma unroll
-                for (int ob = 0; ob < G::NOB; ob++) {
-#pragma unroll
-                    for (int h = 0; h < G::NHIST; h++) xw[ob][h] = hist[ob][h];
-                    xw[ob][G::NDVK - 1] = cur[ob];
-                }
-                phase_b((gi - (G::NDVK - 1)) / (DOWN / 2), xw);
-            }
+        auto shift = [&]() __attribute__((always_inline)) {
 #pragma unroll
             for (int ob = 0; ob < G::NOB; ob++) {
 #pragma unroll
                 for (int h = 0; h + 1 < G::NHIST; h++) hist[ob][h] = hist[ob][h + 1];
                 hist[ob][G::NHIST - 1] = cur[ob];
             }
+        };
+        // forward: two input register sets, alternating over a loop unrolled by two (no copies); the transposed op carries more
+        // state per group (the sign dwords) and spills at two sets: one set + copies
+        constexpr bool PINGPONG = SIGN != AFCM_SIGNS_READ;
+        int gi = 0;
+        if (PINGPONG) {
+#pragma unroll 1
+            for (; gi + 1 < ng; gi += 2) {
+                group(gi, exact_c, lasty_c, a0, a1, sg, hist, cur, amax, anyc);
+                shift();
+                group(gi + 1, exact_c, lasty_c, a1, a0, sg, hist, cur, amax, anyc);
+                shift();
+            }
+            if (gi < ng) group(gi, exact_c, lasty_c, a0, a1, sg, hist, cur, amax, anyc);
+        } else {
+#pragma unroll 1
+            for (; gi < ng; gi++) {
+                group(gi, exact_c, lasty_c, a0, a1, sg, hist, cur, amax, anyc);
+                shift();
+#pragma unroll
+                for (int mb = 0; mb < G::NMB; mb++) a0[mb] = a1[mb];
+            }
         }
         if (SIGN == AFCM_SIGNS_READ) return __builtin_amdgcn_ballot_w64((anyc & 0xaaaaaaaau) != 0) != 0;   // a clamped element in reach
         return __builtin_amdgcn_ballot_w64(!(amax <= cthr1)) != 0;                                        // NaN takes the exact path
     };
-    if (__builtin_expect(run_tile(std::false_type{}), 0)) run_tile(std::true_type{});
+    // (READ never writes codes: one LASTY variant suffices)
+    if (SIGN == AFCM_SIGNS_WRITE && lastY) {
+        if (__builtin_expect(run_strip(std::false_type{}, std::true_type{}), 0)) run_strip(std::true_type{}, std::true_type{});
+    } else {
+        if (__builtin_expect(run_strip(std::false_type{}, std::false_type{}), 0)) run_strip(std::true_type{}, std::false_type{});
+    }
 
-    if (EPI && p.plane_sum != nullptr) {
+    if ((EPI & 1) && p.plane_sum != nullptr) {
         // one plain store into this tile's slot (no atomics: deterministic)
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) psum += __shfl_down(psum, off, 64);
@@ -602,9 +636,10 @@ int launch_wave_tile(const afcm_filtered_lrelu_args* a, FlreluMfmaParams p, hipS
     const long long tiles = (long long)p.tilesX * p.tilesY * a->n * a->c;
     p.total_tiles = (int)tiles;
     dim3 grid((unsigned)((tiles + 3) / 4)), block(256);
-    const bool epi = p.skip != nullptr || p.oscale != nullptr || p.oscale2 != nullptr || p.plane_sum != nullptr;
+    const bool epi = p.oscale != nullptr || p.oscale2 != nullptr || p.plane_sum != nullptr;
 #define AFCM_WAVE_LAUNCH(SIGN) do { \
-        if (epi) hipLaunchKernelGGL((flrelu_wave_kernel<T, UP, DOWN, TOW, TOH, SIGN, 1>), grid, block, 0, st, p); \
+        if (p.skip != nullptr) hipLaunchKernelGGL((flrelu_wave_kernel<T, UP, DOWN, TOW, TOH, SIGN, 3>), grid, block, 0, st, p); \
+        else if (epi) hipLaunchKernelGGL((flrelu_wave_kernel<T, UP, DOWN, TOW, TOH, SIGN, 1>), grid, block, 0, st, p); \
         else hipLaunchKernelGGL((flrelu_wave_kernel<T, UP, DOWN, TOW, TOH, SIGN, 0>), grid, block, 0, st, p); } while (0)
     switch (a->sign_mode) {
         case AFCM_SIGNS_NONE: AFCM_WAVE_LAUNCH(AFCM_SIGNS_NONE); break;
