@@ -192,6 +192,27 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
 
+    bucket_timeline = None
+    if use_dist and step.buckets is not None:
+        # one more (untimed) step with the bucket launches time-stamped on the GPU timeline: where in the backward pass each
+        # gradient bucket's all-reduce is issued (a one-rank run has no peer to exchange with; the N-rank runs overlap from here)
+        ev0, ev1, ev2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        step.buckets.trace = []
+        step.set_input(real_A, real_B, z, c)
+        step.optimizer_G.zero_grad(set_to_none=True)
+        step.forward(update_emas=False)
+        ev0.record()
+        step.backward_G()
+        ev1.record()
+        grads, scale = step.buckets.finish_flat()
+        step.optimizer_G.step(grads=grads, grad_scale=scale)
+        ev2.record()
+        torch.cuda.synchronize()
+        bwd_ms = ev0.elapsed_time(ev1)
+        bucket_timeline = dict(backward_ms=bwd_ms, optimizer_ms=ev1.elapsed_time(ev2),
+                               buckets=[dict(bucket=i, mbytes=round(nb / 1e6, 1), issued_at_ms=round(ev0.elapsed_time(e), 2),
+                                             backward_left_ms=round(bwd_ms - ev0.elapsed_time(e), 2)) for i, nb, e in step.buckets.trace])
+        step.buckets.trace = None
     if rank == 0:
         fams = profiling.summary()
         kernels = {}
@@ -244,6 +265,8 @@ def main():
             'kernels': kernels,
             'cpu_baseline': cpu,
         }
+        if bucket_timeline is not None:
+            out['bucket_timeline'] = bucket_timeline
         print(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()

@@ -226,3 +226,56 @@ def test_single_process_is_a_no_op():
     assert torch.equal(g, m[0].weight.grad)
     with b.no_sync():
         pass
+
+
+def _worker_rebucket(rank, world, port, out_dir):
+    _init(rank, world, port)
+    from afcm_amd.distributed import GradientBuckets
+    torch.manual_seed(0)
+    # `first` is registered LAST but runs FIRST in forward, so its gradient arrives last (the generator's mapping network)
+    body = torch.nn.Sequential(torch.nn.Linear(8, 8), torch.nn.Tanh(), torch.nn.Linear(8, 8), torch.nn.Tanh(), torch.nn.Linear(8, 4))
+    first = torch.nn.Linear(8, 8)
+    params = list(body.parameters()) + list(first.parameters())
+    buckets = GradientBuckets(params, bucket_bytes=1)                       # one parameter per bucket
+    fired, log = [0], []
+    on_grad, launch = buckets._on_grad, buckets._launch
+    for h in buckets._hooks:
+        h.remove()
+    def counting_on_grad(p):
+        fired[0] += 1
+        on_grad(p)
+    def logging_launch(b):
+        log.append(fired[0])
+        launch(b)
+    buckets._launch = logging_launch
+    buckets._hooks = [p.register_post_accumulate_grad_hook(counting_on_grad) for p in params]
+    x = torch.randn(4, 8)
+    per_iter = []
+    for it in range(3):
+        for p in params:
+            p.grad = None
+        fired[0] = 0
+        del log[:]
+        body(first(x)).square().mean().backward()
+        buckets.finish()
+        per_iter.append(list(log))
+    full = [p.grad.clone() for p in params]
+    torch.save(dict(per_iter=per_iter, n=len(params), grads=full), os.path.join(out_dir, f'r{rank}.pt'))
+    dist.destroy_process_group()
+
+
+def test_buckets_are_rebuilt_in_gradient_arrival_order(tmp_path):
+    """Collectives go out in bucket order, so a bucket that completes last must not come first.  Iteration 1 (reverse registration
+    order: the late `first` layer leads) can issue nothing before the end of backward; from iteration 2 on the buckets follow the
+    observed arrival order and each goes out as soon as its own gradient is final.  Gradients stay those of the plain model."""
+    world = 2
+    mp.spawn(_worker_rebucket, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r = torch.load(tmp_path / 'r0.pt')
+    n = r['n']
+    it1, it2, it3 = r['per_iter']
+    assert len(it1) == len(it2) == len(it3) == n
+    assert min(it1) >= n - 1                    # nothing before (almost) every gradient had arrived
+    assert it2 == list(range(1, n + 1)) == it3  # bucket k issued right after the k-th gradient
+    r1 = torch.load(tmp_path / 'r1.pt')
+    for a, b in zip(r['grads'], r1['grads']):
+        assert torch.equal(a, b)
