@@ -1496,7 +1496,12 @@ __device__ __forceinline__ void lds_dma_b128(i32x4 rsrc, unsigned voff, unsigned
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" : : "s"(lds_addr), "v"(voff), "s"(rsrc));
 }
 
-template <typename T, int KS, int NBUF>
+// SMALL (both tensors below 2^31 bytes): ONE buffer descriptor per tensor for the whole kernel; a piece's position is a 32-bit
+// offset added to the lane offsets and its validity (row outside the image, dead step) an OR mask on bit 31.  The general form
+// rebuilds a 128-bit descriptor per piece -- 64-bit base, exact record count, validity select, three v_readfirstlane --
+// ~45 scalar instructions per piece, 310 per K step of 36 MFMAs: the wave's own instruction stream, not the matrix pipe, set
+// the step time (PMC r01e: MFMA pipe 49 % busy, 8.7 SALU per MFMA).
+template <typename T, int KS, int NBUF, bool SMALL>
 __global__ __launch_bounds__(512, 1) void conv2d_wgrad16g_kernel(WgradParams p) {
     static_assert(sizeof(T) == 2, "16-bit types only");
     constexpr int R = 2, KK = KS * KS, XR = R + KS - 1;
@@ -1549,6 +1554,9 @@ __global__ __launch_bounds__(512, 1) void conv2d_wgrad16g_kernel(WgradParams p) 
     const int txr = lane >> 3, trow = 8 * wave + (lane & 7);                     // tail piece: lane = (xr, row), lanes >= 8 XR idle
     const unsigned lp_t = (i0 + trow < p.I) ? (unsigned)((trow * hw + txr * p.W + 64) * 2) : kOob;
     const long long dy_bytes = (long long)p.N * p.O * pq * 2, x_bytes = (long long)p.N * p.I * hw * 2;
+    // SMALL: the two descriptors of the kernel (records = the tensor's bytes: a granule straddling its end reads zeros there)
+    const i32x4 rs_dy = make_rsrc(p.dy, SMALL ? (int)dy_bytes : 0), rs_x = make_rsrc(p.x, SMALL ? (int)x_bytes : 0);
+    unsigned c_dy32 = 0, c_x32 = 0;                                              // byte offsets of (image n, channel o0 / i0)
 
     const int steps_per_img = p.rowgroups * p.qchunks;
     const int s0 = split * p.steps_per_split;
@@ -1574,6 +1582,10 @@ __global__ __launch_bounds__(512, 1) void conv2d_wgrad16g_kernel(WgradParams p) 
         v_t = lp_t | ((unsigned)!((unsigned)(xorg + 64) < (unsigned)p.W && (unsigned)(c_prow0 - p.pad + txr) < (unsigned)p.H) << 31);
         c_dyoff = (long long)ld_n * p.O * pq * 2;
         c_xoff = (long long)ld_n * p.I * hw * 2;
+        if (SMALL) {
+            c_dy32 = (unsigned)((ld_n * p.O + o0) * pq) * 2u;
+            c_x32 = (unsigned)((ld_n * p.I + i0) * hw) * 2u;
+        }
         if (live) {
             if (++ld_qc == p.qchunks) {
                 ld_qc = 0;
@@ -1589,7 +1601,28 @@ __global__ __launch_bounds__(512, 1) void conv2d_wgrad16g_kernel(WgradParams p) 
     };
     auto issue_piece = [&](auto idx) __attribute__((always_inline)) {
         constexpr int I = decltype(idx)::value;
-        if constexpr (I < R) {
+        if constexpr (SMALL) {
+            // offset of the piece (scalar) + lane offset; invalid lanes carry bit 31 in v_*, an invalid piece ORs it in for all
+            if constexpr (I < R) {
+                constexpr int rr = I;
+                const int row = c_prow0 + rr;
+                const unsigned soff = c_dy32 + (unsigned)(row * p.Q + c_q0) * 2u;
+                const unsigned sinv = (row < p.P && c_live) ? 0u : kOob;
+                lds_dma_b128(rs_dy, ((v_dy & ~kOob) + soff) | (v_dy & kOob) | sinv, lds0 + c_bufa + rr * (64 * ROWB) + wave * 1024);
+            } else if constexpr (I < R + XR) {
+                constexpr int xr = I - R;
+                const int row = c_prow0 - p.pad + xr;
+                const unsigned soff = c_x32 + (unsigned)(row * Ws + c_q0 - XLEAD) * 2u;
+                const unsigned sinv = ((unsigned)row < (unsigned)p.H && c_live) ? 0u : kOob;
+                lds_dma_b128(rs_x, ((v_x & ~kOob) + soff) | (v_x & kOob) | sinv, lds0 + c_bufa + DY_BYTES + xr * (64 * ROWB) + wave * 1024);
+            } else {
+                const int row = c_prow0 - p.pad;                                 // lanes add their xr
+                const unsigned soff = c_x32 + (unsigned)(row * Ws + c_q0 - XLEAD) * 2u;
+                const unsigned sinv = c_live ? 0u : kOob;
+                if (lane < 8 * XR)
+                    lds_dma_b128(rs_x, ((v_t & ~kOob) + soff) | (v_t & kOob) | sinv, lds0 + c_bufa + DY_BYTES + XMAIN + wave * (XR * 128));
+            }
+        } else if constexpr (I < R) {
             constexpr int rr = I;
             const int row = c_prow0 + rr;
             const long long off = c_dyoff + ((long long)o0 * pq + row * p.Q + c_q0) * 2;
@@ -2009,8 +2042,13 @@ extern "C" int afcm_conv2d_wgrad(float* dw, float* workspace, const void* dy, co
                            else if (ks == 3) hipLaunchKernelGGL((conv2d_wgrad16_kernel<T, 3, 1, NB>), grid, block, 0, st, p); \
                            else hipLaunchKernelGGL((conv2d_wgrad16_kernel<T, 1, 0, NB>), grid, block, 0, st, p); } while (0)
 #define AFCM_WG16G(T) do { constexpr int NB = 3; \
-                            if (ks == 3) hipLaunchKernelGGL((conv2d_wgrad16g_kernel<T, 3, NB>), grid, block, 0, st, p); \
-                            else hipLaunchKernelGGL((conv2d_wgrad16g_kernel<T, 1, NB>), grid, block, 0, st, p); } while (0)
+                            if (small && ks == 3) hipLaunchKernelGGL((conv2d_wgrad16g_kernel<T, 3, NB, true>), grid, block, 0, st, p); \
+                            else if (small) hipLaunchKernelGGL((conv2d_wgrad16g_kernel<T, 1, NB, true>), grid, block, 0, st, p); \
+                            else if (ks == 3) hipLaunchKernelGGL((conv2d_wgrad16g_kernel<T, 3, NB, false>), grid, block, 0, st, p); \
+                            else hipLaunchKernelGGL((conv2d_wgrad16g_kernel<T, 1, NB, false>), grid, block, 0, st, p); } while (0)
+    static const char* wdesc = getenv("AFCM_WGRAD_DESC");           // tuning aid: "piece" = a descriptor per LDS-DMA piece (the general form)
+    const bool small = !(wdesc && !strcmp(wdesc, "piece")) && (long long)n * cout * p.P * p.Q * 2 < (1ll << 31) - 65536 &&
+                       (long long)n * cin * h * w * 2 < (1ll << 31) - 65536;
     const char* wsel = getenv("AFCM_WGRAD_KERNEL");                 // tuning aid: "regs" (register-staged) or "dword" (4-byte LDS-DMA)
     const bool legacy = wsel && !strcmp(wsel, "regs");
     const bool granule = !(wsel && !strcmp(wsel, "dword")) && ((ks == 3 && pad == 2) || (ks == 1 && pad == 0));
