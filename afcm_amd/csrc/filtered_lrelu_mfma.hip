@@ -620,8 +620,15 @@ static bool wave_family(const afcm_filtered_lrelu_args* a) {
     return a->b == nullptr && (long long)a->xh * a->xw < (1ll << 28) && (long long)a->yh * a->yw < (1ll << 28);
 }
 
+// Output rows per strip of the wave kernels: 32; one 48-row strip for the 36^2 / 38^2 planes (up 2 / down 2).  (Measured and
+// dropped: 16-row strips for down 4, whose 32-row strips need 240-250 registers = two waves per SIMD: at 16 rows a strip still
+// needs 176-199 and computes 1.5x instead of 1.25x its own rows -- forward 1.63 vs 1.89 TB/s over the down-4 layers.)
+static int wave_toh(int up, int down, int yh) {
+    return (up == 2 && down == 2 && yh > 32 && yh <= kTallTOH) ? kTallTOH : 32;
+}
+
 static bool tall_tile(int up, int down, int yh, int sign_mode, bool wave) {
-    if (wave) return up == 2 && down == 2 && yh > 32 && yh <= kTallTOH;    // one 48-row tile for the 36^2 / 38^2 planes
+    if (wave) return wave_toh(up, down, yh) == kTallTOH;
     static const char* force = getenv("AFCM_FLRELU_TALL");      // tuning aid: 0 = never, 1 = rules below (default), 2 = 33..48-row planes only
     const int mode = force ? atoi(force) : 1;
     (void)down;
@@ -645,16 +652,12 @@ static void launch_one(const FlreluMfmaParams& p, bool bias, dim3 grid, dim3 blo
     else hipLaunchKernelGGL((flrelu_mfma_kernel<T, UP, DOWN, TOW, TOH, SIGN, false>), grid, block, 0, st, p);
 }
 
-template <typename T, int UP, int DOWN, int TOW, int TOH>
-static int launch_mfma_tile(const afcm_filtered_lrelu_args* a, hipStream_t st) {
-    typedef MfmaGeom<UP, DOWN, TOW, TOH> G;
-    FlreluMfmaParams p;
+static int fill_params(const afcm_filtered_lrelu_args* a, FlreluMfmaParams& p, int tilesX, int tilesY) {
     p.x = a->x; p.y = a->y; p.b = a->b; p.s = a->signs; p.ws = a->workspace; p.plane_sum = a->plane_sum;
     p.oscale = a->oscale; p.oscale2 = a->oscale2; p.skip = a->skip;
     p.xw = a->xw; p.xh = a->xh; p.yw = a->yw; p.yh = a->yh; p.C = a->c;
     p.px0 = a->px0; p.py0 = a->py0;
-    const bool wave = wave_family(a);
-    p.tilesX = wave ? 1 : cdiv(a->yw, TOW); p.tilesY = cdiv(a->yh, TOH);      // wave kernels: one strip spans the plane's width
+    p.tilesX = tilesX; p.tilesY = tilesY;
     p.slope = a->slope; p.clamp = a->clamp;
     p.sx = a->sx; p.sy = a->sy; p.shq = a->sh; p.swq = a->swb;
     const long long blocks = (long long)p.tilesX * p.tilesY * a->n * a->c;
@@ -665,11 +668,17 @@ static int launch_mfma_tile(const afcm_filtered_lrelu_args* a, hipStream_t st) {
     p.magicT = p.tilesX == 1 ? 0u : (unsigned)(((1ull << 32) + p.tilesX - 1) / p.tilesX);
     p.magicP = tpp == 1 ? 0u : (unsigned)(((1ull << 32) + tpp - 1) / tpp);
     AFCM_REQUIRE((long long)a->xh * a->xw < (1ll << 30), "filtered_lrelu: plane of %d x %d elements is out of range", a->xh, a->xw);
-    if constexpr (!(DOWN == 4 && TOH == kTallTOH)) if (wave) {      // (the wave family has no tall down-4 tile: tall_tile())
-        AFCM_REQUIRE(a->b == nullptr, "filtered_lrelu: sign layout 2 (wave kernels) takes no bias operand");
-        return launch_wave_tile<T, UP, DOWN, TOW, TOH>(a, p, st);
-    }
-    dim3 grid((unsigned)blocks), block(64 * G::NG);
+    p.total_tiles = (int)blocks;
+    return AFCM_OK;
+}
+
+template <typename T, int UP, int DOWN, int TOW, int TOH>
+static int launch_mfma_tile(const afcm_filtered_lrelu_args* a, hipStream_t st) {
+    typedef MfmaGeom<UP, DOWN, TOW, TOH> G;
+    FlreluMfmaParams p;
+    const int rc = fill_params(a, p, cdiv(a->yw, TOW), cdiv(a->yh, TOH));
+    if (rc != AFCM_OK) return rc;
+    dim3 grid((unsigned)p.total_tiles), block(64 * G::NG);
     const bool bias = a->b != nullptr;
     switch (a->sign_mode) {
         case AFCM_SIGNS_NONE: launch_one<T, UP, DOWN, TOW, TOH, AFCM_SIGNS_NONE>(p, bias, grid, block, st); break;
@@ -679,11 +688,26 @@ static int launch_mfma_tile(const afcm_filtered_lrelu_args* a, hipStream_t st) {
     return hip_status(hipGetLastError());
 }
 
+// wave kernels: one strip of wave_toh() output rows spans the plane's width
+template <typename T, int UP, int DOWN>
+static int launch_wave(const afcm_filtered_lrelu_args* a, hipStream_t st) {
+    AFCM_REQUIRE(a->b == nullptr, "filtered_lrelu: sign layout 2 (wave kernels) takes no bias operand");
+    const int toh = wave_toh(UP, DOWN, a->yh);
+    FlreluMfmaParams p;
+    const int rc = fill_params(a, p, 1, cdiv(a->yh, toh));
+    if (rc != AFCM_OK) return rc;
+    if constexpr (UP == 2 && DOWN == 2) {
+        if (toh == kTallTOH) return launch_wave_tile<T, 2, 2, 64, kTallTOH>(a, p, st);
+    }
+    return launch_wave_tile<T, UP, DOWN, MfmaTile<UP, DOWN>::TOW, 32>(a, p, st);
+}
+
 template <typename T, int UP, int DOWN>
 static int launch_mfma(const afcm_filtered_lrelu_args* a, hipStream_t st) {
     constexpr int TOW = MfmaTile<UP, DOWN>::TOW, TOH = MfmaTile<UP, DOWN>::TOH;
+    if (wave_family(a)) return launch_wave<T, UP, DOWN>(a, st);
     if constexpr (UP == 2) {
-        if (tall_tile(UP, DOWN, a->yh, a->sign_mode, wave_family(a))) return launch_mfma_tile<T, UP, DOWN, TOW, kTallTOH>(a, st);
+        if (tall_tile(UP, DOWN, a->yh, a->sign_mode, false)) return launch_mfma_tile<T, UP, DOWN, TOW, kTallTOH>(a, st);
     }
     return launch_mfma_tile<T, UP, DOWN, TOW, TOH>(a, st);
 }
@@ -718,9 +742,9 @@ int flrelu_mfma_sign_layout(const afcm_filtered_lrelu_args* a) { return wave_fam
 
 int flrelu_mfma_tiles(const afcm_filtered_lrelu_args* a) {
     switch (mfma_case(a)) {
-        case 22: return (wave_family(a) ? 1 : cdiv(a->yw, MfmaTile<2, 2>::TOW)) * cdiv(a->yh, tall_tile(2, 2, a->yh, a->sign_mode, wave_family(a)) ? kTallTOH : MfmaTile<2, 2>::TOH);
-        case 24: return (wave_family(a) ? 1 : cdiv(a->yw, MfmaTile<2, 4>::TOW)) * cdiv(a->yh, tall_tile(2, 4, a->yh, a->sign_mode, wave_family(a)) ? kTallTOH : MfmaTile<2, 4>::TOH);
-        case 42: return (wave_family(a) ? 1 : cdiv(a->yw, MfmaTile<4, 2>::TOW)) * cdiv(a->yh, MfmaTile<4, 2>::TOH);
+        case 22: return wave_family(a) ? cdiv(a->yh, wave_toh(2, 2, a->yh)) : cdiv(a->yw, MfmaTile<2, 2>::TOW) * cdiv(a->yh, tall_tile(2, 2, a->yh, a->sign_mode, false) ? kTallTOH : MfmaTile<2, 2>::TOH);
+        case 24: return wave_family(a) ? cdiv(a->yh, wave_toh(2, 4, a->yh)) : cdiv(a->yw, MfmaTile<2, 4>::TOW) * cdiv(a->yh, tall_tile(2, 4, a->yh, a->sign_mode, false) ? kTallTOH : MfmaTile<2, 4>::TOH);
+        case 42: return wave_family(a) ? cdiv(a->yh, wave_toh(4, 2, a->yh)) : cdiv(a->yw, MfmaTile<4, 2>::TOW) * cdiv(a->yh, MfmaTile<4, 2>::TOH);
         default: return 0;
     }
 }

@@ -36,6 +36,10 @@
 #ifndef AFCM_WAVE_STORE_AUX
 #define AFCM_WAVE_STORE_AUX 2
 #endif
+// ... of the input loads
+#ifndef AFCM_WAVE_LOAD_AUX
+#define AFCM_WAVE_LOAD_AUX 0
+#endif
 // ... of the sign-code loads of the transposed op (read once)
 #ifndef AFCM_WAVE_SIGNLOAD_AUX
 #define AFCM_WAVE_SIGNLOAD_AUX 0
@@ -237,7 +241,7 @@ __global__ __launch_bounds__(256, (DOWN == 2 ? AFCM_WAVE_OCC_D2 : AFCM_WAVE_OCC_
 #pragma unroll
             for (int mb = 0; mb < G::NMB; mb++) {
                 union { u32x4 u; frag f; } r;
-                r.u = __builtin_amdgcn_raw_buffer_load_b128(rsx, (unsigned)(xoff0 + 2 * G::IWSTEP * gi + mb * xrow16), 0, 0);
+                r.u = __builtin_amdgcn_raw_buffer_load_b128(rsx, (unsigned)(xoff0 + 2 * G::IWSTEP * gi + mb * xrow16), 0, AFCM_WAVE_LOAD_AUX);
 #pragma unroll
                 for (int w = 0; w < 4; w++) r.u[w] = (unsigned)__builtin_amdgcn_ds_bpermute(to_frag, (int)r.u[w]);
                 a[mb] = r.f;
@@ -633,8 +637,7 @@ __global__ __launch_bounds__(256, (DOWN == 2 ? AFCM_WAVE_OCC_D2 : AFCM_WAVE_OCC_
 // ---------------------------------------------------------------------------------------------
 template <typename T, int UP, int DOWN, int TOW, int TOH>
 int launch_wave_tile(const afcm_filtered_lrelu_args* a, FlreluMfmaParams p, hipStream_t st) {
-    const long long tiles = (long long)p.tilesX * p.tilesY * a->n * a->c;
-    p.total_tiles = (int)tiles;
+    const long long tiles = p.total_tiles;
     dim3 grid((unsigned)((tiles + 3) / 4)), block(256);
     const bool epi = p.oscale != nullptr || p.oscale2 != nullptr || p.plane_sum != nullptr;
 #define AFCM_WAVE_LAUNCH(SIGN) do { \
