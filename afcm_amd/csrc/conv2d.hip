@@ -1986,7 +1986,7 @@ extern "C" int afcm_conv2d(void* y, const void* x, const void* wpacked, const fl
     p.nkc = cdiv(cin, afcm_conv2d_block_k(dtype));
     hipStream_t st = (hipStream_t)stream;
     // 64-row blocks when they waste fewer padded rows than 128-row blocks
-    const char* force = getenv("AFCM_CONV_BM");   // tuning aid: force the 64- or 128-row block
+    static const char* force = getenv("AFCM_CONV_BM");   // tuning aid: force the 64- or 128-row block
     const bool small = force ? (atoi(force) == 64) : ((rows_pad % 128 != 0) || cout <= 64);
     switch (dtype) {
         case AFCM_F32: return small ? launch_conv<float, 64>(p, ks, st) : launch_conv<float, 128>(p, ks, st);
@@ -2004,7 +2004,7 @@ extern "C" int afcm_conv2d_wgrad_splits(int32_t n, int32_t cout, int32_t cin, in
     // One workgroup per CU is resident (LDS ring), so aim for ONE full round of the 256 CUs and never one workgroup more:
     // rounding up (258 workgroups = two rounds) halves the throughput, and every extra split costs a 36 x 64 x 64 x 4 B
     // partial tile written and read back (at 768 workgroups the partials of a 64 -> 64 layer were 2/3 of its time).
-    const char* tgt = getenv("AFCM_WGRAD_WGS");            // tuning aid: workgroups to aim for
+    static const char* tgt = getenv("AFCM_WGRAD_WGS");            // tuning aid: workgroups to aim for
     int splits = (tgt ? atoi(tgt) : 256) / tiles;
     const long long ksteps = (long long)n * p_rows;   // upper bound on the macro-steps of any dtype
     if (splits > ksteps) splits = (int)ksteps;
@@ -2049,7 +2049,7 @@ extern "C" int afcm_conv2d_wgrad(float* dw, float* workspace, const void* dy, co
     static const char* wdesc = getenv("AFCM_WGRAD_DESC");           // tuning aid: "piece" = a descriptor per LDS-DMA piece (the general form)
     const bool small = !(wdesc && !strcmp(wdesc, "piece")) && (long long)n * cout * p.P * p.Q * 2 < (1ll << 31) - 65536 &&
                        (long long)n * cin * h * w * 2 < (1ll << 31) - 65536;
-    const char* wsel = getenv("AFCM_WGRAD_KERNEL");                 // tuning aid: "regs" (register-staged) or "dword" (4-byte LDS-DMA)
+    static const char* wsel = getenv("AFCM_WGRAD_KERNEL");                 // tuning aid: "regs" (register-staged) or "dword" (4-byte LDS-DMA)
     const bool legacy = wsel && !strcmp(wsel, "regs");
     const bool granule = !(wsel && !strcmp(wsel, "dword")) && ((ks == 3 && pad == 2) || (ks == 1 && pad == 0));
     switch (dtype) {

@@ -15,7 +15,8 @@ an object exposing the SAME functions with the SAME argument lists, each impleme
 Error convention as in the reference: argument errors raise RuntimeError; "no fused kernel for this configuration" is not an
 error but return_code = -1 with empty tensors (filtered_lrelu.cpp:52-56), on which the wrapper takes its generic path.
 The sign tensor is opaque to the wrappers (they only hand ``so`` back as ``si`` with shifted sx / sy): its byte layout is this
-library's, not the CUDA plugin's.
+library's, not the CUDA plugin's -- fp32 calls produce the reference's row-major packing as a 4-D tensor; 16-bit calls run the
+matrix-core kernels, whose private layout is tagged by trailing unit dimensions (see filtered_lrelu below).
 """
 import torch
 
@@ -43,19 +44,32 @@ class _FilteredLReluPlugin:
             gain, fu = gain * float(fu.reshape(-1)[0]), None
         if fd.numel() == 1:
             gain, fd = gain * float(fd.reshape(-1)[0]), None
-        # The plugin interface has no slot for this library's per-layer workspace or sign-layout tag, so the plugin surface
-        # always runs the exact kernel family (all dtypes; one sign layout).  The matrix-core family for 16-bit activations is
-        # reached through afcm_amd.torch_utils.ops.filtered_lrelu, which owns both.
+        # 16-bit activations take the matrix-core kernels here as they do through afcm_amd.torch_utils.ops.filtered_lrelu.  The
+        # plugin interface has no slot for the two things those need, so the shim carries them itself: the per-layer workspace of
+        # constant fragments comes from the wrapper's cache (keyed by the filters' addresses and the configuration), and the sign
+        # layout a WRITE call produced is tagged on the returned tensor as trailing unit dimensions (ndim - 4 = layout: 0 the
+        # reference's row-major packing, 1 / 2 the matrix-core kernels' private ones).  The reference wrappers never look inside
+        # ``so`` -- they save it and hand it back as ``si`` (SG3OPS/filtered_lrelu.py:222,258) -- so the tag survives the trip.
+        layout = 0
+        if si is not None:
+            layout = si.ndim - 4
+            if layout not in (0, 1, 2) or any(d != 1 for d in si.shape[4:]):
+                raise RuntimeError('signs tensor was not produced by this plugin')
+            si = si.reshape(si.shape[:4])
         cfg = (int(up), int(down), int(px0), int(px1), int(py0), int(py1), float(gain), float(slope), float(clamp), bool(flip_filter),
-               int(sx), int(sy), 0)
+               int(sx), int(sy), layout)
         try:
-            y, so, _, _ = _flr._run(x, fu, fd, b, si, cfg, bool(writeSigns), allow_mfma=False, no_fallback=True)
+            y, so, layout, _ = _flr._run(x, fu, fd, b, si, cfg, bool(writeSigns), allow_mfma=True, no_fallback=True)
         except _flr.NoFusedKernel:
             return torch.empty([0], dtype=x.dtype, device=x.device), empty, -1
+        if so is not None and layout:
+            so = so.reshape(list(so.shape) + [1] * layout)
         return y, (so if so is not None else empty), 0
 
     @staticmethod
     def filtered_lrelu_act_(x, si, sx, sy, gain, slope, clamp, writeSigns):
+        if si is not None and si.numel() and si.ndim != 4:
+            raise RuntimeError('signs tensor was written by the matrix-core kernels: the unfused activation reads the row-major packing only')
         so = _flr._act_inplace(x, _none_if_empty(si), int(sx), int(sy), float(gain), float(slope), float(clamp), bool(writeSigns))
         return so if so is not None else torch.empty([0], dtype=torch.uint8, device=x.device)
 

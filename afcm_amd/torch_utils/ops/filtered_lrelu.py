@@ -10,6 +10,7 @@ and the backward pass is the same op with up/down and the filters swapped, readi
 other tap counts) take the generic path upfirdn2d -> in-place activation kernel -> upfirdn2d, also on
 the GPU (SG3OPS/filtered_lrelu.py:223-229) -- never a CPU path.
 """
+import collections
 import warnings
 
 import numpy as np
@@ -74,7 +75,11 @@ def _act_inplace(y, si, sx, sy, gain, slope, clamp, write_signs):
     return so
 
 
-_workspaces = {}   # layer configuration -> prepared constant-fragment buffer (or None: no matrix-core kernel)
+# layer configuration -> prepared constant-fragment buffer (or None: no matrix-core kernel).  Bounded, least recently used out
+# first: an entry pins its 18 KB workspace and its two filter tensors, and a program that keeps building filters (a sweep, a
+# long-lived server) must not grow it without limit.  A network holds ~30 distinct configurations (forward + transposed).
+_workspaces = collections.OrderedDict()
+_WORKSPACE_CACHE_ENTRIES = 512
 
 
 def _mfma_workspace(a, fu_t, fd_t, x):
@@ -92,6 +97,10 @@ def _mfma_workspace(a, fu_t, fd_t, x):
         rc = _lib.check(lib.afcm_filtered_lrelu_prepare(a, _lib.stream_ptr(x)), 'filtered_lrelu_prepare')
         # keep the filters alive with the workspace: the key holds their addresses
         _workspaces[key] = (ws, fu_t, fd_t) if rc == 0 else None
+        while len(_workspaces) > _WORKSPACE_CACHE_ENTRIES:
+            _workspaces.popitem(last=False)       # the caching allocator keeps the block until queued kernels have run
+    else:
+        _workspaces.move_to_end(key)
     ent = _workspaces[key]
     return None if ent is None else ent[0]
 

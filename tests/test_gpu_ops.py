@@ -412,6 +412,49 @@ def test_plugin_surface_runs_the_reference_wrapper_call_sequence(name):
     _close(dx, g['dx'], what=name + ' dx (plugin)')
 
 
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('name', ['F1_up2_down2', 'F2_up2_down4', 'F3_up4_down2'])
+def test_plugin_surface_reaches_the_matrix_core_kernels_for_16bit(name, dtype):
+    """a maintainer who swaps only custom_ops.py gets the matrix-core kernels for 16-bit activations.  The
+    shim finds the per-layer workspace itself and tags the private sign layout on ``so`` (trailing unit dimensions), which the
+    reference wrapper hands back untouched for the transposed call.  y and dx vs the CPU oracle on the same 16-bit-rounded
+    inputs, at 16-bit tolerance."""
+    from afcm_amd.torch_utils import custom_ops
+    from oracle import aten_ops as ops
+    plugin = custom_ops.get_plugin(module_name='filtered_lrelu_plugin', sources=[], headers=[], source_dir='.')
+    g = load_golden(name)
+    kw = _flrelu_args(g)
+    up, down, (px0, px1, py0, py1) = kw['up'], kw['down'], kw['padding']
+    gain, slope, flip = kw['gain'], kw['slope'], kw['flip_filter']
+    clamp = float('inf') if kw['clamp'] is None else kw['clamp']
+    fu, fd = _dev(g['fu']), _dev(g['fd'])
+    x, r = _dev(g['x']).to(dtype), _dev(g['r']).to(dtype)
+    b = (_dev(g['b']) if 'b' in g else torch.zeros(x.shape[1], device='cuda')).to(dtype)
+    empty = torch.empty([0], dtype=torch.uint8, device='cuda')
+    y, so, rc = plugin.filtered_lrelu(x, fu, fd, b, empty, up, down, px0, px1, py0, py1, 0, 0, gain, slope, clamp, flip, True)
+    assert rc == 0 and so.dtype == torch.uint8
+    assert so.ndim in (5, 6), 'a 16-bit call through the plugin must run the matrix-core family (tagged sign layout)'
+    xs = x.float().cpu().requires_grad_(True)
+    ref = ops.filtered_lrelu(xs, fu=torch.from_numpy(g['fu']), fd=torch.from_numpy(g['fd']), b=b.float().cpu(), **kw)
+    gref, = torch.autograd.grad(ref, xs, r.float().cpu())
+    ref = ref.detach()
+    tol = 3e-2 if dtype == torch.bfloat16 else 4e-3
+    assert (y.float().cpu() - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
+    fuw, fdw = fu.shape[-1], fd.shape[-1]
+    fuh, fdh = (fu.shape[0], fd.shape[0]) if fu.ndim == 2 else (fuw, fdw)
+    pp = [(fuw - 1) + (fdw - 1) - px0, x.shape[3] * up - y.shape[3] * down + px0 - (up - 1),
+          (fuh - 1) + (fdh - 1) - py0, x.shape[2] * up - y.shape[2] * down + py0 - (up - 1)]
+    sx, sy = 0 - (fuw - 1) + px0, 0 - (fuh - 1) + py0
+    dx, so2, rc = plugin.filtered_lrelu(r.contiguous(), fd, fu, torch.zeros_like(b), so, down, up, *pp, sx, sy, gain * (up ** 2) / (down ** 2),
+                                        slope, float('inf'), not flip, False)
+    assert rc == 0 and so2.numel() == 0
+    rel = ((dx.float().cpu() - gref).norm() / gref.norm()).item()         # 16-bit rounding flips branches near 0: L2, as above
+    assert rel <= (8e-2 if dtype == torch.bfloat16 else 2e-2), rel
+    # the unfused activation reads the reference's row-major packing only: a tagged tensor is refused, not misread
+    with pytest.raises(RuntimeError):
+        plugin.filtered_lrelu_act_(dx.clone(), so, 0, 0, 1.0, slope, float('inf'), False)
+
+
 def test_plugin_surface_upfirdn2d_bias_act_and_error_convention():
     from afcm_amd.torch_utils import custom_ops
     from afcm_amd.torch_utils.ops.bias_act import activation_funcs
