@@ -29,6 +29,7 @@ class FilteredLReluArgs(C.Structure):
         ('flip_filter', C.c_int32), ('sign_mode', C.c_int32),
         ('workspace', C.c_void_p), ('sign_layout', C.c_int32), ('plane_sum_slots', C.c_int32),
         ('plane_sum', C.c_void_p), ('oscale', C.c_void_p), ('skip', C.c_void_p), ('oscale2', C.c_void_p),
+        ('x_pitch', C.c_int32), ('y_pitch', C.c_int32), ('skip_pitch', C.c_int32), ('row_pitch_ok', C.c_int32),
     ]
 
 
@@ -52,10 +53,13 @@ SIGNATURES = {
     'afcm_conv2d_pack_weights': (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     'afcm_conv2d_pack_weights2': (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     'afcm_conv2d': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    'afcm_conv2d_ld': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     'afcm_conv2d_wgrad_splits': (C.c_int, [_i32, _i32, _i32, _i32]),
     'afcm_conv2d_wgrad': (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    'afcm_conv2d_wgrad_ld': (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     'afcm_scale_planes': (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i64, _i32, _vp]),
     'afcm_plane_dot': (C.c_int, [_vp, _vp, _vp, _i32, _i64, _i32, _vp]),
+    'afcm_plane_dot_ld': (C.c_int, [_vp, _vp, _vp, _i32, _i64, _i32, _i32, _i32, _i32, _vp]),
     'afcm_weight_norm_fwd': (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     'afcm_weight_norm_bwd': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     'afcm_style_coefs_fwd': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
@@ -79,8 +83,8 @@ def load():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
-        if lib.afcm_abi_version() != 7:
-            raise RuntimeError(f'libafcm_hip.so ABI version {lib.afcm_abi_version()} does not match this package (7); rebuild it')
+        if lib.afcm_abi_version() != 8:
+            raise RuntimeError(f'libafcm_hip.so ABI version {lib.afcm_abi_version()} does not match this package (8); rebuild it')
         _lib = lib
     return _lib
 

@@ -55,6 +55,7 @@ struct ConvParams {
     const float* oscale;  // [N * Cout] or null
     const float* obias;   // [Cout] or null: y = acc * oscale + obias
     int N, Cin, Cout, H, W, P, Q;
+    int ldx, ldy;         // row pitch (elements) of x / y; = W / Q for dense tensors.  conv2d_fwd16_kernel only.
     int pad;
     int TH, TW, PWL, tilesX, tilesY;
     int Opad, nkc;
@@ -401,17 +402,17 @@ __global__ __launch_bounds__(256, 2) void conv2d_fwd16_kernel(ConvParams p) {
     const bool pvalid = prow < PH;
     const int iy = y0 - p.pad + prow, ix = xorg + 4 * pcol4;
     const bool rowok = pvalid && (unsigned)iy < (unsigned)p.H;
-    const T* xn = (const T*)p.x + (size_t)n * p.Cin * p.H * p.W;
-    const long long pix_off = (long long)(rowok ? iy : 0) * p.W + ix;
+    const T* xn = (const T*)p.x + (size_t)n * p.Cin * p.H * p.ldx;
+    const long long pix_off = (long long)(rowok ? iy : 0) * p.ldx + ix;
     const int pdst = (prow * PWL + 4 * pcol4) * PITCH + cg * 8;
     constexpr unsigned kOob = 0x80000000u;
     const bool d0ok = rowok && (unsigned)ix < (unsigned)p.W, d1ok = rowok && (unsigned)(ix + 2) < (unsigned)p.W;
     const unsigned pmask0 = d0ok ? ~0u : 0u, pmask1 = d1ok ? ~0u : 0u;
     const bool lshift = !d0ok && d1ok;                                                // never touch bytes before a row 0
-    const unsigned pvoff = (d0ok || d1ok) ? (unsigned)(((long long)cg * 8 * p.H * p.W + pix_off + (lshift ? 2 : 0)) * 2ll) : kOob;
-    const long long img_bytes = (long long)p.Cin * p.H * p.W * 2ll;
+    const unsigned pvoff = (d0ok || d1ok) ? (unsigned)(((long long)cg * 8 * p.H * p.ldx + pix_off + (lshift ? 2 : 0)) * 2ll) : kOob;
+    const long long img_bytes = (long long)p.Cin * p.H * p.ldx * 2ll;
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)xn, 0, (int)(img_bytes > 0x7fffffffll ? 0x7fffffffll : img_bytes), 0x00020000);
-    const int hw2 = p.H * p.W * 2;
+    const int hw2 = p.H * p.ldx * 2;
 
     unsigned preg[8][2];
     // Channels past Cin exist only in the last chunk of a layer whose Cin is not a multiple of 16; the chunk's channel offset
@@ -544,9 +545,9 @@ __global__ __launch_bounds__(256, 2) void conv2d_fwd16_kernel(ConvParams p) {
         typedef __attribute__((ext_vector_type(4))) short s16x4;
         constexpr int EROW = 64;
         unsigned char* ebuf = (unsigned char*)lds + wave * (128 * EROW);
-        T* yn = (T*)p.y + (size_t)n * p.Cout * p.P * p.Q;
+        T* yn = (T*)p.y + (size_t)n * p.Cout * p.P * p.ldy;
         const float* osn = p.oscale ? p.oscale + (size_t)n * p.Cout : nullptr;
-        const int pq = p.P * p.Q;
+        const int pq = p.P * p.ldy;
         // read side: lane = (half hh: granule parity, chalf: channel half, i16: channel / address role inside the 16-lane group)
         const int i16 = lane & 15, chalf = (lane >> 4) & 1, hh = lane >> 5;
         const int q4 = i16 >> 2, p4 = i16 & 3;
@@ -565,9 +566,9 @@ __global__ __launch_bounds__(256, 2) void conv2d_fwd16_kernel(ConvParams p) {
             const int j0 = wpx * 128 + (2 * it + hh) * 8;
             const int gpy = (int)__umulhi((unsigned)j0, p.magicTW), gpx = j0 - gpy * p.TW;
             const int gy = y0 + gpy, gx = x0 + gpx;
-            goff[it] = (j0 < p.TH * p.TW && gy < p.P && gx < p.Q) ? gy * p.Q + gx : -1;
+            goff[it] = (j0 < p.TH * p.TW && gy < p.P && gx < p.Q) ? gy * p.ldy + gx : -1;
             gxv[it] = gx;
-            if (gx + 8 <= p.Q) gfullm |= 1u << it;
+            if (gx + 8 <= p.ldy) gfullm |= 1u << it;         // a pitched row has room for the whole granule (columns >= Q: padding)
         }
         const int wr_pix = r32;                                    // + 32 ti
 #pragma unroll
@@ -620,14 +621,14 @@ __global__ __launch_bounds__(256, 2) void conv2d_fwd16_kernel(ConvParams p) {
         }
         return;
     }
-    T* yn = (T*)p.y + (size_t)n * p.Cout * p.P * p.Q;
+    T* yn = (T*)p.y + (size_t)n * p.Cout * p.P * p.ldy;
     // per output-row block: all per-channel scales and biases first (clamped index, no branch around the loads: one wait
     // instead of a round trip per row), then the stores
     int poff[4];                                     // pixel offset inside a plane, -1: not stored
 #pragma unroll
-    for (int ti = 0; ti < 4; ti++) poff[ti] = (pyv[ti] < p.P && pxv[ti] < p.Q) ? pyv[ti] * p.Q + pxv[ti] : -1;
+    for (int ti = 0; ti < 4; ti++) poff[ti] = (pyv[ti] < p.P && pxv[ti] < p.Q) ? pyv[ti] * p.ldy + pxv[ti] : -1;
     const float* osn = p.oscale ? p.oscale + (size_t)n * p.Cout : nullptr;
-    const int pq = p.P * p.Q;
+    const int pq = p.P * p.ldy;
 #pragma unroll
     for (int mi = 0; mi < MI; mi++) {
         float sc[16], ob[16];
@@ -927,11 +928,67 @@ __global__ __launch_bounds__(256) void plane_dot_wave_kernel(float* __restrict__
 // a workspace [split][O][I][KK] and are summed by wgrad_reduce_kernel.
 constexpr int kWgKQ = 64;        // pixels of one output row per K macro-step
 
+// Row-pitched operands (planes [h][ld], the first w columns of a row meaningful -- the 16-bit activation layout of DESIGN.md
+// section 3): 16-byte vectors within a row; the last vector of a row is shifted back to END at column w (no access past the row,
+// the re-read elements are selected out), so nothing depends on what the padding holds.  PER_WAVE: one wave per plane, four
+// planes per workgroup (small planes, as plane_dot_wave_kernel).  Needs w >= 16 / sizeof(T).
+template <typename T, bool PER_WAVE>
+__global__ __launch_bounds__(256) void plane_dot_rows_kernel(float* __restrict__ out, const T* __restrict__ a, const T* __restrict__ b,
+                                                             long long planes, int h, int w, int lda, int ldb) {
+    constexpr int E = 16 / (int)sizeof(T);
+    union V16 { uint4 u; T v[E]; };
+    __shared__ float part[4];
+    const int nthr = PER_WAVE ? 64 : 256;
+    const int t = PER_WAVE ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
+    const long long plane = PER_WAVE ? (long long)blockIdx.x * 4 + (threadIdx.x >> 6) : (long long)blockIdx.x;
+    if (plane >= planes) return;                               // PER_WAVE: a whole wave leaves (no barrier below in that mode)
+    const int nvec = (w + E - 1) / E, total = h * nvec;
+    const unsigned magic = (unsigned)((0x100000000ull + (unsigned)nvec - 1) / (unsigned)nvec);
+    const T* ap = a + plane * h * lda;
+    const T* bp = b ? b + plane * h * ldb : nullptr;
+    float s0 = 0.f, s1 = 0.f;
+    for (int i0 = t; i0 < total; i0 += 4 * nthr) {
+        V16 av[4], bv[4];
+        int skip[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int i = i0 + u * nthr;
+            const int ic = i < total ? i : total - 1;
+            const int row = (int)__umulhi((unsigned)ic, magic), col = (ic - row * nvec) * E;
+            const int colc = col + E <= w ? col : w - E;
+            skip[u] = i < total ? col - colc : E;              // leading elements that an earlier vector already counted (E: none live)
+            av[u].u = *(const uint4*)(ap + (size_t)row * lda + colc);
+            if (bp) bv[u].u = *(const uint4*)(bp + (size_t)row * ldb + colc);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                const float x = e >= skip[u] ? to_f32(av[u].v[e]) : 0.f;
+                const float y = bp ? to_f32(bv[u].v[e]) : 1.f;
+                if (u & 1) s1 = fmaf(x, e >= skip[u] ? y : 0.f, s1); else s0 = fmaf(x, e >= skip[u] ? y : 0.f, s0);
+            }
+        }
+    }
+    float s = s0 + s1;
+#pragma unroll
+    for (int off2 = 32; off2 > 0; off2 >>= 1) s += __shfl_down(s, off2, 64);
+    if (PER_WAVE) {
+        if ((threadIdx.x & 63) == 0) out[plane] = s;
+    } else {
+        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) out[plane] = part[0] + part[1] + part[2] + part[3];
+    }
+}
+
+
 struct WgradParams {
     const void* dy;   // [N, O, P, Q]
     const void* x;    // [N, I, H, W]
     float* part;      // [splits][O][I][KK]
     int N, O, I, H, W, P, Q, pad;
+    int lddy, ldx;                // row pitch (elements) of dy / x; = Q / W for dense tensors.  conv2d_wgrad16g_kernel only.
     int splits, steps_per_split;  // K macro-steps = N * rowgroups * qchunks
     int qchunks;                  // ceil(Q / kWgKQ)
     int rowgroups;                // ceil(P / R)
@@ -1545,14 +1602,14 @@ __global__ __launch_bounds__(512, 1) void conv2d_wgrad16g_kernel(WgradParams p) 
     // ---- load maps.  Wave w stages rows (channels) 8w..8w+7 of both operands: lane = (row, slot) of an 8-row piece.
     const int prow = 8 * wave + (lane >> 3), pslot = lane & 7;
     const int pg = pslot ^ ((prow >> 1) & 7);                                    // logical granule that lives in this slot
-    const int pq = p.P * p.Q, hw = p.H * p.W;
+    const int pq = p.P * p.lddy, hw = p.H * p.ldx;                                // plane strides (rows by pitch)
     // p.W also feeds per-lane offsets, so the compiler keeps it in a VGPR and then evaluates the (uniform) row addresses of the
     // x pieces on the vector pipe; an explicit scalar copy keeps them on the SALU
-    const int Ws = __builtin_amdgcn_readfirstlane(p.W);
+    const int Ws = __builtin_amdgcn_readfirstlane(p.ldx), Qs = __builtin_amdgcn_readfirstlane(p.lddy);
     const unsigned lp_dy = (o0 + prow < p.O) ? (unsigned)(prow * pq * 2 + pg * 16) : kOob;
     const unsigned lp_x = (i0 + prow < p.I) ? (unsigned)(prow * hw * 2 + pg * 16) : kOob;
     const int txr = lane >> 3, trow = 8 * wave + (lane & 7);                     // tail piece: lane = (xr, row), lanes >= 8 XR idle
-    const unsigned lp_t = (i0 + trow < p.I) ? (unsigned)((trow * hw + txr * p.W + 64) * 2) : kOob;
+    const unsigned lp_t = (i0 + trow < p.I) ? (unsigned)((trow * hw + txr * p.ldx + 64) * 2) : kOob;
     const long long dy_bytes = (long long)p.N * p.O * pq * 2, x_bytes = (long long)p.N * p.I * hw * 2;
     // SMALL: the two descriptors of the kernel (records = the tensor's bytes: a granule straddling its end reads zeros there)
     const i32x4 rs_dy = make_rsrc(p.dy, SMALL ? (int)dy_bytes : 0), rs_x = make_rsrc(p.x, SMALL ? (int)x_bytes : 0);
@@ -1606,7 +1663,7 @@ __global__ __launch_bounds__(512, 1) void conv2d_wgrad16g_kernel(WgradParams p) 
             if constexpr (I < R) {
                 constexpr int rr = I;
                 const int row = c_prow0 + rr;
-                const unsigned soff = c_dy32 + (unsigned)(row * p.Q + c_q0) * 2u;
+                const unsigned soff = c_dy32 + (unsigned)(row * Qs + c_q0) * 2u;
                 const unsigned sinv = (row < p.P && c_live) ? 0u : kOob;
                 lds_dma_b128(rs_dy, ((v_dy & ~kOob) + soff) | (v_dy & kOob) | sinv, lds0 + c_bufa + rr * (64 * ROWB) + wave * 1024);
             } else if constexpr (I < R + XR) {
@@ -1625,7 +1682,7 @@ __global__ __launch_bounds__(512, 1) void conv2d_wgrad16g_kernel(WgradParams p) 
         } else if constexpr (I < R) {
             constexpr int rr = I;
             const int row = c_prow0 + rr;
-            const long long off = c_dyoff + ((long long)o0 * pq + row * p.Q + c_q0) * 2;
+            const long long off = c_dyoff + ((long long)o0 * pq + row * Qs + c_q0) * 2;
             lds_dma_b128(make_rsrc((const char*)p.dy + off, records(dy_bytes - off, row < p.P)), v_dy,
                          lds0 + c_bufa + rr * (64 * ROWB) + wave * 1024);
         } else if constexpr (I < R + XR) {
@@ -1966,6 +2023,12 @@ extern "C" int afcm_conv2d_pack_weights(void* dst, const float* w, int32_t dtype
 
 extern "C" int afcm_conv2d(void* y, const void* x, const void* wpacked, const float* oscale, const float* obias, int32_t dtype, int32_t n,
                            int32_t cin, int32_t cout, int32_t h, int32_t w, int32_t ks, int32_t pad, int32_t rows_pad, void* stream) {
+    return afcm_conv2d_ld(y, x, wpacked, oscale, obias, dtype, n, cin, cout, h, w, ks, pad, rows_pad, 0, 0, stream);
+}
+
+extern "C" int afcm_conv2d_ld(void* y, const void* x, const void* wpacked, const float* oscale, const float* obias, int32_t dtype, int32_t n,
+                              int32_t cin, int32_t cout, int32_t h, int32_t w, int32_t ks, int32_t pad, int32_t rows_pad, int32_t x_pitch,
+                              int32_t y_pitch, void* stream) {
     AFCM_REQUIRE(y != nullptr && x != nullptr && wpacked != nullptr, "conv2d: null pointer");
     AFCM_REQUIRE(dtype == AFCM_F32 || dtype == AFCM_F16 || dtype == AFCM_BF16, "x must be float32, float16 or bfloat16");
     AFCM_REQUIRE(n > 0 && cin > 0 && cout > 0 && h > 0 && w > 0, "x is empty");
@@ -1979,6 +2042,13 @@ extern "C" int afcm_conv2d(void* y, const void* x, const void* wpacked, const fl
     p.P = h + 2 * pad - ks + 1; p.Q = w + 2 * pad - ks + 1;
     AFCM_REQUIRE(p.P >= 1 && p.Q >= 1, "output must be at least 1x1");
     p.pad = pad;
+    p.ldx = x_pitch ? x_pitch : w; p.ldy = y_pitch ? y_pitch : p.Q;
+    if (p.ldx != w || p.ldy != p.Q) {
+        static const bool legacy16 = getenv("AFCM_CONV_LEGACY") != nullptr;
+        AFCM_REQUIRE(dtype != AFCM_F32 && ks == 3 && !legacy16, "conv2d: row pitches need the 16-bit 3x3 kernel");
+        AFCM_REQUIRE(p.ldx >= w && p.ldy >= p.Q && ((p.ldx | p.ldy) & 1) == 0, "conv2d: row pitches %d / %d must be even and cover the widths %d / %d", p.ldx, p.ldy, w, p.Q);
+        AFCM_REQUIRE((long long)cout * p.P * p.ldy < (1ll << 30), "conv2d: pitched output image is out of range");
+    }
     choose_tile(p.P, p.Q, ks, &p.TH, &p.TW, &p.PWL);
     p.tilesX = cdiv(p.Q, p.TW); p.tilesY = cdiv(p.P, p.TH);
     p.magicTW = (unsigned)((0x100000000ull + (unsigned)p.TW - 1) / (unsigned)p.TW);
@@ -2014,6 +2084,11 @@ extern "C" int afcm_conv2d_wgrad_splits(int32_t n, int32_t cout, int32_t cin, in
 
 extern "C" int afcm_conv2d_wgrad(float* dw, float* workspace, const void* dy, const void* x, int32_t dtype, int32_t n, int32_t cin,
                                  int32_t cout, int32_t h, int32_t w, int32_t ks, int32_t pad, void* stream) {
+    return afcm_conv2d_wgrad_ld(dw, workspace, dy, x, dtype, n, cin, cout, h, w, ks, pad, 0, 0, stream);
+}
+
+extern "C" int afcm_conv2d_wgrad_ld(float* dw, float* workspace, const void* dy, const void* x, int32_t dtype, int32_t n, int32_t cin,
+                                    int32_t cout, int32_t h, int32_t w, int32_t ks, int32_t pad, int32_t dy_pitch, int32_t x_pitch, void* stream) {
     AFCM_REQUIRE(dw != nullptr && workspace != nullptr && dy != nullptr && x != nullptr, "conv2d_wgrad: null pointer");
     AFCM_REQUIRE(dtype == AFCM_F32 || dtype == AFCM_F16 || dtype == AFCM_BF16, "x must be float32, float16 or bfloat16");
     AFCM_REQUIRE(ks == 1 || ks == 3, "only 1x1 and 3x3 kernels are supported");
@@ -2024,6 +2099,9 @@ extern "C" int afcm_conv2d_wgrad(float* dw, float* workspace, const void* dy, co
     p.P = h + 2 * pad - ks + 1; p.Q = w + 2 * pad - ks + 1;
     AFCM_REQUIRE(p.P >= 1 && p.Q >= 1, "output must be at least 1x1");
     AFCM_REQUIRE(dtype == AFCM_F32 || (w % 2 == 0 && p.Q % 2 == 0), "16-bit conv2d_wgrad needs even widths (got %d, %d)", w, p.Q);
+    p.lddy = dy_pitch ? dy_pitch : p.Q; p.ldx = x_pitch ? x_pitch : w;
+    const bool pitched = p.lddy != p.Q || p.ldx != w;
+    AFCM_REQUIRE(!pitched || (p.lddy >= p.Q && p.ldx >= w && ((p.lddy | p.ldx) & 1) == 0), "conv2d_wgrad: row pitches %d / %d must be even and cover the widths %d / %d", p.lddy, p.ldx, p.Q, w);
     const int R = wgrad_rows_per_step(dtype);
     p.qchunks = cdiv(p.Q, kWgKQ);
     p.rowgroups = cdiv(p.P, R);
@@ -2047,11 +2125,13 @@ extern "C" int afcm_conv2d_wgrad(float* dw, float* workspace, const void* dy, co
                             else if (ks == 3) hipLaunchKernelGGL((conv2d_wgrad16g_kernel<T, 3, NB, false>), grid, block, 0, st, p); \
                             else hipLaunchKernelGGL((conv2d_wgrad16g_kernel<T, 1, NB, false>), grid, block, 0, st, p); } while (0)
     static const char* wdesc = getenv("AFCM_WGRAD_DESC");           // tuning aid: "piece" = a descriptor per LDS-DMA piece (the general form)
-    const bool small = !(wdesc && !strcmp(wdesc, "piece")) && (long long)n * cout * p.P * p.Q * 2 < (1ll << 31) - 65536 &&
-                       (long long)n * cin * h * w * 2 < (1ll << 31) - 65536;
+    const bool small = !(wdesc && !strcmp(wdesc, "piece")) && (long long)n * cout * p.P * p.lddy * 2 < (1ll << 31) - 65536 &&
+                       (long long)n * cin * h * p.ldx * 2 < (1ll << 31) - 65536;
     static const char* wsel = getenv("AFCM_WGRAD_KERNEL");                 // tuning aid: "regs" (register-staged) or "dword" (4-byte LDS-DMA)
     const bool legacy = wsel && !strcmp(wsel, "regs");
     const bool granule = !(wsel && !strcmp(wsel, "dword")) && ((ks == 3 && pad == 2) || (ks == 1 && pad == 0));
+    // rows by pitch: the 16-byte LDS-DMA kernel only (a granule straddling x's right edge is zeroed in LDS whatever follows it)
+    AFCM_REQUIRE(!pitched || (dtype != AFCM_F32 && granule && !legacy), "conv2d_wgrad: row pitches need the 16-bit granule kernel (3x3 pad 2 or 1x1 pad 0)");
     switch (dtype) {
         case AFCM_F32: AFCM_WG(float, 1); break;
         case AFCM_F16: if (legacy) AFCM_WG(f16_t, 2); else if (granule) AFCM_WG16G(f16_t); else AFCM_WG16(f16_t); break;
@@ -2116,5 +2196,31 @@ extern "C" int afcm_plane_dot(float* out, const void* a, const void* b, int32_t 
         default: set_error("plane_dot: bad dtype"); return AFCM_E_INVALID;
     }
 #undef AFCM_PD
+    return hip_status(hipGetLastError());
+}
+
+extern "C" int afcm_plane_dot_ld(float* out, const void* a, const void* b, int32_t dtype, int64_t planes, int32_t h, int32_t w,
+                                 int32_t a_pitch, int32_t b_pitch, void* stream) {
+    AFCM_REQUIRE(out != nullptr && a != nullptr && planes > 0 && h > 0 && w > 0, "plane_dot: empty input");
+    AFCM_REQUIRE(planes < (1ll << 31), "plane_dot: too many planes");
+    const int esize = dtype == AFCM_F32 ? 4 : 2;
+    const int lda = a_pitch ? a_pitch : w, ldb = b_pitch ? b_pitch : w;
+    AFCM_REQUIRE(lda >= w && ldb >= w, "plane_dot: row pitches %d / %d are below the width %d", lda, ldb, w);
+    AFCM_REQUIRE(w >= 16 / esize, "plane_dot: rows of %d elements are shorter than one 16-byte vector", w);
+    AFCM_REQUIRE((((uintptr_t)a | (uintptr_t)b) & 3) == 0 && (esize == 4 || ((w | lda | ldb) & 1) == 0), "plane_dot: rows must start on 4-byte boundaries");
+    AFCM_REQUIRE((long long)h * (lda > ldb ? lda : ldb) < (1ll << 31) / 16, "plane_dot: plane is out of range");
+    hipStream_t st = (hipStream_t)stream;
+    const bool per_wave = (long long)h * w * esize <= 16384;
+    dim3 grid((unsigned)(per_wave ? (planes + 3) / 4 : planes)), block(256);
+#define AFCM_PDR(T) do { \
+        if (per_wave) hipLaunchKernelGGL((plane_dot_rows_kernel<T, true>), grid, block, 0, st, out, (const T*)a, (const T*)b, (long long)planes, h, w, lda, ldb); \
+        else hipLaunchKernelGGL((plane_dot_rows_kernel<T, false>), grid, block, 0, st, out, (const T*)a, (const T*)b, (long long)planes, h, w, lda, ldb); } while (0)
+    switch (dtype) {
+        case AFCM_F32: AFCM_PDR(float); break;
+        case AFCM_F16: AFCM_PDR(f16_t); break;
+        case AFCM_BF16: AFCM_PDR(bf16_t); break;
+        default: set_error("plane_dot: bad dtype"); return AFCM_E_INVALID;
+    }
+#undef AFCM_PDR
     return hip_status(hipGetLastError());
 }

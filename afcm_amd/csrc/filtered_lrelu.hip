@@ -490,6 +490,7 @@ static int dispatch(const afcm_filtered_lrelu_args* a, const FlreluParams& p, hi
 int flrelu_mfma_supported(const afcm_filtered_lrelu_args* a);
 int flrelu_mfma_tiles(const afcm_filtered_lrelu_args* a);
 int flrelu_mfma_sign_layout(const afcm_filtered_lrelu_args* a);
+int flrelu_mfma_row_pitch_ok(const afcm_filtered_lrelu_args* a);
 int flrelu_mfma_launch(const afcm_filtered_lrelu_args* a, bool prepare, hipStream_t st);
 
 }  // namespace afcm
@@ -511,6 +512,7 @@ extern "C" int afcm_filtered_lrelu_shapes(afcm_filtered_lrelu_args* a) {
     a->yw = (int)yw;
     a->yh = (int)yh;
     a->plane_sum_slots = (a->workspace != nullptr && flrelu_mfma_supported(a)) ? flrelu_mfma_tiles(a) : 0;
+    a->row_pitch_ok = (a->workspace != nullptr && flrelu_mfma_row_pitch_ok(a)) ? 1 : 0;
     if (a->sign_mode == AFCM_SIGNS_WRITE) {
         const long long sw_active = yw * a->down - (a->down - 1) + fdt_w;
         const long long sh = yh * a->down - (a->down - 1) + fdt_h;
@@ -547,6 +549,13 @@ extern "C" int afcm_filtered_lrelu(const afcm_filtered_lrelu_args* a, void* stre
     }
     hipStream_t st = (hipStream_t)stream;
     const bool mfma = a->workspace != nullptr && flrelu_mfma_supported(a);
+    if ((a->x_pitch && a->x_pitch != a->xw) || (a->y_pitch && a->y_pitch != a->yw) || (a->skip_pitch && a->skip_pitch != a->yw)) {
+        AFCM_REQUIRE(chk.row_pitch_ok, "filtered_lrelu: the kernel selected for this call takes dense tensors only (row pitches %d / %d / %d)", a->x_pitch, a->y_pitch, a->skip_pitch);
+        AFCM_REQUIRE(a->x_pitch == 0 || a->x_pitch >= a->xw, "x_pitch %d is below the width %d", a->x_pitch, a->xw);
+        AFCM_REQUIRE(a->y_pitch == 0 || (a->y_pitch >= a->yw && a->y_pitch % 8 == 0), "y_pitch %d must cover the width %d in whole 16-byte pieces", a->y_pitch, a->yw);
+        AFCM_REQUIRE(a->skip_pitch == 0 || a->skip_pitch >= a->yw, "skip_pitch %d is below the width %d", a->skip_pitch, a->yw);
+        AFCM_REQUIRE(((a->x_pitch | a->y_pitch | a->skip_pitch) & 1) == 0, "row pitches must be even");
+    }
     AFCM_REQUIRE(mfma || (a->oscale == nullptr && a->oscale2 == nullptr && a->skip == nullptr), "filtered_lrelu: oscale / skip need the matrix-core kernels (16-bit dtype, prepared workspace)");
     if (a->sign_mode == AFCM_SIGNS_READ)
         AFCM_REQUIRE((a->sign_layout != 0) == mfma, "sign tensor layout %d does not match the kernel family selected for this call", a->sign_layout);

@@ -617,7 +617,8 @@ static bool wave_family(const afcm_filtered_lrelu_args* a) {
     if (e != nullptr && atoi(e) == 0) return false;
     if (a->sign_mode == AFCM_SIGNS_READ) return a->sign_layout == 2;
     // no bias operand; offsets + out-of-range markers stay below 2^31
-    return a->b == nullptr && (long long)a->xh * a->xw < (1ll << 28) && (long long)a->yh * a->yw < (1ll << 28);
+    return a->b == nullptr && (long long)a->xh * (a->x_pitch ? a->x_pitch : a->xw) < (1ll << 28) &&
+           (long long)a->yh * (a->y_pitch ? a->y_pitch : a->yw) < (1ll << 28);
 }
 
 // Output rows per strip of the wave kernels: 32; one 48-row strip for the 36^2 / 38^2 planes (up 2 / down 2).  (Measured and
@@ -656,6 +657,7 @@ static int fill_params(const afcm_filtered_lrelu_args* a, FlreluMfmaParams& p, i
     p.x = a->x; p.y = a->y; p.b = a->b; p.s = a->signs; p.ws = a->workspace; p.plane_sum = a->plane_sum;
     p.oscale = a->oscale; p.oscale2 = a->oscale2; p.skip = a->skip;
     p.xw = a->xw; p.xh = a->xh; p.yw = a->yw; p.yh = a->yh; p.C = a->c;
+    p.xld = a->x_pitch ? a->x_pitch : a->xw; p.yld = a->y_pitch ? a->y_pitch : a->yw; p.kld = a->skip_pitch ? a->skip_pitch : a->yw;
     p.px0 = a->px0; p.py0 = a->py0;
     p.tilesX = tilesX; p.tilesY = tilesY;
     p.slope = a->slope; p.clamp = a->clamp;
@@ -667,7 +669,7 @@ static int fill_params(const afcm_filtered_lrelu_args* a, FlreluMfmaParams& p, i
     AFCM_REQUIRE(blocks * tpp < (1ll << 32), "filtered_lrelu: grid of %lld blocks x %lld tiles per plane is out of range", blocks, tpp);
     p.magicT = p.tilesX == 1 ? 0u : (unsigned)(((1ull << 32) + p.tilesX - 1) / p.tilesX);
     p.magicP = tpp == 1 ? 0u : (unsigned)(((1ull << 32) + tpp - 1) / tpp);
-    AFCM_REQUIRE((long long)a->xh * a->xw < (1ll << 30), "filtered_lrelu: plane of %d x %d elements is out of range", a->xh, a->xw);
+    AFCM_REQUIRE((long long)a->xh * p.xld < (1ll << 30), "filtered_lrelu: plane of %d x %d elements is out of range", a->xh, p.xld);
     p.total_tiles = (int)blocks;
     return AFCM_OK;
 }
@@ -739,6 +741,9 @@ int flrelu_mfma_supported(const afcm_filtered_lrelu_args* a) { return mfma_case(
 
 // sign layout a WRITE call of this configuration produces (1: row-quad bytes, 2: column-blocked row-quad bytes)
 int flrelu_mfma_sign_layout(const afcm_filtered_lrelu_args* a) { return wave_family(a) ? 2 : 1; }
+
+// row pitches (x_pitch / y_pitch / skip_pitch): the wave kernels address rows by pitch, the LDS-tile kernels take dense tensors
+int flrelu_mfma_row_pitch_ok(const afcm_filtered_lrelu_args* a) { return mfma_case(a) != 0 && wave_family(a); }
 
 int flrelu_mfma_tiles(const afcm_filtered_lrelu_args* a) {
     switch (mfma_case(a)) {

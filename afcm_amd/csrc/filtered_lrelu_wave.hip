@@ -218,11 +218,11 @@ __global__ __launch_bounds__(256, (DOWN == 2 ? AFCM_WAVE_OCC_D2 : AFCM_WAVE_OCC_
     const float cthr1 = p.clamp / (fmaxf(p.slope, 1.f) * ((const float*)((const char*)p.ws + kWsScalars))[0]);
 
     // ---- input: rows [I0y, +16 NMB) x columns [S0x + IWSTEP gi, +32) per group, straight into A fragments
-    const T* xp = (const T*)p.x + (size_t)plane * p.xh * p.xw;
+    const T* xp = (const T*)p.x + (size_t)plane * p.xh * p.xld;
 #ifdef AFCM_WAVE_EXPERIMENT_NOLOAD    // timing experiment only: every input load falls outside the descriptor
     const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)xp, 0, 0, 0x00020000);
 #else
-    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)xp, 0, p.xh * p.xw * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)xp, 0, p.xh * p.xld * 2, 0x00020000);
 #endif
     // Lane map of the global accesses: an MFMA fragment puts 16 different ROWS on consecutive lanes (lane = 16 g + l15), which the
     // memory pipeline sees as 64 separate 16-byte requests per instruction (measured: the two output stores of a group cost more
@@ -232,8 +232,8 @@ __global__ __launch_bounds__(256, (DOWN == 2 ? AFCM_WAVE_OCC_D2 : AFCM_WAVE_OCC_
     const int to_frag = (4 * l15 + g) * 4;                                // fragment lane (g, l15) reads from access lane 4 l15 + g
     // byte offset of (row I0y + lrow, column S0x + 8 lchk); rows above the plane give a negative offset = beyond the descriptor's
     // range as an unsigned number, rows below it exceed the record count: both read as zero without a predicate
-    const int xoff0 = ((I0y + lrow) * p.xw + S0x + 8 * lchk) * 2;
-    const int xrow16 = 32 * p.xw;                                         // 16 rows, bytes
+    const int xoff0 = ((I0y + lrow) * p.xld + S0x + 8 * lchk) * 2;
+    const int xrow16 = 32 * p.xld;                                         // 16 rows, bytes
     constexpr unsigned kOut = 0x40000000u;                               // out-of-range marker (planes stay below 2^29 bytes)
     auto load_group = [&](int gi, frag (&a)[G::NMB]) __attribute__((always_inline)) {
         const int c0 = S0x + G::IWSTEP * gi;                              // wave-uniform
@@ -313,22 +313,27 @@ __global__ __launch_bounds__(256, (DOWN == 2 ? AFCM_WAVE_OCC_D2 : AFCM_WAVE_OCC_
     };
 
     // ---- output
-    T* const yp = (T*)p.y + (size_t)plane * p.yh * p.yw;
+    T* const yp = (T*)p.y + (size_t)plane * p.yh * p.yld;
 #ifdef AFCM_WAVE_EXPERIMENT_NOSTORE   // timing experiment only: every output store falls outside the descriptor
     const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc((void*)yp, 0, 0, 0x00020000);
 #else
-    const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc((void*)yp, 0, p.yh * p.yw * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc((void*)yp, 0, p.yh * p.yld * 2, 0x00020000);
 #endif
     const bool has_skip = (EPI & 2) && p.skip != nullptr;
     const __amdgpu_buffer_rsrc_t rsk = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(has_skip ? (const T*)p.skip + (size_t)plane * p.yh * p.yw : (const T*)p.x), 0, has_skip ? p.yh * p.yw * 2 : 0, 0x00020000);
+        (void*)(has_skip ? (const T*)p.skip + (size_t)plane * p.yh * p.kld : (const T*)p.x), 0, has_skip ? p.yh * p.kld * 2 : 0, 0x00020000);
     // skip operand: byte offset of (row O0y + lrow, column 4 lchk) (access lane map); rows below the plane exceed the record count
     // and read as zero, columns right of it are selected out per output column block
-    const int koff0 = ((O0y + lrow) * p.yw + 4 * lchk) * 2;
-    const int yrow16 = 32 * p.yw;
+    const int koff0 = ((O0y + lrow) * p.kld + 4 * lchk) * 2;
+    const int krow16 = 32 * p.kld;
     const float osc = (EPI & 1) ? (p.oscale ? p.oscale[plane] : 1.f) * (p.oscale2 ? p.oscale2[plane] : 1.f) : 1.f;
     float psum = 0.f;
     unsigned char* const stage = lds_o[wave];
+    if (p.yld != p.yw) {
+        // a pitched y is written in whole lines up to the pitch: column blocks the strip never produces (past the last started
+        // one) must not carry whatever the LDS held -- the padding's contract is "finite" (include/afcm_hip.h)
+        for (int i = lane * 16; i < TOH * OPITCH; i += 64 * 16) *(uint4*)(stage + i) = make_uint4(0u, 0u, 0u, 0u);
+    }
     const unsigned st_w = (unsigned)(l15 * OPITCH + g * 8);                // fragment lane (g, l15): 4 columns of row l15 (+ 16 ob rows, + 32 B per column block)
     const unsigned st_r = (unsigned)((lane >> 3) * OPITCH + (lane & 7) * 16);   // flush lane: 8 columns (16 B) of row lane / 8 (+ 8 rows per instruction)
     const int fl_row = lane >> 3, fl_chk = lane & 7;
@@ -348,7 +353,7 @@ __global__ __launch_bounds__(256, (DOWN == 2 ? AFCM_WAVE_OCC_D2 : AFCM_WAVE_OCC_
                 // encoder feature of this lane's 4 columns (x + x_skip, NET:376-377), fetched in the access lane map (columns /
                 // rows outside the plane read as zero), moved to the fragment map
                 const int ox = 16 * cb + 4 * lchk;
-                const unsigned off = (unsigned)(koff0 + ob * yrow16 + 32 * cb);
+                const unsigned off = (unsigned)(koff0 + ob * krow16 + 32 * cb);
                 union { unsigned u; T t[2]; } e0, e1;
                 e0.u = __builtin_amdgcn_raw_buffer_load_b32(rsk, (ox + 2 <= p.yw) ? off : kOut, 0, 0);
                 e1.u = __builtin_amdgcn_raw_buffer_load_b32(rsk, (ox + 4 <= p.yw) ? off + 4u : kOut, 0, 0);
@@ -377,17 +382,24 @@ __global__ __launch_bounds__(256, (DOWN == 2 ? AFCM_WAVE_OCC_D2 : AFCM_WAVE_OCC_
         // flush after every fourth column block (and after the last one): 8 rows x 128 bytes per store instruction
         if (slot == 3 || cb == ncb - 1) {
             const int c0 = 64 * (cb >> 2) + 8 * fl_chk;                                         // this lane's first output column
-            const bool full = 64 * (cb >> 2) + 64 <= p.yw;                                      // wave-uniform: the whole 64-column group is inside
-            const unsigned gofs = (unsigned)(((O0y + fl_row) * p.yw + c0) * 2);
+            // wave-uniform: the whole 64-column group lies inside the row (a pitched y: inside the pitch -- its rows start on 128-byte
+            // lines and EVERY flush is whole lines; columns >= yw are padding and receive whatever the staging buffer holds: finite
+            // values, products of in-range data and zeros)
+            const bool full = 64 * (cb >> 2) + 64 <= p.yld;
+            const unsigned gofs = (unsigned)(((O0y + fl_row) * p.yld + c0) * 2);
 #pragma unroll
             for (int j = 0; j < TOH / 8; j++) {
                 const u32x4 v = *(const u32x4*)(stage + st_r + (unsigned)(j * 8 * OPITCH));
-                unsigned off = gofs + (unsigned)(j * 16 * p.yw);
+                unsigned off = gofs + (unsigned)(j * 16 * p.yld);
 #ifdef AFCM_WAVE_EXPERIMENT_STORE_ALIAS  // timing experiment only: all output stores land in one 64 KB window (no HBM write traffic)
                 off &= 0xfff0u;
 #endif
                 if (full) {
                     __builtin_amdgcn_raw_buffer_store_b128(v, rsy, off, 0, AFCM_WAVE_STORE_AUX);
+                } else if (p.yld != p.yw) {
+                    // pitched rows end on a 16-byte boundary: the lanes whose 8 columns lie inside the pitch store, the others fall
+                    // outside the descriptor
+                    __builtin_amdgcn_raw_buffer_store_b128(v, rsy, (c0 + 8 <= p.yld) ? off : kOut, 0, AFCM_WAVE_STORE_AUX);
                 } else {
                     // the group crosses the right edge (or is only partly produced): pair by pair (even plane widths)
 #pragma unroll

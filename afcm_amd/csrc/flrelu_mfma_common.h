@@ -26,6 +26,7 @@ struct FlreluMfmaParams {
     const float* oscale2;  // optional second factor (multiplied)
     const void* skip;      // optional [N*C][yh][yw]: added to the output before the factor
     int xw, xh, yw, yh, C;
+    int xld, yld, kld;     // row pitch (elements) of x, y, skip: wave kernels only (the LDS-tile kernels take dense tensors)
     int px0, py0;
     int tilesX, tilesY;
     unsigned magicT, magicP;   // ceil(2^32 / tilesX), ceil(2^32 / (tilesX * tilesY)): block id -> (plane, tile) on the scalar unit

@@ -13,6 +13,7 @@ import torch
 
 from ... import _lib
 from ... import profiling
+from . import _rows
 
 
 def _pad64(n):
@@ -57,6 +58,11 @@ def scale_planes(x, scale, out_dtype=None):
     """y[n, c] = x[n, c] * scale[n, c] (scale None: cast only)."""
     lib = _lib.load()
     out_dtype = out_dtype or x.dtype
+    full = _rows.whole_buffer(x) if out_dtype == x.dtype else None
+    if full is not None:
+        # a row-pitched x: one pass over its whole buffer (the padding rides along: elementwise, nothing depends on it), y comes
+        # back with the same pitch
+        return scale_planes(full, scale, out_dtype)[..., :x.shape[3]]
     x = x.contiguous()
     y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
     n, c, h, w = x.shape
@@ -69,8 +75,19 @@ def scale_planes(x, scale, out_dtype=None):
 
 
 def plane_dot(a, b=None):
-    """[N, C] fp32: sum over H, W of a * b (b None: plain sum)."""
+    """[N, C] fp32: sum over H, W of a * b (b None: plain sum).  Row-pitched operands (_rows.py) are read in place."""
     lib = _lib.load()
+    if not (a.is_contiguous() and (b is None or b.is_contiguous())) and a.shape[3] * a.element_size() >= 16:
+        a, lda = _rows.rows(a)
+        ldb = 0
+        if b is not None:
+            assert b.shape == a.shape and b.dtype == a.dtype
+            b, ldb = _rows.rows(b)
+        n, c, h, w = a.shape
+        out = torch.empty([n, c], dtype=torch.float32, device=a.device)
+        _lib.check(lib.afcm_plane_dot_ld(out.data_ptr(), a.data_ptr(), _lib.ptr(b), _lib.dtype_code(a), n * c, h, w, lda, ldb, _lib.stream_ptr(a)),
+                   'plane_dot')
+        return out
     a = a.contiguous()
     if a.data_ptr() % 16:                 # a view at an odd storage offset: the kernel wants 16-byte aligned bases
         a = a.clone()
@@ -86,19 +103,37 @@ def plane_dot(a, b=None):
     return out
 
 
-def _conv_raw(x, wp, rows_pad, oscale, cout, ks, pad, obias=None):
+def _pitch_conv(dtype, ks):
+    """Does the conv kernel for this case address rows by pitch?  (The 16-bit 3x3 kernel; C ABI afcm_conv2d_ld.)"""
+    return dtype in (torch.bfloat16, torch.float16) and ks == 3
+
+
+def _pitch_wgrad(dtype, ks, pad):
+    """The 16-byte LDS-DMA weight-gradient kernel (C ABI afcm_conv2d_wgrad_ld)."""
+    return dtype in (torch.bfloat16, torch.float16) and ((ks == 3 and pad == 2) or (ks == 1 and pad == 0))
+
+
+def _conv_raw(x, wp, rows_pad, oscale, cout, ks, pad, obias=None, pitched_out=False):
+    """x dense or row-pitched (_rows.py; kernels without pitch support get a contiguous copy); ``pitched_out``: y row-pitched
+    where the kernel can write one."""
     lib = _lib.load()
     n, cin, h, w = x.shape
     p, q = h + 2 * pad - ks + 1, w + 2 * pad - ks + 1
-    y = torch.empty([n, cout, p, q], dtype=x.dtype, device=x.device)
+    if _pitch_conv(x.dtype, ks):
+        x, xld = _rows.rows(x)
+        y = _rows.empty([n, cout, p, q], x.dtype, x.device, pitched=pitched_out)
+    else:
+        x, xld = _rows.dense(x), w
+        y = torch.empty([n, cout, p, q], dtype=x.dtype, device=x.device)
+    yld = q if y.is_contiguous() else y.stride(2)
     if oscale is not None:
         oscale = oscale.to(torch.float32).contiguous()
     span = profiling.span('conv2d', 2.0 * n * cout * cin * ks * ks * p * q)
     if obias is not None:
         obias = obias.to(torch.float32).contiguous()
         assert obias.numel() == cout
-    _lib.check(lib.afcm_conv2d(y.data_ptr(), x.data_ptr(), wp.data_ptr(), _lib.ptr(oscale), _lib.ptr(obias), _lib.dtype_code(x), n, cin, cout, h, w,
-                               ks, pad, rows_pad, _lib.stream_ptr(x)), 'conv2d')
+    _lib.check(lib.afcm_conv2d_ld(y.data_ptr(), x.data_ptr(), wp.data_ptr(), _lib.ptr(oscale), _lib.ptr(obias), _lib.dtype_code(x), n, cin, cout, h, w,
+                                  ks, pad, rows_pad, 0 if xld == w else xld, 0 if yld == q else yld, _lib.stream_ptr(x)), 'conv2d')
     if span is not None:
         span.end()
     return y
@@ -108,12 +143,16 @@ def _wgrad_raw(dy, x, cout, cin, ks, pad):
     lib = _lib.load()
     n, _, h, w = x.shape
     p = h + 2 * pad - ks + 1
+    if _pitch_wgrad(x.dtype, ks, pad):
+        (dy, lddy), (x, ldx) = _rows.rows(dy), _rows.rows(x)
+    else:
+        (dy, lddy), (x, ldx) = (_rows.dense(dy), dy.shape[3]), (_rows.dense(x), w)
     splits = lib.afcm_conv2d_wgrad_splits(n, cout, cin, p)
     dw = torch.empty([cout, cin, ks, ks], dtype=torch.float32, device=x.device)
     ws = torch.empty([splits, cout, cin, ks, ks], dtype=torch.float32, device=x.device)
     span = profiling.span('conv2d_wgrad', 2.0 * n * cout * cin * ks * ks * p * (w + 2 * pad - ks + 1))
-    _lib.check(lib.afcm_conv2d_wgrad(dw.data_ptr(), ws.data_ptr(), dy.data_ptr(), x.data_ptr(), _lib.dtype_code(x), n, cin, cout,
-                                     h, w, ks, pad, _lib.stream_ptr(x)), 'conv2d_wgrad')
+    _lib.check(lib.afcm_conv2d_wgrad_ld(dw.data_ptr(), ws.data_ptr(), dy.data_ptr(), x.data_ptr(), _lib.dtype_code(x), n, cin, cout,
+                                        h, w, ks, pad, 0 if lddy == dy.shape[3] else lddy, 0 if ldx == w else ldx, _lib.stream_ptr(x)), 'conv2d_wgrad')
     if span is not None:
         span.end()
     return dw

@@ -18,6 +18,7 @@ import torch
 
 from ... import _lib
 from ... import profiling
+from . import _rows
 from . import upfirdn2d as _ufd
 
 
@@ -109,16 +110,19 @@ class NoFusedKernel(Exception):
     """Raised by _run(no_fallback=True) where the reference plugin returns return_code -1 (filtered_lrelu.cpp:52-56)."""
 
 
-def _run(x, fu, fd, b, si, cfg, write_signs, want_plane_sum=False, oscale=None, skip=None, oscale2=None, allow_mfma=True, no_fallback=False):
+def _run(x, fu, fd, b, si, cfg, write_signs, want_plane_sum=False, oscale=None, skip=None, oscale2=None, allow_mfma=True, no_fallback=False,
+         pitched_out=False):
     """One launch of the op (C ABI afcm_filtered_lrelu, or the generic GPU path when there is no fused kernel).
-    Returns (y, signs written or None, sign layout, per-plane output sums or None)."""
+    Returns (y, signs written or None, sign layout, per-plane output sums or None).  x / skip may be row-pitched views (_rows.py):
+    kernels that take a pitch read them in place, the others get a contiguous copy; ``pitched_out``: y comes back row-pitched
+    when the selected kernel can write one (callers that hand y to pitch-aware kernels only)."""
     up, down, px0, px1, py0, py1, gain, slope, clamp, flip_filter, sx, sy, si_layout = cfg
     assert isinstance(x, torch.Tensor) and x.ndim == 4
     _lib.require_gpu(x, fu, fd, b, si)
     lib = _lib.load()
     if x.numel() == 0:
         raise RuntimeError('x is empty')
-    x = x.contiguous()
+    x, xld = _rows.rows(x)
     if b is not None:
         if b.dtype != x.dtype:
             raise RuntimeError('x and b must have the same dtype')
@@ -147,8 +151,17 @@ def _run(x, fu, fd, b, si, cfg, write_signs, want_plane_sum=False, oscale=None, 
     a.workspace = _lib.ptr(ws)
     a.sign_layout = si_layout if si is not None else 0
     a.b = _lib.ptr(b)                     # the kernel family (and with it the sign layout a WRITE call produces) depends on it
+    a.x_pitch = xld if xld != x.shape[3] else 0         # (the kernel family may depend on the plane size in memory)
     _lib.check(lib.afcm_filtered_lrelu_shapes(a), 'filtered_lrelu')
-    y = torch.empty([a.n, a.c, a.yh, a.yw], dtype=x.dtype, device=x.device)
+    kld = 0
+    if skip is not None:
+        skip, kld = _rows.rows(skip)
+    if not a.row_pitch_ok:                               # this call's kernel takes dense tensors
+        x, a.x_pitch = _rows.dense(x), 0
+        if skip is not None:
+            skip, kld = _rows.dense(skip), 0
+    y = _rows.empty([a.n, a.c, a.yh, a.yw], x.dtype, x.device, pitched=bool(pitched_out and a.row_pitch_ok))
+    a.y_pitch = 0 if y.is_contiguous() else y.stride(2)
     so = None
     if write_signs:
         so = torch.empty([a.n, a.c, a.sh, a.swb], dtype=torch.uint8, device=x.device)
@@ -169,8 +182,8 @@ def _run(x, fu, fd, b, si, cfg, write_signs, want_plane_sum=False, oscale=None, 
             oscale = oscale.to(torch.float32).contiguous()
             assert oscale.numel() == a.n * a.c
         if skip is not None:
-            skip = skip.contiguous()
             assert skip.dtype == x.dtype and tuple(skip.shape) == (a.n, a.c, a.yh, a.yw)
+            a.skip_pitch = kld if kld != a.yw else 0
         if oscale2 is not None:
             oscale2 = oscale2.to(torch.float32).contiguous()
             assert oscale2.numel() == a.n * a.c

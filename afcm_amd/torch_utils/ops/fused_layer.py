@@ -30,16 +30,17 @@ class _ConvFilteredLRelu(torch.autograd.Function):
     def forward(ctx, x, w, in_scale, out_scale, bias, fu, fd, skip, next_scale, conv_pad, cfg, prescaled):
         _lib.require_gpu(x, w, in_scale, out_scale, bias, fu, fd, skip, next_scale)
         cout, cin, ks, _ = w.shape
-        x = x.contiguous()
         xs = _conv.scale_planes(x, in_scale) if (in_scale is not None and not prescaled) else x
         ctx.wpt = None
         if ctx.needs_input_grad[0] or (ctx.needs_input_grad[2] and not prescaled):
             (wp, rows_pad), ctx.wpt = _conv.pack_weights_both(w, x.dtype)      # the backward's weight image from the same launch
         else:
             wp, rows_pad = _conv.pack_weights(w, x.dtype, 0)
-        y = _conv._conv_raw(xs, wp, rows_pad, out_scale, cout, ks, conv_pad, obias=bias)
+        # y, z (and dys, dx in backward) are row-pitched: rows on 128-byte lines, read and written in place by the kernels of this
+        # node and of its neighbours (_rows.py)
+        y = _conv._conv_raw(xs, wp, rows_pad, out_scale, cout, ks, conv_pad, obias=bias, pitched_out=True)
         need_grad = any(ctx.needs_input_grad[:5]) or ctx.needs_input_grad[7] or ctx.needs_input_grad[8]
-        z, signs, layout, _ = _flr._run(y, fu, fd, None, None, cfg, need_grad, oscale=next_scale, skip=skip)
+        z, signs, layout, _ = _flr._run(y, fu, fd, None, None, cfg, need_grad, oscale=next_scale, skip=skip, pitched_out=True)
         keep_y = out_scale is not None and ctx.needs_input_grad[3]
         keep_z = next_scale is not None and ctx.needs_input_grad[8]
         ctx.save_for_backward(xs, w, in_scale, out_scale, bias, fu, fd, signs, next_scale, y if keep_y else None, z if keep_z else None)
@@ -52,12 +53,11 @@ class _ConvFilteredLRelu(torch.autograd.Function):
         xs, w, in_scale, out_scale, bias, fu, fd, signs, next_scale, y, z = ctx.saved_tensors
         conv_pad, cfg, prescaled, layout, y_shape, z_shape, has_skip = ctx.meta
         cout, cin, ks, _ = w.shape
-        g = g.contiguous()
         f32 = torch.float32
         assert g.dtype in (torch.bfloat16, torch.float16)
         # dys = d * dL/dy: the transposed filtered_lrelu with both per-plane factors in its epilogue
         bcfg = _flr._backward_cfg(cfg, fu, fd, y_shape, z_shape, layout)
-        dys, _, _, psum = _flr._run(g, fd, fu, None, signs, bcfg, False, want_plane_sum=True, oscale=out_scale, oscale2=next_scale)
+        dys, _, _, psum = _flr._run(g, fd, fu, None, signs, bcfg, False, want_plane_sum=True, oscale=out_scale, oscale2=next_scale, pitched_out=True)
         dx = dw = d_in = d_out = db = d_skip = d_next = None
         # bias / next-styles / demodulation gradients: two plane dot products + ONE small kernel (C ABI afcm_layer_bwd_coefs)
         n, o = int(g.shape[0]), int(g.shape[1])
@@ -83,7 +83,7 @@ class _ConvFilteredLRelu(torch.autograd.Function):
         if ctx.needs_input_grad[0] or (ctx.needs_input_grad[2] and not prescaled):
             wpt, rows_pad = ctx.wpt if (ctx.wpt is not None and ctx.wpt[0].dtype == g.dtype) else _conv.pack_weights(w, g.dtype, 1)
             eff_in = None if prescaled else in_scale
-            dx = _conv._conv_raw(dys, wpt, rows_pad, eff_in, cin, ks, ks - 1 - conv_pad)
+            dx = _conv._conv_raw(dys, wpt, rows_pad, eff_in, cin, ks, ks - 1 - conv_pad, pitched_out=True)
             if ctx.needs_input_grad[2] and eff_in is not None:
                 s2 = in_scale.to(f32).square()
                 d_in = torch.where(s2 > 0, _conv.plane_dot(xs, dx) / s2.clamp_min(1e-30), torch.zeros_like(s2)).to(in_scale.dtype)

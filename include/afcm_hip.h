@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define AFCM_ABI_VERSION 7
+#define AFCM_ABI_VERSION 8
 
 enum { AFCM_F32 = 0, AFCM_F16 = 1, AFCM_BF16 = 2 };
 enum { AFCM_OK = 0, AFCM_E_NOKERNEL = -1, AFCM_E_INVALID = -2 };
@@ -94,6 +94,13 @@ typedef struct afcm_filtered_lrelu_args {
     const void*  skip;      /* NULL, or [N, C, yh, yw] of x's dtype: the encoder feature added after the activation
                                (x + x_skip, NET:376-377), added before oscale.  Matrix-core kernels only.                */
     const float* oscale2;   /* NULL, or a second fp32 [N*C] factor multiplied with oscale (backward: demodulation x styles) */
+    int32_t x_pitch, y_pitch, skip_pitch;
+                            /* row pitch of x / y / skip in ELEMENTS; 0 = dense (pitch = width).  A pitched tensor is
+                               [N, C, H, pitch] in memory with the first W columns of every row meaningful (MI355X layout of the
+                               16-bit activation stream: rows start on 128-byte lines).  Only the kernels
+                               for which afcm_filtered_lrelu_shapes() reports row_pitch_ok take a pitch; with y_pitch set they
+                               write EVERY column of y up to the pitch (finite values; columns >= yw are padding).            */
+    int32_t row_pitch_ok;   /* set by afcm_filtered_lrelu_shapes(): 1 if the kernel selected for these arguments accepts pitches */
 } afcm_filtered_lrelu_args;
 
 /* Output / sign-tensor geometry for the arguments above (filtered_lrelu.cpp:61-94). Fills yh, yw
@@ -174,12 +181,24 @@ int afcm_conv2d_pack_weights2(void* dst_fwd, void* dst_dgrad, const float* w, in
  * For the data gradient call it with the mode-1 packing, cin/cout swapped and pad' = k-1-pad. */
 int afcm_conv2d(void* y, const void* x, const void* wpacked, const float* oscale, const float* obias, int32_t dtype, int32_t n,
                 int32_t cin, int32_t cout, int32_t h, int32_t w, int32_t ks, int32_t pad, int32_t rows_pad, void* stream);
+/* The same with row-pitched activations (x: [N, cin, h, x_pitch], y: [N, cout, P, y_pitch] in memory, the first w / Q columns of
+ * a row meaningful; 0 = dense).  MI355X layout of the 16-bit activation stream: rows start on 128-byte lines.
+ * Pitches are taken by the 16-bit 3x3 kernel only.  Columns >= w of x are never used; columns >= Q of y are padding (the
+ * kernel may write the tail of a row's last 8-pixel granule there). */
+int afcm_conv2d_ld(void* y, const void* x, const void* wpacked, const float* oscale, const float* obias, int32_t dtype, int32_t n,
+                   int32_t cin, int32_t cout, int32_t h, int32_t w, int32_t ks, int32_t pad, int32_t rows_pad, int32_t x_pitch,
+                   int32_t y_pitch, void* stream);
 
 /* Weight gradient dw[cout][cin][k][k] (fp32) = sum_n sum_pixels dy[n,o,p,q] * x[n,i,p+r-pad,q+s-pad].
  * workspace: fp32 [afcm_conv2d_wgrad_splits(...)][cout][cin][k][k]. */
 int afcm_conv2d_wgrad_splits(int32_t n, int32_t cout, int32_t cin, int32_t p_rows);
 int afcm_conv2d_wgrad(float* dw, float* workspace, const void* dy, const void* x, int32_t dtype, int32_t n, int32_t cin,
                       int32_t cout, int32_t h, int32_t w, int32_t ks, int32_t pad, void* stream);
+/* The same with row-pitched operands (0 = dense); 16-bit, 3x3 pad 2 or 1x1 pad 0 only.  Columns >= w of x are never used; of dy,
+ * the columns up to the next multiple of 8 past Q must hold FINITE values (they multiply zeros; every kernel of this library that
+ * writes a pitched tensor fills the whole pitch with finite values). */
+int afcm_conv2d_wgrad_ld(float* dw, float* workspace, const void* dy, const void* x, int32_t dtype, int32_t n, int32_t cin,
+                         int32_t cout, int32_t h, int32_t w, int32_t ks, int32_t pad, int32_t dy_pitch, int32_t x_pitch, void* stream);
 
 /* y[plane, :] = x[plane, :] * scale[plane] with dtype conversion (style modulation s[n,i] of NET:46-47 and the
  * demodulation d[n,o] of NET:50-52 applied to activations instead of weights).  scale may be NULL (pure cast). */
@@ -189,6 +208,9 @@ int afcm_scale_planes(void* y, const void* x, const float* scale, int32_t dtype_
 /* out[plane] = sum_i a[plane,i] * b[plane,i]  (b == NULL: plain sum); fp32 accumulation.  Used for the style /
  * demodulation / bias gradients. */
 int afcm_plane_dot(float* out, const void* a, const void* b, int32_t dtype, int64_t planes, int32_t hw, void* stream);
+/* The same over planes of h rows x w columns with row pitches (elements; 0 = dense); padding columns are never read. */
+int afcm_plane_dot_ld(float* out, const void* a, const void* b, int32_t dtype, int64_t planes, int32_t h, int32_t w,
+                      int32_t a_pitch, int32_t b_pitch, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * The small-tensor half of modulated_conv2d (NET:41-57), fp32, forward and exact backward.  The reference runs it as

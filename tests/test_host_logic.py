@@ -86,3 +86,25 @@ def test_scaled_linear_matches_the_reference_dense_layer_arithmetic():
     assert torch.autograd.gradcheck(lambda x, w, b: _ScaledLinear.apply(x, w, b, 0.3, 0.01), (x, w, b))
     assert torch.autograd.gradgradcheck(lambda x, w, b: _ScaledLinear.apply(x, w, b, 0.3, 0.01), (x, w, b))
     assert torch.autograd.gradcheck(lambda x, w: _ScaledLinear.apply(x, w, None, 0.3, 1.0), (x, w))
+
+
+def test_row_pitch_helpers():
+    """afcm_amd/torch_utils/ops/_rows.py on CPU tensors: the pitched view, its recognition, and everything else falling back to dense."""
+    import torch
+    from afcm_amd.torch_utils.ops import _rows
+    # rows to the next 64 bytes, unless that pads by more than 10 %
+    assert _rows.pitch_for(276, torch.bfloat16) == 288 and _rows.pitch_for(278, torch.bfloat16) == 288 and _rows.pitch_for(148, torch.float16) == 160
+    assert _rows.pitch_for(256, torch.float16) == 256 and _rows.pitch_for(84, torch.bfloat16) == 84 and _rows.pitch_for(36, torch.bfloat16) == 36
+    t = _rows.empty([2, 3, 5, 276], torch.bfloat16, 'cpu')
+    if _rows.ENABLED:
+        assert tuple(t.shape) == (2, 3, 5, 276) and t.stride() == (3 * 5 * 288, 5 * 288, 288, 1) and _rows.pitch_of(t) == 288
+        assert tuple(_rows.whole_buffer(t).shape) == (2, 3, 5, 288)
+        assert _rows.rows(t)[0] is t
+    assert _rows.empty([2, 3, 5, 276], torch.float32, 'cpu').is_contiguous()          # 16-bit streams only
+    assert _rows.empty([2, 3, 5, 256], torch.bfloat16, 'cpu').is_contiguous()         # already whole lines
+    d = torch.zeros(2, 3, 5, 276)
+    assert _rows.pitch_of(d) == 276 and _rows.whole_buffer(d) is None
+    v = torch.zeros(2, 3, 5, 300)[..., 4:280]                                          # some other view: made contiguous
+    assert _rows.pitch_of(v[:, :, ::2]) is None
+    r, ld = _rows.rows(v[:, :, ::2])
+    assert r.is_contiguous() and ld == 276

@@ -14,6 +14,41 @@ from afcm_amd import layer_schedule as sched  # noqa: E402
 from afcm_amd.torch_utils.ops import filtered_lrelu as flr  # noqa: E402
 
 
+def raw_layer(L, x, fu, fd, kw, args):
+    """Forward (sign write) and transposed backward (sign read) through filtered_lrelu._run on dense or row-pitched tensors."""
+    from afcm_amd.torch_utils.ops import _rows, fused_layer
+    pitched = args.raw == 'pitched'
+    cfg = fused_layer._cfg(kw['up'], kw['down'], kw['padding'], kw['gain'], kw['slope'], kw['clamp'])
+    if pitched:
+        xp = _rows.empty(list(x.shape), x.dtype, x.device)
+        xp.copy_(x)
+        x = xp
+    y, signs, layout, _ = flr._run(x, fu, fd, None, None, cfg, True, pitched_out=pitched)
+    g = _rows.empty(list(y.shape), y.dtype, y.device, pitched=pitched)
+    g.copy_(torch.randn(y.shape, device=y.device, dtype=y.dtype))
+    bcfg = flr._backward_cfg(cfg, fu, fd, x.shape, y.shape, layout)
+    tf = tb = float('inf')
+    for _rep in range(args.repeats):
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        for _ in range(2):
+            flr._run(x, fu, fd, None, None, cfg, True, pitched_out=pitched)
+        ev[0].record()
+        for _ in range(args.iters):
+            flr._run(x, fu, fd, None, None, cfg, True, pitched_out=pitched)
+        ev[1].record()
+        for _ in range(2):
+            flr._run(g, fd, fu, None, signs, bcfg, False, pitched_out=pitched)
+        ev[2].record()
+        for _ in range(args.iters):
+            flr._run(g, fd, fu, None, signs, bcfg, False, pitched_out=pitched)
+        ev[3].record()
+        torch.cuda.synchronize()
+        tf = min(tf, ev[0].elapsed_time(ev[1]) / args.iters)
+        tb = min(tb, ev[2].elapsed_time(ev[3]) / args.iters)
+    nbytes = (x.numel() + y.numel()) * x.element_size() + signs.numel()
+    return tf, tb, nbytes
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--batch', type=int, default=16)
@@ -23,6 +58,8 @@ def main():
     ap.add_argument('--repeats', type=int, default=3, help='timed repeats per layer; the fastest is reported (box noise is +-10 %)')
     ap.add_argument('--layers', default='', help='comma-separated layer names (default: all)')
     ap.add_argument('--no-bias', action='store_true', help='b=None: the generator path (the convs add the bias)')
+    ap.add_argument('--raw', choices=['dense', 'pitched'], default=None,
+                    help='drive the launches as the fused layer node does (filtered_lrelu._run, no autograd), on dense or row-pitched tensors')
     args = ap.parse_args()
     dt = {'fp32': torch.float32, 'bf16': torch.bfloat16, 'fp16': torch.float16}[args.dtype]
     pl = sched.plan(args.res, 4, 1, {})
@@ -40,6 +77,13 @@ def main():
         fd = None if L['fd'] is None else L['fd'].cuda()
         kw = dict(up=L['up'], down=L['down'], padding=L['padding'], gain=1.0 if L.get('torgb') else math.sqrt(2),
                   slope=1.0 if L.get('torgb') else 0.2, clamp=256.0)
+        if args.raw:
+            tf, tb, nbytes = raw_layer(L, x.detach(), fu, fd, kw, args)
+            tot_b += nbytes; tot_t += tf; tot_bb += nbytes; tot_tb += tb
+            if key not in seen:
+                seen[key] = 1
+                print(f'{L["name"]:14s} C={L["cout"]:3d} {h:3d}->{L["out_size"]:3d} up{L["up"]} down{L["down"]}  fwd {tf:7.3f} ms {nbytes/tf/1e6:7.1f} GB/s   bwd {tb:7.3f} ms {nbytes/tb/1e6:7.1f} GB/s')
+            continue
         y = flr.filtered_lrelu(x, fu=fu, fd=fd, b=b, **kw)
         signs = y.grad_fn.saved_tensors[2]
         r = torch.randn_like(y)
