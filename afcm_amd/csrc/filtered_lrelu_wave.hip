@@ -23,7 +23,9 @@
 // Per 64x32-output tile: ~600 vector + 142 matrix instructions on one wave instead of 3 x (~490 + 53).
 #include "flrelu_mfma_common.h"
 
-// waves per SIMD the register allocation targets (tuning aids)
+// waves per SIMD the register allocation targets (tuning aids).  Down 2: three (168 registers), except the sign-writing 48-row strips
+// (the 36^2 planes): at 168 registers they spill ~70-100 registers to scratch -- encoder_12 forward 0.075 ms, 0.034 ms with two
+// waves' budget; the sign-reading 48-row kernel spills 20 and is still 10 % faster at three.
 #ifndef AFCM_WAVE_OCC_D2
 #define AFCM_WAVE_OCC_D2 3
 #endif
@@ -159,7 +161,7 @@ __global__ void flrelu_wave_prepare_kernel(char* __restrict__ wsb, const float* 
 //
 // EPI bits: 1 = per-plane factors and per-strip output sums (fused layer node; backward bias gradient), 2 = + encoder skip operand.
 template <typename T, int UP, int DOWN, int TOW, int TOH, int SIGN, int EPI>
-__global__ __launch_bounds__(256, (DOWN == 2 ? AFCM_WAVE_OCC_D2 : AFCM_WAVE_OCC_D4)) void flrelu_wave_kernel(FlreluMfmaParams p) {
+__global__ __launch_bounds__(256, (DOWN == 2 && (TOH <= 32 || SIGN == AFCM_SIGNS_READ) ? AFCM_WAVE_OCC_D2 : AFCM_WAVE_OCC_D4)) void flrelu_wave_kernel(FlreluMfmaParams p) {
     typedef WaveGeom<UP, DOWN, TOW, TOH> G;
     typedef MfmaOps<T> M;
     typedef typename M::frag frag;
