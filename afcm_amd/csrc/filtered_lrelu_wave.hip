@@ -159,7 +159,8 @@ __global__ void flrelu_wave_prepare_kernel(char* __restrict__ wsb, const float* 
 // ranges over the tile -- 210-240 VGPRs, two waves per SIMD, or spills; a wave spends most of its residency waiting on its own
 // MFMA -> convert -> MFMA chains, so the SIMD only fills up with 3-4 of them.)
 //
-// EPI bits: 1 = per-plane factors and per-strip output sums (fused layer node; backward bias gradient), 2 = + encoder skip operand.
+// EPI bits: 1 = per-plane factors (fused layer node), 2 = + encoder skip operand, 4 = per-strip output sums (the backward's bias
+// gradient; kept apart from bit 1: the forward kernels of a training step scale but never sum, and the sums cost them registers).
 template <typename T, int UP, int DOWN, int TOW, int TOH, int SIGN, int EPI>
 __global__ __launch_bounds__(256, (DOWN == 2 && (TOH <= 32 || SIGN == AFCM_SIGNS_READ) ? AFCM_WAVE_OCC_D2 : AFCM_WAVE_OCC_D4)) void flrelu_wave_kernel(FlreluMfmaParams p) {
     typedef WaveGeom<UP, DOWN, TOW, TOH> G;
@@ -366,8 +367,8 @@ __global__ __launch_bounds__(256, (DOWN == 2 && (TOH <= 32 || SIGN == AFCM_SIGNS
                 acc[2] += to_f32(e1.t[0]);
                 acc[3] += to_f32(e1.t[1]);
             }
-            if (EPI & 1) {
-                acc *= osc;
+            if (EPI & 1) acc *= osc;
+            if (EPI & 4) {
                 if (!(lastY || cb == ncb - 1)) {                                              // wave-uniform: every element is inside the plane
                     psum += (acc[0] + acc[1]) + (acc[2] + acc[3]);
                 } else {
@@ -640,7 +641,7 @@ __global__ __launch_bounds__(256, (DOWN == 2 && (TOH <= 32 || SIGN == AFCM_SIGNS
         if (__builtin_expect(run_strip(std::false_type{}, std::false_type{}), 0)) run_strip(std::true_type{}, std::false_type{});
     }
 
-    if ((EPI & 1) && p.plane_sum != nullptr) {
+    if ((EPI & 4) && p.plane_sum != nullptr) {
         // one plain store into this tile's slot (no atomics: deterministic)
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) psum += __shfl_down(psum, off, 64);
@@ -653,10 +654,12 @@ template <typename T, int UP, int DOWN, int TOW, int TOH>
 int launch_wave_tile(const afcm_filtered_lrelu_args* a, FlreluMfmaParams p, hipStream_t st) {
     const long long tiles = p.total_tiles;
     dim3 grid((unsigned)((tiles + 3) / 4)), block(256);
-    const bool epi = p.oscale != nullptr || p.oscale2 != nullptr || p.plane_sum != nullptr;
+    const bool scale = p.oscale != nullptr || p.oscale2 != nullptr, sums = p.plane_sum != nullptr;
 #define AFCM_WAVE_LAUNCH(SIGN) do { \
-        if (p.skip != nullptr) hipLaunchKernelGGL((flrelu_wave_kernel<T, UP, DOWN, TOW, TOH, SIGN, 3>), grid, block, 0, st, p); \
-        else if (epi) hipLaunchKernelGGL((flrelu_wave_kernel<T, UP, DOWN, TOW, TOH, SIGN, 1>), grid, block, 0, st, p); \
+        if (sums && p.skip != nullptr) hipLaunchKernelGGL((flrelu_wave_kernel<T, UP, DOWN, TOW, TOH, SIGN, 7>), grid, block, 0, st, p); \
+        else if (sums) hipLaunchKernelGGL((flrelu_wave_kernel<T, UP, DOWN, TOW, TOH, SIGN, 5>), grid, block, 0, st, p); \
+        else if (p.skip != nullptr) hipLaunchKernelGGL((flrelu_wave_kernel<T, UP, DOWN, TOW, TOH, SIGN, 3>), grid, block, 0, st, p); \
+        else if (scale) hipLaunchKernelGGL((flrelu_wave_kernel<T, UP, DOWN, TOW, TOH, SIGN, 1>), grid, block, 0, st, p); \
         else hipLaunchKernelGGL((flrelu_wave_kernel<T, UP, DOWN, TOW, TOH, SIGN, 0>), grid, block, 0, st, p); } while (0)
     switch (a->sign_mode) {
         case AFCM_SIGNS_NONE: AFCM_WAVE_LAUNCH(AFCM_SIGNS_NONE); break;
