@@ -189,22 +189,75 @@ class DiscriminatorEpilogue(torch.nn.Module):
         return x
 
 
+class MappingNetwork(torch.nn.Module):
+    """The StyleGAN2-style mapping network the discriminator conditions through (layers.py:540-609): optional latent z and label c
+    -> normalised, concatenated -> ``num_layers`` FC + lrelu layers at lr_multiplier 0.01.  Same constructor arguments and
+    state-dict keys (``embed``, ``fc0`` ... , ``w_avg``) as the reference class."""
+
+    def __init__(self, z_dim, c_dim, w_dim, num_ws, num_layers=8, embed_features=None, layer_features=None, activation='lrelu',
+                 lr_multiplier=0.01, w_avg_beta=0.995, **kwargs):
+        super().__init__()
+        self.z_dim, self.c_dim, self.w_dim, self.num_ws, self.num_layers, self.w_avg_beta = z_dim, c_dim, w_dim, num_ws, num_layers, w_avg_beta
+        if embed_features is None:
+            embed_features = w_dim
+        if c_dim == 0:
+            embed_features = 0
+        if layer_features is None:
+            layer_features = w_dim
+        features = [z_dim + embed_features] + [layer_features] * (num_layers - 1) + [w_dim]
+        if c_dim > 0:
+            self.embed = FullyConnectedLayer(c_dim, embed_features)
+        for idx in range(num_layers):
+            setattr(self, f'fc{idx}', FullyConnectedLayer(features[idx], features[idx + 1], activation=activation, lr_multiplier=lr_multiplier))
+        if num_ws is not None and w_avg_beta is not None:
+            self.register_buffer('w_avg', torch.zeros([w_dim]))
+
+    @staticmethod
+    def _normalize_2nd_moment(x, eps=1e-8):
+        return x * (x.square().mean(dim=1, keepdim=True) + eps).rsqrt()                    # layers.py:15-16
+
+    def forward(self, z, c, truncation_psi=1, truncation_cutoff=None, skip_w_avg_update=False, **kwargs):
+        x = None
+        if self.z_dim > 0:
+            assert list(z.shape[1:]) == [self.z_dim]
+            x = self._normalize_2nd_moment(z.to(torch.float32))
+        if self.c_dim > 0:
+            assert list(c.shape[1:]) == [self.c_dim]
+            y = self._normalize_2nd_moment(self.embed(c.to(torch.float32)))
+            x = torch.cat([x, y], dim=1) if x is not None else y
+        for idx in range(self.num_layers):
+            x = getattr(self, f'fc{idx}')(x)
+        if self.w_avg_beta is not None and self.training and not skip_w_avg_update and hasattr(self, 'w_avg'):
+            self.w_avg.copy_(x.detach().mean(dim=0).lerp(self.w_avg, self.w_avg_beta))
+        if self.num_ws is not None:
+            x = x.unsqueeze(1).repeat([1, self.num_ws, 1])
+        if truncation_psi != 1:
+            assert self.w_avg_beta is not None
+            if self.num_ws is None or truncation_cutoff is None:
+                x = self.w_avg.lerp(x, truncation_psi)
+            else:
+                x[:, :truncation_cutoff] = self.w_avg.lerp(x[:, :truncation_cutoff], truncation_psi)
+        return x
+
+
 class CoModDiscriminator(torch.nn.Module):
-    """generator.py:780-836.  ``c_dim > 0`` (a mapped conditioning label) is not used by any shipped configuration
-    (models/stylegan3_model.py:71: c_dim = 0) and raises."""
+    """generator.py:780-836.  ``c_dim > 0`` -- the ADNI / in-house configurations (configs/adni/stylegan3/cmsr.yml:13: the slice
+    fraction conditions D as it conditions G) -- maps the label through ``MappingNetwork(z_dim=0)`` and projects the epilogue's
+    ``cmap_dim`` outputs onto it (generator.py:822-823,833-835,771-773)."""
 
     def __init__(self, c_dim, img_resolution, img_channels, architecture='resnet', channel_base=32768, channel_max=512, num_fp16_res=0,
                  conv_clamp=None, cmap_dim=None, block_kwargs={}, mapping_kwargs={}, epilogue_kwargs={}, **kwargs):
         super().__init__()
-        if c_dim != 0:
-            raise NotImplementedError('conditional discriminator (c_dim > 0) is outside the built path')
         self.c_dim = c_dim
         self.img_resolution = img_resolution
         self.img_resolution_log2 = int(np.log2(img_resolution))
         self.img_channels = img_channels
         self.block_resolutions = [2 ** i for i in range(self.img_resolution_log2, 2, -1)]
         channels_dict = {res: min(channel_base // res, channel_max) for res in self.block_resolutions + [4]}
-        cmap_dim = 0
+        if cmap_dim is None:
+            cmap_dim = channels_dict[4]
+        if c_dim == 0:
+            cmap_dim = 0
         fp16_resolution = max(2 ** (self.img_resolution_log2 + 1 - num_fp16_res), 8)                  # generator.py:808
         common_kwargs = dict(img_channels=img_channels, architecture=architecture, conv_clamp=conv_clamp)
         cur_layer_idx = 0
@@ -214,10 +267,13 @@ class CoModDiscriminator(torch.nn.Module):
                                        first_layer_idx=cur_layer_idx, use_fp16=(res >= fp16_resolution), **block_kwargs, **common_kwargs)
             setattr(self, f'b{res}', block)
             cur_layer_idx += block.num_layers
+        if c_dim > 0:
+            self.mapping = MappingNetwork(z_dim=0, c_dim=c_dim, w_dim=cmap_dim, num_ws=None, w_avg_beta=None, **mapping_kwargs)
         self.b4 = DiscriminatorEpilogue(channels_dict[4], cmap_dim=cmap_dim, resolution=4, **epilogue_kwargs, **common_kwargs)
 
     def forward(self, img, c, **block_kwargs):
         x = None
         for res in self.block_resolutions:
             x, img = getattr(self, f'b{res}')(x, img, **block_kwargs)
-        return self.b4(x, img, None)
+        cmap = self.mapping(None, c) if self.c_dim > 0 else None
+        return self.b4(x, img, cmap)

@@ -6,7 +6,8 @@ Follows (reference tree) CMG = models/networks/CoModGAN:
                          3x3 + down -> blur then strided conv, plain conv)
   Conv2dLayer            CMG/layers.py:115-162         FullyConnectedLayer   CMG/layers.py:81-111
   DiscriminatorBlock     CMG/generator.py:613-692 ('resnet' architecture)   MinibatchStdLayer   :696-718
-  DiscriminatorEpilogue  CMG/generator.py:722-776      CoModDiscriminator    :780-836 (c_dim = 0: no mapping network)
+  DiscriminatorEpilogue  CMG/generator.py:722-776      CoModDiscriminator    :780-836
+  MappingNetwork (z_dim = 0, the label path of a conditional D)   CMG/layers.py:540-609
 Pinned by tests/golden/D*.npz (tools/gen_golden_disc.py: logits, loss gradients, the R1 double backward).
 """
 import numpy as np
@@ -52,10 +53,12 @@ def conv2d_layer(sd, prefix, x, kernel_size, act='linear', down=1, gain=1.0, con
     return ops.bias_act(x, b, act=act, gain=act_gain, clamp=act_clamp)
 
 
-def fully_connected(sd, prefix, x, act='linear'):
+def fully_connected(sd, prefix, x, act='linear', lr_multiplier=1.0):
     w = sd[prefix + 'weight']
-    w = w * (1.0 / np.sqrt(w.shape[1]))                                        # lr_multiplier 1
+    w = w * (lr_multiplier / np.sqrt(w.shape[1]))                              # layers.py:92,98
     b = sd.get(prefix + 'bias')
+    if b is not None and lr_multiplier != 1:
+        b = b * lr_multiplier                                                  # layers.py:93,101-102
     if act == 'linear' and b is not None:
         return torch.addmm(b.unsqueeze(0), x, w.t())
     return ops.bias_act(x.matmul(w.t()), b, act=act)
@@ -74,8 +77,19 @@ def minibatch_std(x, group_size, num_channels=1):
     return torch.cat([x, y], dim=1)
 
 
-def discriminator(sd, img, img_resolution, mbstd_group_size=4, conv_clamp=None):
-    """CoModDiscriminator.forward(img, c=None) for c_dim = 0, architecture 'resnet', fp32."""
+def label_mapping(sd, c, num_layers=8, lr_multiplier=0.01):
+    """MappingNetwork(z_dim=0, num_ws=None, w_avg_beta=None).forward(None, c) (layers.py:578-596): embed, normalise the second moment,
+    ``num_layers`` lrelu FC layers."""
+    y = fully_connected(sd, 'mapping.embed.', c.to(torch.float32))
+    x = y * (y.square().mean(dim=1, keepdim=True) + 1e-8).rsqrt()
+    for idx in range(num_layers):
+        x = fully_connected(sd, f'mapping.fc{idx}.', x, act='lrelu', lr_multiplier=lr_multiplier)
+    return x
+
+
+def discriminator(sd, img, img_resolution, mbstd_group_size=4, conv_clamp=None, c=None):
+    """CoModDiscriminator.forward(img, c), architecture 'resnet', fp32; ``c`` given (and a ``mapping.*`` branch in the state dict):
+    the conditional form -- the epilogue's cmap_dim outputs projected onto the mapped label (generator.py:771-773)."""
     filt = setup_filter([1, 3, 3, 1])
     log2 = int(np.log2(img_resolution))
     x = None
@@ -90,7 +104,11 @@ def discriminator(sd, img, img_resolution, mbstd_group_size=4, conv_clamp=None):
     x = minibatch_std(x, mbstd_group_size)
     x = conv2d_layer(sd, 'b4.conv.', x, 3, act='lrelu', conv_clamp=conv_clamp)
     x = fully_connected(sd, 'b4.fc.', x.flatten(1), act='lrelu')
-    return fully_connected(sd, 'b4.out.', x)
+    x = fully_connected(sd, 'b4.out.', x)
+    if 'mapping.embed.weight' in sd:
+        cmap = label_mapping(sd, c)
+        x = (x * cmap).sum(dim=1, keepdim=True) * (1 / np.sqrt(cmap.shape[1]))
+    return x
 
 
 def d_losses(sd, fake, real, img_resolution, lambda_r1=10.0, **kw):

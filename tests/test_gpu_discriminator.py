@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 def _build(g):
     from afcm_amd.networks_discriminator import CoModDiscriminator
     res, n, cb, cm, group, clamp = [int(v) for v in g['meta']]
-    D = CoModDiscriminator(c_dim=0, img_resolution=res, img_channels=5, channel_base=cb, channel_max=cm,
+    D = CoModDiscriminator(c_dim=(g['c'].shape[1] if 'c' in g else 0), img_resolution=res, img_channels=5, channel_base=cb, channel_max=cm,
                            conv_clamp=None if clamp < 0 else clamp, epilogue_kwargs=dict(mbstd_group_size=group))
     sd = {k[3:]: torch.from_numpy(np.array(v)) for k, v in g.items() if k.startswith('sd/')}
     D.load_state_dict(sd, strict=True)
@@ -21,7 +21,7 @@ def _build(g):
 
 
 @pytest.mark.parametrize('mfma_conv', [True, False])
-@pytest.mark.parametrize('name', ['D1_tiny64', 'D2_tiny128_clamp'])
+@pytest.mark.parametrize('name', ['D1_tiny64', 'D2_tiny128_clamp', 'D3_tiny64_cond'])
 def test_discriminator_matches_reference_golden(name, mfma_conv, monkeypatch):
     """mfma_conv: 1x1 / 3x3 convolutions on the MFMA kernels of csrc/conv2d.hip (second-order through _ScaledConv2d / _ConvWgrad,
     strides by decimation) vs the framework convolution the reference uses."""
@@ -33,14 +33,15 @@ def test_discriminator_matches_reference_golden(name, mfma_conv, monkeypatch):
     names = [str(k) for k in g['names']]
     params = dict(D.named_parameters())
     fake, real = torch.from_numpy(g['fake']).cuda(), torch.from_numpy(g['real']).cuda()
+    c = torch.from_numpy(g['c']).cuda() if 'c' in g else None          # D3: the conditional form (cmsr.yml:13), state dict incl. mapping.*
     # fake half
-    gen_logits = D(fake, None)
+    gen_logits = D(fake, c)
     assert np.abs(gen_logits.detach().cpu().numpy() - g['gen_logits']).max() <= 1e-4
     loss_fake = torch.nn.functional.softplus(gen_logits).mean()
     gf = torch.autograd.grad(loss_fake, [params[k] for k in names])
     # real half + R1 (double backward through upfirdn2d / bias_act / conv)
     real_tmp = real.detach().requires_grad_(True)
-    real_logits = D(real_tmp, None)
+    real_logits = D(real_tmp, c)
     loss_real = torch.nn.functional.softplus(-real_logits).mean()
     r1, = torch.autograd.grad(outputs=[real_logits.sum()], inputs=[real_tmp], create_graph=True, only_inputs=True)
     loss_r1 = r1.square().sum([1, 2, 3]).mean() * 0.5
@@ -54,7 +55,7 @@ def test_discriminator_matches_reference_golden(name, mfma_conv, monkeypatch):
             assert err <= tol, (name, k, what, err, tol)
     # generator term through D
     img = fake.clone().requires_grad_(True)
-    lg = torch.nn.functional.softplus(-D(img, None)).mean()
+    lg = torch.nn.functional.softplus(-D(img, c)).mean()
     gi, = torch.autograd.grad(lg, img)
     d = gi.cpu().numpy().astype(np.float64) - g['g_img']
     rel = float(np.sqrt((d ** 2).sum() / (g['g_img'].astype(np.float64) ** 2).sum()))
@@ -75,6 +76,29 @@ def test_discriminator_full_width_state_dict_and_step():
     r1, = torch.autograd.grad(logits.sum(), x, create_graph=True)
     (torch.nn.functional.softplus(-logits).mean() + 5.0 * r1.square().sum([1, 2, 3]).mean()).backward()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in D.parameters())
+
+
+def test_conditional_discriminator_full_width():
+    """The ADNI / in-house configurations' discriminator (configs/adni/stylegan3/cmsr.yml:11-16: c_dim = 1, mbstd_group_size 16): the
+    label mapping network adds 8 FC layers of 512 + the embedding; one conditioned loss evaluation with R1 runs and every
+    parameter -- mapping network included -- receives a finite gradient."""
+    from afcm_amd.networks_discriminator import CoModDiscriminator
+    D = CoModDiscriminator(c_dim=1, img_resolution=256, img_channels=5, channel_base=int(0.5 * 32768), channel_max=512,
+                           epilogue_kwargs=dict(mbstd_group_size=16)).cuda()
+    n = sum(p.numel() for p in D.parameters())
+    # c_dim = 0 network (24,001,217) with b4.out widened 1 -> 512 (+ 511 x 513) + embed (1 x 512 + 512) + 8 x (512 x 512 + 512)
+    assert n == 24001217 + 511 * 513 + 1024 + 8 * (512 * 512 + 512), n
+    assert [k for k in D.state_dict() if k.startswith('mapping.')][:2] == ['mapping.embed.weight', 'mapping.embed.bias']
+    x = torch.randn(4, 5, 256, 256, device='cuda', requires_grad=True)
+    c = torch.rand(4, 1, device='cuda')
+    logits = D(x, c)
+    assert logits.shape == (4, 1)
+    r1, = torch.autograd.grad(logits.sum(), x, create_graph=True)
+    (torch.nn.functional.softplus(-logits).mean() + 5.0 * r1.square().sum([1, 2, 3]).mean()).backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in D.parameters())
+    # the label matters (at initialisation -- zero embedding bias, second-moment normalisation -- only through its sign; the golden
+    # D3 network has random biases and pins the general case)
+    assert not torch.allclose(D(x.detach(), c), D(x.detach(), -c))
 
 
 def test_full_training_iteration_matches_oracle():

@@ -161,15 +161,18 @@ def test_sign_code_packing():
         assert np.array_equal((packed[..., x >> 2] >> (2 * (x & 3))) & 3, codes[..., x])
 
 
-@pytest.mark.parametrize('name', ['D1_tiny64', 'D2_tiny128_clamp'])
+@pytest.mark.parametrize('name', ['D1_tiny64', 'D2_tiny128_clamp', 'D3_tiny64_cond'])
 def test_discriminator_oracle_matches_reference(name):
     """Row f1: the functional discriminator restatement (oracle/discriminator.py) vs vectors captured from the reference's
-    CoModDiscriminator -- logits, both D loss gradients (incl. the R1 double backward) and the image gradient of the G term."""
+    CoModDiscriminator -- logits, both D loss gradients (incl. the R1 double backward) and the image gradient of the G term.
+    D3: the conditional form (c_dim = 1, configs/adni/stylegan3/cmsr.yml:13): label mapping network + projection."""
     import torch
     from oracle import discriminator as od
     g = load_golden(name)
     res, n, _, _, group, clamp = [int(v) for v in g['meta']]
     kw = dict(mbstd_group_size=group, conv_clamp=None if clamp < 0 else float(clamp))
+    if 'c' in g:
+        kw['c'] = torch.from_numpy(g['c'])
     names = [str(k) for k in g['names']]
     sd = {k[3:]: torch.from_numpy(np.array(v)) for k, v in g.items() if k.startswith('sd/')}
     for k in names:

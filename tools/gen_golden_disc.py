@@ -26,30 +26,40 @@ def main():
     import torch
     from models.networks.CoModGAN.generator import CoModDiscriminator
 
+    only = sys.argv[1:]
     for name, res, kw, n in [('D1_tiny64', 64, dict(channel_base=512, channel_max=16, epilogue_kwargs=dict(mbstd_group_size=2)), 4),
                              ('D2_tiny128_clamp', 128, dict(channel_base=1024, channel_max=12, conv_clamp=256,
-                                                            epilogue_kwargs=dict(mbstd_group_size=2)), 2)]:
+                                                            epilogue_kwargs=dict(mbstd_group_size=2)), 2),
+                             # the conditional form of configs/adni/stylegan3/cmsr.yml:13 (model.D.c_dim = 1: the slice fraction)
+                             ('D3_tiny64_cond', 64, dict(c_dim=1, channel_base=512, channel_max=16, epilogue_kwargs=dict(mbstd_group_size=2)), 4)]:
+        if only and name not in only:
+            continue
         torch.manual_seed(77)
-        D = CoModDiscriminator(c_dim=0, img_resolution=res, img_channels=5, **kw)
+        kw = dict(kw)
+        c_dim = kw.pop('c_dim', 0)
+        D = CoModDiscriminator(c_dim=c_dim, img_resolution=res, img_channels=5, **kw)
         with torch.no_grad():
             for p in D.parameters():                       # biases start at 0: make every term of the arithmetic count
                 if p.ndim == 1:
                     p.add_(torch.randn_like(p) * 0.1)
         fake = torch.randn(n, 5, res, res)
         real = torch.randn(n, 5, res, res)
+        c = torch.rand(n, c_dim) if c_dim > 0 else None
         out = {'sd/' + k: v.detach().numpy() for k, v in D.state_dict().items()}
         out['fake'], out['real'] = fake.numpy(), real.numpy()
+        if c is not None:
+            out['c'] = c.numpy()
         params = dict(D.named_parameters())
         names = sorted(params)
         # D step, fake half (comodgan_model.py:133-135)
-        gen_logits = D(fake, None)
+        gen_logits = D(fake, c)
         loss_fake = torch.nn.functional.softplus(gen_logits).mean()
         g_fake = torch.autograd.grad(loss_fake, [params[k] for k in names])
         out['gen_logits'] = gen_logits.detach().numpy()
         out['loss_fake'] = np.array(loss_fake.item())
         # D step, real half with R1 (comodgan_model.py:137-149), lambda_r1 = 10
         real_tmp = real.detach().requires_grad_(True)
-        real_logits = D(real_tmp, None)
+        real_logits = D(real_tmp, c)
         loss_real = torch.nn.functional.softplus(-real_logits).mean()
         r1_grads = torch.autograd.grad(outputs=[real_logits.sum()], inputs=[real_tmp], create_graph=True, only_inputs=True)[0]
         loss_r1 = r1_grads.square().sum([1, 2, 3]).mean() * 0.5
@@ -59,7 +69,7 @@ def main():
         out['loss_real'], out['loss_r1'] = np.array(loss_real.item()), np.array(loss_r1.item())
         # G step through D (stylegan3_model.py:93-95): gradient w.r.t. the image
         img = fake.detach().requires_grad_(True)
-        loss_g = torch.nn.functional.softplus(-D(img, None)).mean()
+        loss_g = torch.nn.functional.softplus(-D(img, c)).mean()
         out['g_img'] = torch.autograd.grad(loss_g, img)[0].numpy()
         for k, a, b in zip(names, g_fake, g_real):
             out['gfake/' + k] = a.numpy()
