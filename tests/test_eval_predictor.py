@@ -142,3 +142,62 @@ def test_checkpoint_names_round_trip_and_ema_bookkeeping(tmp_path):
     fresh.load_networks('dp', str(tmp_path))
     assert torch.equal(fresh.netG.mapping.weight, net.mapping.weight)
     assert update_ema(step.netG_ema, net, 16, 10 ** 9, ema_kimgs=10.0, ramp=None) == 0.5 ** (16 / 10000.0)
+
+
+def _volumes(d=23, h=40, w=36, seed=3):
+    rng = np.random.default_rng(seed)
+    return {'flair': rng.integers(0, 256, (d, h, w)).astype(np.uint8), 't1_hr4sr': rng.integers(0, 256, (d, h, w)).astype(np.uint8)}
+
+
+def test_slice_dataset_thick_slices_and_fraction():
+    """afcm_amd.data.SliceDataset, the shipped loader configuration (slice_num 4, thickness [5], one modality in, one out; data/
+    cmsr_dataset.py:98-155): A = the thick slices at -1, 0, +1, +2 thicknesses around the target's own, zero planes (-> -1 after
+    normalisation) outside the volume; B = the target slice; slice_idx = the offset inside the thick slice / thickness."""
+    from afcm_amd import data
+    vols = _volumes()
+    ds = data.SliceDataset(vols, phase='val', patch_shape=(1, 32, 32), stride_shape=(1, 32, 32), raw_internal_path_in=['flair'],
+                           raw_internal_path_out=['t1_hr4sr'], thickness=[5], slice_num=4)
+    assert len(ds) == 23                                                    # one patch per slice: the crop made every slice 32 x 32
+    crop = lambda v: v[:, 4:36, 2:34].astype(np.float64)                     # centre crop 40 x 36 -> 32 x 32
+    norm = lambda m: np.clip(2 * (m / 255.0) - 1, -1, 1).astype(np.float32)
+    fl, t1 = crop(vols['flair']), crop(vols['t1_hr4sr'])
+    for idx in (0, 3, 7, 14, 19, 22):
+        it = ds[idx]
+        base = (idx // 5) * 5
+        assert it['A'].shape == (4, 32, 32) and it['B'].shape == (1, 32, 32) and it['A'].dtype == torch.float32
+        for k, pos in enumerate((base - 5, base, base + 5, base + 10)):
+            want = norm(fl[pos]) if 0 <= pos <= 22 else np.full((32, 32), -1.0, dtype=np.float32)
+            assert np.array_equal(it['A'][k].numpy(), want), (idx, k)
+        assert np.array_equal(it['B'][0].numpy(), norm(t1[idx]))
+        assert np.allclose(it['slice_idx'], [(idx - base) / 5]) and it['slice_idx'].dtype == np.float32
+        assert it['B_idx'].item() == idx and it['B_class'].tolist() == [1.0]
+    with pytest.raises(StopIteration):
+        ds[23]
+    # test phase: (A, fraction, position); slice_num 1: the slice itself
+    a, frac, where = data.SliceDataset(vols, phase='test', patch_shape=(1, 32, 32), stride_shape=(1, 32, 32), raw_internal_path_in=['flair'],
+                                       raw_internal_path_out=['t1_hr4sr'], thickness=[5], slice_num=4)[8]
+    assert a.shape == (4, 32, 32) and np.allclose(frac.numpy(), [3 / 5]) and where[0] == slice(8, 9)
+    one = data.SliceDataset(vols, phase='val', patch_shape=(1, 32, 32), stride_shape=(1, 32, 32), raw_internal_path_in=['flair'],
+                            raw_internal_path_out=['t1_hr4sr'], thickness=[5], slice_num=1)[8]
+    assert one['A'].shape == (1, 32, 32) and np.array_equal(one['A'][0].numpy(), norm(fl[8]))
+
+
+def test_slice_dataset_crop_pad_normalise_and_chain():
+    from afcm_amd import data
+    v = np.arange(2 * 5 * 7, dtype=np.float64).reshape(2, 5, 7)
+    got = data.crop_to_fixed(v, (9, 4))                                      # pad rows 5 -> 9 (2 above, 2 below), crop columns 7 -> 4 from 1
+    assert got.shape == (2, 9, 4) and np.array_equal(got[:, 2:7], v[:, :, 1:5]) and not got[:, :2].any() and not got[:, 7:].any()
+    assert np.array_equal(data.crop_to_fixed(v, (5, 7)), v)
+    assert np.allclose(data.normalize(np.array([0.0, 127.5, 255.0, 300.0])), [-1, 0, 1, 1])
+    # patches larger strides: spatial patches inside a slice, last one pulled back to the border (data/utils.py:117-122)
+    ds = data.SliceDataset({'raw': np.zeros((3, 40, 40), np.uint8)}, phase='val', patch_shape=(1, 32, 32), stride_shape=(1, 32, 32), slice_num=1)
+    assert len(ds) == 3
+    ds = data.SliceDataset({'raw': np.zeros((3, 80, 80), np.uint8)}, phase='val', patch_shape=(1, 80, 80), stride_shape=(1, 32, 32), slice_num=1)
+    assert len(ds) == 3 and ds[0]['A'].shape == (1, 80, 80)
+    both = data.cmsr_dataset([_volumes(seed=1), _volumes(d=11, seed=2)], phase='val', patch_shape=(1, 32, 32), stride_shape=(1, 32, 32),
+                             raw_internal_path_in=['flair'], raw_internal_path_out=['t1_hr4sr'], thickness=[5], slice_num=4)
+    assert len(both) == 23 + 11
+    batch = next(iter(torch.utils.data.DataLoader(both, batch_size=4)))
+    assert batch['A'].shape == (4, 4, 32, 32) and batch['B'].shape == (4, 1, 32, 32) and batch['slice_idx'].shape == (4, 1)
+    with pytest.raises(RuntimeError, match='h5py'):
+        data.SliceDataset('/nonexistent/subject.h5', raw_internal_path_in=['flair'], raw_internal_path_out=['t1_hr4sr'])
