@@ -295,14 +295,13 @@ class EncoderLayer(torch.nn.Module, _ResampleGeometry):
 
 
 class Conv2dLayer(torch.nn.Module):
-    """The bottleneck's 3x3 conv + bias + activation (`e_16x16`, NET:635).  Mirrors the subset of
-    models/networks/CoModGAN/layers.py:115-162 the generator uses: no resampling (up = down = 1)."""
+    """The bottleneck's 3x3 conv + bias + activation (`e_16x16`, NET:635): models/networks/CoModGAN/layers.py:115-162.  The generator
+    uses it without resampling (up = down = 1: straight onto the MFMA conv); with up / down it takes the reference's decomposition
+    (torch_utils/ops/conv2d_resample.py: blur + strided / transposed conv, the route the discriminator's layers use)."""
 
     def __init__(self, in_channels, out_channels, kernel_size, bias=True, activation='linear', up=1, down=1,
                  resample_filter=(1, 3, 3, 1), conv_clamp=None, channels_last=False, trainable=True):
         super().__init__()
-        if up != 1 or down != 1:
-            raise NotImplementedError('afcm_amd Conv2dLayer covers the generator bottleneck only (up = down = 1)')
         from .torch_utils.ops import upfirdn2d
         self.activation = activation
         self.up, self.down = up, down
@@ -326,7 +325,12 @@ class Conv2dLayer(torch.nn.Module):
     def forward(self, x, gain=1):
         w = self.weight * self.weight_gain
         b = self.bias.to(x.dtype) if self.bias is not None else None
-        x = conv2d_gradfix.conv2d(input=x, weight=w, padding=self.padding)
+        if self.up == 1 and self.down == 1:
+            x = conv2d_gradfix.conv2d(input=x, weight=w, padding=self.padding)
+        else:
+            from .torch_utils.ops import conv2d_resample
+            x = conv2d_resample.conv2d_resample(x=x, w=w.to(x.dtype), f=self.resample_filter, up=self.up, down=self.down,
+                                                padding=self.padding, flip_weight=(self.up == 1))          # layers.py:156-157
         act_gain = self.act_gain * gain
         act_clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
         return bias_act.bias_act(x, b, act=self.activation, gain=act_gain, clamp=act_clamp)

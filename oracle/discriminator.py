@@ -23,11 +23,28 @@ def setup_filter(f):
     return f / f.sum()
 
 
-def conv2d_resample(x, w, f=None, down=1, padding=0):
-    """The down-only branches of conv2d_resample (flip_weight=True: correlation), conv2d_resample.py:57-155."""
+def conv2d_resample(x, w, f=None, down=1, padding=0, up=1, flip_weight=True):
+    """conv2d_resample.py:57-155.  Down only: the branches the discriminator takes (1x1: decimate then convolve; 3x3: blur then strided
+    conv).  With up > 1: the DEFINITION the reference states as its generic path (:151-155) -- zero-insert upsampling through the
+    low-pass filter (gain up^2), the convolution (true convolution when flip_weight is False, as Conv2dLayer asks for up > 1,
+    layers.py:156), decimation -- not the transposed-convolution decomposition the reference (and the product) actually execute:
+    the golden C1 pins that the two agree."""
     kh, kw = int(w.shape[2]), int(w.shape[3])
     fw = int(f.shape[-1]) if f is not None else 1
     px0 = px1 = py0 = py1 = int(padding)
+    if up > 1:
+        px0 += (fw + up - 1) // 2
+        px1 += (fw - up) // 2
+        py0 += (fw + up - 1) // 2
+        py1 += (fw - up) // 2
+        if down > 1:
+            px0 += (fw - down + 1) // 2
+            px1 += (fw - down) // 2
+            py0 += (fw - down + 1) // 2
+            py1 += (fw - down) // 2
+        x = ops.upfirdn2d(x, f, up=up, padding=[px0, px1, py0, py1], gain=up ** 2)
+        x = F.conv2d(x, w if flip_weight else w.flip([2, 3]))
+        return ops.upfirdn2d(x, f, down=down) if down > 1 else x
     if down > 1:
         px0 += (fw - down + 1) // 2
         px1 += (fw - down) // 2
@@ -43,11 +60,11 @@ def conv2d_resample(x, w, f=None, down=1, padding=0):
     return F.conv2d(x, w, padding=px0)
 
 
-def conv2d_layer(sd, prefix, x, kernel_size, act='linear', down=1, gain=1.0, conv_clamp=None, filt=None):
+def conv2d_layer(sd, prefix, x, kernel_size, act='linear', down=1, gain=1.0, conv_clamp=None, filt=None, up=1):
     w = sd[prefix + 'weight']
     w = w * (1.0 / np.sqrt(w.shape[1] * kernel_size ** 2))                    # layers.py:137,154
     b = sd.get(prefix + 'bias')
-    x = conv2d_resample(x, w, f=filt, down=down, padding=kernel_size // 2)
+    x = conv2d_resample(x, w, f=filt, down=down, padding=kernel_size // 2, up=up, flip_weight=(up == 1))
     act_gain = ops.ACTIVATIONS[act][2] * gain
     act_clamp = conv_clamp * gain if conv_clamp is not None else None
     return ops.bias_act(x, b, act=act, gain=act_gain, clamp=act_clamp)

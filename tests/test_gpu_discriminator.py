@@ -78,6 +78,31 @@ def test_discriminator_full_width_state_dict_and_step():
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in D.parameters())
 
 
+@pytest.mark.parametrize('mfma_conv', [True, False])
+def test_resampling_conv2dlayer_matches_reference_golden(mfma_conv, monkeypatch):
+    """The generator-side Conv2dLayer (afcm_amd/networks_stylegan3.py; CoModGAN/layers.py:115-162) with up / down != 1 -- every branch
+    of conv2d_resample -- vs vectors captured from the reference layer: output and the three gradients."""
+    from afcm_amd.networks_stylegan3 import Conv2dLayer
+    from afcm_amd.torch_utils.ops import conv2d_resample
+    monkeypatch.setattr(conv2d_resample, 'USE_MFMA_CONV', mfma_conv)
+    monkeypatch.setattr(conv2d_resample, 'MFMA_CONV_FP32', mfma_conv)
+    g = load_golden('C1_conv2dlayer_resample')
+    for n, (k, up, down) in enumerate(g['cases']):
+        k, up, down = int(k), int(up), int(down)
+        layer = Conv2dLayer(3, 5, kernel_size=k, up=up, down=down, activation='lrelu', conv_clamp=(2.0 if n == 0 else None))
+        layer.load_state_dict({'weight': torch.from_numpy(g[f'{n}/w']), 'bias': torch.from_numpy(g[f'{n}/b']),
+                               'resample_filter': layer.resample_filter}, strict=True)
+        layer = layer.cuda()
+        x = torch.from_numpy(g[f'{n}/x']).cuda().requires_grad_(True)
+        y = layer(x, gain=0.7)
+        assert tuple(y.shape) == g[f'{n}/y'].shape, (k, up, down)
+        assert np.abs(y.detach().cpu().numpy() - g[f'{n}/y']).max() <= 2e-5, (k, up, down)
+        gx, gw, gb = torch.autograd.grad((y * torch.from_numpy(g[f'{n}/r']).cuda()).sum(), [x, layer.weight, layer.bias])
+        for got, key in ((gx, 'gx'), (gw, 'gw'), (gb, 'gb')):
+            want = g[f'{n}/{key}']
+            assert np.abs(got.cpu().numpy() - want).max() <= 1e-4 * max(1.0, float(np.abs(want).max())), (k, up, down, key)
+
+
 def test_conditional_discriminator_full_width():
     """The ADNI / in-house configurations' discriminator (configs/adni/stylegan3/cmsr.yml:11-16: c_dim = 1, mbstd_group_size 16): the
     label mapping network adds 8 FC layers of 512 + the embedding; one conditioned loss evaluation with R1 runs and every

@@ -195,6 +195,27 @@ def test_discriminator_oracle_matches_reference(name):
     assert np.abs(gi.numpy() - g['g_img']).max() <= 1e-5 * max(1e-3, float(np.abs(g['g_img']).max()))
 
 
+def test_resampling_conv2dlayer_oracle_matches_reference():
+    """The reference's Conv2dLayer with up / down (CoModGAN/layers.py:115-162) for every branch of conv2d_resample, vs the oracle --
+    which computes the up cases from the definition (zero-insert upsample -> filter -> convolution), not from the reference's
+    transposed-convolution decomposition."""
+    import torch
+    from oracle import discriminator as od
+    g = load_golden('C1_conv2dlayer_resample')
+    filt = od.setup_filter([1, 3, 3, 1])
+    for n, (k, up, down) in enumerate(g['cases']):
+        k, up, down = int(k), int(up), int(down)
+        sd = {'weight': torch.from_numpy(g[f'{n}/w']).requires_grad_(True), 'bias': torch.from_numpy(g[f'{n}/b']).requires_grad_(True)}
+        x = torch.from_numpy(g[f'{n}/x']).requires_grad_(True)
+        y = od.conv2d_layer(sd, '', x, k, act='lrelu', down=down, up=up, gain=0.7, conv_clamp=(2.0 if n == 0 else None), filt=filt)
+        assert y.shape == g[f'{n}/y'].shape, (k, up, down)
+        assert np.abs(y.detach().numpy() - g[f'{n}/y']).max() <= 1e-5, (k, up, down)
+        gx, gw, gb = torch.autograd.grad((y * torch.from_numpy(g[f'{n}/r'])).sum(), [x, sd['weight'], sd['bias']])
+        for got, key in ((gx, 'gx'), (gw, 'gw'), (gb, 'gb')):
+            want = g[f'{n}/{key}']
+            assert np.abs(got.numpy() - want).max() <= 1e-5 * max(1.0, float(np.abs(want).max())), (k, up, down, key)
+
+
 def test_filtered_lrelu_branch_override_is_self_consistent():
     """oracle.aten_ops.filtered_lrelu(codes=...) with the oracle's OWN branch decisions reproduces value and gradient of the plain
     call (the instrumentation the GPU gradient-attribution test relies on)."""
