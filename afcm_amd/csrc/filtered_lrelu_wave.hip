@@ -427,12 +427,6 @@ __global__ __launch_bounds__(256, (DOWN == 2 && (TOH <= 32 || SIGN == AFCM_SIGNS
 #pragma unroll
         for (int nbl = 0; nbl < G::NBG; nbl++) {
             const int nb = gi * G::NBG + nbl;
-            // READ: the next column block's sign dwords (sg[0] holds block nb0 on entry, loaded by the previous group; block nb1
-            // goes to sg[1] while nb0 runs, the next group's nb0 back to sg[0] while nb1 runs)
-            if (SIGN == AFCM_SIGNS_READ) {
-                if (nbl == 0) load_signs(nb + 1, sg[1]);
-                else if (gi + 1 < ng) load_signs(nb + 1, sg[0]);
-            }
             // up-x: X1[mb] = In[mb] * UH, packed in pairs as the B operand of up-y / the A operand of the composite operator
             f32x4 x1[G::NMB];
 #pragma unroll
@@ -465,6 +459,17 @@ __global__ __launch_bounds__(256, (DOWN == 2 && (TOH <= 32 || SIGN == AFCM_SIGNS
                             codes[4 * k + j] = __builtin_amdgcn_ubfe(two, 2 * yy, 8);
                         }
                     }
+                }
+                // Both register sets are free once the second block's codes are out: request the NEXT group's two blocks here.
+                // Loads return in order, so what matters is what a request queues behind and how far away its use is: requested at
+                // the top of a group (behind the input window's HBM round trip) with their use half a group away, the codes arrived
+                // late at every block -- the transposed kernels waited 42 % of their time on memory against 23 % in the forward
+                // kernels.  From here the first block has half a group, the second a whole one: backward pass over the generator's
+                // layers 5.45 -> 5.14 ms.  (Each block re-requested right after its own extraction, a whole group ahead for both:
+                // 5.76 ms.)
+                if (nbl == G::NBG - 1 && gi + 1 < ng) {
+                    load_signs(nb + 1, sg[0]);
+                    load_signs(nb + 2, sg[1]);
                 }
             }
             // WRITE: this block's descriptor: rows below the plane / not owned and blocks beyond the tensor fall outside it and
@@ -595,7 +600,10 @@ __global__ __launch_bounds__(256, (DOWN == 2 && (TOH <= 32 || SIGN == AFCM_SIGNS
         frag a0[G::NMB], a1[G::NMB];
         unsigned sg[G::NBG][2][NA + 1];
         load_group(0, a0);
-        if (SIGN == AFCM_SIGNS_READ) load_signs(0, sg[0]);
+        if (SIGN == AFCM_SIGNS_READ) {
+            load_signs(0, sg[0]);
+            load_signs(1, sg[1]);
+        }
         u32x4 hist[G::NOB][G::NHIST], cur[G::NOB];
 #pragma unroll
         for (int ob = 0; ob < G::NOB; ob++)
