@@ -345,7 +345,19 @@ __global__ __launch_bounds__(256, (DOWN == 2 && (TOH <= 32 || SIGN == AFCM_SIGNS
 
     // down-x of output column block cb, transposed: Y'[ocol][orow] = DH2 * X3'; a lane holds 4 consecutive output columns of
     // one row.  xw[t] = the X3 pairs of its K windows.  The packed result goes to the staging buffer.
-    auto phase_b = [&](int cb, const u32x4 (&xw)[G::NOB][G::NDVK]) __attribute__((always_inline)) {
+    // encoder feature of output column block cb in the access lane map (columns / rows outside the plane read as zero): requested
+    // at the top of the group whose down-x pass consumes it -- fetched in place, every column block waited a full memory round trip
+    // (the skip kernels sat in memory waits for 46 % of their residency, the plain ones 23 %)
+    auto load_skip = [&](int cb, unsigned (&sk)[G::NOB][2]) __attribute__((always_inline)) {
+        const int ox = 16 * cb + 4 * lchk;
+#pragma unroll
+        for (int ob = 0; ob < G::NOB; ob++) {
+            const unsigned off = (unsigned)(koff0 + ob * krow16 + 32 * cb);
+            sk[ob][0] = __builtin_amdgcn_raw_buffer_load_b32(rsk, (ox + 2 <= p.yw) ? off : kOut, 0, 0);
+            sk[ob][1] = __builtin_amdgcn_raw_buffer_load_b32(rsk, (ox + 4 <= p.yw) ? off + 4u : kOut, 0, 0);
+        }
+    };
+    auto phase_b = [&](int cb, const u32x4 (&xw)[G::NOB][G::NDVK], const unsigned (&sk)[G::NOB][2]) __attribute__((always_inline)) {
         const int slot = cb & 3;
 #pragma unroll
         for (int ob = 0; ob < G::NOB; ob++) {
@@ -353,15 +365,10 @@ __global__ __launch_bounds__(256, (DOWN == 2 && (TOH <= 32 || SIGN == AFCM_SIGNS
 #pragma unroll
             for (int t = 0; t < G::NDVK; t++) acc = M::mma(dh[t], as_frag<frag>(xw[ob][t]), acc);
             if (EPI & 2) {
-                // encoder feature of this lane's 4 columns (x + x_skip, NET:376-377), fetched in the access lane map (columns /
-                // rows outside the plane read as zero), moved to the fragment map
-                const int ox = 16 * cb + 4 * lchk;
-                const unsigned off = (unsigned)(koff0 + ob * krow16 + 32 * cb);
+                // encoder feature of this lane's 4 columns (x + x_skip, NET:376-377): from the access lane map to the fragment map
                 union { unsigned u; T t[2]; } e0, e1;
-                e0.u = __builtin_amdgcn_raw_buffer_load_b32(rsk, (ox + 2 <= p.yw) ? off : kOut, 0, 0);
-                e1.u = __builtin_amdgcn_raw_buffer_load_b32(rsk, (ox + 4 <= p.yw) ? off + 4u : kOut, 0, 0);
-                e0.u = (unsigned)__builtin_amdgcn_ds_bpermute(to_frag, (int)e0.u);
-                e1.u = (unsigned)__builtin_amdgcn_ds_bpermute(to_frag, (int)e1.u);
+                e0.u = (unsigned)__builtin_amdgcn_ds_bpermute(to_frag, (int)sk[ob][0]);
+                e1.u = (unsigned)__builtin_amdgcn_ds_bpermute(to_frag, (int)sk[ob][1]);
                 acc[0] += to_f32(e0.t[0]);
                 acc[1] += to_f32(e0.t[1]);
                 acc[2] += to_f32(e1.t[0]);
@@ -423,6 +430,11 @@ __global__ __launch_bounds__(256, (DOWN == 2 && (TOH <= 32 || SIGN == AFCM_SIGNS
         constexpr int NVW = LASTY ? G::NVB : G::OWN_VB;                  // row blocks whose codes this strip writes
         // one group ahead, issued before this group's stores: vmcnt counts in order, so waiting for these loads at the top of
         // the next group does not wait for the (younger) stores
+        // the output column block whose last K window is this group's pair: pairs (DOWN / 2) cb ... + NDVK - 1 = gi
+        const bool has_b = gi >= G::NDVK - 1 && (gi - (G::NDVK - 1)) % (DOWN / 2) == 0;
+        const int cb_b = (gi - (G::NDVK - 1)) / (DOWN / 2);
+        unsigned sk[G::NOB][2] = {};
+        if ((EPI & 2) && has_b) load_skip(cb_b, sk);       // ahead of the window: used at the end of THIS group, the window in the next
         if (gi + 1 < ng) load_group(gi + 1, a_nxt);
 #pragma unroll
         for (int nbl = 0; nbl < G::NBG; nbl++) {
@@ -580,8 +592,7 @@ __global__ __launch_bounds__(256, (DOWN == 2 && (TOH <= 32 || SIGN == AFCM_SIGNS
                 cur[ob][2 * nbl + 1] = pack2<T>(x3[2], x3[3]);
             }
         }
-        // the output column block whose last K window is this pair: pairs (DOWN / 2) cb ... + NDVK - 1 = gi
-        if (gi >= G::NDVK - 1 && (gi - (G::NDVK - 1)) % (DOWN / 2) == 0) {
+        if (has_b) {
             u32x4 xw[G::NOB][G::NDVK];
 #pragma unroll
             for (int ob = 0; ob < G::NOB; ob++) {
@@ -589,7 +600,7 @@ __global__ __launch_bounds__(256, (DOWN == 2 && (TOH <= 32 || SIGN == AFCM_SIGNS
                 for (int h = 0; h < G::NHIST; h++) xw[ob][h] = hist[ob][h];
                 xw[ob][G::NDVK - 1] = cur[ob];
             }
-            phase_b((gi - (G::NDVK - 1)) / (DOWN / 2), xw);
+            phase_b(cb_b, xw, sk);
         }
     };
 
