@@ -97,13 +97,13 @@ def _mfma_workspace(a, fu_t, fd_t, x):
         a.fu, a.fd = fu_t.data_ptr(), fd_t.data_ptr()
         rc = _lib.check(lib.afcm_filtered_lrelu_prepare(a, _lib.stream_ptr(x)), 'filtered_lrelu_prepare')
         # keep the filters alive with the workspace: the key holds their addresses
-        _workspaces[key] = (ws, fu_t, fd_t) if rc == 0 else None
+        # (a negative entry pins its filters too: a recycled address must not inherit "no matrix-core kernel")
+        _workspaces[key] = (ws if rc == 0 else None, fu_t, fd_t)
         while len(_workspaces) > _WORKSPACE_CACHE_ENTRIES:
             _workspaces.popitem(last=False)       # the caching allocator keeps the block until queued kernels have run
     else:
         _workspaces.move_to_end(key)
-    ent = _workspaces[key]
-    return None if ent is None else ent[0]
+    return _workspaces[key][0]
 
 
 class NoFusedKernel(Exception):
