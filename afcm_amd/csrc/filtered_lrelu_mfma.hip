@@ -612,13 +612,16 @@ int launch_wave_tile(const afcm_filtered_lrelu_args* a, FlreluMfmaParams p, hipS
 template <typename T, int UP, int DOWN>
 int prepare_wave(const afcm_filtered_lrelu_args* a, hipStream_t st);
 
+constexpr int kWavePitchSlack = 128;        // elements a row pitch may exceed the plane width by (wave kernels)
 static bool wave_family(const afcm_filtered_lrelu_args* a) {
     static const char* e = getenv("AFCM_FLRELU_WAVE");          // tuning aid: 0 = LDS-tile kernels only
     if (e != nullptr && atoi(e) == 0) return false;
     if (a->sign_mode == AFCM_SIGNS_READ) return a->sign_layout == 2;
-    // no bias operand; offsets + out-of-range markers stay below 2^31
-    return a->b == nullptr && (long long)a->xh * (a->x_pitch ? a->x_pitch : a->xw) < (1ll << 28) &&
-           (long long)a->yh * (a->y_pitch ? a->y_pitch : a->yw) < (1ll << 28);
+    // no bias operand; offsets + out-of-range markers stay below 2^31.  Decided on the plane sizes plus the largest pitch overhead
+    // launch_wave() accepts -- NOT on the pitches themselves: afcm_filtered_lrelu_shapes() runs before the caller has chosen them,
+    // and the sign layout / strip geometry it reports must be the one the launch uses.
+    return a->b == nullptr && (long long)a->xh * (a->xw + kWavePitchSlack) < (1ll << 28) &&
+           (long long)a->yh * (a->yw + kWavePitchSlack) < (1ll << 28);
 }
 
 // Output rows per strip of the wave kernels: 32; one 48-row strip for the 36^2 / 38^2 planes (up 2 / down 2).  (Measured and
@@ -694,6 +697,11 @@ static int launch_mfma_tile(const afcm_filtered_lrelu_args* a, hipStream_t st) {
 template <typename T, int UP, int DOWN>
 static int launch_wave(const afcm_filtered_lrelu_args* a, hipStream_t st) {
     AFCM_REQUIRE(a->b == nullptr, "filtered_lrelu: sign layout 2 (wave kernels) takes no bias operand");
+    AFCM_REQUIRE(a->x_pitch == 0 || (a->x_pitch >= a->xw && a->x_pitch <= a->xw + kWavePitchSlack), "filtered_lrelu: x_pitch %d outside [xw, xw + %d]", a->x_pitch, kWavePitchSlack);
+    AFCM_REQUIRE(a->skip_pitch == 0 || (a->skip_pitch >= a->yw && a->skip_pitch <= a->yw + kWavePitchSlack), "filtered_lrelu: skip_pitch %d outside [yw, yw + %d]", a->skip_pitch, kWavePitchSlack);
+    // a pitched y is written in whole 64-column groups: the kernel covers columns < 64 * ceil(yw / 64) only, so a larger pitch would
+    // leave uninitialised padding behind (the layout's contract is finite padding, include/afcm_hip.h)
+    AFCM_REQUIRE(a->y_pitch == 0 || (a->y_pitch >= a->yw && a->y_pitch <= cdiv(a->yw, 64) * 64), "filtered_lrelu: y_pitch %d outside [yw, 64 * ceil(yw / 64) = %d]", a->y_pitch, cdiv(a->yw, 64) * 64);
     const int toh = wave_toh(UP, DOWN, a->yh);
     FlreluMfmaParams p;
     const int rc = fill_params(a, p, 1, cdiv(a->yh, toh));

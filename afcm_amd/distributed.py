@@ -21,7 +21,12 @@ once every one of its gradients is final, so:
   parameter has been accumulated k times;
 * an accumulation that arrives after its bucket was launched anyway (undeclared extra pass) never
   touches the buffer of a collective in flight: the bucket is marked and ``finish*()`` reduces it again
-  from the final ``.grad`` values -- slower (one more collective, a warning says so) but never wrong.
+  from the final ``.grad`` values -- slower (one more collective, a warning says so).  Which buckets are reduced
+  again is decided GLOBALLY when ``static_graph=False`` (the marks ride in the flag vector that is sum-reduced
+  and read on the host anyway: a bucket marked on any rank is repeated on every rank).  With ``static_graph=True``
+  there is no host read in steady state, so the decision is per rank and the extra passes must be the same on
+  every rank (same program, no data-dependent extra ``backward()``): a rank-dependent extra pass would issue
+  a collective its peers do not.
 
 Collectives are always issued in bucket order (a ready bucket waits for its predecessors), so the call
 sequence is the same on every rank whatever order the hooks fire in.  The first iteration fills the buckets
@@ -73,9 +78,14 @@ class GradientBuckets:
         if self.active:
             for p in self.params:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
-            self._flags = torch.zeros(len(self._order), dtype=torch.float32, device=self.params[0].device)
-            self._flags_local = torch.zeros_like(self._flags)
-            self._local = None
+            self._alloc_flags()
+
+    def _alloc_flags(self):
+        # one flag per parameter ("this rank produced a gradient") followed by one per bucket ("this rank wants the bucket reduced again")
+        n = len(self._order) + len(self._buckets)
+        self._flags = torch.zeros(n, dtype=torch.float32, device=self.params[0].device)
+        self._flags_local = torch.zeros_like(self._flags)
+        self._local = None
 
     def _build(self, ordered):
         self._buckets = []          # dicts: params, flat, comm, offs, count, pending, launched, handle, redo
@@ -152,7 +162,7 @@ class GradientBuckets:
         self._build(ordered)
         self._used = None           # the mask follows the bucket order: resolve it again
         self._flag_check = None
-        self._local = None
+        self._alloc_flags()
         self._next = 0
 
     def _on_grad(self, p):
@@ -219,12 +229,10 @@ class GradientBuckets:
             self._fill_from_grads(b, everything=False)
             self._launch(b)
         self._next = len(self._buckets)
-        for b in self._buckets:
-            if b['redo']:
-                b['handle'].wait()
-                self._fill_from_grads(b, everything=True)
-                self._launch(b)
-        local = [p.grad is not None for p in self._order]
+        global_redo = not self.static_graph         # the flags are read on the host every iteration anyway: decide there, for all ranks
+        if not global_redo:
+            self._redo_marked([b['redo'] for b in self._buckets])
+        local = [p.grad is not None for p in self._order] + [bool(b['redo']) and global_redo for b in self._buckets]
         if local != self._local:
             # upload only when this rank's pattern changes (pinned + non-blocking: no host stall behind the queued backward)
             self._local = local
@@ -235,6 +243,9 @@ class GradientBuckets:
             self._flags_local.copy_(host, non_blocking=True)
         self._flags.copy_(self._flags_local)
         fh = dist.all_reduce(self._flags, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        if global_redo:
+            fh.wait()
+            self._redo_marked((self._flags[len(self._order):] > 0).cpu().tolist())
         for b in self._buckets:
             b['handle'].wait()
             if b['comm'] is not None:
@@ -246,16 +257,24 @@ class GradientBuckets:
         self._next = 0
         self._pending_rebuild = self._rebucket
 
+    def _redo_marked(self, marks):
+        for b, m in zip(self._buckets, marks):
+            if m:
+                b['handle'].wait()
+                self._fill_from_grads(b, everything=True)
+                self._launch(b)
+
     def _resolve_used(self):
+        npar = len(self._order)
         if self._used is None or not self.static_graph:
-            self._used = (self._flags > 0).cpu().tolist()          # host sync: first iteration (or every one without static_graph)
+            self._used = (self._flags[:npar] > 0).cpu().tolist()   # host sync: first iteration (or every one without static_graph)
             return
         # steady state: verify the PREVIOUS iteration's flags (their copy finished long ago) and queue this iteration's
         if self._flag_check is not None:
             host, ev = self._flag_check
             if ev is not None:
                 ev.synchronize()
-            seen = (host > 0).tolist()
+            seen = (host[:npar] > 0).tolist()
             if seen != self._used:
                 warnings.warn('GradientBuckets: the set of parameters receiving gradients changed between iterations; the new set '
                               'applies from this iteration on (construct with static_graph=False to follow it exactly).', RuntimeWarning)
@@ -271,7 +290,9 @@ class GradientBuckets:
 
     def finish(self):
         """Wait for the collectives, average, and put the reduced values into .grad (on every rank, also where this rank had
-        produced none).  Parameters for which no rank produced a gradient keep .grad = None."""
+        produced none).  Parameters outside the used set get .grad = None on EVERY rank: with static_graph=True the set is
+        the previous iteration's (corrected one iteration late), and a rank that kept its local, un-reduced gradient for a
+        newly used parameter would let a stock optimizer update it on that rank only."""
         if not self.active:
             return
         self._complete()
@@ -285,6 +306,8 @@ class GradientBuckets:
                         p.grad = red.clone()
                     else:
                         p.grad.copy_(red)
+                else:
+                    p.grad = None
                 i += 1
 
     def finish_flat(self):

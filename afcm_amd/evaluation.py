@@ -1,10 +1,13 @@
 """Image-quality metrics of the reference's validation loop: util/evaluation.py on numpy arrays.
 
 The reference delegates to scikit-image (``skimage.metrics.peak_signal_noise_ratio`` / ``structural_similarity``,
-util/evaluation.py:3-4), an un-pinned dependency that is absent from this image; the two functions are restated here from
-their published definitions (Wang et al. 2004 for SSIM with scikit-image's defaults: 7-wide uniform window, K1 = 0.01,
-K2 = 0.03, sample covariance, border of (win - 1) // 2 cropped before the mean).  PARITY UNPINNED against scikit-image
-itself -- tests pin the restatement to brute-force window loops and closed forms only.
+util/evaluation.py:3-4), which the reference pins to scikit-image 0.19.3 (requirements.txt:3) and which is absent from this
+image; the two functions are restated here from their published definitions (Wang et al. 2004 for SSIM with scikit-image's
+defaults: 7-wide uniform window, K1 = 0.01, K2 = 0.03, sample covariance, border of (win - 1) // 2 cropped before the mean).
+PARITY UNPINNED against scikit-image itself (the package cannot be imported here and the reference holds no metric fixtures) --
+tests pin the restatement to brute-force window loops and closed forms only.  Known numerical difference: scikit-image 0.19
+keeps float32 images in float32 (``_supported_float_type``) where this restatement computes in float64 -- ~1e-6 dB of PSNR on
+the reference's float32 inputs, far below the 0.05 dB bound the north star states.
 
 Callers (train.py:86-99): images mapped to [0, 1] by (x + 1) / 2 and clipped, then ``evaluate_2D``.
 """

@@ -77,12 +77,15 @@ def scale_planes(x, scale, out_dtype=None):
 def plane_dot(a, b=None):
     """[N, C] fp32: sum over H, W of a * b (b None: plain sum).  Row-pitched operands (_rows.py) are read in place."""
     lib = _lib.load()
-    if not (a.is_contiguous() and (b is None or b.is_contiguous())) and a.shape[3] * a.element_size() >= 16:
-        a, lda = _rows.rows(a)
-        ldb = 0
-        if b is not None:
-            assert b.shape == a.shape and b.dtype == a.dtype
-            b, ldb = _rows.rows(b)
+    if b is not None:
+        assert b.shape == a.shape and b.dtype == a.dtype
+    lda = _rows.pitch_of(a)
+    ldb = _rows.pitch_of(b) if b is not None else 0
+    # the pitched kernel's preconditions (afcm_plane_dot_ld): both operands dense or row-pitched AS THEY ARE (pitch_of also checks
+    # the 4-byte base alignment and an even pitch), an even width for 2-byte elements, rows of at least 16 bytes.  Anything else --
+    # an expanded stride-0 gradient, an odd-width plane, a view at an odd element offset -- takes the dense kernel on a copy.
+    if (not (a.is_contiguous() and (b is None or b.is_contiguous())) and lda is not None and ldb is not None
+            and a.shape[3] * a.element_size() >= 16 and (a.element_size() == 4 or a.shape[3] % 2 == 0)):
         n, c, h, w = a.shape
         out = torch.empty([n, c], dtype=torch.float32, device=a.device)
         _lib.check(lib.afcm_plane_dot_ld(out.data_ptr(), a.data_ptr(), _lib.ptr(b), _lib.dtype_code(a), n * c, h, w, lda, ldb, _lib.stream_ptr(a)),

@@ -36,7 +36,7 @@ class _ConvFilteredLRelu(torch.autograd.Function):
             (wp, rows_pad), ctx.wpt = _conv.pack_weights_both(w, x.dtype)      # the backward's weight image from the same launch
         else:
             wp, rows_pad = _conv.pack_weights(w, x.dtype, 0)
-        # y, z (and dys, dx in backward) are row-pitched: rows on 128-byte lines, read and written in place by the kernels of this
+        # y, z (and dys, dx in backward) are row-pitched: rows on 64-byte boundaries (_rows.pitch_for), read and written in place by the kernels of this
         # node and of its neighbours (_rows.py)
         y = _conv._conv_raw(xs, wp, rows_pad, out_scale, cout, ks, conv_pad, obias=bias, pitched_out=True)
         need_grad = any(ctx.needs_input_grad[:5]) or ctx.needs_input_grad[7] or ctx.needs_input_grad[8]

@@ -3,6 +3,7 @@
 
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+    python bench.py --gpus N ...      (no launcher: starts that same torch.distributed.run command itself, as a child process)
 
 One step = one generator training step of the `--model stylegan3` path on one batch of synthetic MR-like slices:
 mapping + encoder + co-modulated decoder forward (HIP filtered_lrelu / bias_act / MFMA convs), lambda_L1 * L1 loss,
@@ -112,11 +113,30 @@ def run_cpu_baseline(res, budget=(120, 200)):
                 points=points)
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start `python -m torch.distributed.run --nproc-per-node N bench.py <same
+    arguments>` as a CHILD process -- this parent has made no GPU call (torch is not even imported yet) and only relays the child's
+    output and exit code; rank 0's JSON line is the last line the child prints to stdout."""
+    import socket
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or n) // n)))
+    print(f'bench.py: --gpus {n} without a launcher, starting: {" ".join(cmd)}', file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env, cwd=os.getcwd())
+
+
 def main():
     args = parse()
     if args.cpu_baseline_worker:
         cpu_baseline_worker(args.res)
         return
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(self_launch(args.gpus))
     import torch
     import torch.distributed as dist
     from afcm_amd import layer_schedule as sched
@@ -128,14 +148,16 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', 1))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit(f'--gpus {args.gpus} needs a torch.distributed.run launch with {args.gpus} ranks (see the module docstring)')
         raise SystemExit(f'--gpus {args.gpus} does not match WORLD_SIZE {world}')
     # rehearsal aid for a one-GPU box: AFCM_BENCH_REHEARSE=1 puts every rank on device 0 and exchanges through gloo (RCCL refuses
     # two ranks on one device) -- exercises the multi-process path (broadcast, bucket hooks, reduced-gradient Adam), not a benchmark
     rehearse = os.environ.get('AFCM_BENCH_REHEARSE') == '1'
     if rehearse:
         local_rank = 0
+    have = torch.cuda.device_count()
+    if local_rank >= have:
+        raise SystemExit(f'bench.py rank {rank}: --gpus {args.gpus} needs {args.gpus} devices, this host shows {have} '
+                         f'(AFCM_BENCH_REHEARSE=1 puts every rank on device 0 over gloo: a path check, not a benchmark)')
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     use_dist = world > 1 or args.force_dist
@@ -238,11 +260,19 @@ def main():
                                     ms_per_step=d['total_ms'] / max(1, timed_with_events))
         dominant = max(kernels, key=lambda k: kernels[k]['total_ms']) if kernels else None
         roofline = dict(kernels[dominant], kernel=dominant) if dominant else None
-        # HBM traffic from rocprofv3 PMC passes of this same command, when a summary has been committed
+        # HBM traffic: NOT measured in this run -- bytes per launch from the committed rocprofv3 PMC passes of this same command
+        # (tools/pmc_traffic.sh -> profiles/pmc_traffic.json, which names the build it was taken on); said so in `traffic_source`
         tpath = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
-        if roofline and os.path.exists(tpath):
+        if os.path.exists(tpath):
             try:
-                roofline['traffic'] = json.load(open(tpath)).get(dominant)
+                t = json.load(open(tpath))
+                src = f'profiles/pmc_traffic.json ({t.get("_source", "rocprofv3 --pmc passes of bench.py")}), not measured in this run'
+                for fam, d in kernels.items():
+                    d['traffic'] = t.get(fam)
+                    d['traffic_source'] = src if t.get(fam) is not None else None
+                if roofline:
+                    roofline['traffic'] = t.get(dominant)
+                    roofline['traffic_source'] = src if t.get(dominant) is not None else None
             except Exception:
                 pass
         cpu = run_cpu_baseline(args.res) if (world == 1 and args.cpu_baseline == 'auto') else None

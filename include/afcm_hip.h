@@ -97,9 +97,11 @@ typedef struct afcm_filtered_lrelu_args {
     int32_t x_pitch, y_pitch, skip_pitch;
                             /* row pitch of x / y / skip in ELEMENTS; 0 = dense (pitch = width).  A pitched tensor is
                                [N, C, H, pitch] in memory with the first W columns of every row meaningful (MI355X layout of the
-                               16-bit activation stream: rows start on 128-byte lines).  Only the kernels
-                               for which afcm_filtered_lrelu_shapes() reports row_pitch_ok take a pitch; with y_pitch set they
-                               write EVERY column of y up to the pitch (finite values; columns >= yw are padding).            */
+                               16-bit activation stream: rows start on 64-byte boundaries).  Only the
+                               kernels for which afcm_filtered_lrelu_shapes() reports row_pitch_ok take a pitch; they accept
+                               x_pitch / skip_pitch up to width + 128 and y_pitch up to 64 * ceil(yw / 64) (AFCM_E_INVALID beyond),
+                               and with y_pitch set they write finite values to every column of y up to the pitch (columns
+                               >= yw are padding).                                                                              */
     int32_t row_pitch_ok;   /* set by afcm_filtered_lrelu_shapes(): 1 if the kernel selected for these arguments accepts pitches */
 } afcm_filtered_lrelu_args;
 
@@ -182,9 +184,10 @@ int afcm_conv2d_pack_weights2(void* dst_fwd, void* dst_dgrad, const float* w, in
 int afcm_conv2d(void* y, const void* x, const void* wpacked, const float* oscale, const float* obias, int32_t dtype, int32_t n,
                 int32_t cin, int32_t cout, int32_t h, int32_t w, int32_t ks, int32_t pad, int32_t rows_pad, void* stream);
 /* The same with row-pitched activations (x: [N, cin, h, x_pitch], y: [N, cout, P, y_pitch] in memory, the first w / Q columns of
- * a row meaningful; 0 = dense).  MI355X layout of the 16-bit activation stream: rows start on 128-byte lines.
- * Pitches are taken by the 16-bit 3x3 kernel only.  Columns >= w of x are never used; columns >= Q of y are padding (the
- * kernel may write the tail of a row's last 8-pixel granule there). */
+ * a row meaningful; 0 = dense).  MI355X layout of the 16-bit activation stream: rows start on 64-byte boundaries.
+ * Pitches are taken by the 16-bit 3x3 kernel only.  Columns >= w of x are never used; columns >= Q of y are padding: the kernel
+ * writes finite values up to the next multiple of 8 past Q (the tail of a row's last 8-pixel granule) and leaves the rest of the
+ * padding UNWRITTEN. */
 int afcm_conv2d_ld(void* y, const void* x, const void* wpacked, const float* oscale, const float* obias, int32_t dtype, int32_t n,
                    int32_t cin, int32_t cout, int32_t h, int32_t w, int32_t ks, int32_t pad, int32_t rows_pad, int32_t x_pitch,
                    int32_t y_pitch, void* stream);
@@ -195,8 +198,8 @@ int afcm_conv2d_wgrad_splits(int32_t n, int32_t cout, int32_t cin, int32_t p_row
 int afcm_conv2d_wgrad(float* dw, float* workspace, const void* dy, const void* x, int32_t dtype, int32_t n, int32_t cin,
                       int32_t cout, int32_t h, int32_t w, int32_t ks, int32_t pad, void* stream);
 /* The same with row-pitched operands (0 = dense); 16-bit, 3x3 pad 2 or 1x1 pad 0 only.  Columns >= w of x are never used; of dy,
- * the columns up to the next multiple of 8 past Q must hold FINITE values (they multiply zeros; every kernel of this library that
- * writes a pitched tensor fills the whole pitch with finite values). */
+ * the columns up to the next multiple of 8 past Q must hold FINITE values (they multiply zeros): afcm_conv2d_ld writes exactly those
+ * columns, afcm_filtered_lrelu writes the whole pitch. */
 int afcm_conv2d_wgrad_ld(float* dw, float* workspace, const void* dy, const void* x, int32_t dtype, int32_t n, int32_t cin,
                          int32_t cout, int32_t h, int32_t w, int32_t ks, int32_t pad, int32_t dy_pitch, int32_t x_pitch, void* stream);
 

@@ -279,3 +279,83 @@ def test_buckets_are_rebuilt_in_gradient_arrival_order(tmp_path):
     r1 = torch.load(tmp_path / 'r1.pt')
     for a, b in zip(r['grads'], r1['grads']):
         assert torch.equal(a, b)
+
+
+def _worker_asymmetric(rank, world, port, out_dir):
+    _init(rank, world, port)
+    from afcm_amd.distributed import GradientBuckets
+    m = _model().double()
+    buckets = GradientBuckets(m.parameters(), bucket_bytes=2048, static_graph=False)
+    buckets.broadcast_parameters(m)
+    torch.manual_seed(7)
+    xf, xr = torch.randn(8, 16, dtype=torch.float64), torch.randn(8, 16, dtype=torch.float64)
+    sl = slice(rank * 4, (rank + 1) * 4)
+    for it in range(3):
+        for p in m.parameters():
+            p.grad = None
+        a, b = _d_losses(m, xf[sl], xr[sl])
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            if rank == 0:           # undeclared second pass on rank 0 only; rank 1 back-propagates the sum in one pass
+                a.backward()
+                b.backward()
+            else:
+                (a + b).backward()
+            buckets.finish()
+    torch.save({n: p.grad.clone() for n, p in m.named_parameters()}, os.path.join(out_dir, f'g{rank}.pt'))
+    dist.destroy_process_group()
+
+
+def test_rank_dependent_extra_pass_is_settled_globally_without_static_graph(tmp_path):
+    """the decision to reduce a bucket again must be the same on every rank.  With static_graph=False the marks ride in
+    the flag vector: rank 0's undeclared second backward makes BOTH ranks repeat the bucket (a per-rank decision would issue a
+    collective the peer does not -- a hang or a size mismatch)."""
+    world = 2
+    mp.spawn(_worker_asymmetric, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    m = _model().double()
+    torch.manual_seed(7)
+    xf, xr = torch.randn(8, 16, dtype=torch.float64), torch.randn(8, 16, dtype=torch.float64)
+    a, b = _d_losses(m, xf, xr)
+    (a + b).backward()
+    for r in range(world):
+        g = torch.load(tmp_path / f'g{r}.pt')
+        for n, p in m.named_parameters():
+            assert (g[n] - p.grad).abs().max().item() <= 1e-12 * max(1.0, p.grad.abs().max().item()), (r, n)
+
+
+def _worker_newly_used(rank, world, port, out_dir):
+    _init(rank, world, port)
+    from afcm_amd.distributed import GradientBuckets
+    m = _model()
+    buckets = GradientBuckets(m.parameters(), bucket_bytes=4096, static_graph=True)
+    buckets.broadcast_parameters(m)
+    torch.manual_seed(5)
+    x, y = torch.randn(8, 16), torch.randn(8, 4)
+    xs, ys = x[rank * 4:(rank + 1) * 4], y[rank * 4:(rank + 1) * 4]
+    state = []
+    for it in range(4):
+        for p in m.parameters():
+            p.grad = None
+        # iterations 0, 1: the last layer is unused everywhere; from iteration 2 on rank 0 uses it
+        out = m(xs) if (rank == 0 and it >= 2) else m[:5](xs)
+        (out - ys).abs().mean().backward()
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            buckets.finish()
+        state.append(None if m[5].weight.grad is None else m[5].weight.grad.clone())
+    torch.save(state, os.path.join(out_dir, f's{rank}.pt'))
+    dist.destroy_process_group()
+
+
+def test_finish_never_leaves_an_unreduced_gradient_on_one_rank(tmp_path):
+    """with static_graph=True the used-parameter mask lags one iteration.  In the iteration where a parameter first
+    receives a gradient on ONE rank, finish() must clear it there too (every rank skips the same set); once the mask has caught up
+    every rank holds the same reduced gradient."""
+    world = 2
+    mp.spawn(_worker_newly_used, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    s0, s1 = torch.load(tmp_path / 's0.pt'), torch.load(tmp_path / 's1.pt')
+    for it in range(4):
+        assert (s0[it] is None) == (s1[it] is None), it           # never a gradient on one rank only
+        if s0[it] is not None:
+            assert torch.equal(s0[it], s1[it])
+    assert s0[0] is None and s0[1] is None and s0[3] is not None

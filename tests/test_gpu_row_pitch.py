@@ -120,6 +120,26 @@ def test_plane_dot_pitched(h, w, dtype):
     assert _rows.pitch_of(sp) == ld and torch.isfinite(sp.float()).all()
 
 
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32])
+def test_plane_dot_operands_outside_the_pitched_kernels_preconditions(dtype):
+    """an expanded (stride-0) operand, an odd-width 16-bit plane behind a pitch, and a dense operand at an odd element
+    offset next to a pitched one must fall through to the dense kernel (on a copy), not raise from afcm_plane_dot_ld."""
+    from afcm_amd.torch_utils.ops import conv2d as conv
+    torch.manual_seed(11)
+    for (h, w) in [(9, 21), (12, 24)]:
+        a = torch.randn(2, 3, h, w, device='cuda').to(dtype)
+        buf = torch.full([2, 3, h, 64], float('nan'), dtype=dtype, device='cuda')
+        buf[..., :w] = a
+        pa = buf[..., :w]
+        g = torch.randn(2, 3, 1, 1, device='cuda').to(dtype).expand(2, 3, h, w)             # stride-0 gradient
+        flat = torch.randn(2 * 3 * h * w + 1, device='cuda').to(dtype)
+        odd = flat[1:].view(2, 3, h, w)                                                      # contiguous, odd element offset
+        for x, y in [(pa, g), (g, pa), (pa, odd), (odd, pa), (g, None)]:
+            want = (x.double() * (y.double() if y is not None else 1.0)).sum(dim=(2, 3))
+            got = conv.plane_dot(x, y)
+            assert (got.double() - want).abs().max().item() <= 1e-4 * want.abs().max().item() + 1e-3, (h, w, dtype)
+
+
 def test_fused_layer_pitched_equals_dense(monkeypatch):
     """The fused layer node with the row-pitched layout on and off: same z, same gradients (bit-identical: the kernels do the same
     arithmetic in the same order, only the addresses differ)."""

@@ -1,6 +1,8 @@
 """CPU tests of the product's host-side logic (no GPU): layer schedule / filter design / padding vs the geometry
 captured from the reference's full-width 256^2 generator, algorithmic work totals, synthetic inputs, module
 construction and state-dict keys."""
+import os
+
 import numpy as np
 import torch
 
@@ -108,3 +110,19 @@ def test_row_pitch_helpers():
     assert _rows.pitch_of(v[:, :, ::2]) is None
     r, ld = _rows.rows(v[:, :, ::2])
     assert r.is_contiguous() and ld == 276
+
+
+def test_bench_gpus_n_launches_itself_and_the_ranks_report_missing_devices():
+    """`python bench.py --gpus 2` with no launcher starts torch.distributed.run as a child (the parent makes no GPU
+    call); on a host without two devices the RANKS say so and the exit code is non-zero -- no SystemExit in the parent."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    env['CUDA_VISIBLE_DEVICES'] = ''
+    env['HIP_VISIBLE_DEVICES'] = ''
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0
+    assert 'torch.distributed.run' in r.stderr
+    assert 'rank 0: --gpus 2 needs 2 devices' in r.stderr and 'rank 1: --gpus 2 needs 2 devices' in r.stderr

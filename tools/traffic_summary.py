@@ -26,4 +26,8 @@ for fam in sorted(set(fetch) | set(write)):
     out[fam] = dict(read_bytes_per_launch=rd, write_bytes_per_launch=wr, bytes_per_launch=rd + wr, launches_fetch_pass=nf, launches_write_pass=nw,
                     note='FETCH_SIZE doubled per the gfx950 correction; per-launch average over all launches of the family in a bench.py run')
     print(f'{fam:16s} read {rd/1e6:9.2f} MB  write {wr/1e6:9.2f} MB per launch  ({nf}/{nw} launches)')
-json.dump({k: v['bytes_per_launch'] for k, v in out.items()}, open(sys.argv[2], 'w'), indent=1) if len(sys.argv) > 2 else None
+if len(sys.argv) > 2:
+    d = {k: v['bytes_per_launch'] for k, v in out.items()}
+    # bench.py quotes this file as roofline.traffic: say which passes / build the bytes come from (argv[3], e.g. "r03, build <sha>")
+    d['_source'] = 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py' + (', ' + sys.argv[3] if len(sys.argv) > 3 else '')
+    json.dump(d, open(sys.argv[2], 'w'), indent=1)
