@@ -1,0 +1,139 @@
+"""Two rows VERDICT r02 found without a GPU test:
+
+* the RCCL code path of the data-parallel step (SURVEY.md row e: `afcm_amd/distributed.py` replaces the reference's
+  torch.nn.DataParallel, models/utils.py:116-120; the buckets are consumed by the optimizer as in comodgan_model.py:136,149's
+  update order): a ONE-rank `nccl` process group on this card -- hooks, bucket rebuild after the first iteration, asynchronous
+  all-reduce on RCCL's stream, `finish_flat()` -> fused scrub + Adam -- must reproduce the plain step;
+* BASELINE configs[2] (ADNI SR x5, configs/adni/.../sr_5.yml): the same generator with the slice label drawn from
+  {0, .2, .4, .6, .8} (data/cmsr_dataset.py:131-151).
+"""
+import copy
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+TINY = dict(channel_base=256, channel_max=8, num_layers=14, num_critical=2, margin_size=10, output_scale=0.25, skip_resolution=128,
+            conv_kernel=3, filter_size=6, lrelu_upsampling=2, use_radial_filters=False, conv_clamp=256,
+            magnitude_ema_beta=0.5 ** (16 / 20e3), cond_mod=True)
+
+
+def _tiny_generator(res, dtype, name):
+    from afcm_amd.networks_stylegan3 import Stylegan3Generator
+    g = load_golden(name)
+    G = Stylegan3Generator(z_dim=32, c_dim=1, w_dim=32, img_resolution=res, img_channels_in=4, img_channels_out=1,
+                           mapping_kwargs=dict(num_layers=2), synthesis_kwargs=dict(TINY, compute_dtype=dtype))
+    sd = {k[3:]: torch.from_numpy(np.array(v)) for k, v in g.items() if k.startswith('sd/')}
+    G.load_state_dict(sd, strict=True)
+    return G, sd, g
+
+
+@pytest.fixture
+def one_rank_rccl():
+    import torch.distributed as dist
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    dist.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{port}', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    try:
+        yield dist
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('dtype,comm,tol', [(torch.float32, None, 0.0), (torch.bfloat16, None, 0.0), (torch.bfloat16, torch.bfloat16, 1e-2)])
+def test_one_rank_rccl_step_equals_plain_step(one_rank_rccl, dtype, comm, tol):
+    """Four training steps of the tiny 128^2 generator (dropout makes train() random: eval() keeps the two runs comparable; the
+    step code does not depend on the mode).  fp32 buckets: a one-rank sum is the identity and the optimizer kernel reads the
+    same numbers from the bucket views as from .grad -> bit-identical parameters.  bf16 on the wire: the gradients are rounded
+    to 8 bits of mantissa once; Adam normalises the step, so after 4 steps the parameters agree to 1e-2 of their scale."""
+    from afcm_amd import synthetic
+    from afcm_amd.stylegan3_model import StyleGAN3GeneratorStep
+    assert one_rank_rccl.get_backend() == 'nccl' and one_rank_rccl.get_world_size() == 1
+    G0, _, _ = _tiny_generator(128, dtype, 'G1_tiny128')
+    G0 = G0.cuda().eval()
+    G1 = copy.deepcopy(G0)
+    plain = StyleGAN3GeneratorStep(G0, lr_G=0.0025, lambda_L1=100.0)
+    rccl = StyleGAN3GeneratorStep(G1, lr_G=0.0025, lambda_L1=100.0, distributed=True, force_collectives=True, comm_dtype=comm,
+                                  bucket_bytes=16 * 1024)
+    assert rccl.buckets.active and rccl.buckets.num_buckets >= 3
+    layouts = []
+    for it in range(4):
+        a, b, z, c = synthetic.generator_inputs(2, size=128, z_dim=32, seed=it, device='cuda')
+        for st in (plain, rccl):
+            st.set_input(a, b, z, c)
+            st.optimize_parameters()
+        layouts.append([id(p) for p in rccl.buckets._order])
+    torch.cuda.synchronize()
+    assert layouts[0] != layouts[-1]                 # the buckets were rebuilt in gradient-arrival order after the first step
+    assert float(plain.loss_G) == pytest.approx(float(rccl.loss_G), rel=max(tol, 1e-6))
+    for (n, p), q in zip(G0.named_parameters(), G1.parameters()):
+        if tol == 0.0:
+            assert torch.equal(p, q), n
+        else:
+            assert (p - q).abs().max().item() <= tol * max(1.0, p.abs().max().item()), n
+
+
+def test_config3_slice_thickness_5_labels_match_oracle():
+    """configs[2]: all five labels of a thickness-5 acquisition through the 256^2 generator (G2 golden weights: the reference's
+    own state dict at reduced width) on the HIP kernels vs the CPU oracle: fp32 forward <= 1e-3 max-abs, one gradient at 1e-2
+    relative L2 (kink flips), the label actually steers the output, bf16 within 30 dB."""
+    from afcm_amd import synthetic
+    from oracle import generator as ogen
+    G, sd, _ = _tiny_generator(256, torch.float32, 'G2_tiny256')
+    real_A, _, z, c = synthetic.generator_inputs(5, size=256, z_dim=32, slice_thickness=5, seed=11)
+    assert set(np.round(c.flatten().numpy() * 5).astype(int)) <= {0, 1, 2, 3, 4}
+    c = torch.arange(5, dtype=torch.float32).view(5, 1) / 5.0            # every label once
+    key = 'synthesis.L3_52_8.affine.weight' if 'synthesis.L3_52_8.affine.weight' in sd else next(k for k in sd if k.endswith('affine.weight'))
+    osd = {k: v.clone() for k, v in sd.items()}
+    osd[key] = osd[key].requires_grad_(True)
+    want = ogen.generator(osd, ogen.plan(256, 4, 1, dict(TINY)), z, c, real_A, mapping_layers=2)
+    r = torch.randn(want.shape, generator=torch.Generator().manual_seed(1))
+    gwant, = torch.autograd.grad((want * r).sum(), [osd[key]])
+    want = want.detach()
+    G = G.cuda().eval()
+    y = G(z.cuda(), c.cuda(), real_A.cuda())
+    ggot, = torch.autograd.grad((y * r.cuda()).sum(), [dict(G.named_parameters())[key]])
+    err = (y.detach().cpu() - want).abs().max().item()
+    assert err <= 1e-3, err
+    rel = ((ggot.cpu().double() - gwant.double()).norm() / gwant.double().norm()).item()
+    assert rel <= 1e-2, rel
+    # the label matters: same z and image, different label -> different output
+    z1, a1 = z[:1].expand(5, -1).contiguous(), real_A[:1].expand(5, -1, -1, -1).contiguous()
+    with torch.no_grad():
+        ys = G(z1.cuda(), c.cuda(), a1.cuda()).cpu()
+    assert (ys[1:] - ys[:1]).abs().amax(dim=(1, 2, 3)).min().item() > 1e-4
+    G.synthesis.compute_dtype = torch.bfloat16
+    with torch.no_grad():
+        y16 = G(z.cuda(), c.cuda(), real_A.cuda()).float().cpu()
+    assert synthetic.psnr(y16, want) >= 30.0
+
+
+def test_config3_full_width_training_step_bf16():
+    """configs[2] at the bench's width: one bf16 training step of the full-width 256^2 generator on a batch whose labels come from
+    synthetic.generator_inputs(slice_thickness=5); loss and every gradient finite, parameters move."""
+    from afcm_amd import synthetic
+    from afcm_amd.layer_schedule import DEFAULT_SYNTHESIS_KWARGS
+    from afcm_amd.networks_stylegan3 import Stylegan3Generator
+    from afcm_amd.stylegan3_model import StyleGAN3GeneratorStep
+    torch.manual_seed(0)
+    G = Stylegan3Generator(z_dim=512, c_dim=1, w_dim=512, img_resolution=256, img_channels_in=4, img_channels_out=1,
+                           mapping_kwargs=dict(num_layers=8),
+                           synthesis_kwargs=dict(DEFAULT_SYNTHESIS_KWARGS, compute_dtype=torch.bfloat16)).cuda().train()
+    step = StyleGAN3GeneratorStep(G, lr_G=0.0025, lambda_L1=100.0)
+    a, b, z, c = synthetic.generator_inputs(4, size=256, slice_thickness=5, seed=2, device='cuda')
+    assert all(abs(v * 5 - round(v * 5)) < 1e-6 for v in c.flatten().tolist())
+    before = G.synthesis.L3_52_512.weight.detach().clone()
+    step.set_input(a, b, z, c)
+    step.optimize_parameters()
+    assert torch.isfinite(step.loss_G).item()
+    assert all(torch.isfinite(p).all().item() for p in G.parameters())
+    assert not torch.equal(before, G.synthesis.L3_52_512.weight)

@@ -63,7 +63,11 @@ def main():
         loss_real = torch.nn.functional.softplus(-real_logits).mean()
         r1_grads = torch.autograd.grad(outputs=[real_logits.sum()], inputs=[real_tmp], create_graph=True, only_inputs=True)[0]
         loss_r1 = r1_grads.square().sum([1, 2, 3]).mean() * 0.5
-        g_real = torch.autograd.grad(loss_real + loss_r1 * 10.0, [params[k] for k in names])
+        g_real = torch.autograd.grad(loss_real + loss_r1 * 10.0, [params[k] for k in names], retain_graph=True)
+        # the R1 term on its own (the double backward): inside greal it is only 0-6 % of the magnitude, so a tolerance on the sum
+        # would pass an R1 error of tens of percent -- pinned separately.  Parameters the penalty does not
+        # reach (e.g. the last bias) have no gradient: stored as zeros.
+        g_r1 = torch.autograd.grad(loss_r1, [params[k] for k in names], allow_unused=True)
         out['real_logits'] = real_logits.detach().numpy()
         out['r1_grads'] = r1_grads.detach().numpy()
         out['loss_real'], out['loss_r1'] = np.array(loss_real.item()), np.array(loss_r1.item())
@@ -74,6 +78,8 @@ def main():
         for k, a, b in zip(names, g_fake, g_real):
             out['gfake/' + k] = a.numpy()
             out['greal/' + k] = b.numpy()
+        for k, a in zip(names, g_r1):
+            out['gr1/' + k] = (torch.zeros_like(params[k]) if a is None else a).numpy()
         out['names'] = np.array(names)
         out['meta'] = np.array([res, n, kw['channel_base'], kw['channel_max'], kw['epilogue_kwargs']['mbstd_group_size'],
                                 int(kw.get('conv_clamp') or -1)], dtype=np.int64)
