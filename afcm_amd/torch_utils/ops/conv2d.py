@@ -85,7 +85,8 @@ def plane_dot(a, b=None):
     # the 4-byte base alignment and an even pitch), an even width for 2-byte elements, rows of at least 16 bytes.  Anything else --
     # an expanded stride-0 gradient, an odd-width plane, a view at an odd element offset -- takes the dense kernel on a copy.
     if (not (a.is_contiguous() and (b is None or b.is_contiguous())) and lda is not None and ldb is not None
-            and a.shape[3] * a.element_size() >= 16 and (a.element_size() == 4 or a.shape[3] % 2 == 0)):
+            and a.shape[3] * a.element_size() >= 16 and (a.element_size() == 4 or a.shape[3] % 2 == 0)
+            and a.data_ptr() % 4 == 0 and (b is None or b.data_ptr() % 4 == 0)):      # (pitch_of takes a dense tensor at any offset)
         n, c, h, w = a.shape
         out = torch.empty([n, c], dtype=torch.float32, device=a.device)
         _lib.check(lib.afcm_plane_dot_ld(out.data_ptr(), a.data_ptr(), _lib.ptr(b), _lib.dtype_code(a), n * c, h, w, lda, ldb, _lib.stream_ptr(a)),

@@ -74,7 +74,7 @@ def test_one_rank_rccl_step_equals_plain_step(one_rank_rccl, dtype, comm, tol):
         layouts.append([id(p) for p in rccl.buckets._order])
     torch.cuda.synchronize()
     assert layouts[0] != layouts[-1]                 # the buckets were rebuilt in gradient-arrival order after the first step
-    assert float(plain.loss_G) == pytest.approx(float(rccl.loss_G), rel=max(tol, 1e-6))
+    assert float(plain.loss_G.detach()) == pytest.approx(float(rccl.loss_G.detach()), rel=max(tol, 1e-6))
     for (n, p), q in zip(G0.named_parameters(), G1.parameters()):
         if tol == 0.0:
             assert torch.equal(p, q), n
