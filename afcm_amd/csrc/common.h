@@ -39,6 +39,17 @@ static inline int hip_status(hipError_t e) { return e == hipSuccess ? AFCM_OK : 
 
 constexpr int cdiv(int a, int b) { return (a + b - 1) / b; }
 constexpr int round_up(int a, int b) { return cdiv(a, b) * b; }
+
+// Workgroup id -> logical work item such that CONSECUTIVE logical items run on ONE XCD (one L2): the hardware deals workgroup
+// ids round-robin over the 8 XCDs, so XCD x executes ids x, x + 8, ...  With total = 8 q + r the XCDs below r own q + 1 items:
+// XCD x's k-th workgroup takes logical item x q + min(x, r) + k -- a bijection for every grid size (r02 remapped only grids that
+// are multiples of 8: the 91- and 181-channel layers, grids of 3276 / 3620 / 6516 workgroups, ran with neighbouring strips on
+// different XCDs and fetched their shared halo rows twice: 1.33x the algorithmic HBM bytes against 1.12x on the remapped layers).
+// Speed only: nothing may depend on where a workgroup actually runs.
+__device__ __forceinline__ int xcd_order(int bid, int total) {
+    const int x = bid & 7, k = bid >> 3, q = total >> 3, r = total & 7;
+    return x * q + (x < r ? x : r) + k;
+}
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 // smallest odd multiple of 4 that is >= a (a itself a multiple of 4)
 constexpr int odd4(int a) { return ((a / 4) % 2 == 1) ? a : a + 4; }

@@ -354,7 +354,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_fwd16_kernel(ConvParams p) {
     int bid = blockIdx.x;
     {
         const int total = gridDim.x;
-        if ((total & 7) == 0) bid = (bid & 7) * (total >> 3) + (bid >> 3);
+        bid = xcd_order(bid, total);
     }
     // integer division runs on the vector pipe even for uniform operands: pin the results to SGPRs, or everything derived
     // from them (image base, buffer descriptor) sits in VGPRs and every buffer load gets a waterfall loop around it
@@ -1329,7 +1329,7 @@ __global__ __launch_bounds__(512, 1) void conv2d_wgrad16_kernel(WgradParams p) {
     const int tiles_i = cdiv(p.I, 64), tiles = tiles_i * cdiv(p.O, 64);
     int bid = blockIdx.x;
     const int total = tiles * p.splits;
-    if ((total & 7) == 0) bid = (bid & 7) * (total >> 3) + (bid >> 3);
+    bid = xcd_order(bid, total);
     const int split = bid / tiles;
     const int tile = bid - split * tiles;
     const int ib = tile % tiles_i, obk = tile / tiles_i;
@@ -1583,7 +1583,7 @@ __global__ __launch_bounds__(512, 1) void conv2d_wgrad16g_kernel(WgradParams p) 
     const int tiles_i = cdiv(p.I, 64), tiles = tiles_i * cdiv(p.O, 64);
     int bid = blockIdx.x;
     const int total = tiles * p.splits;
-    if ((total & 7) == 0) bid = (bid & 7) * (total >> 3) + (bid >> 3);          // XCD x: contiguous logical ids (split-major)
+    bid = xcd_order(bid, total);          // XCD x: contiguous logical ids (split-major)
     // integer division runs on the vector pipe even for uniform operands: pin the results to SGPRs, or every per-step address
     // and descriptor computation derived from them runs as 64-bit VALU code + v_readfirstlane (measured: ~130 vector
     // instructions per step beside the 36 MFMAs)

@@ -72,7 +72,9 @@ struct MfmaGeom {
 // Constant fragments.  Layout: [frag][lane][8] elements of T, then (byte kWsTable) the keep-mask table.
 template <typename T, int UP, int DOWN, int TOW, int TOH>
 __global__ void flrelu_mfma_prepare_kernel(T* __restrict__ ws, const float* __restrict__ fu, const float* __restrict__ fd,
-                                           int px0, int py0, int flip, float gain_total, float slope) {
+                                           int px0, int py0, int flip, float gain_total, float slope, int dshift) {
+    // dshift (aligned READ calls of the wave kernels, else 0): the tile's upsampled rows start dshift rows EARLY -- py0 already
+    // carries it for the up side (everything there derives from py0 - U0y); the down-y taps move by it here
     typedef MfmaGeom<UP, DOWN, TOW, TOH> G;
     const int phx = pos_mod(px0, UP), phy = pos_mod(py0, UP);
     const int odd = (-floor_div(px0, UP)) & 1;                // the staged tile starts one column early when I0x is odd
@@ -104,7 +106,7 @@ __global__ void flrelu_mfma_prepare_kernel(T* __restrict__ ws, const float* __re
             // DVs[t] / DVr[t]: [n][k], n = l15 (orow), k -> urow 32t + krow(g, j) of the window starting at 16*DOWN*ob;
             // scaled by slope (applied to X2) and by 1 - slope (applied to relu(X2))
             const int t2 = frag - G::NB - UP, t = t2 % G::NDVK;
-            const int kk = 32 * t + krow(g, j) - DOWN * l15;
+            const int kk = 32 * t + krow(g, j) - DOWN * l15 - dshift;
             if (kk >= 0 && kk < G::FD) v = (flip ? fd[kk] : fd[G::FD - 1 - kk]) * (t2 < G::NDVK ? slope : 1.f - slope);
         } else {
             // DH[t]: [k][n], k = 8g + j natural (ucol 32t + k of the window starting at 16*DOWN*cb), n = l15 (ocol)
@@ -156,7 +158,7 @@ __global__ __launch_bounds__((64 * MfmaGeom<UP, DOWN, TOW, TOH>::NG), (DOWN == 2
     int bid = blockIdx.x;
     {
         const int total = gridDim.x;
-        if ((total & 7) == 0) bid = (bid & 7) * (total >> 3) + (bid >> 3);
+        bid = xcd_order(bid, total);
     }
     // divisions by multiply-high (exact for the grid sizes the host admits): the compiler's uniform integer division is a
     // ~25-instruction float-reciprocal sequence on the VECTOR unit, three of them per wave
@@ -610,7 +612,7 @@ constexpr int kTallTOH = 48;
 template <typename T, int UP, int DOWN, int TOW, int TOH>
 int launch_wave_tile(const afcm_filtered_lrelu_args* a, FlreluMfmaParams p, hipStream_t st);
 template <typename T, int UP, int DOWN>
-int prepare_wave(const afcm_filtered_lrelu_args* a, hipStream_t st);
+int prepare_wave(const afcm_filtered_lrelu_args* a, int py0_frag, int dshift, hipStream_t st);
 
 constexpr int kWavePitchSlack = 128;        // elements a row pitch may exceed the plane width by (wave kernels)
 static bool wave_family(const afcm_filtered_lrelu_args* a) {
@@ -627,12 +629,36 @@ static bool wave_family(const afcm_filtered_lrelu_args* a) {
 // Output rows per strip of the wave kernels: 32; one 48-row strip for the 36^2 / 38^2 planes (up 2 / down 2).  (Measured and
 // dropped: 16-row strips for down 4, whose 32-row strips need 240-250 registers = two waves per SIMD: at 16 rows a strip still
 // needs 176-199 and computes 1.5x instead of 1.25x its own rows -- forward 1.63 vs 1.89 TB/s over the down-4 layers.)
-static int wave_toh(int up, int down, int yh) {
-    return (up == 2 && down == 2 && yh > 32 && yh <= kTallTOH) ? kTallTOH : 32;
+static int wave_toh(int up, int down, int rows) {
+    return (up == 2 && down == 2 && rows > 32 && rows <= kTallTOH) ? kTallTOH : 32;
+}
+
+// READ calls of the wave kernels: output rows by which the strips' origin moves up (<= 0) so that every strip's first upsampled
+// row, U0y + sy = (ty TOH + oy0) down + sy, is a multiple of 16 = a row block of the sign tensor (kSignsReadAligned in
+// filtered_lrelu_wave.hip).  Possible when sy is a multiple of gcd(down, 16) = down; costs at most 16 / down - 1 extra rows on
+// top of the plane.  Pure host arithmetic on pitch-independent arguments: shapes() and the launch agree.
+// ... and, where sy is not a multiple of `down`, the remaining dshift = (oy0 down + sy) mod 16 < down upsampled rows by which the
+// strips' upsampled grid itself starts early: the constant fragments of such a call are prepared with their rows moved by dshift
+// (the tiles have 6-12 spare rows: (TOH - 1) down + taps + dshift <= 16 NVB for every shape), so EVERY read call is aligned.
+static bool wave_read_origin(const afcm_filtered_lrelu_args* a, int* oy0, int* dshift) {
+    *oy0 = 0;
+    *dshift = 0;
+    static const char* e = getenv("AFCM_FLRELU_READ_ALIGNED");          // tuning aid: 0 = general READ kernels only
+    if (a->sign_mode != AFCM_SIGNS_READ || a->sign_layout != 2 || (e != nullptr && atoi(e) == 0)) return false;
+    const int m = pos_mod(a->sy, 16);
+    *oy0 = -(m / a->down);
+    *dshift = m % a->down;
+    return true;
+}
+// rows the strips of a wave launch have to cover
+static int wave_rows(const afcm_filtered_lrelu_args* a) {
+    int oy0, dshift;
+    wave_read_origin(a, &oy0, &dshift);
+    return a->yh - oy0;
 }
 
 static bool tall_tile(int up, int down, int yh, int sign_mode, bool wave) {
-    if (wave) return wave_toh(up, down, yh) == kTallTOH;
+    if (wave) return wave_toh(up, down, yh) == kTallTOH;                    // (callers pass wave_rows())
     static const char* force = getenv("AFCM_FLRELU_TALL");      // tuning aid: 0 = never, 1 = rules below (default), 2 = 33..48-row planes only
     const int mode = force ? atoi(force) : 1;
     (void)down;
@@ -702,10 +728,14 @@ static int launch_wave(const afcm_filtered_lrelu_args* a, hipStream_t st) {
     // a pitched y is written in whole 64-column groups: the kernel covers columns < 64 * ceil(yw / 64) only, so a larger pitch would
     // leave uninitialised padding behind (the layout's contract is finite padding, include/afcm_hip.h)
     AFCM_REQUIRE(a->y_pitch == 0 || (a->y_pitch >= a->yw && a->y_pitch <= cdiv(a->yw, 64) * 64), "filtered_lrelu: y_pitch %d outside [yw, 64 * ceil(yw / 64) = %d]", a->y_pitch, cdiv(a->yw, 64) * 64);
-    const int toh = wave_toh(UP, DOWN, a->yh);
+    const int toh = wave_toh(UP, DOWN, wave_rows(a));
     FlreluMfmaParams p;
-    const int rc = fill_params(a, p, 1, cdiv(a->yh, toh));
+    const int rc = fill_params(a, p, 1, cdiv(wave_rows(a), toh));
     if (rc != AFCM_OK) return rc;
+    int dshift;
+    p.read_aligned = wave_read_origin(a, &p.oy0, &dshift) ? 1 : 0;
+    p.py0 += dshift;                 // the fragments were prepared for this origin (prepare_mfma)
+    p.sy -= dshift;
     if constexpr (UP == 2 && DOWN == 2) {
         if (toh == kTallTOH) return launch_wave_tile<T, 2, 2, 64, kTallTOH>(a, p, st);
     }
@@ -727,10 +757,15 @@ static int prepare_mfma(const afcm_filtered_lrelu_args* a, hipStream_t st) {
     constexpr int TOW = MfmaTile<UP, DOWN>::TOW, TOH = MfmaTile<UP, DOWN>::TOH;
     typedef MfmaGeom<UP, DOWN, TOW, TOH> G;
     const float gain_total = (float)a->up * (float)a->up * a->gain;
+    // aligned READ calls of the wave kernels: the strips' first upsampled row is (ty TOH + oy0) DOWN - dshift, no longer a multiple
+    // of UP: the up-y fragments are built for the phase of py0 measured from THAT row
+    int oy0 = 0, dshift = 0;
+    if (wave_family(a)) wave_read_origin(a, &oy0, &dshift);
+    const int py0_frag = a->py0 + dshift - oy0 * DOWN;
     hipLaunchKernelGGL((flrelu_mfma_prepare_kernel<T, UP, DOWN, TOW, TOH>), dim3(cdiv(G::NFRAG * 512, 256)), dim3(256), 0, st,
-                       (T*)a->workspace, a->fu, a->fd, a->px0, a->py0, a->flip_filter, gain_total, a->slope);
+                       (T*)a->workspace, a->fu, a->fd, a->px0, py0_frag, a->flip_filter, gain_total, a->slope, dshift);
     const int rc = hip_status(hipGetLastError());
-    return rc != AFCM_OK ? rc : prepare_wave<T, UP, DOWN>(a, st);
+    return rc != AFCM_OK ? rc : prepare_wave<T, UP, DOWN>(a, py0_frag, dshift, st);
 }
 
 static int mfma_case(const afcm_filtered_lrelu_args* a) {
@@ -755,9 +790,9 @@ int flrelu_mfma_row_pitch_ok(const afcm_filtered_lrelu_args* a) { return mfma_ca
 
 int flrelu_mfma_tiles(const afcm_filtered_lrelu_args* a) {
     switch (mfma_case(a)) {
-        case 22: return wave_family(a) ? cdiv(a->yh, wave_toh(2, 2, a->yh)) : cdiv(a->yw, MfmaTile<2, 2>::TOW) * cdiv(a->yh, tall_tile(2, 2, a->yh, a->sign_mode, false) ? kTallTOH : MfmaTile<2, 2>::TOH);
-        case 24: return wave_family(a) ? cdiv(a->yh, wave_toh(2, 4, a->yh)) : cdiv(a->yw, MfmaTile<2, 4>::TOW) * cdiv(a->yh, tall_tile(2, 4, a->yh, a->sign_mode, false) ? kTallTOH : MfmaTile<2, 4>::TOH);
-        case 42: return wave_family(a) ? cdiv(a->yh, wave_toh(4, 2, a->yh)) : cdiv(a->yw, MfmaTile<4, 2>::TOW) * cdiv(a->yh, MfmaTile<4, 2>::TOH);
+        case 22: return wave_family(a) ? cdiv(wave_rows(a), wave_toh(2, 2, wave_rows(a))) : cdiv(a->yw, MfmaTile<2, 2>::TOW) * cdiv(a->yh, tall_tile(2, 2, a->yh, a->sign_mode, false) ? kTallTOH : MfmaTile<2, 2>::TOH);
+        case 24: return wave_family(a) ? cdiv(wave_rows(a), wave_toh(2, 4, wave_rows(a))) : cdiv(a->yw, MfmaTile<2, 4>::TOW) * cdiv(a->yh, tall_tile(2, 4, a->yh, a->sign_mode, false) ? kTallTOH : MfmaTile<2, 4>::TOH);
+        case 42: return wave_family(a) ? cdiv(wave_rows(a), wave_toh(4, 2, wave_rows(a))) : cdiv(a->yw, MfmaTile<4, 2>::TOW) * cdiv(a->yh, MfmaTile<4, 2>::TOH);
         default: return 0;
     }
 }

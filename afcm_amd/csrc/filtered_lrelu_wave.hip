@@ -75,6 +75,10 @@ struct WaveGeom {
     static_assert(lin_q(NOB - 1, NLT - 1) < NQ, "composite operator reaches beyond the packed X1 pairs");
     static_assert(NLIN + NDVK <= kWsWaveFrags, "workspace");
     static_assert((16 * DOWN) % UP == 0, "orow blocks start on input rows");
+    // aligned READ calls start the upsampled rows up to DOWN - 1 rows early (dshift): the spare rows of the last blocks / K windows
+    static_assert(TUH + DOWN - 1 <= 16 * NVB, "row blocks must cover the tile plus the alignment shift");
+    static_assert(15 * DOWN + FD - 1 + DOWN - 1 < 32 * NDVK, "down-y K windows must cover the taps plus the alignment shift");
+    static_assert(LIN_DI + 8 * (NLV - 1) + cdiv(DOWN - 1, UP) <= 32 * NLT, "composite operator windows must cover the alignment shift");
 
 };
 
@@ -102,7 +106,8 @@ __device__ __forceinline__ float down_coef(const float* fd, int FD, int DOWN, in
 // and one scalar: an upper bound of the L1 norm of the rows of UV (|X2| <= bound * max |X1|).
 template <typename T, int UP, int DOWN>
 __global__ void flrelu_wave_prepare_kernel(char* __restrict__ wsb, const float* __restrict__ fu, const float* __restrict__ fd,
-                                           int py0, int flip, float gain_total, float slope) {
+                                           int py0, int flip, float gain_total, float slope, int dshift) {
+    // dshift: see flrelu_mfma_prepare_kernel (py0 carries it already; the down-y taps of the composite operator move by it)
     typedef WaveGeom<UP, DOWN, 32, 32> G;                      // fragment contents do not depend on the tile shape
     constexpr int FU = kFUT * UP, FD = kFUT * DOWN;
     const int phy = pos_mod(py0, UP);
@@ -117,8 +122,8 @@ __global__ void flrelu_wave_prepare_kernel(char* __restrict__ wsb, const float* 
             if (di >= 0) {
                 float acc = 0.f;
                 for (int kk = 0; kk < FD; kk++) {
-                    const int u = DOWN * l15 + kk;             // upsampled row, from the block's first
-                    acc += down_coef(fd, FD, DOWN, flip, l15, u) * up_coef(fu, FU, UP, phy, flip, u, di);
+                    const int u = DOWN * l15 + kk + dshift;    // upsampled row, from the block's first
+                    acc += down_coef(fd, FD, DOWN, flip, l15, u - dshift) * up_coef(fu, FU, UP, phy, flip, u, di);
                 }
                 v = acc * gain_total * slope;
             }
@@ -161,22 +166,38 @@ __global__ void flrelu_wave_prepare_kernel(char* __restrict__ wsb, const float* 
 //
 // EPI bits: 1 = per-plane factors (fused layer node), 2 = + encoder skip operand, 4 = per-strip output sums (the backward's bias
 // gradient; kept apart from bit 1: the forward kernels of a training step scale but never sum, and the sums cost them registers).
+//
+// SIGN: AFCM_SIGNS_NONE / WRITE / READ, or kSignsReadAligned (this file only): READ with the strips' origin moved up by p.oy0
+// output rows so that every strip's first upsampled row falls on a 16-row block of the sign tensor (the host does that whenever
+// (oy0 DOWN + sy) can be made a multiple of 16: every up-2 / down-2 backward of the generator).  The window then starts on a
+// quad-row and on a byte of the code dwords: 2-3 dwords per column block instead of 6 (no second "hi" set, no per-tile v_perm /
+// v_bfe to re-align quads), a third of the registers for codes -- the general READ kernels retired 8.6 vector instructions per
+// MFMA against 5.8 in the forward (profiles/r02_bench_pmc.txt) and were 56 % of the family's time.
+constexpr int kSignsReadAligned = 3;
 template <typename T, int UP, int DOWN, int TOW, int TOH, int SIGN, int EPI>
-__global__ __launch_bounds__(256, (DOWN == 2 && (TOH <= 32 || SIGN == AFCM_SIGNS_READ) ? AFCM_WAVE_OCC_D2 : AFCM_WAVE_OCC_D4)) void flrelu_wave_kernel(FlreluMfmaParams p) {
+__global__ __launch_bounds__(256, (DOWN == 2 && (TOH <= 32 || SIGN == AFCM_SIGNS_READ || SIGN == kSignsReadAligned) ? AFCM_WAVE_OCC_D2 : AFCM_WAVE_OCC_D4)) void flrelu_wave_kernel(FlreluMfmaParams p) {
     typedef WaveGeom<UP, DOWN, TOW, TOH> G;
     typedef MfmaOps<T> M;
     typedef typename M::frag frag;
-    __shared__ uint2 lds_tab[SIGN == AFCM_SIGNS_READ ? 256 : 1];          // READ: sign byte -> keep masks of its 4 rows
+    constexpr bool RD = SIGN == AFCM_SIGNS_READ || SIGN == kSignsReadAligned, RA = SIGN == kSignsReadAligned;
+    __shared__ uint2 lds_tab[RD ? 256 : 1];                               // READ: sign byte -> keep masks of its 4 rows
     // Output staging, private to each wave: 64 output columns (4 column blocks) x TOH rows, flushed as full 128-byte row segments.
     // (Stored straight from the accumulators a column block is 32 bytes per row: those reach HBM as partial lines -- measured
     // 1.9x / 2.5x the algorithmic write traffic in forward / backward.)
     constexpr int OPITCH = 144;                                            // bytes per staged row: 128 + 16 (16-byte aligned, spreads banks)
     __shared__ __attribute__((aligned(16))) unsigned char lds_o[4][TOH * OPITCH];
+    // Encoder-skip staging (EPI & 2), private to each wave: the skip rows of TWO output column blocks (64 bytes per row) arrive by
+    // 16-byte loads in the access lane map, are parked here and read back in the fragment lane map.  (r02 fetched every column
+    // block by itself: two 4-byte loads per lane = 32 bytes per row and instruction, and the four visits of a 128-byte line were
+    // a whole group apart -- the L1 had long dropped it: profiles/r03: HBM reads of the skip kernels 2.0-2.7x the algorithmic
+    // bytes, L12 forward 232 us against 122-145 us for the same plane without a skip.)
+    constexpr int KPITCH = 80;                                             // bytes per staged skip row: 64 + 16
+    __shared__ __attribute__((aligned(16))) unsigned char lds_k[(EPI & 2) ? 4 : 1][(EPI & 2) ? TOH * KPITCH : 16];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, g = lane >> 4;
-    if (SIGN == AFCM_SIGNS_READ) {
+    if (RD) {
         if (tid < 128) ((uint4*)lds_tab)[tid] = ((const uint4*)((const char*)p.ws + kWsTable))[tid];
         __syncthreads();
     }
@@ -184,7 +205,7 @@ __global__ __launch_bounds__(256, (DOWN == 2 && (TOH <= 32 || SIGN == AFCM_SIGNS
     int bid = blockIdx.x;
     {
         const int total = gridDim.x;
-        if ((total & 7) == 0) bid = (bid & 7) * (total >> 3) + (bid >> 3);
+        bid = xcd_order(bid, total);
     }
     const int wt = bid * 4 + wave;                                       // this wave's strip: TOH output rows x the plane's width
     if (wt >= p.total_tiles) return;
@@ -192,7 +213,7 @@ __global__ __launch_bounds__(256, (DOWN == 2 && (TOH <= 32 || SIGN == AFCM_SIGNS
     const int tile = wt - plane * (p.tilesX * p.tilesY);
     const int ty = p.magicT ? (int)__umulhi((unsigned)tile, p.magicT) : tile;
     const int tx = tile - ty * p.tilesX;
-    const int O0x = 0, O0y = ty * TOH;                                    // (tilesX = 1: a strip spans the plane)
+    const int O0y = ty * TOH + (RA ? p.oy0 : 0);                          // (tilesX = 1: a strip spans the plane; RA: origin moved up, oy0 <= 0)
     const int U0x = 0, U0y = O0y * DOWN;
     (void)tx;
     // column groups: the last output column block, cdiv(yw, 16) - 1, ends on X3 pair (DOWN / 2) cb + NDVK - 1
@@ -281,12 +302,12 @@ __global__ __launch_bounds__(256, (DOWN == 2 && (TOH <= 32 || SIGN == AFCM_SIGNS
     const unsigned sgw_off = (unsigned)((((U0y >> 4) >> 2) * 4 + g) * 64 + l15 * 4);
     const int v4_end = lastY ? nV4 : min(nV4, ((U0y >> 4) + G::OWN_VB) >> 2);
     // READ: lane (g, l15) follows column U0x + sx + l15 and quad-rows r0 + 4 vb (lo) and r0 + 4 vb + 1 (hi), r0 = Q0 + g
-    const int yy = p.sy & 3;                                               // row offset inside a quad (U0y is a multiple of 4)
+    const int yy = (U0y + p.sy) & 3;                                       // row offset inside a quad (0 for the aligned READ kernels)
     const int Q0 = (U0y + p.sy) >> 2;
     int sgr_lo = 0, sgr_hi = 0, sgr_dl = 0, sgr_dh = 0;
     unsigned sgr_sl = 0, sgr_sh = 0;
     __amdgpu_buffer_rsrc_t rss = rsx;
-    if (SIGN == AFCM_SIGNS_READ) {
+    if (RD) {
         rss = __builtin_amdgcn_make_buffer_rsrc((void*)splane, 0, p.shq * p.swq, 0x00020000);
         const int c = U0x + p.sx + l15, r0 = Q0 + g, r1 = r0 + 1;
         // columns left of the tensor give a negative block = a negative offset, columns right of it a block beyond the last:
@@ -299,19 +320,21 @@ __global__ __launch_bounds__(256, (DOWN == 2 && (TOH <= 32 || SIGN == AFCM_SIGNS
     }
     // dword groups outside the tensor would alias a neighbouring column block: select them out (wave-uniform fast case)
     const bool rows_inside = Q0 >= 0 && (((Q0 + 4) >> 2) >> 2) + NA + 1 <= nV4;
+    // RA: dwords per column block -- code bytes sl .. sl + NVB - 1 of the lane's dword run (sl = (first row block) & 3, wave-uniform)
+    constexpr int NL = RA ? cdiv(3 + G::NVB, 4) : NA + 1;
     // READ: the sign dwords of a group's two column blocks, fetched one group ahead like the input window (consumed right after
     // the up-y products: fetched in place, every column block exposed a full memory round trip)
-    auto load_signs = [&](int nb, unsigned (&sg)[2][NA + 1]) __attribute__((always_inline)) {
+    auto load_signs = [&](int nb, unsigned (&sg)[RA ? 1 : 2][NL]) __attribute__((always_inline)) {
         const int blo = sgr_lo + nb * blkbytes, bhi = sgr_hi + nb * blkbytes;
 #pragma unroll
-        for (int i = 0; i <= NA; i++) {
+        for (int i = 0; i < NL; i++) {
             unsigned ol = (unsigned)(blo + 256 * i), oh = (unsigned)(bhi + 256 * i);
             if (!rows_inside) {
                 ol = ((unsigned)(sgr_dl + i) < (unsigned)nV4) ? ol : 0x80000000u;
                 oh = ((unsigned)(sgr_dh + i) < (unsigned)nV4) ? oh : 0x80000000u;
             }
             sg[0][i] = __builtin_amdgcn_raw_buffer_load_b32(rss, ol, 0, AFCM_WAVE_SIGNLOAD_AUX);
-            sg[1][i] = (yy != 0) ? __builtin_amdgcn_raw_buffer_load_b32(rss, oh, 0, AFCM_WAVE_SIGNLOAD_AUX) : 0u;
+            if constexpr (!RA) sg[1][i] = (yy != 0) ? __builtin_amdgcn_raw_buffer_load_b32(rss, oh, 0, AFCM_WAVE_SIGNLOAD_AUX) : 0u;
         }
     };
 
@@ -325,9 +348,8 @@ __global__ __launch_bounds__(256, (DOWN == 2 && (TOH <= 32 || SIGN == AFCM_SIGNS
     const bool has_skip = (EPI & 2) && p.skip != nullptr;
     const __amdgpu_buffer_rsrc_t rsk = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(has_skip ? (const T*)p.skip + (size_t)plane * p.yh * p.kld : (const T*)p.x), 0, has_skip ? p.yh * p.kld * 2 : 0, 0x00020000);
-    // skip operand: byte offset of (row O0y + lrow, column 4 lchk) (access lane map); rows below the plane exceed the record count
-    // and read as zero, columns right of it are selected out per output column block
-    const int koff0 = ((O0y + lrow) * p.kld + 4 * lchk) * 2;
+    // skip operand: byte offset of (row O0y + lrow, column 8 lchk) (access lane map)
+    const int koff0 = ((O0y + lrow) * p.kld + 8 * lchk) * 2;
     const int krow16 = 32 * p.kld;
     const float osc = (EPI & 1) ? (p.oscale ? p.oscale[plane] : 1.f) * (p.oscale2 ? p.oscale2[plane] : 1.f) : 1.f;
     float psum = 0.f;
@@ -348,16 +370,21 @@ __global__ __launch_bounds__(256, (DOWN == 2 && (TOH <= 32 || SIGN == AFCM_SIGNS
     // encoder feature of output column block cb in the access lane map (columns / rows outside the plane read as zero): requested
     // at the top of the group whose down-x pass consumes it -- fetched in place, every column block waited a full memory round trip
     // (the skip kernels sat in memory waits for 46 % of their residency, the plain ones 23 %)
-    auto load_skip = [&](int cb, unsigned (&sk)[G::NOB][2]) __attribute__((always_inline)) {
-        const int ox = 16 * cb + 4 * lchk;
+    // skip rows of output column blocks (cb, cb + 1), cb even: one 16-byte load per lane and 16 rows (access lane map: 4 lanes =
+    // 64 contiguous bytes of a row).  Requested one group before the first down-x pass that needs them and parked in LDS at the
+    // top of that group (the registers are live for one group in two).  Rows below the plane exceed the record count and read
+    // as zero; columns right of the plane hold the next row's head (dense) or padding (pitched): finite, never stored or summed.
+    unsigned char* const kstage = lds_k[(EPI & 2) ? wave : 0];
+    auto load_skip = [&](int cb, u32x4 (&skw)[G::NOB]) __attribute__((always_inline)) {
 #pragma unroll
-        for (int ob = 0; ob < G::NOB; ob++) {
-            const unsigned off = (unsigned)(koff0 + ob * krow16 + 32 * cb);
-            sk[ob][0] = __builtin_amdgcn_raw_buffer_load_b32(rsk, (ox + 2 <= p.yw) ? off : kOut, 0, 0);
-            sk[ob][1] = __builtin_amdgcn_raw_buffer_load_b32(rsk, (ox + 4 <= p.yw) ? off + 4u : kOut, 0, 0);
-        }
+        for (int ob = 0; ob < G::NOB; ob++)
+            skw[ob] = __builtin_amdgcn_raw_buffer_load_b128(rsk, (unsigned)(koff0 + ob * krow16 + 32 * cb), 0, 0);
     };
-    auto phase_b = [&](int cb, const u32x4 (&xw)[G::NOB][G::NDVK], const unsigned (&sk)[G::NOB][2]) __attribute__((always_inline)) {
+    auto park_skip = [&](const u32x4 (&skw)[G::NOB]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int ob = 0; ob < G::NOB; ob++) *(u32x4*)(kstage + (unsigned)((16 * ob + lrow) * KPITCH + 16 * lchk)) = skw[ob];
+    };
+    auto phase_b = [&](int cb, const u32x4 (&xw)[G::NOB][G::NDVK]) __attribute__((always_inline)) {
         const int slot = cb & 3;
 #pragma unroll
         for (int ob = 0; ob < G::NOB; ob++) {
@@ -365,10 +392,15 @@ __global__ __launch_bounds__(256, (DOWN == 2 && (TOH <= 32 || SIGN == AFCM_SIGNS
 #pragma unroll
             for (int t = 0; t < G::NDVK; t++) acc = M::mma(dh[t], as_frag<frag>(xw[ob][t]), acc);
             if (EPI & 2) {
-                // encoder feature of this lane's 4 columns (x + x_skip, NET:376-377): from the access lane map to the fragment map
+                // encoder feature of this lane's 4 columns (x + x_skip, NET:376-377), fragment lane map, from the parked rows
+                const uint2 e = *(const uint2*)(kstage + (unsigned)((16 * ob + l15) * KPITCH + (cb & 1) * 32 + g * 8));
                 union { unsigned u; T t[2]; } e0, e1;
-                e0.u = (unsigned)__builtin_amdgcn_ds_bpermute(to_frag, (int)sk[ob][0]);
-                e1.u = (unsigned)__builtin_amdgcn_ds_bpermute(to_frag, (int)sk[ob][1]);
+                e0.u = e.x;
+                e1.u = e.y;
+                if (16 * cb + 16 > p.yw) {                       // wave-uniform: the plane's last column block -- columns right of
+                    if (16 * cb + 4 * g + 2 > p.yw) e0.u = 0u;   // the plane are the next row's head or padding (anything, NaN included)
+                    if (16 * cb + 4 * g + 4 > p.yw) e1.u = 0u;
+                }
                 acc[0] += to_f32(e0.t[0]);
                 acc[1] += to_f32(e0.t[1]);
                 acc[2] += to_f32(e1.t[0]);
@@ -376,11 +408,11 @@ __global__ __launch_bounds__(256, (DOWN == 2 && (TOH <= 32 || SIGN == AFCM_SIGNS
             }
             if (EPI & 1) acc *= osc;
             if (EPI & 4) {
-                if (!(lastY || cb == ncb - 1)) {                                              // wave-uniform: every element is inside the plane
+                if (!(lastY || cb == ncb - 1 || (RA && O0y < 0))) {                            // wave-uniform: every element is inside the plane
                     psum += (acc[0] + acc[1]) + (acc[2] + acc[3]);
                 } else {
                     const int fx = 16 * cb + 4 * g;                                            // fragment lane map
-                    const bool rin = O0y + 16 * ob + l15 < p.yh;
+                    const bool rin = (unsigned)(O0y + 16 * ob + l15) < (unsigned)p.yh;
                     psum += (rin && fx + 2 <= p.yw ? acc[0] + acc[1] : 0.f) + (rin && fx + 4 <= p.yw ? acc[2] + acc[3] : 0.f);
                 }
             }
@@ -424,8 +456,8 @@ __global__ __launch_bounds__(256, (DOWN == 2 && (TOH <= 32 || SIGN == AFCM_SIGNS
     // completes.  EXACT: the rare second pass over a strip in which the clamp was reached.  LASTY: the strip also writes the codes of
     // its halo row blocks (every other strip leaves them to the strip below and skips their extraction).
     // One group; the caller alternates two register sets for everything that is carried from one group to the next.
-    auto group = [&](int gi, auto exact_c, auto lasty_c, frag (&a_in)[G::NMB], frag (&a_nxt)[G::NMB], unsigned (&sg)[G::NBG][2][NA + 1],
-                     u32x4 (&hist)[G::NOB][G::NHIST], u32x4 (&cur)[G::NOB], float& amax, unsigned& anyc) __attribute__((always_inline)) {
+    auto group = [&](int gi, auto exact_c, auto lasty_c, frag (&a_in)[G::NMB], frag (&a_nxt)[G::NMB], unsigned (&sg)[G::NBG][RA ? 1 : 2][NL],
+                     u32x4 (&hist)[G::NOB][G::NHIST], u32x4 (&cur)[G::NOB], u32x4 (&skw)[G::NOB], float& amax, unsigned& anyc) __attribute__((always_inline)) {
         constexpr bool EXACT = decltype(exact_c)::value, LASTY = decltype(lasty_c)::value;
         constexpr int NVW = LASTY ? G::NVB : G::OWN_VB;                  // row blocks whose codes this strip writes
         // one group ahead, issued before this group's stores: vmcnt counts in order, so waiting for these loads at the top of
@@ -433,8 +465,15 @@ __global__ __launch_bounds__(256, (DOWN == 2 && (TOH <= 32 || SIGN == AFCM_SIGNS
         // the output column block whose last K window is this group's pair: pairs (DOWN / 2) cb ... + NDVK - 1 = gi
         const bool has_b = gi >= G::NDVK - 1 && (gi - (G::NDVK - 1)) % (DOWN / 2) == 0;
         const int cb_b = (gi - (G::NDVK - 1)) / (DOWN / 2);
-        unsigned sk[G::NOB][2] = {};
-        if ((EPI & 2) && has_b) load_skip(cb_b, sk);       // ahead of the window: used at the end of THIS group, the window in the next
+        if (EPI & 2) {
+            // this group's down-x pass opens a column-block pair: its skip rows were requested a group ago (older than the window
+            // that the group waited for) -- park them; the NEXT group opens one: request its rows, ahead of the next window
+            if (has_b && (cb_b & 1) == 0) park_skip(skw);
+            const int gn = gi + 1;
+            const bool nxt_b = gn >= G::NDVK - 1 && (gn - (G::NDVK - 1)) % (DOWN / 2) == 0;
+            const int cb_n = (gn - (G::NDVK - 1)) / (DOWN / 2);
+            if (nxt_b && (cb_n & 1) == 0 && cb_n < ncb) load_skip(cb_n, skw);
+        }
         if (gi + 1 < ng) load_group(gi + 1, a_nxt);
 #pragma unroll
         for (int nbl = 0; nbl < G::NBG; nbl++) {
@@ -446,7 +485,7 @@ __global__ __launch_bounds__(256, (DOWN == 2 && (TOH <= 32 || SIGN == AFCM_SIGNS
             frag q[G::NQ];
 #pragma unroll
             for (int m = 0; m < G::NQ; m++) q[m] = pack_pair<T>(x1[m], (m + 1 < G::NMB) ? x1[m + 1] : zero4);
-            if (SIGN != AFCM_SIGNS_READ && !EXACT) {
+            if (!RD && !EXACT) {
 #pragma unroll
                 for (int mb = 0; mb < G::NMB; mb++) {
                     amax = __builtin_elementwise_maximum(__builtin_elementwise_maximum(amax, __builtin_fabsf(x1[mb][0])), __builtin_fabsf(x1[mb][1]));
@@ -455,7 +494,22 @@ __global__ __launch_bounds__(256, (DOWN == 2 && (TOH <= 32 || SIGN == AFCM_SIGNS
             }
             // READ: the codes of this block's X2 tiles
             unsigned codes[G::NVB];
-            if (SIGN == AFCM_SIGNS_READ) {
+            if (RA) {
+#pragma unroll
+                for (int i = 0; i < NL; i++) anyc |= sg[nbl][0][i];
+                // code bytes sl .. sl + NVB - 1 of the dword run: one funnel shift per 4 row blocks, then a byte each
+#pragma unroll
+                for (int k = 0; k < NA; k++) {
+                    const unsigned four = __builtin_amdgcn_alignbyte(k + 1 < NL ? sg[nbl][0][k + 1] : 0u, sg[nbl][0][k], sgr_sl);
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        if (4 * k + j < G::NVB) codes[4 * k + j] = __builtin_amdgcn_ubfe(four, 8 * j, 8);
+                }
+                if (nbl == G::NBG - 1 && gi + 1 < ng) {
+                    load_signs(nb + 1, sg[0]);
+                    load_signs(nb + 2, sg[1]);
+                }
+            } else if (RD) {
 #pragma unroll
                 for (int i = 0; i <= NA; i++) anyc |= sg[nbl][0][i] | sg[nbl][1][i];
 #pragma unroll
@@ -503,7 +557,7 @@ __global__ __launch_bounds__(256, (DOWN == 2 && (TOH <= 32 || SIGN == AFCM_SIGNS
                 unsigned r0 = 0, r1 = 0;
                 if (vb < G::NVB) {
                     f32x4 x2 = M::mma(uv[vb % UP], q[vb / UP], zero4);
-                    if (SIGN == AFCM_SIGNS_READ) {
+                    if (RD) {
                         if (!EXACT) {
                             const uint2 keep = lds_tab[codes[vb]];
                             r0 = pack2<T>(x2[0], x2[1]) & keep.x;
@@ -600,7 +654,7 @@ __global__ __launch_bounds__(256, (DOWN == 2 && (TOH <= 32 || SIGN == AFCM_SIGNS
                 for (int h = 0; h < G::NHIST; h++) xw[ob][h] = hist[ob][h];
                 xw[ob][G::NDVK - 1] = cur[ob];
             }
-            phase_b(cb_b, xw, sk);
+            phase_b(cb_b, xw);
         }
     };
 
@@ -609,17 +663,22 @@ __global__ __launch_bounds__(256, (DOWN == 2 && (TOH <= 32 || SIGN == AFCM_SIGNS
         unsigned anyc = 0;
         if (decltype(exact_c)::value) psum = 0.f;
         frag a0[G::NMB], a1[G::NMB];
-        unsigned sg[G::NBG][2][NA + 1];
+        unsigned sg[G::NBG][RA ? 1 : 2][NL];
         load_group(0, a0);
-        if (SIGN == AFCM_SIGNS_READ) {
+        if (RD) {
             load_signs(0, sg[0]);
             load_signs(1, sg[1]);
         }
-        u32x4 hist[G::NOB][G::NHIST], cur[G::NOB];
+        u32x4 hist[G::NOB][G::NHIST], cur[G::NOB], skw[G::NOB];
 #pragma unroll
-        for (int ob = 0; ob < G::NOB; ob++)
+        for (int ob = 0; ob < G::NOB; ob++) {
+            skw[ob] = (u32x4){0u, 0u, 0u, 0u};
 #pragma unroll
             for (int h = 0; h < G::NHIST; h++) hist[ob][h] = (u32x4){0u, 0u, 0u, 0u};
+        }
+        // the first down-x pass runs in group NDVK - 1 >= 1: when that is group 1 its skip rows are requested here (group 0 does
+        // it itself for later ones)
+        static_assert(G::NDVK - 1 >= 1, "the first down-x pass must not be in group 0");
         auto shift = [&]() __attribute__((always_inline)) {
 #pragma unroll
             for (int ob = 0; ob < G::NOB; ob++) {
@@ -630,27 +689,27 @@ __global__ __launch_bounds__(256, (DOWN == 2 && (TOH <= 32 || SIGN == AFCM_SIGNS
         };
         // forward: two input register sets, alternating over a loop unrolled by two (no copies); the transposed op carries more
         // state per group (the sign dwords) and spills at two sets: one set + copies
-        constexpr bool PINGPONG = SIGN != AFCM_SIGNS_READ;
+        constexpr bool PINGPONG = SIGN != AFCM_SIGNS_READ && !(EPI & 2) && !(RA && TOH > 32);      // RA carries a third of the code registers: two sets fit      // (the skip kernels carry the parked-skip registers: one set there too)
         int gi = 0;
         if (PINGPONG) {
 #pragma unroll 1
             for (; gi + 1 < ng; gi += 2) {
-                group(gi, exact_c, lasty_c, a0, a1, sg, hist, cur, amax, anyc);
+                group(gi, exact_c, lasty_c, a0, a1, sg, hist, cur, skw, amax, anyc);
                 shift();
-                group(gi + 1, exact_c, lasty_c, a1, a0, sg, hist, cur, amax, anyc);
+                group(gi + 1, exact_c, lasty_c, a1, a0, sg, hist, cur, skw, amax, anyc);
                 shift();
             }
-            if (gi < ng) group(gi, exact_c, lasty_c, a0, a1, sg, hist, cur, amax, anyc);
+            if (gi < ng) group(gi, exact_c, lasty_c, a0, a1, sg, hist, cur, skw, amax, anyc);
         } else {
 #pragma unroll 1
             for (; gi < ng; gi++) {
-                group(gi, exact_c, lasty_c, a0, a1, sg, hist, cur, amax, anyc);
+                group(gi, exact_c, lasty_c, a0, a1, sg, hist, cur, skw, amax, anyc);
                 shift();
 #pragma unroll
                 for (int mb = 0; mb < G::NMB; mb++) a0[mb] = a1[mb];
             }
         }
-        if (SIGN == AFCM_SIGNS_READ) return __builtin_amdgcn_ballot_w64((anyc & 0xaaaaaaaau) != 0) != 0;   // a clamped element in reach
+        if (RD) return __builtin_amdgcn_ballot_w64((anyc & 0xaaaaaaaau) != 0) != 0;   // a clamped element in reach
         return __builtin_amdgcn_ballot_w64(!(amax <= cthr1)) != 0;                                        // NaN takes the exact path
     };
     // (READ never writes codes: one LASTY variant suffices)
@@ -683,18 +742,21 @@ int launch_wave_tile(const afcm_filtered_lrelu_args* a, FlreluMfmaParams p, hipS
     switch (a->sign_mode) {
         case AFCM_SIGNS_NONE: AFCM_WAVE_LAUNCH(AFCM_SIGNS_NONE); break;
         case AFCM_SIGNS_WRITE: AFCM_WAVE_LAUNCH(AFCM_SIGNS_WRITE); break;
-        default: AFCM_WAVE_LAUNCH(AFCM_SIGNS_READ); break;
+        default:
+            if (p.read_aligned) AFCM_WAVE_LAUNCH(kSignsReadAligned);
+            else AFCM_WAVE_LAUNCH(AFCM_SIGNS_READ);
+            break;
     }
 #undef AFCM_WAVE_LAUNCH
     return hip_status(hipGetLastError());
 }
 
 template <typename T, int UP, int DOWN>
-int prepare_wave(const afcm_filtered_lrelu_args* a, hipStream_t st) {
+int prepare_wave(const afcm_filtered_lrelu_args* a, int py0_frag, int dshift, hipStream_t st) {
     typedef WaveGeom<UP, DOWN, 32, 32> G;
     const float gain_total = (float)a->up * (float)a->up * a->gain;
     hipLaunchKernelGGL((flrelu_wave_prepare_kernel<T, UP, DOWN>), dim3(cdiv((G::NLIN + G::NDVK) * 512, 256)), dim3(256), 0, st,
-                       (char*)a->workspace, a->fu, a->fd, a->py0, a->flip_filter, gain_total, a->slope);
+                       (char*)a->workspace, a->fu, a->fd, py0_frag, a->flip_filter, gain_total, a->slope, dshift);
     return hip_status(hipGetLastError());
 }
 
@@ -705,10 +767,15 @@ int prepare_wave(const afcm_filtered_lrelu_args* a, hipStream_t st) {
     AFCM_WAVE_INST(T, 2, 2, 64, 48)   \
     AFCM_WAVE_INST(T, 2, 4, 32, 32)   \
     AFCM_WAVE_INST(T, 4, 2, 64, 32)   \
-    template int prepare_wave<T, 2, 2>(const afcm_filtered_lrelu_args*, hipStream_t); \
-    template int prepare_wave<T, 2, 4>(const afcm_filtered_lrelu_args*, hipStream_t); \
-    template int prepare_wave<T, 4, 2>(const afcm_filtered_lrelu_args*, hipStream_t);
-AFCM_WAVE_INST_T(bf16_t)
+    template int prepare_wave<T, 2, 2>(const afcm_filtered_lrelu_args*, int, int, hipStream_t); \
+    template int prepare_wave<T, 2, 4>(const afcm_filtered_lrelu_args*, int, int, hipStream_t); \
+    template int prepare_wave<T, 4, 2>(const afcm_filtered_lrelu_args*, int, int, hipStream_t);
+// one translation unit per element type (Makefile: filtered_lrelu_wave.o = bf16, filtered_lrelu_wave_f16.o = f16): the two halves
+// compile in parallel
+#ifdef AFCM_WAVE_F16
 AFCM_WAVE_INST_T(f16_t)
+#else
+AFCM_WAVE_INST_T(bf16_t)
+#endif
 
 }  // namespace afcm

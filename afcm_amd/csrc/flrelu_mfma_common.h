@@ -33,6 +33,7 @@ struct FlreluMfmaParams {
     float slope, clamp;
     int sx, sy, shq, swq;  // sign tensor: rows of quads, bytes per row
     int total_tiles;       // wave kernels: tilesX * tilesY * planes (one wave per tile)
+    int oy0, read_aligned; // wave kernels, READ: strips start at output row ty * TOH + oy0 (oy0 <= 0) so that they fall on 16-row blocks of the sign tensor
 };
 
 constexpr int kFUT = 6;            // taps per polyphase branch of the up filter (filter_size of the model)

@@ -88,8 +88,11 @@ def _mfma_workspace(a, fu_t, fd_t, x):
     (C ABI afcm_filtered_lrelu_prepare).  Returns a device tensor or None."""
     if x.dtype not in (torch.bfloat16, torch.float16) or fu_t is None or fd_t is None:
         return None
+    # a READ call on codes of the wave kernels (layout 2) gets fragments whose rows are moved so that its strips fall on the sign
+    # tensor's row blocks (csrc/filtered_lrelu_mfma.hip wave_read_origin): the shift depends on sy mod 16
+    aligned_read = (a.sy % 16) if (a.sign_mode == _lib.SIGNS_READ and a.sign_layout == 2) else None
     key = (x.device, x.dtype, fu_t.data_ptr(), fu_t._version, fd_t.data_ptr(), fd_t._version, a.fuw, a.fuh, a.fdw, a.fdh,
-           a.up, a.down, a.px0, a.py0, a.gain, a.slope, a.flip_filter)
+           a.up, a.down, a.px0, a.py0, a.gain, a.slope, a.flip_filter, aligned_read)
     if key not in _workspaces:
         lib = _lib.load()
         ws = torch.empty([lib.afcm_filtered_lrelu_workspace_bytes()], dtype=torch.uint8, device=x.device)
@@ -144,6 +147,7 @@ def _run(x, fu, fd, b, si, cfg, write_signs, want_plane_sum=False, oscale=None, 
     a.sign_mode = _lib.SIGNS_WRITE if write_signs else (_lib.SIGNS_READ if si is not None else _lib.SIGNS_NONE)
     # 16-bit activations: matrix-core kernels (signs in the row-quad layout); a given sign tensor fixes the family
     ws = None
+    a.sign_layout = si_layout if si is not None else 0      # (prepare: a READ call's fragments depend on the layout it reads)
     if allow_mfma and (si is None or si_layout in (1, 2)):
         ws = _mfma_workspace(a, fu_t, fd_t, x)
         if si is not None and ws is None:
