@@ -259,17 +259,17 @@ __global__ __launch_bounds__(256, (DOWN == 2 && (TOH <= 32 || SIGN == AFCM_SIGNS
     const int xoff0 = ((I0y + lrow) * p.xld + S0x + 8 * lchk) * 2;
     const int xrow16 = 32 * p.xld;                                         // 16 rows, bytes
     constexpr unsigned kOut = 0x40000000u;                               // out-of-range marker (planes stay below 2^29 bytes)
-    auto load_group = [&](int gi, frag (&a)[G::NMB]) __attribute__((always_inline)) {
+    // Loads only: the window arrives in the ACCESS lane map and stays there, untouched, until the group that consumes it converts
+    // it (to_frags).  r02 converted right here, load -> ds_bpermute inside the same basic block (the fast / edge branch pins it
+    // there), so the wave waited for every window on the spot -- a full memory round trip per group with nothing but the SIMD's
+    // other two waves to cover it: the "memory waits" of profiles/r02_bench_pmc.txt and the reason the compute-only build ran at
+    // twice the speed.  (ISA of the r02 build: buffer_load_dwordx4 x3, s_waitcnt vmcnt(2), ds_bpermute x4, vmcnt(1), ...)
+    auto load_group = [&](int gi, u32x4 (&raw)[G::NMB]) __attribute__((always_inline)) {
         const int c0 = S0x + G::IWSTEP * gi;                              // wave-uniform
         if (__builtin_expect(c0 >= 0 && c0 + 32 <= p.xw, 1)) {
 #pragma unroll
-            for (int mb = 0; mb < G::NMB; mb++) {
-                union { u32x4 u; frag f; } r;
-                r.u = __builtin_amdgcn_raw_buffer_load_b128(rsx, (unsigned)(xoff0 + 2 * G::IWSTEP * gi + mb * xrow16), 0, AFCM_WAVE_LOAD_AUX);
-#pragma unroll
-                for (int w = 0; w < 4; w++) r.u[w] = (unsigned)__builtin_amdgcn_ds_bpermute(to_frag, (int)r.u[w]);
-                a[mb] = r.f;
-            }
+            for (int mb = 0; mb < G::NMB; mb++)
+                raw[mb] = __builtin_amdgcn_raw_buffer_load_b128(rsx, (unsigned)(xoff0 + 2 * G::IWSTEP * gi + mb * xrow16), 0, AFCM_WAVE_LOAD_AUX);
         } else {
             // the window crosses the left or right edge of the plane: dword by dword, columns outside it read as zero
             // (even plane widths: the two elements of a dword are in or out together; rows outside: as above, except that a
@@ -281,13 +281,19 @@ __global__ __launch_bounds__(256, (DOWN == 2 && (TOH <= 32 || SIGN == AFCM_SIGNS
 #pragma unroll
             for (int mb = 0; mb < G::NMB; mb++) {
                 const unsigned ro = (I0y + 16 * mb + lrow < 0) ? kOut : (unsigned)(xoff0 + mb * xrow16);
-                union { u32x4 u; frag f; } r;
 #pragma unroll
-                for (int w = 0; w < 4; w++) r.u[w] = __builtin_amdgcn_raw_buffer_load_b32(rsx, ro + cofs[w], 0, 0);
-#pragma unroll
-                for (int w = 0; w < 4; w++) r.u[w] = (unsigned)__builtin_amdgcn_ds_bpermute(to_frag, (int)r.u[w]);
-                a[mb] = r.f;
+                for (int w = 0; w < 4; w++) raw[mb][w] = __builtin_amdgcn_raw_buffer_load_b32(rsx, ro + cofs[w], 0, 0);
             }
+        }
+    };
+    // access lane map -> MFMA A fragments (ds_bpermute: no LDS allocation), at the top of the group that multiplies them
+    auto to_frags = [&](const u32x4 (&raw)[G::NMB], frag (&a)[G::NMB]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int mb = 0; mb < G::NMB; mb++) {
+            union { u32x4 u; frag f; } r;
+#pragma unroll
+            for (int w = 0; w < 4; w++) r.u[w] = (unsigned)__builtin_amdgcn_ds_bpermute(to_frag, (int)raw[mb][w]);
+            a[mb] = r.f;
         }
     };
 
@@ -421,8 +427,17 @@ __global__ __launch_bounds__(256, (DOWN == 2 && (TOH <= 32 || SIGN == AFCM_SIGNS
             w.y = pack2<T>(acc[2], acc[3]);
             *(uint2*)(stage + st_w + (unsigned)(ob * 16 * OPITCH + slot * 32)) = w;
         }
-        // flush after every fourth column block (and after the last one): 8 rows x 128 bytes per store instruction
-        if (slot == 3 || cb == ncb - 1) {
+    };
+    // flush of the staged 64-column group that column block cb completed (every fourth block, and the last one): 8 rows x 128 bytes
+    // per store instruction.  Called at the TOP of the group after the one that staged it, ahead of that group's window request:
+    // s_waitcnt vmcnt counts loads and stores together, in order, so the wait for a window covers everything older and must
+    // name the exact number of younger operations -- with the flush (4 to 16 stores, by path) BEHIND the window request the
+    // compiler had to assume the path without it, and on every fourth group the wait for the window also drained the four
+    // stores issued a moment before (ISA of the r02 build: s_waitcnt vmcnt(2) at the top of every group).  Now the only younger
+    // operations are the group's sign stores: the same count on every path.
+    auto flush = [&](int cb) __attribute__((always_inline)) {
+        const int slot = cb & 3;
+        {
             const int c0 = 64 * (cb >> 2) + 8 * fl_chk;                                         // this lane's first output column
             // wave-uniform: the whole 64-column group lies inside the row (a pitched y: inside the pitch -- its rows start on 128-byte
             // lines and EVERY flush is whole lines; columns >= yw are padding and receive whatever the staging buffer holds: finite
@@ -456,7 +471,7 @@ __global__ __launch_bounds__(256, (DOWN == 2 && (TOH <= 32 || SIGN == AFCM_SIGNS
     // completes.  EXACT: the rare second pass over a strip in which the clamp was reached.  LASTY: the strip also writes the codes of
     // its halo row blocks (every other strip leaves them to the strip below and skips their extraction).
     // One group; the caller alternates two register sets for everything that is carried from one group to the next.
-    auto group = [&](int gi, auto exact_c, auto lasty_c, frag (&a_in)[G::NMB], frag (&a_nxt)[G::NMB], unsigned (&sg)[G::NBG][RA ? 1 : 2][NL],
+    auto group = [&](int gi, auto exact_c, auto lasty_c, u32x4 (&raw)[G::NMB], unsigned (&sg)[G::NBG][RA ? 1 : 2][NL],
                      u32x4 (&hist)[G::NOB][G::NHIST], u32x4 (&cur)[G::NOB], u32x4 (&skw)[G::NOB], float& amax, unsigned& anyc) __attribute__((always_inline)) {
         constexpr bool EXACT = decltype(exact_c)::value, LASTY = decltype(lasty_c)::value;
         constexpr int NVW = LASTY ? G::NVB : G::OWN_VB;                  // row blocks whose codes this strip writes
@@ -465,6 +480,17 @@ __global__ __launch_bounds__(256, (DOWN == 2 && (TOH <= 32 || SIGN == AFCM_SIGNS
         // the output column block whose last K window is this group's pair: pairs (DOWN / 2) cb ... + NDVK - 1 = gi
         const bool has_b = gi >= G::NDVK - 1 && (gi - (G::NDVK - 1)) % (DOWN / 2) == 0;
         const int cb_b = (gi - (G::NDVK - 1)) / (DOWN / 2);
+        // this group's window (requested a group ago: the only younger memory operations are the last group's sign stores) into
+        // fragments; then the stores of the 64-column output group the previous down-x pass may have completed; then the
+        // requests for the next group, the window last, into the same registers
+        frag a_in[G::NMB];
+        to_frags(raw, a_in);
+        {
+            const int gp = gi - 1;
+            const bool prv_b = gp >= G::NDVK - 1 && (gp - (G::NDVK - 1)) % (DOWN / 2) == 0;
+            const int cb_p = (gp - (G::NDVK - 1)) / (DOWN / 2);
+            if (prv_b && ((cb_p & 3) == 3 || cb_p == ncb - 1)) flush(cb_p);
+        }
         if (EPI & 2) {
             // this group's down-x pass opens a column-block pair: its skip rows were requested a group ago (older than the window
             // that the group waited for) -- park them; the NEXT group opens one: request its rows, ahead of the next window
@@ -474,7 +500,7 @@ __global__ __launch_bounds__(256, (DOWN == 2 && (TOH <= 32 || SIGN == AFCM_SIGNS
             const int cb_n = (gn - (G::NDVK - 1)) / (DOWN / 2);
             if (nxt_b && (cb_n & 1) == 0 && cb_n < ncb) load_skip(cb_n, skw);
         }
-        if (gi + 1 < ng) load_group(gi + 1, a_nxt);
+        if (gi + 1 < ng) load_group(gi + 1, raw);
 #pragma unroll
         for (int nbl = 0; nbl < G::NBG; nbl++) {
             const int nb = gi * G::NBG + nbl;
@@ -662,9 +688,20 @@ __global__ __launch_bounds__(256, (DOWN == 2 && (TOH <= 32 || SIGN == AFCM_SIGNS
         float amax = 0.f;
         unsigned anyc = 0;
         if (decltype(exact_c)::value) psum = 0.f;
-        frag a0[G::NMB], a1[G::NMB];
+        u32x4 raw[G::NMB];
         unsigned sg[G::NBG][RA ? 1 : 2][NL];
-        load_group(0, a0);
+        load_group(0, raw);
+        if (SIGN == AFCM_SIGNS_WRITE) {
+            // The wait for a window names the number of YOUNGER memory operations (vmcnt is one in-order counter for loads and
+            // stores): inside the loop those are the sign stores of the group that ran meanwhile.  The compiler merges the loop's
+            // entry state with the back edge's and takes the stricter: with nothing behind the first request it emitted
+            // vmcnt(2 / 1 / 0) for every iteration, i.e. every group also waited for its predecessor's sign stores to be
+            // acknowledged.  As many stores behind the first request as a group issues (out of range: dropped by the memory
+            // pipeline, counted like any other) make the two states equal.
+            constexpr int NVW = decltype(lasty_c)::value ? G::NVB : G::OWN_VB;
+#pragma unroll
+            for (int i = 0; i < G::NBG * cdiv(NVW, 4); i++) __builtin_amdgcn_raw_buffer_store_b32(0u, rsx, kOut + 256u * i, 0, AFCM_WAVE_STORE_AUX);   // (distinct, non-adjacent offsets: identical or adjacent stores are merged)
+        }
         if (RD) {
             load_signs(0, sg[0]);
             load_signs(1, sg[1]);
@@ -679,36 +716,17 @@ __global__ __launch_bounds__(256, (DOWN == 2 && (TOH <= 32 || SIGN == AFCM_SIGNS
         // the first down-x pass runs in group NDVK - 1 >= 1: when that is group 1 its skip rows are requested here (group 0 does
         // it itself for later ones)
         static_assert(G::NDVK - 1 >= 1, "the first down-x pass must not be in group 0");
-        auto shift = [&]() __attribute__((always_inline)) {
+#pragma unroll 1
+        for (int gi = 0; gi < ng; gi++) {
+            group(gi, exact_c, lasty_c, raw, sg, hist, cur, skw, amax, anyc);
 #pragma unroll
             for (int ob = 0; ob < G::NOB; ob++) {
 #pragma unroll
                 for (int h = 0; h + 1 < G::NHIST; h++) hist[ob][h] = hist[ob][h + 1];
                 hist[ob][G::NHIST - 1] = cur[ob];
             }
-        };
-        // forward: two input register sets, alternating over a loop unrolled by two (no copies); the transposed op carries more
-        // state per group (the sign dwords) and spills at two sets: one set + copies
-        constexpr bool PINGPONG = SIGN != AFCM_SIGNS_READ && !(EPI & 2) && !(RA && TOH > 32);      // RA carries a third of the code registers: two sets fit      // (the skip kernels carry the parked-skip registers: one set there too)
-        int gi = 0;
-        if (PINGPONG) {
-#pragma unroll 1
-            for (; gi + 1 < ng; gi += 2) {
-                group(gi, exact_c, lasty_c, a0, a1, sg, hist, cur, skw, amax, anyc);
-                shift();
-                group(gi + 1, exact_c, lasty_c, a1, a0, sg, hist, cur, skw, amax, anyc);
-                shift();
-            }
-            if (gi < ng) group(gi, exact_c, lasty_c, a0, a1, sg, hist, cur, skw, amax, anyc);
-        } else {
-#pragma unroll 1
-            for (; gi < ng; gi++) {
-                group(gi, exact_c, lasty_c, a0, a1, sg, hist, cur, skw, amax, anyc);
-                shift();
-#pragma unroll
-                for (int mb = 0; mb < G::NMB; mb++) a0[mb] = a1[mb];
-            }
         }
+        flush(ncb - 1);                                   // the last group completed the last column block
         if (RD) return __builtin_amdgcn_ballot_w64((anyc & 0xaaaaaaaau) != 0) != 0;   // a clamped element in reach
         return __builtin_amdgcn_ballot_w64(!(amax <= cthr1)) != 0;                                        // NaN takes the exact path
     };
@@ -739,15 +757,22 @@ int launch_wave_tile(const afcm_filtered_lrelu_args* a, FlreluMfmaParams p, hipS
         else if (p.skip != nullptr) hipLaunchKernelGGL((flrelu_wave_kernel<T, UP, DOWN, TOW, TOH, SIGN, 3>), grid, block, 0, st, p); \
         else if (scale) hipLaunchKernelGGL((flrelu_wave_kernel<T, UP, DOWN, TOW, TOH, SIGN, 1>), grid, block, 0, st, p); \
         else hipLaunchKernelGGL((flrelu_wave_kernel<T, UP, DOWN, TOW, TOH, SIGN, 0>), grid, block, 0, st, p); } while (0)
+    // sign-reading calls are the transposed op: there is no encoder skip to add (forward-only operand), so those variants are not built
+#define AFCM_WAVE_LAUNCH_RD(SIGN) do { \
+        AFCM_REQUIRE(p.skip == nullptr, "filtered_lrelu: a skip operand next to a sign tensor to READ is not supported by the wave kernels"); \
+        if (sums) hipLaunchKernelGGL((flrelu_wave_kernel<T, UP, DOWN, TOW, TOH, SIGN, 5>), grid, block, 0, st, p); \
+        else if (scale) hipLaunchKernelGGL((flrelu_wave_kernel<T, UP, DOWN, TOW, TOH, SIGN, 1>), grid, block, 0, st, p); \
+        else hipLaunchKernelGGL((flrelu_wave_kernel<T, UP, DOWN, TOW, TOH, SIGN, 0>), grid, block, 0, st, p); } while (0)
     switch (a->sign_mode) {
         case AFCM_SIGNS_NONE: AFCM_WAVE_LAUNCH(AFCM_SIGNS_NONE); break;
         case AFCM_SIGNS_WRITE: AFCM_WAVE_LAUNCH(AFCM_SIGNS_WRITE); break;
         default:
-            if (p.read_aligned) AFCM_WAVE_LAUNCH(kSignsReadAligned);
-            else AFCM_WAVE_LAUNCH(AFCM_SIGNS_READ);
+            if (p.read_aligned) AFCM_WAVE_LAUNCH_RD(kSignsReadAligned);
+            else AFCM_WAVE_LAUNCH_RD(AFCM_SIGNS_READ);
             break;
     }
 #undef AFCM_WAVE_LAUNCH
+#undef AFCM_WAVE_LAUNCH_RD
     return hip_status(hipGetLastError());
 }
 

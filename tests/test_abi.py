@@ -104,3 +104,47 @@ def test_operator_library_is_registered_with_the_plugin_schemas():
     assert 'int grad, int dim, int act, float alpha, float gain, float clamp' in str(torch.ops.afcm.bias_act.default._schema)
     with pytest.raises(NotImplementedError):
         torch.ops.afcm.upfirdn2d(torch.zeros(1, 1, 4, 4), torch.ones(1, 1), 1, 1, 1, 1, 0, 0, 0, 0, False, 1.0)
+
+
+def _wave_kernel_table():
+    """{(dtype, up, down, tow, toh, sign, epi): resources} of the built wave filtered_lrelu kernels (code-object metadata)."""
+    import re
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, 'tools'))
+    from kernel_resources import kernel_resources
+    table = {}
+    for obj, dt in (('filtered_lrelu_wave.o', 'bf16'), ('filtered_lrelu_wave_f16.o', 'f16')):
+        path = os.path.join(root, 'afcm_amd', 'csrc', obj)
+        if not os.path.exists(path):
+            pytest.skip(f'{obj} not built (run __graft_entry__.build())')
+        for k in kernel_resources(path):
+            m = re.search(r'flrelu_wave_kernelI(?:DF16b|DF16_)Li(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E', k['name'])
+            if not m:
+                m = re.search(r'flrelu_wave_kernel<[^,]+, (\d+), (\d+), (\d+), (\d+), (\d+), (\d+)>', k['name'])
+            if m:
+                table[(dt,) + tuple(int(v) for v in m.groups())] = k
+    return table
+
+
+def test_hot_filtered_lrelu_kernels_do_not_spill():
+    """"zero scratch in <.,2,2,64,32,2,5> / <.,4,2,64,32,2,5> (check .vgpr_spill_count in the code-object notes in CI,
+    not by eye)".  Every wave kernel the training step launches -- sign-writing forward with the plain / per-plane-factor / skip
+    epilogues, aligned sign-reading transposed op (SIGN 3) with the plain / factor / factor + plane-sum epilogues -- must have NO
+    scratch; the one-strip 48-row kernels of the 36^2 planes may keep a handful of dwords (measured faster at three waves per
+    SIMD with <= 6 spilled registers than at two waves without)."""
+    t = _wave_kernel_table()
+    assert len(t) >= 100, len(t)
+    WRITE, RA = 1, 3
+    for dt in ('bf16', 'f16'):
+        for (up, down, tow) in ((2, 2, 64), (2, 4, 32), (4, 2, 64)):
+            for sign, epis in ((WRITE, (0, 1) + ((3,) if (up, down) == (2, 2) else ())), (RA, (0, 1, 5))):
+                for epi in epis:
+                    k = t[(dt, up, down, tow, 32, sign, epi)]
+                    assert k.get('scratch', 0) == 0 and k.get('vgpr_spill', 0) == 0, (dt, up, down, sign, epi, k)
+        for epi in (0, 1):
+            k = t[(dt, 2, 2, 64, 48, WRITE, epi)]
+            assert k.get('scratch', 0) == 0, k
+        for epi in (0, 1, 5):
+            k = t[(dt, 2, 2, 64, 48, RA, epi)]
+            assert k.get('vgpr_spill', 0) <= 6, k
