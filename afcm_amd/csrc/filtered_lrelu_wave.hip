@@ -193,6 +193,16 @@ __global__ __launch_bounds__(256, (DOWN == 2 && (TOH <= 32 || SIGN == AFCM_SIGNS
     // bytes, L12 forward 232 us against 122-145 us for the same plane without a skip.)
     constexpr int KPITCH = 80;                                             // bytes per staged skip row: 64 + 16
     __shared__ __attribute__((aligned(16))) unsigned char lds_k[(EPI & 2) ? 4 : 1][(EPI & 2) ? TOH * KPITCH : 16];
+    // Input ring, private to each wave: the strip's 16 NMB input rows x the two most recent 64-byte column PIECES.  The K window of
+    // a group is 64 bytes wide but advances by 32 (up 2) or 16 (up 4) bytes: requested as windows (r02) every input byte crossed
+    // the L1 -> L2 path two (four) times, and that path -- not HBM, not latency -- is what the kernels ran into: a load-only
+    // replica of the access pattern (tools/ubench/strip_read.hip, profiles/r03_strip_read.txt) tops out at 2.5 TB/s of plane bytes
+    // with overlapping 64-byte windows, whatever the prefetch depth or occupancy, against 4.6 TB/s for the same instructions on
+    // disjoint 64-byte pieces.  So every byte is requested ONCE (one piece per 2 (4) groups, two (four) groups ahead of its first
+    // use), parked here, and a group's A fragments are plain 16-byte LDS reads at the window's offset (the ds_bpermute lane-map
+    // change is gone with them).  144-byte rows: 16 consecutive rows x 16 bytes hit 64 distinct banks.
+    constexpr int IPITCH = 144;
+    __shared__ __attribute__((aligned(16))) unsigned char lds_in[4][16 * G::NMB * IPITCH];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -253,31 +263,32 @@ __global__ __launch_bounds__(256, (DOWN == 2 && (TOH <= 32 || SIGN == AFCM_SIGNS
     // than all of its arithmetic).  So loads and stores use lane = 4 row + chunk -- 4 consecutive lanes cover 64 (stores: 32)
     // contiguous bytes -- and ds_bpermute moves the dwords between that map and the fragment map: no LDS allocation, no VALU.
     const int lrow = lane >> 2, lchk = lane & 3;
-    const int to_frag = (4 * l15 + g) * 4;                                // fragment lane (g, l15) reads from access lane 4 l15 + g
     // byte offset of (row I0y + lrow, column S0x + 8 lchk); rows above the plane give a negative offset = beyond the descriptor's
     // range as an unsigned number, rows below it exceed the record count: both read as zero without a predicate
     const int xoff0 = ((I0y + lrow) * p.xld + S0x + 8 * lchk) * 2;
     const int xrow16 = 32 * p.xld;                                         // 16 rows, bytes
     constexpr unsigned kOut = 0x40000000u;                               // out-of-range marker (planes stay below 2^29 bytes)
-    // Loads only: the window arrives in the ACCESS lane map and stays there, untouched, until the group that consumes it converts
-    // it (to_frags).  r02 converted right here, load -> ds_bpermute inside the same basic block (the fast / edge branch pins it
-    // there), so the wave waited for every window on the spot -- a full memory round trip per group with nothing but the SIMD's
-    // other two waves to cover it: the "memory waits" of profiles/r02_bench_pmc.txt and the reason the compute-only build ran at
-    // twice the speed.  (ISA of the r02 build: buffer_load_dwordx4 x3, s_waitcnt vmcnt(2), ds_bpermute x4, vmcnt(1), ...)
-    auto load_group = [&](int gi, u32x4 (&raw)[G::NMB]) __attribute__((always_inline)) {
-        const int c0 = S0x + G::IWSTEP * gi;                              // wave-uniform
+    // piece k = input columns [S0x + 32 k, + 32): 16 rows x 64 bytes per instruction (access lane map), loads only -- the data
+    // stays in these registers until park_piece() (r02 converted right behind the load, inside the fast / edge branch, and so
+    // waited for every window on the spot)
+    unsigned char* const ring = lds_in[wave];
+    constexpr int ABYTES = 2 * G::IWSTEP;                                  // bytes the window advances per group (32 / 16)
+    constexpr int PGRP = 64 / ABYTES;                                      // groups per piece
+    static_assert(64 % ABYTES == 0 && PGRP >= 2, "pieces of 64 bytes, at least two groups each");
+    auto load_piece = [&](int k, u32x4 (&raw)[G::NMB]) __attribute__((always_inline)) {
+        const int c0 = S0x + 32 * k;                                      // wave-uniform
         if (__builtin_expect(c0 >= 0 && c0 + 32 <= p.xw, 1)) {
 #pragma unroll
             for (int mb = 0; mb < G::NMB; mb++)
-                raw[mb] = __builtin_amdgcn_raw_buffer_load_b128(rsx, (unsigned)(xoff0 + 2 * G::IWSTEP * gi + mb * xrow16), 0, AFCM_WAVE_LOAD_AUX);
+                raw[mb] = __builtin_amdgcn_raw_buffer_load_b128(rsx, (unsigned)(xoff0 + 64 * k + mb * xrow16), 0, AFCM_WAVE_LOAD_AUX);
         } else {
-            // the window crosses the left or right edge of the plane: dword by dword, columns outside it read as zero
+            // the piece crosses the left or right edge of the plane: dword by dword, columns outside it read as zero
             // (even plane widths: the two elements of a dword are in or out together; rows outside: as above, except that a
             // negative row offset plus the marker must not wrap back into range)
             const int col = c0 + 8 * lchk;
             unsigned cofs[4];
 #pragma unroll
-            for (int w = 0; w < 4; w++) cofs[w] = (unsigned)(col + 2 * w) < (unsigned)p.xw ? (unsigned)(2 * G::IWSTEP * gi + 4 * w) : kOut;
+            for (int w = 0; w < 4; w++) cofs[w] = (unsigned)(col + 2 * w) < (unsigned)p.xw ? (unsigned)(64 * k + 4 * w) : kOut;
 #pragma unroll
             for (int mb = 0; mb < G::NMB; mb++) {
                 const unsigned ro = (I0y + 16 * mb + lrow < 0) ? kOut : (unsigned)(xoff0 + mb * xrow16);
@@ -286,15 +297,15 @@ __global__ __launch_bounds__(256, (DOWN == 2 && (TOH <= 32 || SIGN == AFCM_SIGNS
             }
         }
     };
-    // access lane map -> MFMA A fragments (ds_bpermute: no LDS allocation), at the top of the group that multiplies them
-    auto to_frags = [&](const u32x4 (&raw)[G::NMB], frag (&a)[G::NMB]) __attribute__((always_inline)) {
+    auto park_piece = [&](int k, const u32x4 (&raw)[G::NMB]) __attribute__((always_inline)) {
 #pragma unroll
-        for (int mb = 0; mb < G::NMB; mb++) {
-            union { u32x4 u; frag f; } r;
+        for (int mb = 0; mb < G::NMB; mb++) *(u32x4*)(ring + (unsigned)((16 * mb + lrow) * IPITCH + (k & 1) * 64 + 16 * lchk)) = raw[mb];
+    };
+    // A fragments of group gi: lane (g, l15) takes the 16 bytes at window offset 16 g of row l15; ring position = byte mod 128
+    auto frags = [&](int gi, frag (&a)[G::NMB]) __attribute__((always_inline)) {
+        const unsigned o = (unsigned)(l15 * IPITCH) + ((unsigned)(ABYTES * gi + 16 * g) & 127u);
 #pragma unroll
-            for (int w = 0; w < 4; w++) r.u[w] = (unsigned)__builtin_amdgcn_ds_bpermute(to_frag, (int)raw[mb][w]);
-            a[mb] = r.f;
-        }
+        for (int mb = 0; mb < G::NMB; mb++) a[mb] = *(const frag*)(ring + o + (unsigned)(16 * mb * IPITCH));
     };
 
     // ---- sign codes (layout 2, see above)
@@ -339,6 +350,9 @@ __global__ __launch_bounds__(256, (DOWN == 2 && (TOH <= 32 || SIGN == AFCM_SIGNS
                 ol = ((unsigned)(sgr_dl + i) < (unsigned)nV4) ? ol : 0x80000000u;
                 oh = ((unsigned)(sgr_dh + i) < (unsigned)nV4) ? oh : 0x80000000u;
             }
+#ifdef AFCM_WAVE_EXPERIMENT_NOSIGNLOAD  // timing experiment only (wrong results): every code load falls outside the descriptor
+            ol |= 0x80000000u;
+#endif
             sg[0][i] = __builtin_amdgcn_raw_buffer_load_b32(rss, ol, 0, AFCM_WAVE_SIGNLOAD_AUX);
             if constexpr (!RA) sg[1][i] = (yy != 0) ? __builtin_amdgcn_raw_buffer_load_b32(rss, oh, 0, AFCM_WAVE_SIGNLOAD_AUX) : 0u;
         }
@@ -480,11 +494,29 @@ __global__ __launch_bounds__(256, (DOWN == 2 && (TOH <= 32 || SIGN == AFCM_SIGNS
         // the output column block whose last K window is this group's pair: pairs (DOWN / 2) cb ... + NDVK - 1 = gi
         const bool has_b = gi >= G::NDVK - 1 && (gi - (G::NDVK - 1)) % (DOWN / 2) == 0;
         const int cb_b = (gi - (G::NDVK - 1)) / (DOWN / 2);
-        // this group's window (requested a group ago: the only younger memory operations are the last group's sign stores) into
-        // fragments; then the stores of the 64-column output group the previous down-x pass may have completed; then the
-        // requests for the next group, the window last, into the same registers
+        // aligned READ: code bytes sl .. sl + NVB - 1 of each column block's dword run, one funnel shift per 4 row blocks -- taken
+        // first, so that the registers can take the next group's request below and nothing younger than the codes is waited for
+        unsigned four[G::NBG][NA] = {};
+        if (RA) {
+#pragma unroll
+            for (int nbl = 0; nbl < G::NBG; nbl++) {
+#pragma unroll
+                for (int i = 0; i < NL; i++) anyc |= sg[nbl][0][i];
+#pragma unroll
+                for (int k = 0; k < NA; k++)
+                    four[nbl][k] = __builtin_amdgcn_alignbyte(k + 1 < NL ? sg[nbl][0][k + 1] : 0u, sg[nbl][0][k], sgr_sl);
+            }
+        }
+        // the window of group PGRP (k - 1) + 1 is the first to reach into piece k: park it (requested PGRP groups ago, or before
+        // the loop) and request piece k + 1 into the same registers; then this group's fragments; then the stores of the 64-column
+        // output group the previous down-x pass may have completed
+        if (gi % PGRP == 1) {
+            const int k = (gi - 1) / PGRP + 1;
+            park_piece(k, raw);
+            load_piece(k + 1, raw);                  // (past the plane's right edge: dropped by the descriptor)
+        }
         frag a_in[G::NMB];
-        to_frags(raw, a_in);
+        frags(gi, a_in);
         {
             const int gp = gi - 1;
             const bool prv_b = gp >= G::NDVK - 1 && (gp - (G::NDVK - 1)) % (DOWN / 2) == 0;
@@ -500,7 +532,12 @@ __global__ __launch_bounds__(256, (DOWN == 2 && (TOH <= 32 || SIGN == AFCM_SIGNS
             const int cb_n = (gn - (G::NDVK - 1)) / (DOWN / 2);
             if (nxt_b && (cb_n & 1) == 0 && cb_n < ncb) load_skip(cb_n, skw);
         }
-        if (gi + 1 < ng) load_group(gi + 1, raw);
+        if (RA) {
+            // (unconditional: past the last group the blocks lie outside the tensor and read as zero; a condition here costs
+            // register copies that wait for the window just requested)
+            load_signs((gi + 1) * G::NBG, sg[0]);
+            load_signs((gi + 1) * G::NBG + 1, sg[1]);
+        }
 #pragma unroll
         for (int nbl = 0; nbl < G::NBG; nbl++) {
             const int nb = gi * G::NBG + nbl;
@@ -521,20 +558,12 @@ __global__ __launch_bounds__(256, (DOWN == 2 && (TOH <= 32 || SIGN == AFCM_SIGNS
             // READ: the codes of this block's X2 tiles
             unsigned codes[G::NVB];
             if (RA) {
+                // a byte of the funnel-shifted runs (top of the group) each
 #pragma unroll
-                for (int i = 0; i < NL; i++) anyc |= sg[nbl][0][i];
-                // code bytes sl .. sl + NVB - 1 of the dword run: one funnel shift per 4 row blocks, then a byte each
-#pragma unroll
-                for (int k = 0; k < NA; k++) {
-                    const unsigned four = __builtin_amdgcn_alignbyte(k + 1 < NL ? sg[nbl][0][k + 1] : 0u, sg[nbl][0][k], sgr_sl);
+                for (int k = 0; k < NA; k++)
 #pragma unroll
                     for (int j = 0; j < 4; j++)
-                        if (4 * k + j < G::NVB) codes[4 * k + j] = __builtin_amdgcn_ubfe(four, 8 * j, 8);
-                }
-                if (nbl == G::NBG - 1 && gi + 1 < ng) {
-                    load_signs(nb + 1, sg[0]);
-                    load_signs(nb + 2, sg[1]);
-                }
+                        if (4 * k + j < G::NVB) codes[4 * k + j] = __builtin_amdgcn_ubfe(four[nbl][k], 8 * j, 8);
             } else if (RD) {
 #pragma unroll
                 for (int i = 0; i <= NA; i++) anyc |= sg[nbl][0][i] | sg[nbl][1][i];
@@ -585,7 +614,11 @@ __global__ __launch_bounds__(256, (DOWN == 2 && (TOH <= 32 || SIGN == AFCM_SIGNS
                     f32x4 x2 = M::mma(uv[vb % UP], q[vb / UP], zero4);
                     if (RD) {
                         if (!EXACT) {
+#ifdef AFCM_WAVE_EXPERIMENT_NOTABLE     // timing experiment only (wrong results): no keep-mask lookup
+                            const uint2 keep = make_uint2(0xffffffffu ^ codes[vb], 0xffffffffu);
+#else
                             const uint2 keep = lds_tab[codes[vb]];
+#endif
                             r0 = pack2<T>(x2[0], x2[1]) & keep.x;
                             r1 = pack2<T>(x2[2], x2[3]) & keep.y;
                         } else {
@@ -690,14 +723,16 @@ __global__ __launch_bounds__(256, (DOWN == 2 && (TOH <= 32 || SIGN == AFCM_SIGNS
         if (decltype(exact_c)::value) psum = 0.f;
         u32x4 raw[G::NMB];
         unsigned sg[G::NBG][RA ? 1 : 2][NL];
-        load_group(0, raw);
+        load_piece(0, raw);
+        park_piece(0, raw);                          // (the one exposed round trip of the strip)
+        load_piece(1, raw);
         if (SIGN == AFCM_SIGNS_WRITE) {
-            // The wait for a window names the number of YOUNGER memory operations (vmcnt is one in-order counter for loads and
-            // stores): inside the loop those are the sign stores of the group that ran meanwhile.  The compiler merges the loop's
-            // entry state with the back edge's and takes the stricter: with nothing behind the first request it emitted
-            // vmcnt(2 / 1 / 0) for every iteration, i.e. every group also waited for its predecessor's sign stores to be
-            // acknowledged.  As many stores behind the first request as a group issues (out of range: dropped by the memory
-            // pipeline, counted like any other) make the two states equal.
+            // The wait for a piece (park_piece) names the number of YOUNGER memory operations it may leave in flight (vmcnt is one
+            // in-order counter for loads and stores): at least the sign stores of the group that ran since.  The loop head is also
+            // reachable straight from here, with nothing behind the request -- for the compiler's count, not in fact -- and the
+            // stricter state wins: it emitted vmcnt(2 / 1 / 0), i.e. every park also waited for the sign stores issued a moment
+            // before.  As many stores behind the first request as a group issues (out of range: dropped by the memory pipeline,
+            // counted like any other) make the two states equal.
             constexpr int NVW = decltype(lasty_c)::value ? G::NVB : G::OWN_VB;
 #pragma unroll
             for (int i = 0; i < G::NBG * cdiv(NVW, 4); i++) __builtin_amdgcn_raw_buffer_store_b32(0u, rsx, kOut + 256u * i, 0, AFCM_WAVE_STORE_AUX);   // (distinct, non-adjacent offsets: identical or adjacent stores are merged)
