@@ -286,8 +286,13 @@ struct FlreluTile {
                 const int oy = O0y + p0 + t;
                 if (oy < p.yh) {
                     T* dst = yp + (size_t)oy * p.yw + ox;
-                    if (ox < p.yw) dst[0] = from_f32<T>(acc[t].x);
-                    if (ox + 1 < p.yw) dst[1] = from_f32<T>(acc[t].y);
+                    if (sizeof(T) == 4 && ox + 1 < p.yw && ((p.yw & 1) == 0)) {
+                        // even plane widths: the pair starts on an 8-byte boundary -- one store instead of two interleaved ones
+                        *(float2*)dst = acc[t];
+                    } else {
+                        if (ox < p.yw) dst[0] = from_f32<T>(acc[t].x);
+                        if (ox + 1 < p.yw) dst[1] = from_f32<T>(acc[t].y);
+                    }
                 }
             }
         }
@@ -307,7 +312,8 @@ __global__ __launch_bounds__(NT) void flrelu_sep_kernel(FlreluParams p, const fl
     unsigned* sgn = (unsigned*)(lds + K::SZ_A + K::SZ_B + round_up(K::NCOEF, 4));
 
     const int tid = threadIdx.x;
-    int bid = blockIdx.x;
+    // XCD-aware order: consecutive logical tiles (neighbours of one plane, shared halos) stay on one XCD / one L2
+    int bid = xcd_order(blockIdx.x, gridDim.x);
     const int tx = bid % p.tilesX;
     bid /= p.tilesX;
     const int ty = bid % p.tilesY;
