@@ -143,9 +143,18 @@ def _conv_raw(x, wp, rows_pad, oscale, cout, ks, pad, obias=None, pitched_out=Fa
     return y
 
 
+_FRAME_WGRAD_MAX = 1 << 24        # elements of dy up to which a pad-1 weight gradient is computed as pad-2 on a zero-framed dy
+
+
 def _wgrad_raw(dy, x, cout, cin, ks, pad):
     lib = _lib.load()
     n, _, h, w = x.shape
+    work = 2.0 * n * cout * cin * ks * ks * (h + 2 * pad - ks + 1) * (w + 2 * pad - ks + 1)      # algorithmic flops (before any framing)
+    if ks == 3 and pad == 1 and x.dtype in (torch.bfloat16, torch.float16) and dy.numel() <= _FRAME_WGRAD_MAX:
+        # pad-1 weight gradients only have the dword LDS-DMA kernel (0.41 PF/s on the generator's 512 -> 512 bottleneck conv at
+        # 36^2: 236 us); with dy framed by one ring of zeros the same sums are a pad-2 weight gradient, which the 16-byte granule
+        # kernel takes.  Worth it while the framing copy is small (the discriminator's large planes: measured, no gain).
+        dy, pad = torch.nn.functional.pad(dy, [1, 1, 1, 1]), 2
     p = h + 2 * pad - ks + 1
     if _pitch_wgrad(x.dtype, ks, pad):
         (dy, lddy), (x, ldx) = _rows.rows(dy), _rows.rows(x)
@@ -154,7 +163,7 @@ def _wgrad_raw(dy, x, cout, cin, ks, pad):
     splits = lib.afcm_conv2d_wgrad_splits(n, cout, cin, p)
     dw = torch.empty([cout, cin, ks, ks], dtype=torch.float32, device=x.device)
     ws = torch.empty([splits, cout, cin, ks, ks], dtype=torch.float32, device=x.device)
-    span = profiling.span('conv2d_wgrad', 2.0 * n * cout * cin * ks * ks * p * (w + 2 * pad - ks + 1))
+    span = profiling.span('conv2d_wgrad', work)
     _lib.check(lib.afcm_conv2d_wgrad_ld(dw.data_ptr(), ws.data_ptr(), dy.data_ptr(), x.data_ptr(), _lib.dtype_code(x), n, cin, cout,
                                         h, w, ks, pad, 0 if lddy == dy.shape[3] else lddy, 0 if ldx == w else ldx, _lib.stream_ptr(x)), 'conv2d_wgrad')
     if span is not None:

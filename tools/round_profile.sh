@@ -1,21 +1,26 @@
 #!/bin/bash
 # usage: tools/round_profile.sh <tag>   (run on the GPU box, from the repo root)
-# The round's evidence set: GPU tests, the bench line, smoke, a kernel trace of the bench command, HBM traffic and issue-slot
-# counters (each --pmc pass in its own run, no trace domains next to --pmc), per-layer tables.  Everything lands in gpurun_out/.
+# The round's evidence set: GPU tests, the bench line, smoke, a kernel trace of the bench command with HBM traffic (FETCH_SIZE /
+# WRITE_SIZE, each --pmc pass in its own run, no trace domains next to --pmc), the per-launch in-step table of the filtered_lrelu
+# kernels, issue / wait counters of the wave kernels, per-layer tables.  Everything lands in gpurun_out/.
 set -e
 tag=$1
 export TMPDIR=/tmp
-python -m pytest tests -m gpu -x -q > gpurun_out/${tag}_tests.log 2>&1
+python -m pytest tests -m gpu -x -q > gpurun_out/${tag}_tests.log 2>&1 < /dev/null
 echo tests done
-python bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
+python bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err < /dev/null
 echo bench done
-python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/${tag}_smoke.log 2>&1
-bash tools/pmc_traffic.sh ${tag}_traf bench.py --steps 4 --warmup 2 --cpu-baseline off --no-kernel-timing > gpurun_out/${tag}_traffic.log 2>&1
-python tools/traffic_summary.py gpurun_out/${tag}_traf gpurun_out/${tag}_pmc_traffic.json > gpurun_out/${tag}_bench_hbm_traffic.txt 2>&1
+python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/${tag}_smoke.log 2>&1 < /dev/null
+bash tools/r03_step_profile.sh ${tag} < /dev/null > /dev/null 2>&1 || true
+cp gpurun_out/${tag}_traf/trace/*/*kernel_stats.csv gpurun_out/${tag}_bench_kernel_stats.csv 2>/dev/null || true
 echo traffic done
-bash tools/pmc_flrelu.sh ${tag}_pmc bench.py --steps 2 --warmup 1 --cpu-baseline off --no-kernel-timing > gpurun_out/${tag}_pmc.log 2>&1
-python tools/pmc_table.py gpurun_out/${tag}_pmc > gpurun_out/${tag}_bench_pmc_raw.txt 2>&1
+bash tools/pmc_wave.sh ${tag}_pmcw bench.py --steps 2 --warmup 1 --cpu-baseline off --no-kernel-timing < /dev/null > /dev/null 2>&1 || true
+python tools/pmc_wave_table.py gpurun_out/${tag}_pmcw > gpurun_out/${tag}_flrelu_pmc_wave.txt 2>&1 || true
+bash tools/pmc_flrelu.sh ${tag}_pmc bench.py --steps 2 --warmup 1 --cpu-baseline off --no-kernel-timing < /dev/null > gpurun_out/${tag}_pmc.log 2>&1 || true
+python tools/pmc_table.py gpurun_out/${tag}_pmc > gpurun_out/${tag}_bench_pmc_raw.txt 2>&1 || true
 echo pmc done
-python tools/bench_conv.py --dtype bf16 > gpurun_out/${tag}_conv_layers_bf16.txt 2>&1
-python tools/bench_flrelu.py --dtype bf16 --no-bias > gpurun_out/${tag}_flrelu_layers_bf16.txt 2>&1
+python tools/bench_conv.py --dtype bf16 > gpurun_out/${tag}_conv_layers_bf16.txt 2>&1 < /dev/null || true
+python tools/bench_flrelu.py --dtype bf16 --no-bias --raw pitched > gpurun_out/${tag}_flrelu_layers_bf16.txt 2>&1 < /dev/null || true
+python tools/bench_flrelu.py --dtype fp32 > gpurun_out/${tag}_flrelu_layers_fp32.txt 2>&1 < /dev/null || true
+timeout -k 5 120 tools/ubench/strip_read.bin > gpurun_out/${tag}_strip_read.txt 2>&1 || true
 echo ALLDONE

@@ -11,7 +11,7 @@
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
 template <int MODE, int DEPTH, int LDSKB>
-__global__ __launch_bounds__(256) void k(const unsigned short* x, unsigned* out, int PL, int H, int LD, int W, int strips, int spin) {
+__global__ __launch_bounds__(256) void k(const unsigned short* x, unsigned* out, int PL, int H, int LD, int W, int strips, int spin, int reps) {
     __shared__ unsigned pad[LDSKB * 1024 / 4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wt = blockIdx.x * 4 + wave;
     if (threadIdx.x == 0) pad[0] = 0;
@@ -21,6 +21,7 @@ __global__ __launch_bounds__(256) void k(const unsigned short* x, unsigned* out,
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)xp, 0, H * LD * 2, 0x00020000);
     const int row0 = ty * 32 - 7;
     unsigned acc = 0;
+    for (int rep = 0; rep < reps; rep++)
     if (MODE == 0) {
         const int lrow = lane >> 2, lchk = lane & 3;
         const int ng = (W * 2 + 31) / 32;                              // 32 bytes of advance per group
@@ -106,15 +107,15 @@ __global__ __launch_bounds__(256) void k(const unsigned short* x, unsigned* out,
     if (acc == 0x12345678u) out[wt] = acc + pad[lane];
 }
 
-template <int MODE, int DEPTH, int LDSKB> void run(const char* name, int PL, int H, int W, int LD, int spin, unsigned short* x, unsigned* out) {
+template <int MODE, int DEPTH, int LDSKB> void run(const char* name, int PL, int H, int W, int LD, int spin, unsigned short* x, unsigned* out, int reps = 1) {
     const int strips = (H + 31) / 32, waves = PL * strips;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int i = 0; i < 2; i++) k<MODE, DEPTH, LDSKB><<<(waves + 3) / 4, 256>>>(x, out, PL, H, LD, W, strips, spin);
+    for (int i = 0; i < 2; i++) k<MODE, DEPTH, LDSKB><<<(waves + 3) / 4, 256>>>(x, out, PL, H, LD, W, strips, spin, reps);
     hipEventRecord(e0);
-    for (int i = 0; i < 10; i++) k<MODE, DEPTH, LDSKB><<<(waves + 3) / 4, 256>>>(x, out, PL, H, LD, W, strips, spin);
+    for (int i = 0; i < 10; i++) k<MODE, DEPTH, LDSKB><<<(waves + 3) / 4, 256>>>(x, out, PL, H, LD, W, strips, spin, reps);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 10;
-    printf("%-22s depth %d, %d WG/CU, spin %4d: %7.3f ms  %7.1f GB/s of plane bytes\n", name, DEPTH, 160 / LDSKB, spin, ms, (double)PL * H * LD * 2 / ms / 1e6);
+    printf("%-22s depth %d, %d WG/CU, spin %4d, %5d planes x %3d sweeps: %7.3f ms  %7.1f GB/s of plane bytes\n", name, DEPTH, 160 / LDSKB, spin, PL, reps, ms, (double)reps * PL * H * LD * 2 / ms / 1e6);
 }
 int main(int argc, char** argv) {
     const int PL = 16 * 128, H = 278, W = 278, LD = 288;
@@ -130,6 +131,14 @@ int main(int argc, char** argv) {
         run<2, 2, 40>("halves 32B x 32 rows", PL, H, W, LD, spin, x, out);
         run<3, 1, 40>("pieces 64B x 16 rows", PL, H, W, LD, spin, x, out);
         run<3, 2, 40>("pieces 64B x 16 rows", PL, H, W, LD, spin, x, out);
+    }
+    // the same patterns on a working set that stays in the L2s (8 x 4 MB): 96 planes = 15 MB, swept 40 times by the same waves --
+    // what the CU <-> L2 path delivers when HBM is out of the picture
+    for (int spin : {0}) {
+        run<0, 1, 40>("windows 64B x 16 rows", 96, H, W, LD, spin, x, out, 40); run<0, 1, 40>("windows 64B x 16 rows", 1024, H, W, LD, spin, x, out, 6); run<3, 1, 40>("pieces 64B x 16 rows", 1024, H, W, LD, spin, x, out, 6); run<1, 1, 40>("lines 128B x 8 rows", 1024, H, W, LD, spin, x, out, 6); run<3, 1, 40>("pieces 64B x 16 rows", 384, H, W, LD, spin, x, out, 16);
+        run<1, 1, 40>("lines 128B x 8 rows", 96, H, W, LD, spin, x, out, 40);
+        run<3, 1, 40>("pieces 64B x 16 rows", 96, H, W, LD, spin, x, out, 40);
+        run<3, 2, 40>("pieces 64B x 16 rows", 96, H, W, LD, spin, x, out, 40);
     }
     return 0;
 }
