@@ -137,3 +137,35 @@ def test_config3_full_width_training_step_bf16():
     assert torch.isfinite(step.loss_G).item()
     assert all(torch.isfinite(p).all().item() for p in G.parameters())
     assert not torch.equal(before, G.synthesis.L3_52_512.weight)
+
+
+def test_config5_full_width_512_training_step_fp16():
+    """BASELINE configs[4]'s per-GPU workload at reduced batch: one fp16 training step of the FULL-WIDTH 512^2 generator (52.4 M parameters,
+    plane sizes 36 ... 532: every wave-kernel geometry incl. the 48-row strips and the 532-wide planes) -- loss and parameters finite,
+    parameters move, and the evaluation forward of the same weights in fp32 agrees with the fp16 forward to 40 dB (the network-level
+    parity at 512^2 is pinned by the G3_tiny512 golden, tests/test_gpu_generator.py)."""
+    from afcm_amd import synthetic
+    from afcm_amd.layer_schedule import DEFAULT_SYNTHESIS_KWARGS
+    from afcm_amd.networks_stylegan3 import Stylegan3Generator
+    from afcm_amd.stylegan3_model import StyleGAN3GeneratorStep
+    torch.manual_seed(0)
+    G = Stylegan3Generator(z_dim=512, c_dim=1, w_dim=512, img_resolution=512, img_channels_in=4, img_channels_out=1,
+                           mapping_kwargs=dict(num_layers=8),
+                           synthesis_kwargs=dict(DEFAULT_SYNTHESIS_KWARGS, compute_dtype=torch.float16)).cuda().train()
+    assert abs(sum(p.numel() for p in G.parameters()) - 52.4e6) < 0.3e6
+    a, b, z, c = synthetic.generator_inputs(2, size=512, seed=4, device='cuda')
+    G.eval()
+    with torch.no_grad():
+        y16 = G(z, c, a).float()
+        G.synthesis.compute_dtype = torch.float32
+        y32 = G(z, c, a).float()
+        G.synthesis.compute_dtype = torch.float16
+    assert synthetic.psnr(y16.cpu(), y32.cpu()) >= 40.0
+    G.train()
+    step = StyleGAN3GeneratorStep(G, lr_G=0.0025, lambda_L1=100.0)
+    before = G.synthesis.encoder_4.weight.detach().clone()
+    step.set_input(a, b, z, c)
+    step.optimize_parameters()
+    assert torch.isfinite(step.loss_G).item()
+    assert all(torch.isfinite(p).all().item() for p in G.parameters())
+    assert not torch.equal(before, G.synthesis.encoder_4.weight)
