@@ -33,6 +33,21 @@ class FilteredLReluArgs(C.Structure):
     ]
 
 
+AFFINE_MAX = 16
+
+
+class AffineBank(C.Structure):
+    """Mirror of `afcm_affine_bank` (include/afcm_hip.h)."""
+    _fields_ = [
+        ('layers', C.c_int32), ('n', C.c_int32), ('kw', C.c_int32), ('kg', C.c_int32),
+        ('w_stride_n', C.c_int64), ('w_stride_l', C.c_int64),
+        ('w', C.c_void_p), ('g', C.c_void_p),
+        ('weight', C.c_void_p * AFFINE_MAX), ('bias', C.c_void_p * AFFINE_MAX),
+        ('cout', C.c_int32 * AFFINE_MAX), ('w_index', C.c_int32 * AFFINE_MAX),
+        ('alpha', C.c_float * AFFINE_MAX), ('beta', C.c_float * AFFINE_MAX),
+    ]
+
+
 _lib = None
 
 # name -> (restype, argtypes); every symbol include/afcm_hip.h declares must be listed here
@@ -65,6 +80,9 @@ SIGNATURES = {
     'afcm_style_coefs_fwd': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     'afcm_style_coefs_bwd': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     'afcm_layer_bwd_coefs': (C.c_int, [_vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp]),
+    'afcm_affine_bank_workspace_bytes': (C.c_int64, [C.POINTER(AffineBank)]),
+    'afcm_affine_bank_fwd': (C.c_int, [C.POINTER(AffineBank), C.POINTER(C.c_void_p), _vp]),
+    'afcm_affine_bank_bwd': (C.c_int, [C.POINTER(AffineBank), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _vp, _vp, _vp, _vp]),
     'afcm_adam_chunk_elems': (C.c_int32, []),
     'afcm_adam_multi': (C.c_int, [_vp, _i32, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _i32, _f32, _f32, _i32, _vp]),
 }

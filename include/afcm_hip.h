@@ -269,6 +269,35 @@ int afcm_adam_multi(const afcm_adam_entry* table, int32_t n, int64_t total_chunk
                     float one_minus_beta1, float one_minus_beta2, float bias_correction2_sqrt, float eps, float grad_scale, int32_t scrub, float posinf, float neginf,
                     int32_t write_grad, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * The style affine layers of all SynthesisLayers at once (NET:349-352 `styles = self.affine(cat(w, global_w))`, FullyConnectedLayer
+ * NET:69-104; ToRGB's extra factor NET:351 rides in alpha / beta): for layer l
+ *     y_l[n][c] = alpha_l * sum_k x_l[n][k] W_l[c][k] + beta_l * b_l[c],   x_l[n] = [ w[n][w_index_l][0:kw] | g[n][0:kg] ]
+ * and its gradients (dW_l = alpha_l dy_l^T x_l, db_l = beta_l sum_n dy_l, dws[n][l] / dg[n] = the two halves of alpha_l dy_l W_l, dg summed
+ * over the layers).  All fp32, rows 16-byte aligned, kw and kg multiples of 4, kw + kg <= 1536, at most AFCM_AFFINE_MAX layers;
+ * AFCM_E_NOKERNEL otherwise (the caller runs the layers one by one).  Replaces 15 cat + 15 GEMM launches forward and 30 GEMMs + 15
+ * reductions + 14 accumulations backward by 1 + 3 launches.  No atomics: bit-reproducible.
+ * y / dy / dweight / dbias are HOST arrays of `layers` device pointers ([n][cout_l], [cout_l][kw + kg], [cout_l]); a NULL dy_l means
+ * zeros, NULL dweight_l / dbias_l are skipped, dweight == dbias == NULL skips the weight pass, dws == NULL the input pass.
+ * dws: [n][layers][kw], dg: [n][kg]; workspace: afcm_affine_bank_workspace_bytes() bytes (input pass only).
+ * ---------------------------------------------------------------------------------------- */
+#define AFCM_AFFINE_MAX 16
+typedef struct afcm_affine_bank {
+    int32_t layers, n, kw, kg;
+    int64_t w_stride_n, w_stride_l;               /* elements between batch rows / between latents of the ws tensor */
+    const float* w;                               /* ws: w[n * w_stride_n + w_index_l * w_stride_l + k] */
+    const float* g;                               /* [n][kg] or NULL when kg == 0 */
+    const float* weight[AFCM_AFFINE_MAX];         /* [cout_l][kw + kg] */
+    const float* bias[AFCM_AFFINE_MAX];           /* [cout_l] or NULL */
+    int32_t cout[AFCM_AFFINE_MAX];
+    int32_t w_index[AFCM_AFFINE_MAX];
+    float alpha[AFCM_AFFINE_MAX], beta[AFCM_AFFINE_MAX];
+} afcm_affine_bank;
+int64_t afcm_affine_bank_workspace_bytes(const afcm_affine_bank* a);
+int afcm_affine_bank_fwd(const afcm_affine_bank* a, float* const* y, void* stream);
+int afcm_affine_bank_bwd(const afcm_affine_bank* a, const float* const* dy, float* const* dweight, float* const* dbias, float* dws, float* dg,
+                         void* workspace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -585,3 +585,42 @@ def test_bias_act_vector_and_element_paths(act, shape, dtype, tol):
             assert a is None or a.abs().max().item() == 0
         elif a is not None:
             _close(a, b_, tol=8 * tol, what=f'{act} {shape} {nm}')
+
+
+@pytest.mark.parametrize('n,kw,kg,couts', [(16, 512, 1024, [512, 362, 181, 91, 64, 1]), (5, 32, 1024, [8, 8, 7]), (20, 64, 0, [33, 16])])
+def test_affine_bank_matches_the_layers_one_by_one(n, kw, kg, couts):
+    """torch_utils/ops/affine_bank.py (C ABI afcm_affine_bank_*): the styles of several SynthesisLayers' affine FCs (NET:349-352,
+    FullyConnectedLayer NET:69-104, ToRGB factor NET:351) from one launch and every gradient from three, against the FullyConnectedLayer
+    modules called one by one on cat(w, global_w): forward 1e-5, gradients 1e-4 relative (fp32 sums in a different order); a batch of 20
+    goes through the 16-row kernels twice (second pass accumulates the weight gradients); layers without a gradient contribute zeros."""
+    from afcm_amd.networks_stylegan3 import FullyConnectedLayer
+    from afcm_amd.torch_utils.ops import affine_bank as ab
+    torch.manual_seed(3)
+    nl = len(couts)
+    fcs = [FullyConnectedLayer(kw + kg, c, bias_init=1).cuda() for c in couts]
+    for fc in fcs:
+        with torch.no_grad():
+            fc.bias.add_(torch.randn_like(fc.bias) * 0.1)
+    ws = torch.randn(n, nl + 2, kw, device='cuda', requires_grad=True)
+    g = torch.randn(n, kg, device='cuda', requires_grad=True) if kg else None
+    scales = [1.0] * (nl - 1) + [0.125]
+    specs = [ab.Spec(fc, 1 + l, sc) for l, (fc, sc) in enumerate(zip(fcs, scales))]
+    assert ab.supported(ws, g, specs)
+    got = ab.affine_bank(ws, g, specs)
+    want = [fc(torch.cat((ws[:, 1 + l], g), 1) if kg else ws[:, 1 + l]) * sc for l, (fc, sc) in enumerate(zip(fcs, scales))]
+    for a, b in zip(got, want):
+        assert (a - b).abs().max().item() <= 1e-5 * max(1.0, b.abs().max().item())
+    rs = [torch.randn_like(b) for b in want]
+    rs[1] = None                                      # this layer's styles receive no gradient
+    params = [p for fc in fcs for p in (fc.weight, fc.bias)]
+    ins = [ws] + ([g] if kg else []) + params
+    loss_g = sum((a * r).sum() for a, r in zip(got, rs) if r is not None)
+    loss_w = sum((b * r).sum() for b, r in zip(want, rs) if r is not None)
+    gg = torch.autograd.grad(loss_g, ins, allow_unused=True)
+    gw = torch.autograd.grad(loss_w, ins, allow_unused=True)
+    for i, (a, b) in enumerate(zip(gg, gw)):
+        if b is None:
+            assert a is None or a.abs().max().item() == 0.0, i
+            continue
+        assert a is not None, i
+        assert (a - b).abs().max().item() <= 1e-4 * max(1e-3, b.abs().max().item()), (i, (a - b).abs().max().item(), b.abs().max().item())
