@@ -48,6 +48,15 @@ class AffineBank(C.Structure):
     ]
 
 
+MODULATION_MAX = 16
+
+
+class ModulationLayer(C.Structure):
+    """Mirror of `afcm_modulation_layer` (include/afcm_hip.h)."""
+    _fields_ = [('cout', C.c_int32), ('cin', C.c_int32), ('kk', C.c_int32), ('demodulate', C.c_int32)] + [
+        (k, C.c_void_p) for k in ('w', 't', 'magnitude', 'w_hat', 'wsq', 'scale', 's_eff', 'd', 'r', 'g_hat', 'g_s', 'g_d', 'dw', 'dt', 'workspace')]
+
+
 _lib = None
 
 # name -> (restype, argtypes); every symbol include/afcm_hip.h declares must be listed here
@@ -82,6 +91,9 @@ SIGNATURES = {
     'afcm_layer_bwd_coefs': (C.c_int, [_vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp]),
     'afcm_affine_bank_workspace_bytes': (C.c_int64, [C.POINTER(AffineBank)]),
     'afcm_affine_bank_fwd': (C.c_int, [C.POINTER(AffineBank), C.POINTER(C.c_void_p), _vp]),
+    'afcm_modulation_bank_workspace_floats': (C.c_int64, [_i32, _i32, _i32, _i32]),
+    'afcm_modulation_bank_fwd': (C.c_int, [C.POINTER(ModulationLayer), _i32, _i32, _vp]),
+    'afcm_modulation_bank_bwd': (C.c_int, [C.POINTER(ModulationLayer), _i32, _i32, _vp]),
     'afcm_affine_bank_bwd': (C.c_int, [C.POINTER(AffineBank), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _vp, _vp, _vp, _vp]),
     'afcm_adam_chunk_elems': (C.c_int32, []),
     'afcm_adam_multi': (C.c_int, [_vp, _i32, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _i32, _f32, _f32, _i32, _vp]),

@@ -23,11 +23,9 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 // one workgroup per output channel o.  PT > 0: the row (I * KK <= 256 * PT elements) is read ONCE, all loads in flight, and
 // stays in registers for the three uses (sum of squares, w_hat, wsq through an LDS copy); PT == 0: any row length, three passes.
 template <int PT>
-__global__ __launch_bounds__(256) void weight_norm_fwd_kernel(float* __restrict__ w_hat, float* __restrict__ wsq, float* __restrict__ scale,
-                                                              const float* __restrict__ w, int I, int KK) {
-    __shared__ float red[4];
-    __shared__ float row[PT > 0 ? 256 * PT : 1];
-    const int o = blockIdx.x, n = I * KK;
+__device__ __forceinline__ void weight_norm_fwd_body(float* red, float* row, int o, float* __restrict__ w_hat, float* __restrict__ wsq,
+                                                     float* __restrict__ scale, const float* __restrict__ w, int I, int KK) {
+    const int n = I * KK;
     const float* wo = w + (size_t)o * n;
     float ss = 0.f;
     if constexpr (PT > 0) {
@@ -66,12 +64,20 @@ __global__ __launch_bounds__(256) void weight_norm_fwd_kernel(float* __restrict_
     }
 }
 
+template <int PT>
+__global__ __launch_bounds__(256) void weight_norm_fwd_kernel(float* __restrict__ w_hat, float* __restrict__ wsq, float* __restrict__ scale,
+                                                              const float* __restrict__ w, int I, int KK) {
+    __shared__ float red[4];
+    __shared__ float row[PT > 0 ? 256 * PT : 1];
+    weight_norm_fwd_body<PT>(red, row, blockIdx.x, w_hat, wsq, scale, w, I, KK);
+}
+
 // dw = scale * (G - w_hat * mean(G . w_hat)),  G = g_hat + 2 w_hat g_wsq[o,i].  PT as above: operands read once, kept in registers.
 template <int PT>
-__global__ __launch_bounds__(256) void weight_norm_bwd_kernel(float* __restrict__ dw, const float* __restrict__ g_hat, const float* __restrict__ g_wsq,
-                                                              const float* __restrict__ w_hat, const float* __restrict__ scale, int I, int KK) {
-    __shared__ float red[4];
-    const int o = blockIdx.x, n = I * KK;
+__device__ __forceinline__ void weight_norm_bwd_body(float* red, int o, float* __restrict__ dw, const float* __restrict__ g_hat,
+                                                     const float* __restrict__ g_wsq, const float* __restrict__ w_hat,
+                                                     const float* __restrict__ scale, int I, int KK) {
+    const int n = I * KK;
     const size_t base = (size_t)o * n;
     float dot = 0.f;
     if constexpr (PT > 0) {
@@ -111,14 +117,18 @@ __global__ __launch_bounds__(256) void weight_norm_bwd_kernel(float* __restrict_
     }
 }
 
+template <int PT>
+__global__ __launch_bounds__(256) void weight_norm_bwd_kernel(float* __restrict__ dw, const float* __restrict__ g_hat, const float* __restrict__ g_wsq,
+                                                              const float* __restrict__ w_hat, const float* __restrict__ scale, int I, int KK) {
+    __shared__ float red[4];
+    weight_norm_bwd_body<PT>(red, blockIdx.x, dw, g_hat, g_wsq, w_hat, scale, I, KK);
+}
+
 // workgroups (n, o-chunk of 32): every workgroup recomputes the batch-wide mean (N * I <= a few thousand elements) and its
 // sample's s_hat^2 row; a wave per output channel reads the wsq row coalesced (lanes over i) and reduces by shuffles
-__global__ __launch_bounds__(256) void style_coefs_fwd_kernel(float* __restrict__ s_eff, float* __restrict__ d, float* __restrict__ r_out,
-                                                              const float* __restrict__ t, const float* __restrict__ wsq,
-                                                              const float* __restrict__ magnitude, int N, int I, int O, int demod) {
-    __shared__ float red[4];
-    extern __shared__ float s2[];                       // s_hat[n, :]^2
-    const int n = blockIdx.x, oc = blockIdx.y;
+__device__ __forceinline__ void style_coefs_fwd_body(float* red, float* s2, int n, int oc, float* __restrict__ s_eff, float* __restrict__ d,
+                                                     float* __restrict__ r_out, const float* __restrict__ t, const float* __restrict__ wsq,
+                                                     const float* __restrict__ magnitude, int N, int I, int O, int demod) {
     float r = 1.f;
     if (demod) {
         float ss = 0.f;
@@ -164,15 +174,21 @@ __global__ __launch_bounds__(256) void style_coefs_fwd_kernel(float* __restrict_
     }
 }
 
+__global__ __launch_bounds__(256) void style_coefs_fwd_kernel(float* __restrict__ s_eff, float* __restrict__ d, float* __restrict__ r_out,
+                                                              const float* __restrict__ t, const float* __restrict__ wsq,
+                                                              const float* __restrict__ magnitude, int N, int I, int O, int demod) {
+    __shared__ float red[4];
+    extern __shared__ float s2[];                       // s_hat[n, :]^2
+    style_coefs_fwd_body(red, s2, blockIdx.x, blockIdx.y, s_eff, d, r_out, t, wsq, magnitude, N, I, O, demod);
+}
+
 // phase 1, workgroups (n, i-chunk of 64): Q[n,o] = -1/2 g_d d^3;  G[n,i] = gain g_s + 2 s_hat[n,i] sum_o Q[n,o] wsq[o,i];
 // partial[n, chunk] = sum_{i in chunk} G[n,i] s_hat[n,i].  The sum over o is split four ways over the workgroup's waves.
-__global__ __launch_bounds__(256) void style_coefs_bwd1_kernel(float* __restrict__ G, float* __restrict__ Q, float* __restrict__ partial,
-                                                               const float* __restrict__ g_s, const float* __restrict__ g_d,
-                                                               const float* __restrict__ t, const float* __restrict__ d, const float* __restrict__ wsq,
-                                                               const float* __restrict__ magnitude, const float* __restrict__ r_in, int I, int O, int demod) {
-    __shared__ float us[4][64];
-    extern __shared__ float q_s[];                      // Q[n, :]
-    const int n = blockIdx.x, ib = blockIdx.y, IB = gridDim.y;
+__device__ __forceinline__ void style_coefs_bwd1_body(float (*us)[64], float* q_s, int n, int ib, int IB, float* __restrict__ G,
+                                                      float* __restrict__ Q, float* __restrict__ partial, const float* __restrict__ g_s,
+                                                      const float* __restrict__ g_d, const float* __restrict__ t, const float* __restrict__ d,
+                                                      const float* __restrict__ wsq, const float* __restrict__ magnitude,
+                                                      const float* __restrict__ r_in, int I, int O, int demod) {
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int i = ib * 64 + tx;
     const float r = r_in[0], g = magnitude ? rsqrtf(magnitude[0]) : 1.f;
@@ -206,14 +222,23 @@ __global__ __launch_bounds__(256) void style_coefs_bwd1_kernel(float* __restrict
     if (tx == 0) partial[(size_t)n * IB + ib] = dot;
 }
 
+__global__ __launch_bounds__(256) void style_coefs_bwd1_kernel(float* __restrict__ G, float* __restrict__ Q, float* __restrict__ partial,
+                                                               const float* __restrict__ g_s, const float* __restrict__ g_d,
+                                                               const float* __restrict__ t, const float* __restrict__ d, const float* __restrict__ wsq,
+                                                               const float* __restrict__ magnitude, const float* __restrict__ r_in, int I, int O, int demod) {
+    __shared__ float us[4][64];
+    extern __shared__ float q_s[];                      // Q[n, :]
+    style_coefs_bwd1_body(us, q_s, blockIdx.x, blockIdx.y, gridDim.y, G, Q, partial, g_s, g_d, t, d, wsq, magnitude, r_in, I, O, demod);
+}
+
 // phase 2: workgroups [0, N): dt[n,:] = r (G - s_hat mean(G . s_hat)) (demod) or G (no demod);
 //          workgroups [N, N+O): g_wsq[o,i] = sum_n Q[n,o] s_hat[n,i]^2
-__global__ __launch_bounds__(256) void style_coefs_bwd2_kernel(float* __restrict__ dt, float* __restrict__ g_wsq, const float* __restrict__ G,
-                                                               const float* __restrict__ Q, const float* __restrict__ partial,
-                                                               const float* __restrict__ t, const float* __restrict__ r_in, int N, int I, int O, int demod, int NP) {
+__device__ __forceinline__ void style_coefs_bwd2_body(int bx, float* __restrict__ dt, float* __restrict__ g_wsq, const float* __restrict__ G,
+                                                      const float* __restrict__ Q, const float* __restrict__ partial, const float* __restrict__ t,
+                                                      const float* __restrict__ r_in, int N, int I, int O, int demod, int NP) {
     const float r = r_in[0];
-    if ((int)blockIdx.x < N) {
-        const int n = blockIdx.x;
+    if (bx < N) {
+        const int n = bx;
         float m = 0.f;
         if (demod) {
             for (int k = 0; k < NP; k++) m += partial[k];
@@ -224,7 +249,7 @@ __global__ __launch_bounds__(256) void style_coefs_bwd2_kernel(float* __restrict
             dt[(size_t)n * I + i] = demod ? r * (gg - t[(size_t)n * I + i] * r * m) : gg;
         }
     } else if (demod && g_wsq != nullptr) {
-        const int o = blockIdx.x - N;
+        const int o = bx - N;
         for (int i = threadIdx.x; i < I; i += 256) {
             float acc = 0.f;
             for (int n = 0; n < N; n++) {
@@ -234,6 +259,12 @@ __global__ __launch_bounds__(256) void style_coefs_bwd2_kernel(float* __restrict
             g_wsq[(size_t)o * I + i] = acc;
         }
     }
+}
+
+__global__ __launch_bounds__(256) void style_coefs_bwd2_kernel(float* __restrict__ dt, float* __restrict__ g_wsq, const float* __restrict__ G,
+                                                               const float* __restrict__ Q, const float* __restrict__ partial,
+                                                               const float* __restrict__ t, const float* __restrict__ r_in, int N, int I, int O, int demod, int NP) {
+    style_coefs_bwd2_body((int)blockIdx.x, dt, g_wsq, G, Q, partial, t, r_in, N, I, O, demod, NP);
 }
 
 // Small-tensor tail of a fused layer's backward (torch_utils/ops/fused_layer.py), one workgroup (one wave) per output channel:
@@ -263,6 +294,79 @@ __global__ __launch_bounds__(64) void layer_bwd_coefs_kernel(float* __restrict__
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
     if (db && threadIdx.x == 0) db[o] = acc;
+}
+
+// ---- the bank: the kernels above over a list of layers in one launch each.  The layer table rides in the kernel arguments (by value);
+// blk[] holds the first workgroup of every layer for the launch at hand, a workgroup finds its layer by a scalar scan.
+struct ModBank {
+    int count, n;
+    int blk[AFCM_MODULATION_MAX + 1];
+    afcm_modulation_layer L[AFCM_MODULATION_MAX];
+};
+
+__device__ __forceinline__ int bank_layer(const ModBank& b, int bid) {
+    int l = 0;
+    while (l + 1 < b.count && bid >= b.blk[l + 1]) l++;
+    return l;
+}
+
+__global__ __launch_bounds__(256) void modulation_bank_norm_fwd_kernel(const ModBank b) {
+    __shared__ float red[4];
+    __shared__ float row[256 * 18];
+    const int l = bank_layer(b, blockIdx.x), o = blockIdx.x - b.blk[l];
+    const afcm_modulation_layer& L = b.L[l];
+    const int n = L.cin * L.kk;
+    if (n <= 256 * 4) weight_norm_fwd_body<4>(red, row, o, L.w_hat, L.wsq, L.scale, L.w, L.cin, L.kk);
+    else if (n <= 256 * 18) weight_norm_fwd_body<18>(red, row, o, L.w_hat, L.wsq, L.scale, L.w, L.cin, L.kk);
+    else weight_norm_fwd_body<0>(red, row, o, L.w_hat, L.wsq, L.scale, L.w, L.cin, L.kk);
+}
+
+__global__ __launch_bounds__(256) void modulation_bank_coefs_fwd_kernel(const ModBank b) {
+    __shared__ float red[4];
+    extern __shared__ float dyn[];
+    const int l = bank_layer(b, blockIdx.x), loc = blockIdx.x - b.blk[l];
+    const afcm_modulation_layer& L = b.L[l];
+    const int ocs = L.demodulate ? (L.cout + 31) / 32 : 1;
+    style_coefs_fwd_body(red, dyn, loc / ocs, loc % ocs, L.s_eff, L.d, L.r, L.t, L.wsq, L.magnitude, b.n, L.cin, L.cout, L.demodulate);
+}
+
+// workspace of a layer: G [n, cin] | Q [n, cout] | partial [n, ceil(cin / 64)] | g_wsq [cout, cin]   (Q and g_wsq: demodulating layers)
+__device__ __forceinline__ void bank_workspace(const afcm_modulation_layer& L, int n, float*& G, float*& Q, float*& partial, float*& g_wsq) {
+    G = L.workspace;
+    Q = G + (size_t)n * L.cin;
+    partial = Q + (size_t)n * (L.demodulate ? L.cout : 0);
+    g_wsq = partial + (size_t)n * ((L.cin + 63) / 64);
+}
+
+__global__ __launch_bounds__(256) void modulation_bank_coefs_bwd1_kernel(const ModBank b) {
+    __shared__ float us[4][64];
+    extern __shared__ float dyn[];
+    const int l = bank_layer(b, blockIdx.x), loc = blockIdx.x - b.blk[l];
+    const afcm_modulation_layer& L = b.L[l];
+    const int IB = (L.cin + 63) / 64;
+    float *G, *Q, *partial, *g_wsq;
+    bank_workspace(L, b.n, G, Q, partial, g_wsq);
+    style_coefs_bwd1_body(us, dyn, loc / IB, loc % IB, IB, G, Q, partial, L.g_s, L.g_d, L.t, L.d, L.wsq, L.magnitude, L.r, L.cin, L.cout, L.demodulate);
+}
+
+__global__ __launch_bounds__(256) void modulation_bank_coefs_bwd2_kernel(const ModBank b) {
+    const int l = bank_layer(b, blockIdx.x), loc = blockIdx.x - b.blk[l];
+    const afcm_modulation_layer& L = b.L[l];
+    float *G, *Q, *partial, *g_wsq;
+    bank_workspace(L, b.n, G, Q, partial, g_wsq);
+    style_coefs_bwd2_body(loc, L.dt, g_wsq, G, Q, partial, L.t, L.r, b.n, L.cin, L.cout, L.demodulate, b.n * ((L.cin + 63) / 64));
+}
+
+__global__ __launch_bounds__(256) void modulation_bank_norm_bwd_kernel(const ModBank b) {
+    __shared__ float red[4];
+    const int l = bank_layer(b, blockIdx.x), o = blockIdx.x - b.blk[l];
+    const afcm_modulation_layer& L = b.L[l];
+    float *G, *Q, *partial, *g_wsq;
+    bank_workspace(L, b.n, G, Q, partial, g_wsq);
+    const int n = L.cin * L.kk;
+    if (n <= 256 * 4) weight_norm_bwd_body<4>(red, o, L.dw, L.g_hat, g_wsq, L.w_hat, L.scale, L.cin, L.kk);
+    else if (n <= 256 * 18) weight_norm_bwd_body<18>(red, o, L.dw, L.g_hat, g_wsq, L.w_hat, L.scale, L.cin, L.kk);
+    else weight_norm_bwd_body<0>(red, o, L.dw, L.g_hat, g_wsq, L.w_hat, L.scale, L.cin, L.kk);
 }
 
 }  // namespace afcm
@@ -323,5 +427,67 @@ extern "C" int afcm_style_coefs_bwd(float* dt, float* g_wsq, float* workspace, c
                        magnitude, r, cin, cout, demodulate);
     hipLaunchKernelGGL(style_coefs_bwd2_kernel, dim3(n + ((demodulate && g_wsq) ? cout : 0)), dim3(256), 0, st, dt, g_wsq, G, Q, partial, t, r, n, cin,
                        cout, demodulate, n * ib);
+    return hip_status(hipGetLastError());
+}
+
+// ---- modulation bank (include/afcm_hip.h) ----
+static int bank_check(const afcm_modulation_layer* layers, int32_t count, int32_t n, bool bwd) {
+    AFCM_REQUIRE(layers && count > 0 && count <= AFCM_MODULATION_MAX && n > 0, "modulation_bank: bad arguments (1..%d layers)", AFCM_MODULATION_MAX);
+    for (int l = 0; l < count; l++) {
+        const afcm_modulation_layer& L = layers[l];
+        AFCM_REQUIRE(L.cin > 0 && L.cin <= 16384 && L.t && L.r, "modulation_bank: layer %d: styles / r missing or cin outside 1..16384", l);
+        if (L.demodulate)
+            AFCM_REQUIRE(L.cout > 0 && L.cout <= 16384 && L.kk > 0 && L.w_hat && L.wsq && L.scale && L.d,
+                         "modulation_bank: layer %d demodulates: w_hat / wsq / scale / d needed, cout in 1..16384", l);
+        if (bwd) AFCM_REQUIRE(L.dt && L.workspace, "modulation_bank: layer %d: dt / workspace missing", l);
+        else AFCM_REQUIRE(L.s_eff && (!L.demodulate || L.w), "modulation_bank: layer %d: s_eff / w missing", l);
+    }
+    return AFCM_OK;
+}
+
+extern "C" int64_t afcm_modulation_bank_workspace_floats(int32_t n, int32_t cin, int32_t cout, int32_t demodulate) {
+    if (n <= 0 || cin <= 0 || (demodulate && cout <= 0)) return -1;
+    return (int64_t)n * cin + (int64_t)n * ((cin + 63) / 64) + (demodulate ? (int64_t)n * cout + (int64_t)cout * cin : 0);
+}
+
+extern "C" int afcm_modulation_bank_fwd(const afcm_modulation_layer* layers, int32_t count, int32_t n, void* stream) {
+    if (int rc = bank_check(layers, count, n, false)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    ModBank b;
+    b.count = count;
+    b.n = n;
+    int max_cin = 1;
+    for (int l = 0; l < count; l++) { b.L[l] = layers[l]; max_cin = layers[l].cin > max_cin ? layers[l].cin : max_cin; }
+    int tot = 0;
+    for (int l = 0; l < count; l++) { b.blk[l] = tot; tot += layers[l].demodulate ? layers[l].cout : 0; }
+    b.blk[count] = tot;
+    if (tot > 0) hipLaunchKernelGGL(modulation_bank_norm_fwd_kernel, dim3(tot), dim3(256), 0, st, b);
+    tot = 0;
+    for (int l = 0; l < count; l++) { b.blk[l] = tot; tot += n * (layers[l].demodulate ? (layers[l].cout + 31) / 32 : 1); }
+    b.blk[count] = tot;
+    hipLaunchKernelGGL(modulation_bank_coefs_fwd_kernel, dim3(tot), dim3(256), max_cin * sizeof(float), st, b);
+    return hip_status(hipGetLastError());
+}
+
+extern "C" int afcm_modulation_bank_bwd(const afcm_modulation_layer* layers, int32_t count, int32_t n, void* stream) {
+    if (int rc = bank_check(layers, count, n, true)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    ModBank b;
+    b.count = count;
+    b.n = n;
+    int max_cout = 1;
+    for (int l = 0; l < count; l++) { b.L[l] = layers[l]; if (layers[l].demodulate && layers[l].cout > max_cout) max_cout = layers[l].cout; }
+    int tot = 0;
+    for (int l = 0; l < count; l++) { b.blk[l] = tot; tot += n * ((layers[l].cin + 63) / 64); }
+    b.blk[count] = tot;
+    hipLaunchKernelGGL(modulation_bank_coefs_bwd1_kernel, dim3(tot), dim3(256), max_cout * sizeof(float), st, b);
+    tot = 0;
+    for (int l = 0; l < count; l++) { b.blk[l] = tot; tot += n + ((layers[l].demodulate && layers[l].dw) ? layers[l].cout : 0); }
+    b.blk[count] = tot;
+    hipLaunchKernelGGL(modulation_bank_coefs_bwd2_kernel, dim3(tot), dim3(256), 0, st, b);
+    tot = 0;
+    for (int l = 0; l < count; l++) { b.blk[l] = tot; tot += (layers[l].demodulate && layers[l].dw) ? layers[l].cout : 0; }
+    b.blk[count] = tot;
+    if (tot > 0) hipLaunchKernelGGL(modulation_bank_norm_bwd_kernel, dim3(tot), dim3(256), 0, st, b);
     return hip_status(hipGetLastError());
 }

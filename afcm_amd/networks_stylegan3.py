@@ -16,7 +16,7 @@ import torch
 import torch.nn.functional as F
 
 from . import layer_schedule as sched
-from .torch_utils.ops import affine_bank, bias_act, conv2d_gradfix, filtered_lrelu, fused_layer
+from .torch_utils.ops import affine_bank, bias_act, conv2d_gradfix, filtered_lrelu, fused_layer, modulation_bank
 from .torch_utils.ops.conv2d import modulation_coefficients_fused, scaled_conv2d
 from .torch_utils.ops.conv2d import modulated_conv2d  # noqa: F401  (re-exported: NET:25 lives in this module)
 
@@ -452,7 +452,12 @@ class SynthesisNetwork(torch.nn.Module):
             g32 = img_global.to(torch.float32).contiguous()
             if affine_bank.supported(ws_all, g32, specs):
                 styles = affine_bank.affine_bank(ws_all, g32, specs)
-                mods = [layer.modulation_from_styles(st) for layer, st in zip(layers, styles)]
+                # ... and every layer's (w_hat, in_scale, out_scale) from two (three backward): torch_utils/ops/modulation_bank.py
+                items = [modulation_bank.Item(layer.weight, st, layer.magnitude_ema, not layer.is_torgb) for layer, st in zip(layers, styles)]
+                if modulation_bank.supported(items):
+                    mods = modulation_bank.modulation_bank(items)
+                else:
+                    mods = [layer.modulation_from_styles(st) for layer, st in zip(layers, styles)]
         if mods is None:
             mods = [layer.modulation(w, img_global) for layer, w in zip(layers, ws[1:])] if fuse else [None] * len(layers)
         prescaled = False

@@ -298,6 +298,39 @@ int afcm_affine_bank_fwd(const afcm_affine_bank* a, float* const* y, void* strea
 int afcm_affine_bank_bwd(const afcm_affine_bank* a, const float* const* dy, float* const* dweight, float* const* dbias, float* dws, float* dg,
                          void* workspace, void* stream);
 
+/* ----------------------------------------------------------------------------------------
+ * Modulation bank: afcm_weight_norm_* and afcm_style_coefs_* (above) for a LIST of layers in 2 launches forward and 3 backward, whatever
+ * the number of layers -- the decoder's 15 SynthesisLayers take 29 + 44 launches one by one (NET:41-57, 346-352 per layer).  Same
+ * arithmetic, same kernels' bodies: bit-identical to the per-layer entry points.  Per layer, forward:
+ *     demodulate != 0:  w [cout][cin][kk] -> w_hat (same shape), wsq [cout][cin], scale [cout];  t [n][cin] -> s_eff [n][cin], d [n][cout], r [1]
+ *     demodulate == 0:  t -> s_eff, r (= 1); w / w_hat / wsq / scale / d unused (the caller convolves with w itself)
+ * backward (g_hat / g_s / g_d: gradients of w_hat / s_eff / d, NULL = zeros): dw [cout][cin][kk] (NULL: skipped), dt [n][cin];
+ * reads the forward's w_hat, wsq, scale, d, r, t, magnitude; workspace: afcm_modulation_bank_workspace_floats() floats per layer.
+ * `layers` is a HOST array of `count` <= AFCM_MODULATION_MAX entries; it is copied into the kernel arguments.
+ * ---------------------------------------------------------------------------------------- */
+#define AFCM_MODULATION_MAX 16
+typedef struct afcm_modulation_layer {
+    int32_t cout, cin, kk, demodulate;
+    const float* w;
+    const float* t;
+    const float* magnitude;                       /* [1] (input_gain = rsqrt(magnitude), NET:346) or NULL (gain 1) */
+    float* w_hat;
+    float* wsq;
+    float* scale;
+    float* s_eff;
+    float* d;
+    float* r;
+    const float* g_hat;                           /* backward only from here on */
+    const float* g_s;
+    const float* g_d;
+    float* dw;
+    float* dt;
+    float* workspace;
+} afcm_modulation_layer;
+int64_t afcm_modulation_bank_workspace_floats(int32_t n, int32_t cin, int32_t cout, int32_t demodulate);
+int afcm_modulation_bank_fwd(const afcm_modulation_layer* layers, int32_t count, int32_t n, void* stream);
+int afcm_modulation_bank_bwd(const afcm_modulation_layer* layers, int32_t count, int32_t n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -624,3 +624,48 @@ def test_affine_bank_matches_the_layers_one_by_one(n, kw, kg, couts):
             continue
         assert a is not None, i
         assert (a - b).abs().max().item() <= 1e-4 * max(1e-3, b.abs().max().item()), (i, (a - b).abs().max().item(), b.abs().max().item())
+
+
+@pytest.mark.parametrize('n', [1, 16])
+def test_modulation_bank_is_bit_identical_to_the_layers_one_by_one(n):
+    """torch_utils/ops/modulation_bank.py (C ABI afcm_modulation_bank_*): (w_hat, in_scale, out_scale) of a list of layers (NET:41-57,
+    346-352) from 2 launches and the weight / style gradients from 3, against ``modulation_coefficients_fused`` layer by layer: the same
+    kernel bodies, so every output and gradient must match bit for bit.  Covers the three row-length classes of the weight kernels
+    (<= 1024, <= 4608, longer), a 1x1 layer, a layer without magnitude, the layer that does not demodulate (ToRGB) and output gradients
+    that are missing (None) or present for w_hat / in_scale / out_scale independently."""
+    from afcm_amd.torch_utils.ops import modulation_bank as mb
+    from afcm_amd.torch_utils.ops.conv2d import modulation_coefficients_fused
+    torch.manual_seed(11)
+    shapes = [(64, 32, 3, True), (37, 100, 3, True), (16, 512, 3, True), (24, 1024, 3, True), (8, 700, 1, True), (3, 64, 1, False), (512, 512, 3, True)]
+    ws = [torch.randn(o, i, k, k, device='cuda', requires_grad=True) for o, i, k, _ in shapes]
+    ts = [torch.randn(n, i, device='cuda', requires_grad=True) for _, i, _, _ in shapes]
+    mags = [None if l == 1 else torch.rand([], device='cuda') + 0.5 for l in range(len(shapes))]
+    items = [mb.Item(w, t, m, dm) for w, t, m, (_, _, _, dm) in zip(ws, ts, mags, shapes)]
+    assert mb.supported(items)
+    got = mb.modulation_bank(items)
+    want = [modulation_coefficients_fused(w, t, demodulate=dm, magnitude=m) for w, t, m, (_, _, _, dm) in zip(ws, ts, mags, shapes)]
+    for l, (a, b) in enumerate(zip(got, want)):
+        for x, y in zip(a, b):
+            assert (x is None) == (y is None), l
+            if x is not None:
+                assert torch.equal(x, y), (l, (x - y).abs().max().item())
+    # gradients: a random cotangent on every output, except layer 2 (none on w_hat), layer 3 (none on out_scale), layer 4 (in_scale only)
+    def loss(mods):
+        tot = 0
+        gen = torch.Generator(device='cuda').manual_seed(5)
+        for l, (w_hat, s, d) in enumerate(mods):
+            rw = torch.randn(w_hat.shape, device='cuda', generator=gen)
+            rs = torch.randn(s.shape, device='cuda', generator=gen)
+            rd = torch.randn(d.shape, device='cuda', generator=gen) if d is not None else None
+            if l not in (2, 4):
+                tot = tot + (w_hat * rw).sum()
+            tot = tot + (s * rs).sum()
+            if d is not None and l not in (3, 4):
+                tot = tot + (d * rd).sum()
+        return tot
+    gg = torch.autograd.grad(loss(got), ws + ts, allow_unused=True)
+    gw = torch.autograd.grad(loss(want), ws + ts, allow_unused=True)
+    for i, (a, b) in enumerate(zip(gg, gw)):
+        assert (a is None) == (b is None), i
+        if a is not None:
+            assert torch.equal(a, b), (i, (a - b).abs().max().item(), b.abs().max().item())
