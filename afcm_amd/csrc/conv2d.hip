@@ -1492,6 +1492,11 @@ __device__ __forceinline__ void lds_dma_dword(i32x4 rsrc, unsigned voff, unsigne
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, 0 offen lds" : : "s"(lds_addr), "v"(voff), "s"(rsrc));
 }
 
+// 16 bytes per lane: lane l lands at lds_addr + 16*l
+__device__ __forceinline__ void lds_dma_b128(i32x4 rsrc, unsigned voff, unsigned lds_addr) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" : : "s"(lds_addr), "v"(voff), "s"(rsrc));
+}
+
 __device__ __forceinline__ i32x4 make_rsrc(const void* base, int num_records) {
     // the descriptor is wave-uniform by construction; readfirstlane pins it to SGPRs for the "s" asm operand
     const unsigned long long a = (unsigned long long)base;
@@ -1507,22 +1512,25 @@ __device__ __forceinline__ i32x4 make_rsrc(const void* base, int num_records) {
 // 16-bit 3x3 forward / data-gradient kernel, r03 "gather" structure: the activation patch reaches LDS by LDS-DMA, the wave's own
 // instruction stream never touches it on the way in.  conv2d_fwd16_kernel loads the patch into registers, transposes it there
 // (NCHW hands a lane consecutive pixels of one channel, an MFMA B fragment wants 8 channels of one pixel) and writes it with four
-// ds_write_b128 per thread and chunk -- the measured limiter (ablations above).  LDS-DMA cannot transpose 16-bit elements, but it
-// GATHERS dwords: lane l of a `buffer_load_dword ... lds` fetches any dword and lands it at M0 + 4 l.  A dword of an NCHW row is a
-// pixel PAIR of one channel; with lane = (pair j of 4, channel c of 16) one instruction lays down [pair][16 channels] x 2 pixels,
-// 256 contiguous bytes, so the patch image in LDS is [row][pair][channel][2 pixels]: a lane's 8 channels of a pair are 32
-// contiguous bytes (two ds_read_b128).  The last step, 2 pixels x (c, c + 1) -> (c, c + 1) of one pixel, is one v_perm_b32 per
-// fragment dword at READ time -- the "pixel phase" scheme of conv2d_fwd16d_kernel: a lane owns an output pixel pair, reads the two
-// input pairs that cover the four pixels 2p - pad .. 2p - pad + 3 of a tap row (4 x b128), builds the four phase fragments (16
-// perms) and feeds the tap row's 3 (kx) x 2 (parity) x MI MFMAs.  Out-of-image rows / columns and channels past Cin are
-// out-of-range offsets: the DMA writes zeros, no masks anywhere.  Per chunk and wave: NI DMA instructions (their lane offsets
-// sit in an LDS table, fixed for the kernel), 24 ds_read_b128 (36 before), 96 v_perm (the ~20 staging instructions, 8 global
-// loads and 4 ds_write_b128 are gone), ONE barrier, placed two taps before the chunk ends so that the next chunk's first tap row
-// is read and permuted under the last MFMAs.  Groups of 4 pairs (256 B) sit 272 B apart: the 16 lanes of a ds_read_b128 lane
-// group then hit 16 different 16-byte bank groups (conflict-free where the pair index of lane 0 is a multiple of 4).
-constexpr int kGatherNI = 16;                        // DMA instructions per wave and chunk (groups: 4 x 16 = 64 per buffer)
-constexpr int kGatherGroup = 272;                    // bytes between groups of 4 pairs
-constexpr int kGatherBuf = 4 * kGatherNI * kGatherGroup;
+// ds_write_b128 per thread and chunk -- the measured limiter (ablations above).  LDS-DMA cannot transpose, but the transposition
+// can be split: the DMA brings 16-byte pieces (4 pixel PAIRS of one channel) with lane = (channel c of 16, piece ql of 4), so one
+// instruction lays down [channel][4 pieces][4 pairs] = 1 KB of a patch row; a lane that needs pair P of 8 channels reads 8 dwords
+// 64 bytes apart (four ds_read2_b32: dwords of channels (c, c + 1) land in adjacent registers), and the last step, 2 pixels x (c,
+// c + 1) -> (c, c + 1) of one pixel, is one v_perm_b32 per fragment dword -- the "pixel phase" scheme of conv2d_fwd16d_kernel: a
+// lane owns an output pixel pair, reads the two input pairs that cover the four pixels 2p - pad .. 2p - pad + 3 of a tap row, builds
+// the four phase fragments (16 perms) and feeds the tap row's 3 (kx) x 2 (parity) x MI MFMAs.  Rows outside the image and channels
+// past Cin are out-of-range offsets (the DMA writes zeros); the patch starts 8 pixels left of the tile, so at the left image edge
+// whole pieces fall outside; the one piece column that straddles the RIGHT edge is trimmed in LDS by the wave that fetched it
+// (tiles of the last tile column only).  Per chunk and wave: <= 6 DMA instructions, 48 ds_read2_b32, 96 v_perm (the ~20 staging
+// instructions, 8 global loads and 4 ds_write_b128 are gone), ONE barrier, placed three taps before the chunk ends so that the
+// next chunk's first tap row is read and permuted under the last MFMAs.  Blocks of 4 pieces x 16 channels (1 KB) sit 1088 B
+// apart: 32 lanes with consecutive pairs hit 32 different banks.
+// (First version: dword pieces, lane = (pair, channel), [pair][channel] rows read by ds_read_b128 -- 16 instructions per wave and
+// chunk, each touching 16 cache lines: 35 % of the kernel's time, 0.88-1.01 PF/s against 1.35-1.56 without the DMA.)
+constexpr int kGatherNI = 6;                         // DMA instructions per wave and chunk (blocks: 4 x 6 = 24 per buffer)
+constexpr int kGatherBlock = 1088;                   // bytes between blocks of [16 channels][4 pieces][16 B]
+constexpr int kGatherBuf = 4 * kGatherNI * kGatherBlock;
+__host__ __device__ inline int gather_quads(int TW, int pad) { return (TW + 9 - pad) / 8 + 1; }   // 8-pixel pieces per patch row
 template <typename T, int BM_O>
 __global__ __launch_bounds__(256, 2) void conv2d_fwd16g_kernel(ConvParams p) {
     static_assert(sizeof(T) == 2 && BM_O == 128, "16-bit types, 128-row blocks");
@@ -1550,39 +1558,62 @@ __global__ __launch_bounds__(256, 2) void conv2d_fwd16g_kernel(ConvParams p) {
     const int y0 = ty * p.TH, x0 = tx * p.TW;
     const int o0 = ob * BM_O;
     const int TWP = p.TW >> 1;
-    const int PH = p.TH + KS - 1, G = (TWP + 1 + 3) >> 2;               // patch rows, groups of 4 pairs per row
-    const int xorg = x0 - p.pad;                                          // first patch pixel (even)
+    const int PH = p.TH + KS - 1;
+    const int NB = (gather_quads(p.TW, p.pad) + 3) >> 2;                  // blocks of 4 pieces per patch row
+    const int px_org = x0 - 8;                                            // first patch pixel
+    const int PB = (8 - p.pad) >> 1;                                      // patch pair of the first input pixel of output pair 0
 
     const T* xn = (const T*)p.x + (size_t)n * p.Cin * p.H * p.ldx;
     const long long img_bytes = (long long)p.Cin * p.H * p.ldx * 2ll;
     const int hw2 = p.H * p.ldx * 2;
     constexpr unsigned kOob = 0x80000000u;
 
-    // DMA lane offsets (fixed for the kernel): instruction i of wave w fills group 4 i + w = (row, group of the row); lane = (pair j, channel c)
+    // DMA lane offsets (fixed for the kernel): instruction i of wave w fills block 4 i + w = (row, block of the row); lane = (channel
+    // c, piece ql); the piece that straddles the right image edge keeps `cut` = its number of valid pairs (4: nothing to trim)
     unsigned voff[NI];
-    {
-        const int j = lane >> 4, c = lane & 15;
+    bool any_cut = false;
+    const int dc = lane >> 2, dql = lane & 3;
 #pragma unroll
-        for (int i = 0; i < NI; i++) {
-            const int idx = 4 * i + wave;
-            const int row = idx / G, grp = idx - row * G;
-            const int iy = y0 - p.pad + row, ix = xorg + 2 * (4 * grp + j);
-            const bool ok = row < PH && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-            voff[i] = ok ? (unsigned)(((c * p.H + iy) * p.ldx + ix) * 2) : kOob;
-        }
+    for (int i = 0; i < NI; i++) {
+        const int idx = 4 * i + wave;
+        const int row = idx / NB, blk = idx - row * NB;
+        const int iy = y0 - p.pad + row, ix = px_org + 8 * (4 * blk + dql);
+        const bool ok = row < PH && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        voff[i] = ok ? (unsigned)(((dc * p.H + iy) * p.ldx + ix) * 2) : kOob;
+        any_cut |= ok && ix + 8 > p.W;
     }
+    const bool edge_tile = __builtin_amdgcn_readfirstlane(__ballot(any_cut) != 0ull) != 0;   // wave-uniform
     // chunk kc -> buffer kc & 1; channels past Cin (and every chunk past the last) fall outside the descriptor
     auto issue_dma = [&](int kc) __attribute__((always_inline)) {
         const long long skip = (long long)kc * BK * hw2;
         const long long left = img_bytes - skip;
         const i32x4 rs = make_rsrc((const char*)xn + skip, left > 0 ? (int)left : 0);
-        const unsigned dst = lds0 + (kc & 1) * kGatherBuf + wave * kGatherGroup;
+        const unsigned dst = lds0 + (kc & 1) * kGatherBuf + wave * kGatherBlock;
 #pragma unroll
-        for (int i = 0; i < NI; i++) lds_dma_dword(rs, voff[i], dst + i * (4 * kGatherGroup));
+        for (int i = 0; i < NI; i++) lds_dma_b128(rs, voff[i], dst + i * (4 * kGatherBlock));
+    };
+    // pairs right of the image inside this wave's straddling pieces (next row's head or padding in memory) -> zero.  Runs after the
+    // wave's own DMA has landed and before the barrier that publishes the buffer; tiles of the last tile column only.
+    auto trim = [&](int buf) __attribute__((always_inline)) {
+        if (edge_tile) {
+#pragma unroll
+            for (int i = 0; i < NI; i++) {
+                const int idx = 4 * i + wave;
+                const int blk = idx % NB;
+                const int ix = px_org + 8 * (4 * blk + dql);
+                const int valid = (p.W - ix) >> 1;                        // pairs of the piece inside the row
+                if (voff[i] != kOob && valid < 4) {
+                    unsigned* piece = (unsigned*)(lds + buf * kGatherBuf + idx * kGatherBlock + lane * 16);
+#pragma unroll
+                    for (int k = 1; k < 4; k++)
+                        if (k >= valid) piece[k] = 0u;
+                }
+            }
+        }
     };
 
-    // B reads: this lane's two pixel pairs (ti = 0, 1), each needs the patch pairs pxp and pxp + 1 of rows py + ky: byte offsets
-    // of its 8 channels (32 B) in those pairs at ky = 0
+    // B reads: this lane's two pixel pairs (ti = 0, 1), each needs the patch pairs pxp + PB and pxp + PB + 1 of rows py + ky: byte
+    // offset of the dword of channel 8 h in those pairs at ky = 0 (channels: + 64 bytes each)
     unsigned boff[2][2];
     int jslot[2];
 #pragma unroll
@@ -1592,10 +1623,12 @@ __global__ __launch_bounds__(256, 2) void conv2d_fwd16g_kernel(ConvParams p) {
         if (py >= p.TH) { py = 0; pxp = 0; }                            // slots outside the tile: any valid address, never stored
         jslot[ti] = js;
 #pragma unroll
-        for (int j = 0; j < 2; j++)
-            boff[ti][j] = (unsigned)((py * G + ((pxp + j) >> 2)) * kGatherGroup + ((pxp + j) & 3) * 64 + h * 32);
+        for (int j = 0; j < 2; j++) {
+            const int pp = pxp + PB + j, q = pp >> 2;
+            boff[ti][j] = (unsigned)((py * NB + (q >> 2)) * kGatherBlock + h * 512 + (q & 3) * 16 + (pp & 3) * 4);
+        }
     }
-    const unsigned rowstride = (unsigned)(G * kGatherGroup);
+    const unsigned rowstride = (unsigned)(NB * kGatherBlock);
 
     f32x16 acc[MI][4];                                                    // [mi][2 ti + parity]
 #pragma unroll
@@ -1616,19 +1649,20 @@ __global__ __launch_bounds__(256, 2) void conv2d_fwd16g_kernel(ConvParams p) {
     //   as its last tap has issued: phases 0 / 1 (from pair j = 0 of the next row) under taps kx = 1 / 2, phases 2 / 3 (pair j = 1 of
     //   the row itself) under taps kx = 0 / 1 of that row; the raw pair j = 0 of the next row is read under tap kx = 0, pair j = 1
     //   under tap kx = 2, each one tap before its first perm.  32 fragment + 32 raw registers, nothing waits on LDS.
-    u32x4 raw[2][2][2];                                                   // [pair j][ti][channels 0-3 / 4-7 of the lane's eight]
+    unsigned raw[2][2][8];                                                // [pair j][ti][channel of the lane's eight]: 2 pixels each
     auto read_pair = [&](int buf, int ky, int j) __attribute__((always_inline)) {
         const unsigned char* b = lds + buf * kGatherBuf;
         const unsigned ro = (unsigned)ky * rowstride;
 #pragma unroll
-        for (int ti = 0; ti < 2; ti++) {
+        for (int ti = 0; ti < 2; ti++)
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
 #ifdef AFCM_GATHER_EXPERIMENT_NOREAD
-            asm volatile("" : "+v"(raw[j][ti][0]), "+v"(raw[j][ti][1]) : "v"(b + (boff[ti][j] + ro)));
+                asm volatile("" : "+v"(raw[j][ti][c]) : "v"(b + (boff[ti][j] + ro)));
 #else
-            raw[j][ti][0] = *(const u32x4*)(b + (boff[ti][j] + ro));
-            raw[j][ti][1] = *(const u32x4*)(b + (boff[ti][j] + ro) + 16);
+                raw[j][ti][c] = *(const unsigned*)(b + (boff[ti][j] + ro) + 64 * c);
 #endif
-        }
+            }
     };
     union FragU { u32x4 u; frag_t f; };
     FragU bf[2][4];                                                       // [ti][phase]
@@ -1639,9 +1673,9 @@ __global__ __launch_bounds__(256, 2) void conv2d_fwd16g_kernel(ConvParams p) {
 #pragma unroll
             for (int r = 0; r < 4; r++)
 #ifdef AFCM_GATHER_EXPERIMENT_NOPERM
-                bf[ti][q].u[r] = raw[q >> 1][ti][r >> 1][2 * (r & 1) + (q & 1)];
+                bf[ti][q].u[r] = raw[q >> 1][ti][2 * r + (q & 1)];
 #else
-                bf[ti][q].u[r] = __builtin_amdgcn_perm(raw[q >> 1][ti][r >> 1][2 * (r & 1) + 1], raw[q >> 1][ti][r >> 1][2 * (r & 1)], sel);
+                bf[ti][q].u[r] = __builtin_amdgcn_perm(raw[q >> 1][ti][2 * r + 1], raw[q >> 1][ti][2 * r], sel);
 #endif
     };
 
@@ -1652,6 +1686,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_fwd16g_kernel(ConvParams p) {
 #pragma unroll
         for (int mi = 0; mi < MI; mi++) ar[t][mi] = load_a(0, t, mi);
     asm volatile("s_waitcnt vmcnt(0)");
+    trim(0);
     __syncthreads();
     read_pair(0, 0, 0);
     read_pair(0, 0, 1);
@@ -1670,6 +1705,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_fwd16g_kernel(ConvParams p) {
                 // the next chunk's patch: every wave's DMA has landed (issued before this chunk's first ring refill, so all but the
                 // loads of the last taps are younger) and nobody reads its old contents any more
                 asm volatile("s_waitcnt vmcnt(%0)" : : "n"(3 * MI));
+                trim((kc + 1) & 1);
                 __syncthreads();
             }
             frag_t a[MI];
@@ -1701,15 +1737,10 @@ __global__ __launch_bounds__(256, 2) void conv2d_fwd16g_kernel(ConvParams p) {
             __builtin_amdgcn_sched_group_barrier(0x020, MI, 0);
             if constexpr (kx == 0) {
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
+                for (int j = 0; j < 4 * MI; j++) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
                     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                }
-#pragma unroll
-                for (int j = 4; j < 4 * MI; j++) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
                 }
             } else if constexpr (kx == 1) {
 #pragma unroll
@@ -1719,14 +1750,9 @@ __global__ __launch_bounds__(256, 2) void conv2d_fwd16g_kernel(ConvParams p) {
                 }
             } else {
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
+                for (int j = 0; j < 4 * MI; j++) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                     __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
-                }
-#pragma unroll
-                for (int j = 4; j < 4 * MI; j++) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
                     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                 }
             }
@@ -2094,9 +2120,6 @@ __global__ __launch_bounds__(512, 1) void conv2d_wgrad16_kernel(WgradParams p) {
 // LDS image of one step:   dy [rr 0..1][o 64][8 granules]   x main [xr][ch 64][8 granules]   x tail [ch>>3][xr][ch&7][1 granule]
 // with granule g of row r at slot g ^ ((r >> 1) & 7); B fragments of tap column s are the 5-dword window
 // (granule g).d3, (granule g+1).d0..3 shifted by s.
-__device__ __forceinline__ void lds_dma_b128(i32x4 rsrc, unsigned voff, unsigned lds_addr) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" : : "s"(lds_addr), "v"(voff), "s"(rsrc));
-}
 
 // SMALL (both tensors below 2^31 bytes): ONE buffer descriptor per tensor for the whole kernel; a piece's position is a 32-bit
 // offset added to the lane offsets and its validity (row outside the image, dead step) an OR mask on bit 31.  The general form
@@ -2520,7 +2543,7 @@ static int launch_conv(ConvParams p, int ks, hipStream_t st) {
         const bool direct = (direct_s != nullptr && atoi(direct_s) != 0) && (p.pad & 1) == 0 && (p.W & 1) == 0 && (p.Q & 1) == 0 &&
                             ((p.ldx | p.ldy) & 1) == 0 && (long long)p.Cin * p.H * p.ldx * 2ll < (1ll << 31);
         static const char* gather_s = getenv("AFCM_CONV_GATHER");             // experiment: 1 = the LDS-DMA gather kernel
-        const int gather_rows = (p.TH + 2) * (((p.TW >> 1) + 1 + 3) >> 2);    // groups of 4 pairs in the patch
+        const int gather_rows = (p.TH + 2) * ((gather_quads(p.TW, p.pad) + 3) >> 2);   // 1 KB blocks in the patch
         const bool gather = (gather_s != nullptr && atoi(gather_s) != 0) && BM_O == 128 && (p.pad & 1) == 0 && (p.W & 1) == 0 && (p.Q & 1) == 0 &&
                             ((p.ldx | p.ldy) & 1) == 0 && (long long)p.Cin * p.H * p.ldx * 2ll < (1ll << 31) && gather_rows <= 4 * kGatherNI;
         if constexpr (BM_O == 128) {
