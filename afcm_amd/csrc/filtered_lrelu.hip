@@ -14,6 +14,7 @@
 //   u[U0 + up*m + a] = sum_j F[kmin(a) + up*j] * x[I0 + m + o(a) + j]
 //   o(a) = (a > ph),  kmin(a) = o(a) ? up - (a - ph) : ph - a,   F = flip ? fu : reversed(fu)
 #include <stdlib.h>
+#include <type_traits>
 #include "common.h"
 
 namespace afcm {
@@ -31,6 +32,7 @@ struct FlreluParams {
     int flip;
     int sx, sy, sh, swb;
     float fscale;  // pointwise kernel only: product of the 1x1 filters
+    int planes;    // strip kernel only: N * C
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -426,6 +428,256 @@ __global__ __launch_bounds__(256) void flrelu_pointwise_kernel(FlreluParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Strip kernel (r03, fp32): one WAVE owns a strip of SW output columns x SH output rows of one plane and marches down it one input
+// row per step, with every intermediate in registers or in the wave's own 1-3 KB of LDS -- no workgroup barrier, no tile halo in y
+// (the tile kernel above recomputes (FD - DOWN) upsampled rows per 20-row tile, 1.55x the useful FMAs at up 2 / down 2 and 4.4x at
+// down 4), and an instruction stream close to the arithmetic: profiles/r03_flrelu_fp32_pmc.txt has the tile kernel 75 % VALU-issue-
+// bound at 289 vector operations per output where the four FIR passes need 47 packed FMAs.
+//   lane l <-> input column I0x + l.  Per step (input row I0y + it):
+//     up-x   the row goes through LDS so that a lane sees its 6 right neighbours: UP upsampled columns per lane, 7 taps each (the
+//            phase-dependent one-column offset o(a) of the polyphase form is folded into a 7-tap table with one zero: no selects)
+//     up-y   a ring of the last 6 up-x rows in registers (static indices: the step loop is unrolled over the ring period) + the new
+//            row -> UP upsampled rows x UP columns, 7 taps each; gain, leaky ReLU, clamp, 2-bit codes (written as whole dwords by
+//            the first lane of each 16-column group after a DPP OR-reduction; READ: the row's sign dwords are fetched one step ahead
+//            by the first lanes and spread through LDS)
+//     down-x the UP activated rows go through LDS; lane j reads the FD taps of output column j (8-byte reads, even / odd taps in the
+//            two halves of packed FMAs)
+//     down-y scatter form: each new down-x row adds into the FD / DOWN output rows it contributes to (a ring of 6 accumulators,
+//            static indices); the accumulator that received its last tap is stored and reset.
+//   Signs: a strip owns the SW DOWN upsampled columns of its outputs (a multiple of 16: whole dwords), a segment the SH DOWN rows of
+//   its outputs, the last strip / segment the rest.  Lanes 58..63 have no full tap support: they compute on zero padding and own nothing.
+template <int LO, int HI, typename F>
+__device__ __forceinline__ void strip_static_for(F&& f) {
+    if constexpr (LO < HI) {
+        f(std::integral_constant<int, LO>{});
+        strip_static_for<LO + 1, HI>(f);
+    }
+}
+
+template <int UP, int DOWN>
+struct StripGeom {
+    static constexpr int FUT = 6, FU = FUT * UP, FD = FUT * DOWN;
+    static constexpr int SW = (UP == 2 && DOWN == 2) ? 48 : (UP == 2 && DOWN == 4) ? 20 : 104;   // output columns per strip
+    static constexpr int NU = 64 * UP;                          // upsampled columns per row of the strip
+    static constexpr int OPL = SW > 64 ? 2 : 1;                 // output columns per lane
+    static constexpr int PERIOD = (UP == 2 && DOWN == 4) ? 12 : 6;   // steps after which the up-y ring AND the down-y ring repeat
+    static constexpr int GS = 16 / UP;                          // lanes per sign dword
+    static constexpr int NW = NU / 16 + 1;                      // sign dwords a row's window can touch (READ)
+    static_assert((SW * DOWN) % 16 == 0, "sign ownership must fall on dword boundaries");
+    static_assert(DOWN * (SW - 1) + FD <= UP * 58, "the strip's outputs must stay inside the columns with full tap support");
+    static_assert((UP * PERIOD) % (DOWN * 6) == 0 && PERIOD % 6 == 0, "ring periods");
+};
+
+template <typename T, int UP, int DOWN, int SIGN>
+__global__ __launch_bounds__(256) void flrelu_strip_kernel(FlreluParams p, const float* __restrict__ fu, const float* __restrict__ fd) {
+    typedef StripGeom<UP, DOWN> G;
+    constexpr int FUT = G::FUT, FU = G::FU, FD = G::FD, SW = G::SW, NU = G::NU, OPL = G::OPL, PERIOD = G::PERIOD, GS = G::GS, NW = G::NW;
+    __shared__ float s_in[4][72];                                // input row of the wave + zero pad for the neighbours of lanes 58..63
+    __shared__ __attribute__((aligned(16))) float s_u[4][UP][NU];   // the UP activated rows of a step
+    __shared__ unsigned s_sg[4][UP][NW + 1];                     // READ: sign dwords of the step's rows
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int SH = cdiv(p.yh, p.tilesY);
+    int wt = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave);
+    if (wt >= p.tilesX * p.tilesY * p.planes) return;
+    const int tx = wt % p.tilesX; wt /= p.tilesX;
+    const int ty = wt % p.tilesY;
+    const int plane = wt / p.tilesY;
+    const bool lastX = tx == p.tilesX - 1, lastY = ty == p.tilesY - 1;
+    const int O0x = tx * SW, O0y = ty * SH;
+    const int U0x = O0x * DOWN, U0y = O0y * DOWN;
+    const int I0x = -floor_div(p.px0 - U0x, UP), phx = pos_mod(p.px0 - U0x, UP);
+    const int I0y = -floor_div(p.py0 - U0y, UP), phy = pos_mod(p.py0 - U0y, UP);
+
+    // 7-tap polyphase tables (uniform: scalar registers): c7[a][t] multiplies row / column (first + t), t = 0..6
+    float cx7[UP][7], cy7[UP][7], cd[FD];
+#pragma unroll
+    for (int a = 0; a < UP; a++) {
+        const int ox = (a > phx) ? 1 : 0, oy = (a > phy) ? 1 : 0;
+        const int kx = ox ? UP - (a - phx) : phx - a, ky = oy ? UP - (a - phy) : phy - a;
+#pragma unroll
+        for (int t = 0; t < 7; t++) {
+            const int jx = t - ox, jy = t - oy;
+            const int ix = kx + UP * (jx < 0 ? 0 : jx > 5 ? 5 : jx), iy = ky + UP * (jy < 0 ? 0 : jy > 5 ? 5 : jy);
+            const float vx = p.flip ? fu[ix] : fu[FU - 1 - ix], vy = p.flip ? fu[iy] : fu[FU - 1 - iy];
+            cx7[a][t] = (jx >= 0 && jx < FUT) ? vx : 0.f;
+            cy7[a][t] = (jy >= 0 && jy < FUT) ? vy : 0.f;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < FD; k++) cd[k] = p.flip ? fd[k] : fd[FD - 1 - k];
+
+    float* const in_row = s_in[wave];
+    if (lane < 8) in_row[64 + lane] = 0.f;
+    if (SIGN == AFCM_SIGNS_READ && lane < UP) s_sg[wave][lane][NW] = 0u;
+    const T* const xp = (const T*)p.x + (size_t)plane * p.xh * p.xw;
+    T* const yp = (T*)p.y + (size_t)plane * p.yh * p.yw;
+    unsigned char* const splane = p.s + (size_t)plane * p.sh * p.swb;
+    const float bias = p.b ? to_f32(((const T*)p.b)[plane % p.C]) : 0.f;     // added inside the image only (the padding is zero)
+    const int ix = I0x + lane;
+    const bool colok = (unsigned)ix < (unsigned)p.xw;
+
+    // rows this wave has to walk: the last tap of its last output row, in WRITE mode of the last segment also the last sign row
+    const int SHv = min(SH, p.yh - O0y);
+    int qmax = DOWN * (SHv - 1) + FD - 1;
+    if (SIGN == AFCM_SIGNS_WRITE && lastY) qmax = max(qmax, p.sh - 1 - U0y);
+    const int NIT = qmax / UP + 7;
+
+    // READ: dword window of a sign row and this lane's bit offset inside it
+    const int w0 = floor_div(U0x + p.sx, 16);
+    const int sbit = pos_mod(U0x + p.sx, 16) * 2 + 2 * UP * lane;
+    const int sword = sbit >> 5, sshift = sbit & 31;
+    const int wpr = p.swb >> 2;
+    auto fetch_signs = [&](int it, unsigned (&sg)[UP]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int a = 0; a < UP; a++) {
+            const int Y = U0y + UP * (it - 6) + a + p.sy, wi = w0 + lane;
+            const bool ok = lane < NW && (unsigned)Y < (unsigned)p.sh && (unsigned)wi < (unsigned)wpr;
+            sg[a] = ok ? ((const unsigned*)(splane + (size_t)(ok ? Y : 0) * p.swb))[ok ? wi : 0] : 0u;
+        }
+    };
+    auto fetch_input = [&](int it) __attribute__((always_inline)) -> float {
+        const int iy = I0y + it;
+        const bool ok = colok && (unsigned)iy < (unsigned)p.xh;
+        return ok ? to_f32(xp[(size_t)(ok ? iy : 0) * p.xw + (ok ? ix : 0)]) + bias : 0.f;
+    };
+
+    float ring[6][UP];
+#pragma unroll
+    for (int j = 0; j < 6; j++)
+#pragma unroll
+        for (int a = 0; a < UP; a++) ring[j][a] = 0.f;
+    float acc[6][OPL];
+#pragma unroll
+    for (int j = 0; j < 6; j++)
+#pragma unroll
+        for (int o = 0; o < OPL; o++) acc[j][o] = 0.f;
+
+    float xnext = fetch_input(0);
+    unsigned sgnext[UP];
+#pragma unroll
+    for (int a = 0; a < UP; a++) sgnext[a] = 0u;
+    if (SIGN == AFCM_SIGNS_READ) fetch_signs(6, sgnext);
+
+    for (int base = 0; base < NIT; base += PERIOD) {
+        strip_static_for<0, PERIOD>([&](auto phc) __attribute__((always_inline)) {
+            constexpr int ph = decltype(phc)::value;
+            const int it = base + ph;
+            if (it < NIT) {
+                // ---- up-x
+                const float xin = xnext;
+                xnext = fetch_input(it + 1);
+                in_row[lane] = xin;
+                __builtin_amdgcn_wave_barrier();
+                float nb[7];
+                nb[0] = xin;
+#pragma unroll
+                for (int t = 1; t < 7; t++) nb[t] = in_row[lane + t];
+                __builtin_amdgcn_wave_barrier();
+                float R[UP];
+#pragma unroll
+                for (int a = 0; a < UP; a++) {
+                    float s0 = 0.f;
+#pragma unroll
+                    for (int t = 0; t < 7; t++) s0 = fmaf(cx7[a][t], nb[t], s0);
+                    R[a] = s0;
+                }
+                if (it >= 6) {
+                    // ---- up-y: rows m + t, t = 0..5 in ring[(ph + t) % 6], row m + 6 = R;  m = it - 6
+                    unsigned sg[UP];
+                    if (SIGN == AFCM_SIGNS_READ) {
+#pragma unroll
+                        for (int a = 0; a < UP; a++) sg[a] = sgnext[a];
+                        fetch_signs(it + 1, sgnext);
+#pragma unroll
+                        for (int a = 0; a < UP; a++)
+                            if (lane < NW) s_sg[wave][a][lane] = sg[a];
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                    const int q0 = UP * (it - 6);                 // first upsampled row of the step, relative to U0y
+#pragma unroll
+                    for (int ay = 0; ay < UP; ay++) {
+                        float v[UP];
+#pragma unroll
+                        for (int ax = 0; ax < UP; ax++) {
+                            float s0 = 0.f;
+#pragma unroll
+                            for (int t = 0; t < 6; t++) s0 = fmaf(cy7[ay][t], ring[(ph + t) % 6][ax], s0);
+                            v[ax] = fmaf(cy7[ay][6], R[ax], s0);
+                        }
+                        unsigned codes = 0u;
+                        if (SIGN == AFCM_SIGNS_READ) {
+                            const unsigned lo = s_sg[wave][ay][sword], hi = s_sg[wave][ay][sword + 1];
+                            codes = __builtin_amdgcn_alignbit(hi, lo, sshift);
+                        }
+                        unsigned nib = 0u;
+#pragma unroll
+                        for (int ax = 0; ax < UP; ax++) nib |= act_elem<SIGN>(v[ax], p.gain, p.slope, p.clamp, codes >> (2 * ax)) << (2 * ax);
+                        if (SIGN == AFCM_SIGNS_WRITE) {
+                            int word = (int)(nib << ((lane % GS) * 2 * UP));
+                            word |= __builtin_amdgcn_mov_dpp(word, 0xB1, 0xF, 0xF, true);              // quad_perm [1,0,3,2]
+                            word |= __builtin_amdgcn_mov_dpp(word, 0x4E, 0xF, 0xF, true);              // quad_perm [2,3,0,1]
+                            if (GS == 8) word |= __builtin_amdgcn_mov_dpp(word, 0x141, 0xF, 0xF, true);   // row_half_mirror
+                            const int q = q0 + ay, Y = U0y + q, X0 = U0x + UP * lane;
+                            const bool own = ((UP * lane < SW * DOWN) || lastX) && ((q < SH * DOWN) || lastY);
+                            if ((lane % GS) == 0 && lane + GS <= 58 && own && (X0 >> 2) < p.swb && Y < p.sh)
+                                *(int*)(splane + (size_t)Y * p.swb + (X0 >> 2)) = word;
+                        }
+                        if constexpr (UP == 2) *(float2*)(&s_u[wave][ay][UP * lane]) = make_float2(v[0], v[1]);
+                        else *(float4*)(&s_u[wave][ay][UP * lane]) = make_float4(v[0], v[1], v[2], v[3]);
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    // ---- down-x and down-y
+#pragma unroll
+                    for (int ay = 0; ay < UP; ay++) {
+                        constexpr int QS_BASE = ((UP * (ph - 6)) % (DOWN * 6) + DOWN * 6) % (DOWN * 6);
+                        const int qs = (QS_BASE + ay) % (DOWN * 6);       // the row's index modulo the down-y period (compile time after unrolling)
+                        float d[OPL];
+#pragma unroll
+                        for (int o = 0; o < OPL; o++) {
+                            const int j = min(lane + 64 * o, SW - 1);
+                            const float2* src = (const float2*)(&s_u[wave][ay][DOWN * j]);
+                            float e0 = 0.f, e1 = 0.f;
+#pragma unroll
+                            for (int k2 = 0; k2 < FD / 2; k2++) {
+                                const float2 t2 = src[k2];
+                                e0 = fmaf(cd[2 * k2], t2.x, e0);
+                                e1 = fmaf(cd[2 * k2 + 1], t2.y, e1);
+                            }
+                            d[o] = e0 + e1;
+                        }
+#pragma unroll
+                        for (int i = 0; i < 6; i++) {
+                            const int slot = ((qs / DOWN - i) % 6 + 6) % 6, k = qs % DOWN + DOWN * i;
+#pragma unroll
+                            for (int o = 0; o < OPL; o++) acc[slot][o] = fmaf(cd[k], d[o], acc[slot][o]);
+                        }
+                        if (qs % DOWN == DOWN - 1) {
+                            const int slot = ((qs / DOWN - 5) % 6 + 6) % 6;
+                            const int pr = (q0 + ay - (FD - 1)) / DOWN;     // exact: q - (FD - 1) is a multiple of DOWN here
+                            if (q0 + ay >= FD - 1 && pr < SHv) {
+#pragma unroll
+                                for (int o = 0; o < OPL; o++) {
+                                    const int j = lane + 64 * o;
+                                    if (j < SW && O0x + j < p.yw) yp[(size_t)(O0y + pr) * p.yw + O0x + j] = from_f32<T>(acc[slot][o]);
+                                }
+                            }
+#pragma unroll
+                            for (int o = 0; o < OPL; o++) acc[slot][o] = 0.f;
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+                // the new up-x row replaces the oldest one
+#pragma unroll
+                for (int a = 0; a < UP; a++) ring[ph % 6][a] = R[a];
+            }
+        });
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 template <typename T, int UP, int DOWN, int FUT, int FD, int TOW, int TOH, int RO, int NT>
 static int launch_sep(const afcm_filtered_lrelu_args* a, FlreluParams p, hipStream_t st) {
     p.tilesX = cdiv(a->yw, TOW);
@@ -443,6 +695,25 @@ static int launch_sep(const afcm_filtered_lrelu_args* a, FlreluParams p, hipStre
         default:
             hipLaunchKernelGGL((flrelu_sep_kernel<T, UP, DOWN, FUT, FD, TOW, TOH, RO, NT, AFCM_SIGNS_READ>), grid, block, 0, st, p, a->fu, a->fd);
             break;
+    }
+    return hip_status(hipGetLastError());
+}
+
+template <typename T, int UP, int DOWN>
+static int launch_strip(const afcm_filtered_lrelu_args* a, FlreluParams p, hipStream_t st) {
+    typedef StripGeom<UP, DOWN> G;
+    p.tilesX = cdiv(a->yw, G::SW);
+    static const char* rows_s = getenv("AFCM_FLRELU_STRIP_ROWS");       // tuning aid: output rows per segment
+    const int rows = rows_s ? atoi(rows_s) : 96;
+    p.tilesY = a->yh <= rows ? 1 : (a->yh + rows / 2) / rows;
+    p.planes = a->n * a->c;
+    const long long waves = (long long)p.tilesX * p.tilesY * p.planes;
+    AFCM_REQUIRE(waves > 0 && waves < (1ll << 31), "filtered_lrelu: grid of %lld waves is out of range", waves);
+    dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+    switch (a->sign_mode) {
+        case AFCM_SIGNS_NONE: hipLaunchKernelGGL((flrelu_strip_kernel<T, UP, DOWN, AFCM_SIGNS_NONE>), grid, block, 0, st, p, a->fu, a->fd); break;
+        case AFCM_SIGNS_WRITE: hipLaunchKernelGGL((flrelu_strip_kernel<T, UP, DOWN, AFCM_SIGNS_WRITE>), grid, block, 0, st, p, a->fu, a->fd); break;
+        default: hipLaunchKernelGGL((flrelu_strip_kernel<T, UP, DOWN, AFCM_SIGNS_READ>), grid, block, 0, st, p, a->fu, a->fd); break;
     }
     return hip_status(hipGetLastError());
 }
@@ -466,6 +737,14 @@ static int launch_pointwise(FlreluParams p, int planes, int sign_mode, hipStream
 template <typename T>
 static int dispatch(const afcm_filtered_lrelu_args* a, const FlreluParams& p, hipStream_t st) {
     const bool sep = (a->fuh == 0 && a->fdh == 0);
+    if constexpr (sizeof(T) == 4) {
+        // fp32: the strip kernel (planes below 2^31 elements; the tile kernel stays for the 16-bit calls with a bias operand)
+        static const char* strip_s = getenv("AFCM_FLRELU_STRIP");       // tuning aid: 0 = tile kernel only
+        const bool strip = sep && !(strip_s != nullptr && atoi(strip_s) == 0) && (long long)a->xw * a->xh < (1ll << 30) && (long long)a->yw * a->yh < (1ll << 30);
+        if (strip && a->up == 2 && a->down == 2 && a->fuw == 12 && a->fdw == 12) return launch_strip<T, 2, 2>(a, p, st);
+        if (strip && a->up == 2 && a->down == 4 && a->fuw == 12 && a->fdw == 24) return launch_strip<T, 2, 4>(a, p, st);
+        if (strip && a->up == 4 && a->down == 2 && a->fuw == 24 && a->fdw == 12) return launch_strip<T, 4, 2>(a, p, st);
+    }
     if (sep && a->up == 2 && a->down == 2 && a->fuw == 12 && a->fdw == 12)
     {
         // Tile height by mode (measured, fp32, batch 16): the sign-writing forward runs 10 % faster on 20-row tiles (53 KB of LDS:
@@ -576,6 +855,7 @@ extern "C" int afcm_filtered_lrelu(const afcm_filtered_lrelu_args* a, void* stre
     p.slope = a->slope; p.clamp = a->clamp; p.flip = a->flip_filter;
     p.sx = a->sx; p.sy = a->sy; p.sh = a->sh; p.swb = a->swb;
     p.fscale = 1.f;
+    p.planes = a->n * a->c;
 
     // 1x1 filters, no resampling: pointwise kernel.  The two taps are folded into the launch: they are
     // read back on the host only when the caller did not pass NULL (= identity).
@@ -616,7 +896,7 @@ extern "C" int afcm_filtered_lrelu_act(void* x, uint8_t* signs, int32_t dtype, i
     p.xw = w; p.xh = h; p.yw = w; p.yh = h; p.C = c;
     p.px0 = p.py0 = 0; p.tilesX = p.tilesY = 0;
     p.gain = gain; p.slope = slope; p.clamp = clamp; p.flip = 0;
-    p.sx = sx; p.sy = sy; p.sh = sh; p.swb = swb; p.fscale = 1.f;
+    p.sx = sx; p.sy = sy; p.sh = sh; p.swb = swb; p.fscale = 1.f; p.planes = n * c;
     hipStream_t st = (hipStream_t)stream;
     switch (dtype) {
         case AFCM_F32: return launch_pointwise<float>(p, n * c, sign_mode, st);
