@@ -433,7 +433,7 @@ __global__ __launch_bounds__(256) void flrelu_pointwise_kernel(FlreluParams p) {
 // (the tile kernel above recomputes (FD - DOWN) upsampled rows per 20-row tile, 1.55x the useful FMAs at up 2 / down 2 and 4.4x at
 // down 4), and an instruction stream close to the arithmetic: profiles/r03_flrelu_fp32_pmc.txt has the tile kernel 75 % VALU-issue-
 // bound at 289 vector operations per output where the four FIR passes need 47 packed FMAs.
-//   lane l <-> input column I0x + l.  Per step (input row I0y + it):
+//   lane l <-> input columns I0x + l, I0x + 64 + l (CPL column blocks).  Per step (input row I0y + it):
 //     up-x   the row goes through LDS so that a lane sees its 6 right neighbours: UP upsampled columns per lane, 7 taps each (the
 //            phase-dependent one-column offset o(a) of the polyphase form is folded into a 7-tap table with one zero: no selects)
 //     up-y   a ring of the last 6 up-x rows in registers (static indices: the step loop is unrolled over the ring period) + the new
@@ -445,7 +445,7 @@ __global__ __launch_bounds__(256) void flrelu_pointwise_kernel(FlreluParams p) {
 //     down-y scatter form: each new down-x row adds into the FD / DOWN output rows it contributes to (a ring of 6 accumulators,
 //            static indices); the accumulator that received its last tap is stored and reset.
 //   Signs: a strip owns the SW DOWN upsampled columns of its outputs (a multiple of 16: whole dwords), a segment the SH DOWN rows of
-//   its outputs, the last strip / segment the rest.  Lanes 58..63 have no full tap support: they compute on zero padding and own nothing.
+//   its outputs, the last strip / segment the rest.  The last 6 columns have no full tap support: they compute on zero padding, own nothing.
 template <int LO, int HI, typename F>
 __device__ __forceinline__ void strip_static_for(F&& f) {
     if constexpr (LO < HI) {
@@ -454,25 +454,32 @@ __device__ __forceinline__ void strip_static_for(F&& f) {
     }
 }
 
-template <int UP, int DOWN>
+template <int UP, int DOWN, int CPL_>
 struct StripGeom {
     static constexpr int FUT = 6, FU = FUT * UP, FD = FUT * DOWN;
-    static constexpr int SW = (UP == 2 && DOWN == 2) ? 48 : (UP == 2 && DOWN == 4) ? 20 : 104;   // output columns per strip
-    static constexpr int NU = 64 * UP;                          // upsampled columns per row of the strip
-    static constexpr int OPL = SW > 64 ? 2 : 1;                 // output columns per lane
+    // CPL input columns per lane, in blocks: lane l holds columns l, 64 + l, ... of the strip's 64 CPL (coalesced row loads; the up
+    // stages run once per block, the right halo -- 6 columns -- is paid once per strip: 87.5 % of the columns useful at CPL 2, 75 % at 1)
+    // The host picks CPL per configuration: 1 for up 2 / down 2 (48-column strips quantise the generator's plane widths better than
+    // 112-column ones: enc3 forward 0.91 vs 1.06 ms) and up 4 (registers), 2 for down 4 (56 output lanes instead of 24: 1.26 vs 1.68 ms)
+    static constexpr int CPL = CPL_;
+    static constexpr int NC = 64 * CPL;                         // input columns of the strip
+    static constexpr int SW = ((UP * (NC - 6) - FD) / DOWN + 1) / (16 / DOWN) * (16 / DOWN);   // output columns per strip: whole sign dwords
+    static constexpr int NU = NC * UP;                          // upsampled columns per row of the strip
+    static constexpr int OPL = cdiv(SW, 64);                    // output columns per lane
     static constexpr int PERIOD = (UP == 2 && DOWN == 4) ? 12 : 6;   // steps after which the up-y ring AND the down-y ring repeat
     static constexpr int GS = 16 / UP;                          // lanes per sign dword
     static constexpr int NW = NU / 16 + 1;                      // sign dwords a row's window can touch (READ)
     static_assert((SW * DOWN) % 16 == 0, "sign ownership must fall on dword boundaries");
-    static_assert(DOWN * (SW - 1) + FD <= UP * 58, "the strip's outputs must stay inside the columns with full tap support");
+    static_assert(DOWN * (SW - 1) + FD <= UP * (NC - 6), "the strip's outputs must stay inside the columns with full tap support");
     static_assert((UP * PERIOD) % (DOWN * 6) == 0 && PERIOD % 6 == 0, "ring periods");
+    static_assert(NW <= 64, "one lane per sign dword");
 };
 
-template <typename T, int UP, int DOWN, int SIGN>
+template <typename T, int UP, int DOWN, int CPL_, int SIGN>
 __global__ __launch_bounds__(256) void flrelu_strip_kernel(FlreluParams p, const float* __restrict__ fu, const float* __restrict__ fd) {
-    typedef StripGeom<UP, DOWN> G;
-    constexpr int FUT = G::FUT, FU = G::FU, FD = G::FD, SW = G::SW, NU = G::NU, OPL = G::OPL, PERIOD = G::PERIOD, GS = G::GS, NW = G::NW;
-    __shared__ float s_in[4][72];                                // input row of the wave + zero pad for the neighbours of lanes 58..63
+    typedef StripGeom<UP, DOWN, CPL_> G;
+    constexpr int FUT = G::FUT, FU = G::FU, FD = G::FD, SW = G::SW, NU = G::NU, NC = G::NC, CPL = G::CPL, OPL = G::OPL, PERIOD = G::PERIOD, GS = G::GS, NW = G::NW;
+    __shared__ float s_in[4][NC + 8];                            // input row of the wave + zero pad for the neighbours of the last 6 columns
     __shared__ __attribute__((aligned(16))) float s_u[4][UP][NU];   // the UP activated rows of a step
     __shared__ unsigned s_sg[4][UP][NW + 1];                     // READ: sign dwords of the step's rows
 
@@ -509,14 +516,12 @@ __global__ __launch_bounds__(256) void flrelu_strip_kernel(FlreluParams p, const
     for (int k = 0; k < FD; k++) cd[k] = p.flip ? fd[k] : fd[FD - 1 - k];
 
     float* const in_row = s_in[wave];
-    if (lane < 8) in_row[64 + lane] = 0.f;
+    if (lane < 8) in_row[NC + lane] = 0.f;
     if (SIGN == AFCM_SIGNS_READ && lane < UP) s_sg[wave][lane][NW] = 0u;
     const T* const xp = (const T*)p.x + (size_t)plane * p.xh * p.xw;
     T* const yp = (T*)p.y + (size_t)plane * p.yh * p.yw;
     unsigned char* const splane = p.s + (size_t)plane * p.sh * p.swb;
     const float bias = p.b ? to_f32(((const T*)p.b)[plane % p.C]) : 0.f;     // added inside the image only (the padding is zero)
-    const int ix = I0x + lane;
-    const bool colok = (unsigned)ix < (unsigned)p.xw;
 
     // rows this wave has to walk: the last tap of its last output row, in WRITE mode of the last segment also the last sign row
     const int SHv = min(SH, p.yh - O0y);
@@ -524,10 +529,9 @@ __global__ __launch_bounds__(256) void flrelu_strip_kernel(FlreluParams p, const
     if (SIGN == AFCM_SIGNS_WRITE && lastY) qmax = max(qmax, p.sh - 1 - U0y);
     const int NIT = qmax / UP + 7;
 
-    // READ: dword window of a sign row and this lane's bit offset inside it
+    // READ: dword window of a sign row and this lane's bit offset inside it (column block c: + 128 UP bits)
     const int w0 = floor_div(U0x + p.sx, 16);
     const int sbit = pos_mod(U0x + p.sx, 16) * 2 + 2 * UP * lane;
-    const int sword = sbit >> 5, sshift = sbit & 31;
     const int wpr = p.swb >> 2;
     auto fetch_signs = [&](int it, unsigned (&sg)[UP]) __attribute__((always_inline)) {
 #pragma unroll
@@ -537,24 +541,31 @@ __global__ __launch_bounds__(256) void flrelu_strip_kernel(FlreluParams p, const
             sg[a] = ok ? ((const unsigned*)(splane + (size_t)(ok ? Y : 0) * p.swb))[ok ? wi : 0] : 0u;
         }
     };
-    auto fetch_input = [&](int it) __attribute__((always_inline)) -> float {
+    auto fetch_input = [&](int it, float (&xv)[CPL]) __attribute__((always_inline)) {
         const int iy = I0y + it;
-        const bool ok = colok && (unsigned)iy < (unsigned)p.xh;
-        return ok ? to_f32(xp[(size_t)(ok ? iy : 0) * p.xw + (ok ? ix : 0)]) + bias : 0.f;
+#pragma unroll
+        for (int c = 0; c < CPL; c++) {
+            const int ix = I0x + 64 * c + lane;
+            const bool ok = (unsigned)ix < (unsigned)p.xw && (unsigned)iy < (unsigned)p.xh;
+            xv[c] = ok ? to_f32(xp[(size_t)(ok ? iy : 0) * p.xw + (ok ? ix : 0)]) + bias : 0.f;
+        }
     };
 
-    float ring[6][UP];
+    float ring[6][CPL][UP];
 #pragma unroll
     for (int j = 0; j < 6; j++)
 #pragma unroll
-        for (int a = 0; a < UP; a++) ring[j][a] = 0.f;
+        for (int c = 0; c < CPL; c++)
+#pragma unroll
+            for (int a = 0; a < UP; a++) ring[j][c][a] = 0.f;
     float acc[6][OPL];
 #pragma unroll
     for (int j = 0; j < 6; j++)
 #pragma unroll
         for (int o = 0; o < OPL; o++) acc[j][o] = 0.f;
 
-    float xnext = fetch_input(0);
+    float xnext[CPL];
+    fetch_input(0, xnext);
     unsigned sgnext[UP];
 #pragma unroll
     for (int a = 0; a < UP; a++) sgnext[a] = 0u;
@@ -566,27 +577,33 @@ __global__ __launch_bounds__(256) void flrelu_strip_kernel(FlreluParams p, const
             const int it = base + ph;
             if (it < NIT) {
                 // ---- up-x
-                const float xin = xnext;
-                xnext = fetch_input(it + 1);
-                in_row[lane] = xin;
+                float xin[CPL];
+#pragma unroll
+                for (int c = 0; c < CPL; c++) xin[c] = xnext[c];
+                fetch_input(it + 1, xnext);
+#pragma unroll
+                for (int c = 0; c < CPL; c++) in_row[64 * c + lane] = xin[c];
                 __builtin_amdgcn_wave_barrier();
-                float nb[7];
-                nb[0] = xin;
+                float R[CPL][UP];
 #pragma unroll
-                for (int t = 1; t < 7; t++) nb[t] = in_row[lane + t];
-                __builtin_amdgcn_wave_barrier();
-                float R[UP];
+                for (int c = 0; c < CPL; c++) {
+                    float nb[7];
+                    nb[0] = xin[c];
 #pragma unroll
-                for (int a = 0; a < UP; a++) {
-                    float s0 = 0.f;
+                    for (int t = 1; t < 7; t++) nb[t] = in_row[64 * c + lane + t];
 #pragma unroll
-                    for (int t = 0; t < 7; t++) s0 = fmaf(cx7[a][t], nb[t], s0);
-                    R[a] = s0;
+                    for (int a = 0; a < UP; a++) {
+                        float s0 = 0.f;
+#pragma unroll
+                        for (int t = 0; t < 7; t++) s0 = fmaf(cx7[a][t], nb[t], s0);
+                        R[c][a] = s0;
+                    }
                 }
+                __builtin_amdgcn_wave_barrier();
                 if (it >= 6) {
                     // ---- up-y: rows m + t, t = 0..5 in ring[(ph + t) % 6], row m + 6 = R;  m = it - 6
-                    unsigned sg[UP];
                     if (SIGN == AFCM_SIGNS_READ) {
+                        unsigned sg[UP];
 #pragma unroll
                         for (int a = 0; a < UP; a++) sg[a] = sgnext[a];
                         fetch_signs(it + 1, sgnext);
@@ -598,34 +615,39 @@ __global__ __launch_bounds__(256) void flrelu_strip_kernel(FlreluParams p, const
                     const int q0 = UP * (it - 6);                 // first upsampled row of the step, relative to U0y
 #pragma unroll
                     for (int ay = 0; ay < UP; ay++) {
-                        float v[UP];
 #pragma unroll
-                        for (int ax = 0; ax < UP; ax++) {
-                            float s0 = 0.f;
+                        for (int c = 0; c < CPL; c++) {
+                            float v[UP];
 #pragma unroll
-                            for (int t = 0; t < 6; t++) s0 = fmaf(cy7[ay][t], ring[(ph + t) % 6][ax], s0);
-                            v[ax] = fmaf(cy7[ay][6], R[ax], s0);
-                        }
-                        unsigned codes = 0u;
-                        if (SIGN == AFCM_SIGNS_READ) {
-                            const unsigned lo = s_sg[wave][ay][sword], hi = s_sg[wave][ay][sword + 1];
-                            codes = __builtin_amdgcn_alignbit(hi, lo, sshift);
-                        }
-                        unsigned nib = 0u;
+                            for (int ax = 0; ax < UP; ax++) {
+                                float s0 = 0.f;
 #pragma unroll
-                        for (int ax = 0; ax < UP; ax++) nib |= act_elem<SIGN>(v[ax], p.gain, p.slope, p.clamp, codes >> (2 * ax)) << (2 * ax);
-                        if (SIGN == AFCM_SIGNS_WRITE) {
-                            int word = (int)(nib << ((lane % GS) * 2 * UP));
-                            word |= __builtin_amdgcn_mov_dpp(word, 0xB1, 0xF, 0xF, true);              // quad_perm [1,0,3,2]
-                            word |= __builtin_amdgcn_mov_dpp(word, 0x4E, 0xF, 0xF, true);              // quad_perm [2,3,0,1]
-                            if (GS == 8) word |= __builtin_amdgcn_mov_dpp(word, 0x141, 0xF, 0xF, true);   // row_half_mirror
-                            const int q = q0 + ay, Y = U0y + q, X0 = U0x + UP * lane;
-                            const bool own = ((UP * lane < SW * DOWN) || lastX) && ((q < SH * DOWN) || lastY);
-                            if ((lane % GS) == 0 && lane + GS <= 58 && own && (X0 >> 2) < p.swb && Y < p.sh)
-                                *(int*)(splane + (size_t)Y * p.swb + (X0 >> 2)) = word;
+                                for (int t = 0; t < 6; t++) s0 = fmaf(cy7[ay][t], ring[(ph + t) % 6][c][ax], s0);
+                                v[ax] = fmaf(cy7[ay][6], R[c][ax], s0);
+                            }
+                            unsigned codes = 0u;
+                            if (SIGN == AFCM_SIGNS_READ) {
+                                const int sb = sbit + 128 * UP * c;
+                                const unsigned lo = s_sg[wave][ay][sb >> 5], hi = s_sg[wave][ay][(sb >> 5) + 1];
+                                codes = __builtin_amdgcn_alignbit(hi, lo, sb & 31);
+                            }
+                            unsigned nib = 0u;
+#pragma unroll
+                            for (int ax = 0; ax < UP; ax++) nib |= act_elem<SIGN>(v[ax], p.gain, p.slope, p.clamp, codes >> (2 * ax)) << (2 * ax);
+                            if (SIGN == AFCM_SIGNS_WRITE) {
+                                int word = (int)(nib << ((lane % GS) * 2 * UP));
+                                word |= __builtin_amdgcn_mov_dpp(word, 0xB1, 0xF, 0xF, true);              // quad_perm [1,0,3,2]
+                                word |= __builtin_amdgcn_mov_dpp(word, 0x4E, 0xF, 0xF, true);              // quad_perm [2,3,0,1]
+                                if (GS == 8) word |= __builtin_amdgcn_mov_dpp(word, 0x141, 0xF, 0xF, true);   // row_half_mirror
+                                const int col = 64 * c + lane;
+                                const int q = q0 + ay, Y = U0y + q, X0 = U0x + UP * col;
+                                const bool own = ((UP * col < SW * DOWN) || lastX) && ((q < SH * DOWN) || lastY);
+                                if ((lane % GS) == 0 && col + GS <= NC - 6 && own && (X0 >> 2) < p.swb && Y < p.sh)
+                                    *(int*)(splane + (size_t)Y * p.swb + (X0 >> 2)) = word;
+                            }
+                            if constexpr (UP == 2) *(float2*)(&s_u[wave][ay][UP * (64 * c + lane)]) = make_float2(v[0], v[1]);
+                            else *(float4*)(&s_u[wave][ay][UP * (64 * c + lane)]) = make_float4(v[0], v[1], v[2], v[3]);
                         }
-                        if constexpr (UP == 2) *(float2*)(&s_u[wave][ay][UP * lane]) = make_float2(v[0], v[1]);
-                        else *(float4*)(&s_u[wave][ay][UP * lane]) = make_float4(v[0], v[1], v[2], v[3]);
                     }
                     __builtin_amdgcn_wave_barrier();
                     // ---- down-x and down-y
@@ -671,7 +693,9 @@ __global__ __launch_bounds__(256) void flrelu_strip_kernel(FlreluParams p, const
                 }
                 // the new up-x row replaces the oldest one
 #pragma unroll
-                for (int a = 0; a < UP; a++) ring[ph % 6][a] = R[a];
+                for (int c = 0; c < CPL; c++)
+#pragma unroll
+                    for (int a = 0; a < UP; a++) ring[ph % 6][c][a] = R[c][a];
             }
         });
     }
@@ -699,9 +723,9 @@ static int launch_sep(const afcm_filtered_lrelu_args* a, FlreluParams p, hipStre
     return hip_status(hipGetLastError());
 }
 
-template <typename T, int UP, int DOWN>
+template <typename T, int UP, int DOWN, int CPL>
 static int launch_strip(const afcm_filtered_lrelu_args* a, FlreluParams p, hipStream_t st) {
-    typedef StripGeom<UP, DOWN> G;
+    typedef StripGeom<UP, DOWN, CPL> G;
     p.tilesX = cdiv(a->yw, G::SW);
     static const char* rows_s = getenv("AFCM_FLRELU_STRIP_ROWS");       // tuning aid: output rows per segment
     const int rows = rows_s ? atoi(rows_s) : 96;
@@ -711,9 +735,9 @@ static int launch_strip(const afcm_filtered_lrelu_args* a, FlreluParams p, hipSt
     AFCM_REQUIRE(waves > 0 && waves < (1ll << 31), "filtered_lrelu: grid of %lld waves is out of range", waves);
     dim3 grid((unsigned)((waves + 3) / 4)), block(256);
     switch (a->sign_mode) {
-        case AFCM_SIGNS_NONE: hipLaunchKernelGGL((flrelu_strip_kernel<T, UP, DOWN, AFCM_SIGNS_NONE>), grid, block, 0, st, p, a->fu, a->fd); break;
-        case AFCM_SIGNS_WRITE: hipLaunchKernelGGL((flrelu_strip_kernel<T, UP, DOWN, AFCM_SIGNS_WRITE>), grid, block, 0, st, p, a->fu, a->fd); break;
-        default: hipLaunchKernelGGL((flrelu_strip_kernel<T, UP, DOWN, AFCM_SIGNS_READ>), grid, block, 0, st, p, a->fu, a->fd); break;
+        case AFCM_SIGNS_NONE: hipLaunchKernelGGL((flrelu_strip_kernel<T, UP, DOWN, CPL, AFCM_SIGNS_NONE>), grid, block, 0, st, p, a->fu, a->fd); break;
+        case AFCM_SIGNS_WRITE: hipLaunchKernelGGL((flrelu_strip_kernel<T, UP, DOWN, CPL, AFCM_SIGNS_WRITE>), grid, block, 0, st, p, a->fu, a->fd); break;
+        default: hipLaunchKernelGGL((flrelu_strip_kernel<T, UP, DOWN, CPL, AFCM_SIGNS_READ>), grid, block, 0, st, p, a->fu, a->fd); break;
     }
     return hip_status(hipGetLastError());
 }
@@ -741,9 +765,9 @@ static int dispatch(const afcm_filtered_lrelu_args* a, const FlreluParams& p, hi
         // fp32: the strip kernel (planes below 2^31 elements; the tile kernel stays for the 16-bit calls with a bias operand)
         static const char* strip_s = getenv("AFCM_FLRELU_STRIP");       // tuning aid: 0 = tile kernel only
         const bool strip = sep && !(strip_s != nullptr && atoi(strip_s) == 0) && (long long)a->xw * a->xh < (1ll << 30) && (long long)a->yw * a->yh < (1ll << 30);
-        if (strip && a->up == 2 && a->down == 2 && a->fuw == 12 && a->fdw == 12) return launch_strip<T, 2, 2>(a, p, st);
-        if (strip && a->up == 2 && a->down == 4 && a->fuw == 12 && a->fdw == 24) return launch_strip<T, 2, 4>(a, p, st);
-        if (strip && a->up == 4 && a->down == 2 && a->fuw == 24 && a->fdw == 12) return launch_strip<T, 4, 2>(a, p, st);
+        if (strip && a->up == 2 && a->down == 2 && a->fuw == 12 && a->fdw == 12) return launch_strip<T, 2, 2, 1>(a, p, st);
+        if (strip && a->up == 2 && a->down == 4 && a->fuw == 12 && a->fdw == 24) return launch_strip<T, 2, 4, 2>(a, p, st);
+        if (strip && a->up == 4 && a->down == 2 && a->fuw == 24 && a->fdw == 12) return launch_strip<T, 4, 2, 1>(a, p, st);
     }
     if (sep && a->up == 2 && a->down == 2 && a->fuw == 12 && a->fdw == 12)
     {
