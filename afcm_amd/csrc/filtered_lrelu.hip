@@ -475,7 +475,7 @@ struct StripGeom {
     static_assert(NW <= 64, "one lane per sign dword");
 };
 
-template <typename T, int UP, int DOWN, int CPL_, int SIGN>
+template <typename T, int UP, int DOWN, int CPL_, int SIGN, bool FASTACT>
 __global__ __launch_bounds__(256) void flrelu_strip_kernel(FlreluParams p, const float* __restrict__ fu, const float* __restrict__ fd) {
     typedef StripGeom<UP, DOWN, CPL_> G;
     constexpr int FUT = G::FUT, FU = G::FU, FD = G::FD, SW = G::SW, NU = G::NU, NC = G::NC, CPL = G::CPL, OPL = G::OPL, PERIOD = G::PERIOD, GS = G::GS, NW = G::NW;
@@ -513,7 +513,10 @@ __global__ __launch_bounds__(256) void flrelu_strip_kernel(FlreluParams p, const
         }
     }
 #pragma unroll
-    for (int k = 0; k < FD; k++) cd[k] = p.flip ? fd[k] : fd[FD - 1 - k];
+    for (int k = 0; k < FD; k++) {
+        cd[k] = p.flip ? fd[k] : fd[FD - 1 - k];
+        asm volatile("" : "+v"(cd[k]));                          // vector registers: the scalar file is full (the compiler parked them in VGPR lanes and read them back every step)
+    }
 
     float* const in_row = s_in[wave];
     if (lane < 8) in_row[NC + lane] = 0.f;
@@ -541,14 +544,21 @@ __global__ __launch_bounds__(256) void flrelu_strip_kernel(FlreluParams p, const
             sg[a] = ok ? ((const unsigned*)(splane + (size_t)(ok ? Y : 0) * p.swb))[ok ? wi : 0] : 0u;
         }
     };
-    auto fetch_input = [&](int it, float (&xv)[CPL]) __attribute__((always_inline)) {
-        const int iy = I0y + it;
+    // the row is requested one step before its use: clamped address (no branch around the load, nothing waits on it here); validity and
+    // the bias are applied when the value is consumed
+    bool colok[CPL];
+    int colx[CPL];
 #pragma unroll
-        for (int c = 0; c < CPL; c++) {
-            const int ix = I0x + 64 * c + lane;
-            const bool ok = (unsigned)ix < (unsigned)p.xw && (unsigned)iy < (unsigned)p.xh;
-            xv[c] = ok ? to_f32(xp[(size_t)(ok ? iy : 0) * p.xw + (ok ? ix : 0)]) + bias : 0.f;
-        }
+    for (int c = 0; c < CPL; c++) {
+        const int ix = I0x + 64 * c + lane;
+        colok[c] = (unsigned)ix < (unsigned)p.xw;
+        colx[c] = min(max(ix, 0), p.xw - 1);
+    }
+    auto fetch_input = [&](int it, T (&xv)[CPL]) __attribute__((always_inline)) {
+        const int iy = min(max(I0y + it, 0), p.xh - 1);
+        const T* row = xp + (size_t)iy * p.xw;
+#pragma unroll
+        for (int c = 0; c < CPL; c++) xv[c] = row[colx[c]];
     };
 
     float ring[6][CPL][UP];
@@ -564,7 +574,7 @@ __global__ __launch_bounds__(256) void flrelu_strip_kernel(FlreluParams p, const
 #pragma unroll
         for (int o = 0; o < OPL; o++) acc[j][o] = 0.f;
 
-    float xnext[CPL];
+    T xnext[CPL];
     fetch_input(0, xnext);
     unsigned sgnext[UP];
 #pragma unroll
@@ -578,8 +588,9 @@ __global__ __launch_bounds__(256) void flrelu_strip_kernel(FlreluParams p, const
             if (it < NIT) {
                 // ---- up-x
                 float xin[CPL];
+                const bool rowok = (unsigned)(I0y + it) < (unsigned)p.xh;
 #pragma unroll
-                for (int c = 0; c < CPL; c++) xin[c] = xnext[c];
+                for (int c = 0; c < CPL; c++) xin[c] = (rowok && colok[c]) ? to_f32(xnext[c]) + bias : 0.f;
                 fetch_input(it + 1, xnext);
 #pragma unroll
                 for (int c = 0; c < CPL; c++) in_row[64 * c + lane] = xin[c];
@@ -632,8 +643,22 @@ __global__ __launch_bounds__(256) void flrelu_strip_kernel(FlreluParams p, const
                                 codes = __builtin_amdgcn_alignbit(hi, lo, sb & 31);
                             }
                             unsigned nib = 0u;
+                            if (SIGN != AFCM_SIGNS_READ && FASTACT) {
+                                // 0 <= slope <= 1: leaky ReLU = max(v, slope v) and the clamp a med3 -- the same values bit for bit
+                                // (act_elem: select on the sign bit, compare, select), two instructions fewer per element
 #pragma unroll
-                            for (int ax = 0; ax < UP; ax++) nib |= act_elem<SIGN>(v[ax], p.gain, p.slope, p.clamp, codes >> (2 * ax)) << (2 * ax);
+                                for (int ax = 0; ax < UP; ax++) {
+                                    const float g = v[ax] * p.gain;
+                                    const float w = fmaxf(g, g * p.slope);
+                                    unsigned code = __float_as_uint(g) >> 31;
+                                    if (fabsf(w) > p.clamp) code = 2u;
+                                    v[ax] = __builtin_amdgcn_fmed3f(w, -p.clamp, p.clamp);
+                                    nib |= code << (2 * ax);
+                                }
+                            } else {
+#pragma unroll
+                                for (int ax = 0; ax < UP; ax++) nib |= act_elem<SIGN>(v[ax], p.gain, p.slope, p.clamp, codes >> (2 * ax)) << (2 * ax);
+                            }
                             if (SIGN == AFCM_SIGNS_WRITE) {
                                 int word = (int)(nib << ((lane % GS) * 2 * UP));
                                 word |= __builtin_amdgcn_mov_dpp(word, 0xB1, 0xF, 0xF, true);              // quad_perm [1,0,3,2]
@@ -734,10 +759,17 @@ static int launch_strip(const afcm_filtered_lrelu_args* a, FlreluParams p, hipSt
     const long long waves = (long long)p.tilesX * p.tilesY * p.planes;
     AFCM_REQUIRE(waves > 0 && waves < (1ll << 31), "filtered_lrelu: grid of %lld waves is out of range", waves);
     dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+    const bool fast = a->slope >= 0.f && a->slope <= 1.f && a->clamp >= 0.f;     // (NaN fails every comparison: general form)
     switch (a->sign_mode) {
-        case AFCM_SIGNS_NONE: hipLaunchKernelGGL((flrelu_strip_kernel<T, UP, DOWN, CPL, AFCM_SIGNS_NONE>), grid, block, 0, st, p, a->fu, a->fd); break;
-        case AFCM_SIGNS_WRITE: hipLaunchKernelGGL((flrelu_strip_kernel<T, UP, DOWN, CPL, AFCM_SIGNS_WRITE>), grid, block, 0, st, p, a->fu, a->fd); break;
-        default: hipLaunchKernelGGL((flrelu_strip_kernel<T, UP, DOWN, CPL, AFCM_SIGNS_READ>), grid, block, 0, st, p, a->fu, a->fd); break;
+        case AFCM_SIGNS_NONE:
+            if (fast) hipLaunchKernelGGL((flrelu_strip_kernel<T, UP, DOWN, CPL, AFCM_SIGNS_NONE, true>), grid, block, 0, st, p, a->fu, a->fd);
+            else hipLaunchKernelGGL((flrelu_strip_kernel<T, UP, DOWN, CPL, AFCM_SIGNS_NONE, false>), grid, block, 0, st, p, a->fu, a->fd);
+            break;
+        case AFCM_SIGNS_WRITE:
+            if (fast) hipLaunchKernelGGL((flrelu_strip_kernel<T, UP, DOWN, CPL, AFCM_SIGNS_WRITE, true>), grid, block, 0, st, p, a->fu, a->fd);
+            else hipLaunchKernelGGL((flrelu_strip_kernel<T, UP, DOWN, CPL, AFCM_SIGNS_WRITE, false>), grid, block, 0, st, p, a->fu, a->fd);
+            break;
+        default: hipLaunchKernelGGL((flrelu_strip_kernel<T, UP, DOWN, CPL, AFCM_SIGNS_READ, false>), grid, block, 0, st, p, a->fu, a->fd); break;
     }
     return hip_status(hipGetLastError());
 }
