@@ -513,10 +513,18 @@ __global__ __launch_bounds__(256) void flrelu_strip_kernel(FlreluParams p, const
         }
     }
 #pragma unroll
-    for (int k = 0; k < FD; k++) {
-        cd[k] = p.flip ? fd[k] : fd[FD - 1 - k];
-        asm volatile("" : "+v"(cd[k]));                          // vector registers: the scalar file is full (the compiler parked them in VGPR lanes and read them back every step)
-    }
+    for (int k = 0; k < FD; k++) cd[k] = p.flip ? fd[k] : fd[FD - 1 - k];
+    // the up-x taps as (a, a + 1) pairs in VECTOR registers: with all three tables in the scalar file it overflows (the compiler parked
+    // taps in VGPR lanes and read them back every step: 11 of 117 vector instructions per step); pairs keep the packed FMAs
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 cxp[UP / 2][7];
+#pragma unroll
+    for (int a2 = 0; a2 < UP / 2; a2++)
+#pragma unroll
+        for (int t = 0; t < 7; t++) {
+            cxp[a2][t] = (f32x2){cx7[2 * a2][t], cx7[2 * a2 + 1][t]};
+            asm volatile("" : "+v"(cxp[a2][t]));
+        }
 
     float* const in_row = s_in[wave];
     if (lane < 8) in_row[NC + lane] = 0.f;
@@ -561,13 +569,13 @@ __global__ __launch_bounds__(256) void flrelu_strip_kernel(FlreluParams p, const
         for (int c = 0; c < CPL; c++) xv[c] = row[colx[c]];
     };
 
-    float ring[6][CPL][UP];
+    f32x2 ring[6][CPL][UP / 2];                                  // up-x rows: (a, a + 1) column pairs
 #pragma unroll
     for (int j = 0; j < 6; j++)
 #pragma unroll
         for (int c = 0; c < CPL; c++)
 #pragma unroll
-            for (int a = 0; a < UP; a++) ring[j][c][a] = 0.f;
+            for (int a2 = 0; a2 < UP / 2; a2++) ring[j][c][a2] = (f32x2){0.f, 0.f};
     float acc[6][OPL];
 #pragma unroll
     for (int j = 0; j < 6; j++)
@@ -595,7 +603,7 @@ __global__ __launch_bounds__(256) void flrelu_strip_kernel(FlreluParams p, const
 #pragma unroll
                 for (int c = 0; c < CPL; c++) in_row[64 * c + lane] = xin[c];
                 __builtin_amdgcn_wave_barrier();
-                float R[CPL][UP];
+                f32x2 R[CPL][UP / 2];
 #pragma unroll
                 for (int c = 0; c < CPL; c++) {
                     float nb[7];
@@ -603,11 +611,11 @@ __global__ __launch_bounds__(256) void flrelu_strip_kernel(FlreluParams p, const
 #pragma unroll
                     for (int t = 1; t < 7; t++) nb[t] = in_row[64 * c + lane + t];
 #pragma unroll
-                    for (int a = 0; a < UP; a++) {
-                        float s0 = 0.f;
+                    for (int a2 = 0; a2 < UP / 2; a2++) {
+                        f32x2 s0 = (f32x2){0.f, 0.f};
 #pragma unroll
-                        for (int t = 0; t < 7; t++) s0 = fmaf(cx7[a][t], nb[t], s0);
-                        R[c][a] = s0;
+                        for (int t = 0; t < 7; t++) s0 = __builtin_elementwise_fma(cxp[a2][t], (f32x2){nb[t], nb[t]}, s0);
+                        R[c][a2] = s0;
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
@@ -630,11 +638,13 @@ __global__ __launch_bounds__(256) void flrelu_strip_kernel(FlreluParams p, const
                         for (int c = 0; c < CPL; c++) {
                             float v[UP];
 #pragma unroll
-                            for (int ax = 0; ax < UP; ax++) {
-                                float s0 = 0.f;
+                            for (int a2 = 0; a2 < UP / 2; a2++) {
+                                f32x2 s0 = (f32x2){0.f, 0.f};
 #pragma unroll
-                                for (int t = 0; t < 6; t++) s0 = fmaf(cy7[ay][t], ring[(ph + t) % 6][c][ax], s0);
-                                v[ax] = fmaf(cy7[ay][6], R[c][ax], s0);
+                                for (int t = 0; t < 6; t++) s0 = __builtin_elementwise_fma((f32x2){cy7[ay][t], cy7[ay][t]}, ring[(ph + t) % 6][c][a2], s0);
+                                s0 = __builtin_elementwise_fma((f32x2){cy7[ay][6], cy7[ay][6]}, R[c][a2], s0);
+                                v[2 * a2] = s0.x;
+                                v[2 * a2 + 1] = s0.y;
                             }
                             unsigned codes = 0u;
                             if (SIGN == AFCM_SIGNS_READ) {
@@ -647,13 +657,18 @@ __global__ __launch_bounds__(256) void flrelu_strip_kernel(FlreluParams p, const
                                 // 0 <= slope <= 1: leaky ReLU = max(v, slope v) and the clamp a med3 -- the same values bit for bit
                                 // (act_elem: select on the sign bit, compare, select), two instructions fewer per element
 #pragma unroll
-                                for (int ax = 0; ax < UP; ax++) {
-                                    const float g = v[ax] * p.gain;
-                                    const float w = fmaxf(g, g * p.slope);
-                                    unsigned code = __float_as_uint(g) >> 31;
-                                    if (fabsf(w) > p.clamp) code = 2u;
-                                    v[ax] = __builtin_amdgcn_fmed3f(w, -p.clamp, p.clamp);
-                                    nib |= code << (2 * ax);
+                                for (int a2 = 0; a2 < UP / 2; a2++) {
+                                    const f32x2 g2 = (f32x2){v[2 * a2], v[2 * a2 + 1]} * (f32x2){p.gain, p.gain};
+                                    const f32x2 t2 = g2 * (f32x2){p.slope, p.slope};
+#pragma unroll
+                                    for (int e = 0; e < 2; e++) {
+                                        const int ax = 2 * a2 + e;
+                                        const float w = fmaxf(g2[e], t2[e]);
+                                        unsigned code = __float_as_uint(g2[e]) >> 31;
+                                        if (fabsf(w) > p.clamp) code = 2u;
+                                        v[ax] = __builtin_amdgcn_fmed3f(w, -p.clamp, p.clamp);
+                                        nib |= code << (2 * ax);
+                                    }
                                 }
                             } else {
 #pragma unroll
@@ -684,15 +699,11 @@ __global__ __launch_bounds__(256) void flrelu_strip_kernel(FlreluParams p, const
 #pragma unroll
                         for (int o = 0; o < OPL; o++) {
                             const int j = min(lane + 64 * o, SW - 1);
-                            const float2* src = (const float2*)(&s_u[wave][ay][DOWN * j]);
-                            float e0 = 0.f, e1 = 0.f;
+                            const f32x2* src = (const f32x2*)(&s_u[wave][ay][DOWN * j]);
+                            f32x2 e2 = (f32x2){0.f, 0.f};                   // even / odd taps in the two halves
 #pragma unroll
-                            for (int k2 = 0; k2 < FD / 2; k2++) {
-                                const float2 t2 = src[k2];
-                                e0 = fmaf(cd[2 * k2], t2.x, e0);
-                                e1 = fmaf(cd[2 * k2 + 1], t2.y, e1);
-                            }
-                            d[o] = e0 + e1;
+                            for (int k2 = 0; k2 < FD / 2; k2++) e2 = __builtin_elementwise_fma((f32x2){cd[2 * k2], cd[2 * k2 + 1]}, src[k2], e2);
+                            d[o] = e2.x + e2.y;
                         }
 #pragma unroll
                         for (int i = 0; i < 6; i++) {
@@ -720,7 +731,7 @@ __global__ __launch_bounds__(256) void flrelu_strip_kernel(FlreluParams p, const
 #pragma unroll
                 for (int c = 0; c < CPL; c++)
 #pragma unroll
-                    for (int a = 0; a < UP; a++) ring[ph % 6][c][a] = R[c][a];
+                    for (int a2 = 0; a2 < UP / 2; a2++) ring[ph % 6][c][a2] = R[c][a2];
             }
         });
     }
