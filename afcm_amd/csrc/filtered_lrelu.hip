@@ -454,7 +454,7 @@ __device__ __forceinline__ void strip_static_for(F&& f) {
     }
 }
 
-template <int UP, int DOWN, int CPL_>
+template <int UP, int DOWN, int CPL_, int SIGN_>
 struct StripGeom {
     static constexpr int FUT = 6, FU = FUT * UP, FD = FUT * DOWN;
     // CPL input columns per lane, in blocks: lane l holds columns l, 64 + l, ... of the strip's 64 CPL (coalesced row loads; the up
@@ -463,13 +463,14 @@ struct StripGeom {
     // 112-column ones: enc3 forward 0.91 vs 1.06 ms) and up 4 (registers), 2 for down 4 (56 output lanes instead of 24: 1.26 vs 1.68 ms)
     static constexpr int CPL = CPL_;
     static constexpr int NC = 64 * CPL;                         // input columns of the strip
-    static constexpr int SW = ((UP * (NC - 6) - FD) / DOWN + 1) / (16 / DOWN) * (16 / DOWN);   // output columns per strip: whole sign dwords
+    static constexpr int SWMAX = (UP * (NC - 6) - FD) / DOWN + 1;                           // outputs with full tap support
+    static constexpr int SW = SIGN_ == AFCM_SIGNS_WRITE ? SWMAX / (16 / DOWN) * (16 / DOWN) : SWMAX;   // sign writers: whole dwords per strip
     static constexpr int NU = NC * UP;                          // upsampled columns per row of the strip
     static constexpr int OPL = cdiv(SW, 64);                    // output columns per lane
     static constexpr int PERIOD = (UP == 2 && DOWN == 4) ? 12 : 6;   // steps after which the up-y ring AND the down-y ring repeat
     static constexpr int GS = 16 / UP;                          // lanes per sign dword
     static constexpr int NW = NU / 16 + 1;                      // sign dwords a row's window can touch (READ)
-    static_assert((SW * DOWN) % 16 == 0, "sign ownership must fall on dword boundaries");
+    static_assert(SIGN_ != AFCM_SIGNS_WRITE || (SW * DOWN) % 16 == 0, "sign ownership must fall on dword boundaries");
     static_assert(DOWN * (SW - 1) + FD <= UP * (NC - 6), "the strip's outputs must stay inside the columns with full tap support");
     static_assert((UP * PERIOD) % (DOWN * 6) == 0 && PERIOD % 6 == 0, "ring periods");
     static_assert(NW <= 64, "one lane per sign dword");
@@ -477,7 +478,7 @@ struct StripGeom {
 
 template <typename T, int UP, int DOWN, int CPL_, int SIGN, bool FASTACT>
 __global__ __launch_bounds__(256) void flrelu_strip_kernel(FlreluParams p, const float* __restrict__ fu, const float* __restrict__ fd) {
-    typedef StripGeom<UP, DOWN, CPL_> G;
+    typedef StripGeom<UP, DOWN, CPL_, SIGN> G;
     constexpr int FUT = G::FUT, FU = G::FU, FD = G::FD, SW = G::SW, NU = G::NU, NC = G::NC, CPL = G::CPL, OPL = G::OPL, PERIOD = G::PERIOD, GS = G::GS, NW = G::NW;
     __shared__ float s_in[4][NC + 8];                            // input row of the wave + zero pad for the neighbours of the last 6 columns
     __shared__ __attribute__((aligned(16))) float s_u[4][UP][NU];   // the UP activated rows of a step
@@ -761,8 +762,7 @@ static int launch_sep(const afcm_filtered_lrelu_args* a, FlreluParams p, hipStre
 
 template <typename T, int UP, int DOWN, int CPL>
 static int launch_strip(const afcm_filtered_lrelu_args* a, FlreluParams p, hipStream_t st) {
-    typedef StripGeom<UP, DOWN, CPL> G;
-    p.tilesX = cdiv(a->yw, G::SW);
+    p.tilesX = a->sign_mode == AFCM_SIGNS_WRITE ? cdiv(a->yw, StripGeom<UP, DOWN, CPL, AFCM_SIGNS_WRITE>::SW) : cdiv(a->yw, StripGeom<UP, DOWN, CPL, AFCM_SIGNS_NONE>::SW);
     static const char* rows_s = getenv("AFCM_FLRELU_STRIP_ROWS");       // tuning aid: output rows per segment
     const int rows = rows_s ? atoi(rows_s) : 96;
     p.tilesY = a->yh <= rows ? 1 : (a->yh + rows / 2) / rows;
