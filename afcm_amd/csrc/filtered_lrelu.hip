@@ -527,22 +527,6 @@ __global__ __launch_bounds__(256) void flrelu_strip_kernel(FlreluParams p, const
             asm volatile("" : "+v"(cxp[a2][t]));
         }
 
-    // |u| <= bnd max |x| for every upsampled element (L1 norms of the polyphase taps, the gain included)
-    float bnd;
-    {
-        float lx = 0.f, ly = 0.f;
-#pragma unroll
-        for (int a = 0; a < UP; a++) {
-            float sx1 = 0.f, sy1 = 0.f;
-#pragma unroll
-            for (int t = 0; t < 7; t++) { sx1 += fabsf(cx7[a][t]); sy1 += fabsf(cy7[a][t]); }
-            lx = fmaxf(lx, sx1); ly = fmaxf(ly, sy1);
-        }
-        bnd = lx * ly * fabsf(p.gain) * 1.0001f;                 // (rounding of the sums themselves)
-    }
-    float xmax = 0.f;                                            // largest |x + bias| this lane has fed in so far
-    bool noclamp = true;
-
     float* const in_row = s_in[wave];
     if (lane < 8) in_row[NC + lane] = 0.f;
     if (SIGN == AFCM_SIGNS_READ && lane < UP) s_sg[wave][lane][NW] = 0u;
@@ -617,12 +601,6 @@ __global__ __launch_bounds__(256) void flrelu_strip_kernel(FlreluParams p, const
 #pragma unroll
                 for (int c = 0; c < CPL; c++) xin[c] = (rowok && colok[c]) ? to_f32(xnext[c]) + bias : 0.f;
                 fetch_input(it + 1, xnext);
-                if (SIGN != AFCM_SIGNS_READ && FASTACT) {
-#pragma unroll
-                    for (int c = 0; c < CPL; c++) xmax = fmaxf(xmax, fabsf(xin[c]));
-                    // NaN / Inf inputs fail the comparison: general form
-                    noclamp = __builtin_amdgcn_readfirstlane(__ballot(!(xmax * bnd <= p.clamp)) == 0ull);
-                }
 #pragma unroll
                 for (int c = 0; c < CPL; c++) in_row[64 * c + lane] = xin[c];
                 __builtin_amdgcn_wave_barrier();
@@ -678,34 +656,19 @@ __global__ __launch_bounds__(256) void flrelu_strip_kernel(FlreluParams p, const
                             unsigned nib = 0u;
                             if (SIGN != AFCM_SIGNS_READ && FASTACT) {
                                 // 0 <= slope <= 1: leaky ReLU = max(v, slope v) and the clamp a med3 -- the same values bit for bit
-                                // (act_elem: select on the sign bit, compare, select), two instructions fewer per element; and where
-                                // no element of the rows seen so far can reach the clamp (|u| <= L1(fu_x) L1(fu_y) max |x|), the
-                                // clamp's compare / select / med3 are skipped altogether (wave-uniform branch)
-                                if (noclamp) {
+                                // (act_elem: select on the sign bit, compare, select), two instructions fewer per element
 #pragma unroll
-                                    for (int a2 = 0; a2 < UP / 2; a2++) {
-                                        const f32x2 g2 = (f32x2){v[2 * a2], v[2 * a2 + 1]} * (f32x2){p.gain, p.gain};
-                                        const f32x2 t2 = g2 * (f32x2){p.slope, p.slope};
+                                for (int a2 = 0; a2 < UP / 2; a2++) {
+                                    const f32x2 g2 = (f32x2){v[2 * a2], v[2 * a2 + 1]} * (f32x2){p.gain, p.gain};
+                                    const f32x2 t2 = g2 * (f32x2){p.slope, p.slope};
 #pragma unroll
-                                        for (int e = 0; e < 2; e++) {
-                                            v[2 * a2 + e] = fmaxf(g2[e], t2[e]);
-                                            nib |= (__float_as_uint(g2[e]) >> 31) << (2 * (2 * a2 + e));
-                                        }
-                                    }
-                                } else {
-#pragma unroll
-                                    for (int a2 = 0; a2 < UP / 2; a2++) {
-                                        const f32x2 g2 = (f32x2){v[2 * a2], v[2 * a2 + 1]} * (f32x2){p.gain, p.gain};
-                                        const f32x2 t2 = g2 * (f32x2){p.slope, p.slope};
-#pragma unroll
-                                        for (int e = 0; e < 2; e++) {
-                                            const int ax = 2 * a2 + e;
-                                            const float w = fmaxf(g2[e], t2[e]);
-                                            unsigned code = __float_as_uint(g2[e]) >> 31;
-                                            if (fabsf(w) > p.clamp) code = 2u;
-                                            v[ax] = __builtin_amdgcn_fmed3f(w, -p.clamp, p.clamp);
-                                            nib |= code << (2 * ax);
-                                        }
+                                    for (int e = 0; e < 2; e++) {
+                                        const int ax = 2 * a2 + e;
+                                        const float w = fmaxf(g2[e], t2[e]);
+                                        unsigned code = __float_as_uint(g2[e]) >> 31;
+                                        if (fabsf(w) > p.clamp) code = 2u;
+                                        v[ax] = __builtin_amdgcn_fmed3f(w, -p.clamp, p.clamp);
+                                        nib |= code << (2 * ax);
                                     }
                                 }
                             } else {
