@@ -669,3 +669,32 @@ def test_modulation_bank_is_bit_identical_to_the_layers_one_by_one(n):
         assert (a is None) == (b is None), i
         if a is not None:
             assert torch.equal(a, b), (i, (a - b).abs().max().item(), b.abs().max().item())
+
+
+@pytest.mark.parametrize('layer,h,w,flip', [('enc1', 201, 113, False), ('enc1', 97, 50, True), ('enc4', 230, 262, False), ('enc4', 75, 118, True),
+                                           ('dec3', 61, 58, False), ('dec3', 120, 27, True)])
+def test_fp32_strip_kernel_on_ragged_planes(layer, h, w, flip):
+    """csrc/filtered_lrelu.hip flrelu_strip_kernel (fp32: one wave marches down a column strip) on plane shapes that are no multiple of
+    anything: several strips with a ragged last one (48 / 56 / 104 output columns per strip), two or three row segments (96 rows each),
+    odd widths and heights, flipped filters -- forward, sign-reading backward and bias gradient against the CPU oracle at 2e-5 of the
+    output's scale (the golden fixtures F1-F12 are small: one strip, one segment).  The three generator configurations: up 2 / down 2,
+    up 2 / down 4 (two column blocks per lane), up 4 / down 2."""
+    from afcm_amd.torch_utils.ops import filtered_lrelu as flr
+    from oracle import aten_ops as ops
+    from oracle import generator as ogen
+    pl = ogen.plan(256, 4, 1, {})
+    L = {'enc1': pl['enc'][1], 'enc4': pl['enc'][4], 'dec3': pl['dec'][3]}[layer]
+    torch.manual_seed(h * 1000 + w)
+    x = torch.randn(1, 3, h, w) * 2.0
+    b = torch.randn(3) * 0.3
+    kw = dict(up=L['up'], down=L['down'], padding=L['padding'], gain=float(np.sqrt(2)), slope=0.2, clamp=3.0, flip_filter=flip)
+    xr, br = x.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = ops.filtered_lrelu(xr, fu=L['fu'], fd=L['fd'], b=br, **kw)
+    xg, bg = x.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+    got = flr.filtered_lrelu(xg, fu=L['fu'].cuda(), fd=L['fd'].cuda(), b=bg, **kw)
+    _close(got, ref, what=f'{layer} {h}x{w} y')
+    r = torch.randn_like(ref)
+    gref = torch.autograd.grad((ref * r).sum(), [xr, br])
+    ggot = torch.autograd.grad((got * r.cuda()).sum(), [xg, bg])
+    _close(ggot[0], gref[0], what=f'{layer} {h}x{w} dx')
+    _close(ggot[1], gref[1], tol=1e-4, what=f'{layer} {h}x{w} db')
