@@ -57,6 +57,15 @@ class ModulationLayer(C.Structure):
         (k, C.c_void_p) for k in ('w', 't', 'magnitude', 'w_hat', 'wsq', 'scale', 's_eff', 'd', 'r', 'g_hat', 'g_s', 'g_d', 'dw', 'dt', 'workspace')]
 
 
+PACK_MAX = 32
+
+
+class PackEntry(C.Structure):
+    """Mirror of `afcm_pack_entry` (include/afcm_hip.h)."""
+    _fields_ = [('dst_fwd', C.c_void_p), ('dst_dgrad', C.c_void_p), ('w', C.c_void_p),
+                ('cout', C.c_int32), ('cin', C.c_int32), ('rows_pad_fwd', C.c_int32), ('rows_pad_dgrad', C.c_int32)]
+
+
 _lib = None
 
 # name -> (restype, argtypes); every symbol include/afcm_hip.h declares must be listed here
@@ -94,6 +103,7 @@ SIGNATURES = {
     'afcm_modulation_bank_workspace_floats': (C.c_int64, [_i32, _i32, _i32, _i32]),
     'afcm_modulation_bank_fwd': (C.c_int, [C.POINTER(ModulationLayer), _i32, _i32, _vp]),
     'afcm_modulation_bank_bwd': (C.c_int, [C.POINTER(ModulationLayer), _i32, _i32, _vp]),
+    'afcm_conv2d_pack_bank': (C.c_int, [C.POINTER(PackEntry), _i32, _i32, _i32, _vp]),
     'afcm_affine_bank_bwd': (C.c_int, [C.POINTER(AffineBank), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _vp, _vp, _vp, _vp]),
     'afcm_adam_chunk_elems': (C.c_int32, []),
     'afcm_adam_multi': (C.c_int, [_vp, _i32, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _i32, _f32, _f32, _i32, _vp]),

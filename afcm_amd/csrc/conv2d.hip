@@ -891,12 +891,11 @@ __global__ __launch_bounds__(256) void conv2d_pack_kernel(T* __restrict__ dst, c
 // image of a layer come out of ONE launch (a null destination skips that image).  The per-element gather kernel above is kept
 // as the definition the layout test checks against.
 template <typename T, int KK, int BK>
-__global__ __launch_bounds__(256) void conv2d_pack_tile_kernel(T* __restrict__ dst0, T* __restrict__ dst1, const float* __restrict__ w, int O,
-                                                               int I, int rows_pad0, int rows_pad1) {
+__device__ __forceinline__ void pack_tile_body(float* tile, int bx, int by, T* __restrict__ dst0, T* __restrict__ dst1, const float* __restrict__ w,
+                                               int O, int I, int rows_pad0, int rows_pad1) {
     constexpr int TO = 16, TI = 64, ROW = TI * KK + 1;             // + 1: the 8 channel runs of a store start 9 floats apart
-    __shared__ float tile[TO * ROW];
     struct alignas(8 * sizeof(T)) Out { T v[8]; };
-    const int i0 = blockIdx.x * TI, o0 = blockIdx.y * TO;
+    const int i0 = bx * TI, o0 = by * TO;
     {
         // all of a thread's loads in flight before the first LDS write (left as a loop, each load waited for its predecessor:
         // 36 serial round trips = 10 us for any layer size)
@@ -958,6 +957,31 @@ __global__ __launch_bounds__(256) void conv2d_pack_tile_kernel(T* __restrict__ d
             *(Out*)(dst1 + (((size_t)kcg * KK + tap) * rows_pad1 + i0 + i) * BK + half * 8) = v;
         }
     }
+}
+
+template <typename T, int KK, int BK>
+__global__ __launch_bounds__(256) void conv2d_pack_tile_kernel(T* __restrict__ dst0, T* __restrict__ dst1, const float* __restrict__ w, int O,
+                                                               int I, int rows_pad0, int rows_pad1) {
+    __shared__ float tile[16 * (64 * KK + 1)];
+    pack_tile_body<T, KK, BK>(tile, blockIdx.x, blockIdx.y, dst0, dst1, w, O, I, rows_pad0, rows_pad1);
+}
+
+// the same for a list of layers in one launch (C ABI afcm_conv2d_pack_bank): the table rides in the kernel arguments, a workgroup
+// finds its layer by a scalar scan over the first-block table
+struct PackBank {
+    int count;
+    int blk[AFCM_PACK_MAX + 1];
+    int gx[AFCM_PACK_MAX];
+    afcm_pack_entry e[AFCM_PACK_MAX];
+};
+template <typename T, int KK, int BK>
+__global__ __launch_bounds__(256) void conv2d_pack_bank_kernel(const PackBank b) {
+    __shared__ float tile[16 * (64 * KK + 1)];
+    int l = 0;
+    while (l + 1 < b.count && (int)blockIdx.x >= b.blk[l + 1]) l++;
+    const int loc = blockIdx.x - b.blk[l];
+    const afcm_pack_entry& e = b.e[l];
+    pack_tile_body<T, KK, BK>(tile, loc % b.gx[l], loc / b.gx[l], (T*)e.dst_fwd, (T*)e.dst_dgrad, e.w, e.cout, e.cin, e.rows_pad_fwd, e.rows_pad_dgrad);
 }
 
 // 4 consecutive elements as one vector access (8 B for 16-bit types, 16 B for fp32); planes are 4-element aligned when hw % 4 == 0
@@ -2608,6 +2632,45 @@ extern "C" int afcm_conv2d_pack_weights(void* dst, const float* w, int32_t dtype
     AFCM_REQUIRE(mode == 0 || mode == 1, "mode must be 0 (forward) or 1 (data gradient)");
     return mode == 0 ? afcm_conv2d_pack_weights2(dst, nullptr, w, dtype, cout, cin, ks, rows_pad, 0, stream)
                      : afcm_conv2d_pack_weights2(nullptr, dst, w, dtype, cout, cin, ks, 0, rows_pad, stream);
+}
+
+template <typename T>
+static void launch_pack_bank(const PackBank& b, int blocks, int ks, hipStream_t st) {
+    constexpr int BKT = ConvCfg<T>::BK;
+    if (ks == 3) hipLaunchKernelGGL((conv2d_pack_bank_kernel<T, 9, BKT>), dim3(blocks), dim3(256), 0, st, b);
+    else hipLaunchKernelGGL((conv2d_pack_bank_kernel<T, 1, BKT>), dim3(blocks), dim3(256), 0, st, b);
+}
+
+extern "C" int afcm_conv2d_pack_bank(const afcm_pack_entry* entries, int32_t count, int32_t dtype, int32_t ks, void* stream) {
+    AFCM_REQUIRE(entries != nullptr && count > 0 && count <= AFCM_PACK_MAX, "conv2d_pack_bank: 1..%d entries", AFCM_PACK_MAX);
+    AFCM_REQUIRE(dtype == AFCM_F32 || dtype == AFCM_F16 || dtype == AFCM_BF16, "dtype must be float32, float16 or bfloat16");
+    AFCM_REQUIRE(ks == 1 || ks == 3, "only 1x1 and 3x3 kernels are supported");
+    const int BK = afcm_conv2d_block_k(dtype);
+    PackBank b;
+    b.count = count;
+    int tot = 0;
+    for (int l = 0; l < count; l++) {
+        const afcm_pack_entry& e = entries[l];
+        AFCM_REQUIRE(e.w != nullptr && (e.dst_fwd != nullptr || e.dst_dgrad != nullptr) && e.cout > 0 && e.cin > 0, "conv2d_pack_bank: entry %d: null pointer or empty weights", l);
+        AFCM_REQUIRE(e.dst_fwd == nullptr || (e.rows_pad_fwd >= e.cout && e.rows_pad_fwd % 64 == 0), "conv2d_pack_bank: entry %d: rows_pad must be a multiple of 64 covering the rows", l);
+        AFCM_REQUIRE(e.dst_dgrad == nullptr || (e.rows_pad_dgrad >= e.cin && e.rows_pad_dgrad % 64 == 0), "conv2d_pack_bank: entry %d: rows_pad must be a multiple of 64 covering the rows", l);
+        AFCM_REQUIRE((((uintptr_t)e.dst_fwd | (uintptr_t)e.dst_dgrad) & 31) == 0, "conv2d_pack_bank: entry %d: destinations must be 32-byte aligned", l);
+        // as launch_pack8: tiles cover the padded row ranges of both images
+        const int omax = e.dst_fwd ? e.rows_pad_fwd : round_up(e.cout, BK), imax = e.dst_dgrad ? e.rows_pad_dgrad : round_up(e.cin, BK);
+        const int gx = cdiv(imax > e.cin ? imax : e.cin, 64), gy = cdiv(omax > e.cout ? omax : e.cout, 16);
+        b.e[l] = e;
+        b.gx[l] = gx;
+        b.blk[l] = tot;
+        tot += gx * gy;
+    }
+    b.blk[count] = tot;
+    hipStream_t st = (hipStream_t)stream;
+    switch (dtype) {
+        case AFCM_F32: launch_pack_bank<float>(b, tot, ks, st); break;
+        case AFCM_F16: launch_pack_bank<f16_t>(b, tot, ks, st); break;
+        default: launch_pack_bank<bf16_t>(b, tot, ks, st); break;
+    }
+    return hip_status(hipGetLastError());
 }
 
 extern "C" int afcm_conv2d(void* y, const void* x, const void* wpacked, const float* oscale, const float* obias, int32_t dtype, int32_t n,

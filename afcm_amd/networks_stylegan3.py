@@ -17,6 +17,7 @@ import torch.nn.functional as F
 
 from . import layer_schedule as sched
 from .torch_utils.ops import affine_bank, bias_act, conv2d_gradfix, filtered_lrelu, fused_layer, modulation_bank
+from .torch_utils.ops import conv2d as _conv_ops
 from .torch_utils.ops.conv2d import modulation_coefficients_fused, scaled_conv2d
 from .torch_utils.ops.conv2d import modulated_conv2d  # noqa: F401  (re-exported: NET:25 lives in this module)
 
@@ -215,10 +216,11 @@ class SynthesisLayer(torch.nn.Module, _ResampleGeometry):
         return fused_layer.available(x, self.weight, self.up_filter, self.down_filter, conv_pad=self.conv_kernel - 1, **self._act_args())
 
     def forward(self, x, w, global_w, E_features=None, include_skip=True, noise_mode='random', force_fp32=False, update_emas=False,
-                _mod=None, _prescaled=False, _next_scale=None):
+                _mod=None, _prescaled=False, _next_scale=None, _packed=None):
         """Reference signature (NET:336).  The underscore arguments are SynthesisNetwork's fusion hooks: `_mod` = this layer's
         precomputed modulation(), `_prescaled` = x already carries this layer's styles, `_next_scale` = the next layer's
-        styles to fold into this layer's output (fused node only)."""
+        styles to fold into this layer's output (fused node only), `_packed` = the two MFMA images of this layer's normalised weight
+        from the network's multi-layer pack (fused node only)."""
         assert noise_mode in ['random', 'const', 'none']  # unused, as in the reference
         _assert_shape(x, [None, self.in_channels, int(self.in_size[1]), int(self.in_size[0])])
         _assert_shape(w, [x.shape[0], self.w_dim])
@@ -235,7 +237,7 @@ class SynthesisLayer(torch.nn.Module, _ResampleGeometry):
         if self.fusable(x):
             x = fused_layer.conv_filtered_lrelu(x, w_hat, in_scale, out_scale, self.bias, self.up_filter, self.down_filter,
                                                 conv_pad=self.conv_kernel - 1, skip=x_skip, next_scale=_next_scale,
-                                                prescaled=_prescaled, **act)
+                                                prescaled=_prescaled, packed=_packed, **act)
         else:
             assert _next_scale is None, 'only the fused node can pre-scale its output'
             with torch.autograd.profiler.record_function('modulated_conv2d'):
@@ -274,7 +276,7 @@ class EncoderLayer(torch.nn.Module, _ResampleGeometry):
                                out_half_width, conv_kernel, filter_size, lrelu_upsampling, use_radial_filters, False,
                                is_critically_sampled)
 
-    def forward(self, x, force_fp32=False, update_emas=False):
+    def forward(self, x, force_fp32=False, update_emas=False, _packed=None):
         _assert_shape(x, [None, self.in_channels, int(self.in_size[1]), int(self.in_size[0])])
         if update_emas:
             with torch.autograd.profiler.record_function('update_magnitude_ema'):
@@ -289,7 +291,7 @@ class EncoderLayer(torch.nn.Module, _ResampleGeometry):
             if key not in self._gain_planes:
                 self._gain_planes[key] = torch.full([x.shape[0], self.out_channels], float(self.weight_gain), dtype=torch.float32, device=x.device)
             x = fused_layer.conv_filtered_lrelu(x, self.weight, None, self._gain_planes[key], self.bias, self.up_filter, self.down_filter,
-                                                conv_pad=self.conv_kernel - 1, **act)
+                                                conv_pad=self.conv_kernel - 1, packed=_packed, **act)
         else:
             w = self.weight * self.weight_gain
             x = conv2d_gradfix.conv2d(input=x, weight=w, padding=self.conv_kernel - 1)
@@ -424,11 +426,19 @@ class SynthesisNetwork(torch.nn.Module):
         ws = ws.to(torch.float32).unbind(dim=1)
         img_in = F.pad(img_in.to(self.compute_dtype), [self.margin_size] * 4, 'constant', 0)
 
+        # every conv weight of the step exists before its first convolution: the 16-bit MFMA images (forward + data gradient) of all
+        # 3x3 layers from one launch per half of the network (conv2d.pack_weights_bank) instead of one 8 us launch per layer
+        bank16 = self.compute_dtype in (torch.bfloat16, torch.float16) and img_in.is_cuda
+        enc_layers = [getattr(self, f'encoder_{idx}') for idx in range(self.num_layers)]
+        enc_packs = [None] * len(enc_layers)
+        if bank16 and all(layer.conv_kernel == 3 for layer in enc_layers) and len(enc_layers) <= _conv_ops.PACK_MAX:
+            enc_packs = _conv_ops.pack_weights_bank([layer.weight for layer in enc_layers], self.compute_dtype)
+
         E_features = {}
         for idx in range(self.num_layers):
             rev_idx = self.num_layers - idx - 1
             rev_prev = self.num_layers - max(idx - 1, 0) - 1
-            img_in = getattr(self, f'encoder_{idx}')(img_in)   # the reference passes no kwargs to the encoder (NET:678)
+            img_in = enc_layers[idx](img_in, _packed=enc_packs[idx])   # the reference passes no kwargs to the encoder (NET:678)
             if (self.sizes[rev_idx] != self.sizes[rev_prev]) and self.sizes[rev_prev] != self.sizes[0]:
                 E_features[self.sizes[rev_idx]] = img_in
 
@@ -460,6 +470,12 @@ class SynthesisNetwork(torch.nn.Module):
                     mods = [layer.modulation_from_styles(st) for layer, st in zip(layers, styles)]
         if mods is None:
             mods = [layer.modulation(w, img_global) for layer, w in zip(layers, ws[1:])] if fuse else [None] * len(layers)
+        dec_packs = [None] * len(layers)
+        if bank16 and fuse and mods[0] is not None:
+            k3 = [i for i, layer in enumerate(layers) if layer.conv_kernel == 3]
+            if 0 < len(k3) <= _conv_ops.PACK_MAX:
+                for i, pk in zip(k3, _conv_ops.pack_weights_bank([mods[i][0] for i in k3], self.compute_dtype)):
+                    dec_packs[i] = pk
         prescaled = False
         for idx, (layer, w) in enumerate(zip(layers, ws[1:])):
             nxt = min(idx + 1, len(self.layer_names) - 1)
@@ -470,7 +486,7 @@ class SynthesisNetwork(torch.nn.Module):
                 include_skip = False
             next_scale = mods[idx + 1][1] if (fuse and idx + 1 < len(layers) and layer.fusable(x)) else None
             x = layer(x, w, img_global, E_features, include_skip, _mod=mods[idx], _prescaled=prescaled, _next_scale=next_scale,
-                      **layer_kwargs)
+                      _packed=dec_packs[idx], **layer_kwargs)
             prescaled = next_scale is not None
         if self.output_scale != 1:
             x = x * self.output_scale

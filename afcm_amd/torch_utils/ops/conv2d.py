@@ -54,6 +54,34 @@ def pack_weights_both(w, dtype):
     return (d0, rp0), (d1, rp1)
 
 
+PACK_MAX = _lib.PACK_MAX
+
+
+def pack_weights_bank(ws, dtype):
+    """``pack_weights_both`` for a list of same-kernel-size weights in ONE launch (C ABI afcm_conv2d_pack_bank): a list of
+    ((packed, rows_pad), (packed_t, rows_pad_t)), bit-identical to the per-layer calls."""
+    lib = _lib.load()
+    assert 0 < len(ws) <= _lib.PACK_MAX
+    ks = int(ws[0].shape[2])
+    assert ks in (1, 3) and all(tuple(w.shape[2:]) == (ks, ks) for w in ws), 'one kernel size (1x1 or 3x3) per bank'
+    code = _lib._DTYPES[dtype]
+    bk = lib.afcm_conv2d_block_k(code)
+    table = (_lib.PackEntry * len(ws))()
+    out, keep = [], []
+    for e, w in zip(table, ws):
+        o, i = int(w.shape[0]), int(w.shape[1])
+        w32 = w.detach().to(torch.float32).contiguous()
+        keep.append(w32)
+        rp0, rp1 = _pad64(o), _pad64(i)
+        d0 = torch.empty([(i + bk - 1) // bk, ks * ks, rp0, bk], dtype=dtype, device=w.device)
+        d1 = torch.empty([(o + bk - 1) // bk, ks * ks, rp1, bk], dtype=dtype, device=w.device)
+        e.dst_fwd, e.dst_dgrad, e.w = d0.data_ptr(), d1.data_ptr(), w32.data_ptr()
+        e.cout, e.cin, e.rows_pad_fwd, e.rows_pad_dgrad = o, i, rp0, rp1
+        out.append(((d0, rp0), (d1, rp1)))
+    _lib.check(lib.afcm_conv2d_pack_bank(table, len(ws), code, ks, _lib.stream_ptr(ws[0])), 'conv2d_pack_bank')
+    return out
+
+
 def scale_planes(x, scale, out_dtype=None):
     """y[n, c] = x[n, c] * scale[n, c] (scale None: cast only)."""
     lib = _lib.load()

@@ -27,12 +27,15 @@ from . import filtered_lrelu as _flr
 
 class _ConvFilteredLRelu(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, in_scale, out_scale, bias, fu, fd, skip, next_scale, conv_pad, cfg, prescaled):
+    def forward(ctx, x, w, in_scale, out_scale, bias, fu, fd, skip, next_scale, conv_pad, cfg, prescaled, packed=None):
         _lib.require_gpu(x, w, in_scale, out_scale, bias, fu, fd, skip, next_scale)
         cout, cin, ks, _ = w.shape
         xs = _conv.scale_planes(x, in_scale) if (in_scale is not None and not prescaled) else x
         ctx.wpt = None
-        if ctx.needs_input_grad[0] or (ctx.needs_input_grad[2] and not prescaled):
+        if packed is not None and packed[0][0].dtype == x.dtype:
+            # both weight images come from the caller's multi-layer pack (conv2d.pack_weights_bank)
+            (wp, rows_pad), ctx.wpt = packed
+        elif ctx.needs_input_grad[0] or (ctx.needs_input_grad[2] and not prescaled):
             (wp, rows_pad), ctx.wpt = _conv.pack_weights_both(w, x.dtype)      # the backward's weight image from the same launch
         else:
             wp, rows_pad = _conv.pack_weights(w, x.dtype, 0)
@@ -89,7 +92,7 @@ class _ConvFilteredLRelu(torch.autograd.Function):
                 d_in = torch.where(s2 > 0, _conv.plane_dot(xs, dx) / s2.clamp_min(1e-30), torch.zeros_like(s2)).to(in_scale.dtype)
         if ctx.needs_input_grad[1]:
             dw = _conv._wgrad_raw(dys, xs, cout, cin, ks, conv_pad).to(w.dtype)
-        return dx, dw, d_in, d_out, db, None, None, d_skip, d_next, None, None, None
+        return dx, dw, d_in, d_out, db, None, None, d_skip, d_next, None, None, None, None
 
 
 def _cfg(up, down, padding, gain, slope, clamp):
@@ -107,8 +110,9 @@ def available(x, w, fu, fd, up, down, padding, gain, slope, clamp, conv_pad):
 
 
 def conv_filtered_lrelu(x, w, in_scale, out_scale, bias, fu, fd, up, down, padding, gain, slope, clamp, conv_pad, skip=None,
-                        next_scale=None, prescaled=False):
+                        next_scale=None, prescaled=False, packed=None):
     """z = (filtered_lrelu(out_scale * conv(w, in_scale * x) + bias; fu, fd, up, down, padding, gain, slope, clamp) + skip)
-    * next_scale.  ``prescaled``: x already carries in_scale (the producer's epilogue applied it)."""
+    * next_scale.  ``prescaled``: x already carries in_scale (the producer's epilogue applied it).  ``packed``: the two weight
+    images of `w` from ``conv2d.pack_weights_bank`` (the caller packed several layers in one launch), else they are made here."""
     cfg = _cfg(up, down, padding, gain, slope, clamp)
-    return _ConvFilteredLRelu.apply(x, w, in_scale, out_scale, bias, fu, fd, skip, next_scale, int(conv_pad), cfg, bool(prescaled))
+    return _ConvFilteredLRelu.apply(x, w, in_scale, out_scale, bias, fu, fd, skip, next_scale, int(conv_pad), cfg, bool(prescaled), packed)

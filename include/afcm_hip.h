@@ -331,6 +331,21 @@ int64_t afcm_modulation_bank_workspace_floats(int32_t n, int32_t cin, int32_t co
 int afcm_modulation_bank_fwd(const afcm_modulation_layer* layers, int32_t count, int32_t n, void* stream);
 int afcm_modulation_bank_bwd(const afcm_modulation_layer* layers, int32_t count, int32_t n, void* stream);
 
+/* ----------------------------------------------------------------------------------------
+ * afcm_conv2d_pack_weights2 for a LIST of layers in one launch: every conv weight of the generator (the encoder's parameters, the
+ * decoder's normalised weights from afcm_modulation_bank_fwd) exists before the first convolution of a step, so its 29 pack launches
+ * (8 us each) become two (3x3 kernels; the 1x1 ToRGB keeps its own).  Same images bit for bit.  dst_fwd / dst_dgrad: as
+ * afcm_conv2d_pack_weights2 (either may be NULL); `entries` is a HOST array of count <= AFCM_PACK_MAX, copied into the kernel arguments.
+ * ---------------------------------------------------------------------------------------- */
+#define AFCM_PACK_MAX 32
+typedef struct afcm_pack_entry {
+    void* dst_fwd;
+    void* dst_dgrad;
+    const float* w;                               /* [cout][cin][ks][ks] fp32 */
+    int32_t cout, cin, rows_pad_fwd, rows_pad_dgrad;
+} afcm_pack_entry;
+int afcm_conv2d_pack_bank(const afcm_pack_entry* entries, int32_t count, int32_t dtype, int32_t ks, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -295,3 +295,21 @@ def test_experimental_conv_kernels_parity(flag):
     r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'conv_kernel_parity.py')], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert 'worst' in r.stdout
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize('ks', [3, 1])
+def test_pack_weights_bank_is_bit_identical_to_the_layers_one_by_one(dtype, ks):
+    """conv2d.pack_weights_bank (C ABI afcm_conv2d_pack_bank): the forward and data-gradient MFMA images of a list of weights from ONE
+    launch against pack_weights_both layer by layer -- same kernel body behind a layer index, so every byte must match.  Shapes: channel
+    counts that are no multiple of the 16-channel K chunk or of the 64-row padding, a 1-output layer, the 512 x 512 bottleneck."""
+    from afcm_amd.torch_utils.ops import conv2d as C
+    torch.manual_seed(2)
+    shapes = [(64, 4), (91, 64), (128, 91), (181, 128), (512, 512), (1, 64), (37, 100)]
+    ws = [torch.randn(o, i, ks, ks, device='cuda') for o, i in shapes]
+    got = C.pack_weights_bank(ws, dtype)
+    for w, ((d0, rp0), (d1, rp1)) in zip(ws, got):
+        (e0, q0), (e1, q1) = C.pack_weights_both(w, dtype)
+        assert (rp0, rp1) == (q0, q1)
+        # rows past cout / cin inside the 64-row padding are never read by the conv kernels' valid outputs, but both routes zero them
+        assert torch.equal(d0.view(torch.uint8), e0.view(torch.uint8)) and torch.equal(d1.view(torch.uint8), e1.view(torch.uint8)), tuple(w.shape)
