@@ -123,8 +123,8 @@ def load():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
-        if lib.afcm_abi_version() != 8:
-            raise RuntimeError(f'libafcm_hip.so ABI version {lib.afcm_abi_version()} does not match this package (8); rebuild it')
+        if lib.afcm_abi_version() != 9:
+            raise RuntimeError(f'libafcm_hip.so ABI version {lib.afcm_abi_version()} does not match this package (9); rebuild it')
         _lib = lib
     return _lib
 
