@@ -103,6 +103,7 @@ SIGNATURES = {
     'afcm_modulation_bank_workspace_floats': (C.c_int64, [_i32, _i32, _i32, _i32]),
     'afcm_modulation_bank_fwd': (C.c_int, [C.POINTER(ModulationLayer), _i32, _i32, _vp]),
     'afcm_modulation_bank_bwd': (C.c_int, [C.POINTER(ModulationLayer), _i32, _i32, _vp]),
+    'afcm_conv2d_stride2': (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     'afcm_conv2d_pack_bank': (C.c_int, [C.POINTER(PackEntry), _i32, _i32, _i32, _vp]),
     'afcm_affine_bank_bwd': (C.c_int, [C.POINTER(AffineBank), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _vp, _vp, _vp, _vp]),
     'afcm_adam_chunk_elems': (C.c_int32, []),

@@ -46,6 +46,7 @@ template <> struct ConvCfg<f16_t>  { static constexpr int BK = 16, PITCH = 24; }
 template <> struct ConvCfg<float>  { static constexpr int BK = 8,  PITCH = 9;  };   // 36-byte rows: conflict-free b32
 
 constexpr int kPatchMax = 416;   // LDS patch capacity in pixels
+constexpr int kPatchMaxS2 = 704; // ... of the stride-2 kernel (two staging items per thread: <= 1024)
 constexpr int kSlots = 256;      // output pixels per workgroup
 
 struct ConvParams {
@@ -655,6 +656,336 @@ __global__ __launch_bounds__(256, 2) void conv2d_fwd16_kernel(ConvParams p) {
         }
     }
 }
+
+// Stride-2 form of conv2d_fwd16_kernel for the discriminator's down-sampling convs (CoModGAN/generator.py:613-692: blur, then a 3x3
+// conv at stride 2): the r01/r02 route computed the stride-1 result and decimated it -- four times the MFMAs, a full-resolution
+// write and a decimation copy.  Here an output pixel (py, px) reads the patch at (2 py + r, 2 px + s): same packed weights, same
+// tap loop, B fragment addresses twice as far apart.  The patch of a tile is ~4x its outputs, so a workgroup takes 128 output
+// pixels (two 32-pixel blocks per wave) under a (2 TH + 1) x (2 TW + 2) patch of up to kPatchMaxS2 pixels (two staging items per
+// thread), 68 KB of LDS double-buffered: still two workgroups per CU.  Bit-identical to the even pixels of the stride-1 result
+// (same K order).  Forward only: the gradients of a strided conv are convolutions with the zero-stuffed dy and keep the stride-1 kernels.
+template <typename T, int BM_O>
+__global__ __launch_bounds__(256, 2) void conv2d_fwd16s2_kernel(ConvParams p) {
+    static_assert(sizeof(T) == 2, "16-bit types only");
+    typedef ConvCfg<T> C;
+    constexpr int KS = 3, KK = 9, BK = C::BK, PITCH = C::PITCH, MI = BM_O / 64, RING = 3;
+    constexpr int NT = 2, PXW = 32 * NT, STRIDE = 2, NITEM = 2, PMAX = kPatchMaxS2;   // 128 output pixels per workgroup, two staging items per thread
+    typedef typename std::conditional<std::is_same<T, bf16_t>::value, bf16x8, f16x8>::type frag_t;
+    typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+    __shared__ __attribute__((aligned(16))) T lds[2 * PMAX * PITCH + 4 * PITCH];      // + a sink for lanes outside the patch
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wo = wave & 1, wpx = wave >> 1;
+    const int r32 = lane & 31, h = lane >> 5;
+
+    int bid = blockIdx.x;
+    {
+        const int total = gridDim.x;
+        bid = xcd_order(bid, total);
+    }
+    // integer division runs on the vector pipe even for uniform operands: pin the results to SGPRs, or everything derived
+    // from them (image base, buffer descriptor) sits in VGPRs and every buffer load gets a waterfall loop around it
+    const int tx = __builtin_amdgcn_readfirstlane(bid % p.tilesX); bid /= p.tilesX;
+    const int ty = __builtin_amdgcn_readfirstlane(bid % p.tilesY); bid /= p.tilesY;
+    const int n = __builtin_amdgcn_readfirstlane(bid % p.N);
+    const int ob = __builtin_amdgcn_readfirstlane(bid / p.N);
+    const int y0 = ty * p.TH, x0 = tx * p.TW;
+    const int o0 = ob * BM_O;
+    const int PH = (p.TH - 1) * STRIDE + KS, PWL = p.PWL;
+    const int xorg = (x0 * STRIDE - p.pad) & ~1;
+    const int xoff = (x0 * STRIDE - p.pad) - xorg;
+
+    int bbase[NT], pyv[NT], pxv[NT];
+#pragma unroll
+    for (int ti = 0; ti < NT; ti++) {
+        const int j = wpx * PXW + ti * 32 + r32;
+        int py = j / p.TW, px = j - py * p.TW;
+        const bool valid = j < p.TH * p.TW;
+        if (!valid) { py = 0; px = 0; }
+        pyv[ti] = valid ? y0 + py : p.P;             // invalid slots fall outside the image -> never stored
+        pxv[ti] = x0 + px;
+        bbase[ti] = (py * STRIDE * PWL + px * STRIDE + xoff) * PITCH + h * 8;
+    }
+
+    f32x16 acc[MI][NT];
+#pragma unroll
+    for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+        for (int ti = 0; ti < NT; ti++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[mi][ti][e] = 0.f;
+
+    // ---- A fragments: straight from the packed weights
+    const T* wlane = (const T*)p.wp + (size_t)(o0 + wo * (BM_O / 2) + r32) * BK + h * 8;
+    const size_t wtap = (size_t)p.Opad * BK;                       // elements per tap
+    auto load_a = [&](int kc, int tap, int mi) __attribute__((always_inline)) {
+        return *(const frag_t*)(wlane + ((size_t)kc * KK + tap) * wtap + mi * 32 * BK);
+    };
+
+    // ---- patch staging (one item = 4 pixels x 8 channels), as in conv2d_fwd_kernel
+    const int cg = (tid >> 5) & 1, pg = (tid & 31) + 32 * (tid >> 6);
+    const int pcols = PWL >> 2;
+    const T* xn = (const T*)p.x + (size_t)n * p.Cin * p.H * p.ldx;
+    constexpr unsigned kOob = 0x80000000u;
+    const long long img_bytes = (long long)p.Cin * p.H * p.ldx * 2ll;
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)xn, 0, (int)(img_bytes > 0x7fffffffll ? 0x7fffffffll : img_bytes), 0x00020000);
+    const int hw2 = p.H * p.ldx * 2;
+    bool pvalid[NITEM], lshift[NITEM];
+    int pdst[NITEM];
+    unsigned pmask0[NITEM], pmask1[NITEM], pvoff[NITEM];
+#pragma unroll
+    for (int it = 0; it < NITEM; it++) {
+        const int item = pg + 128 * it;
+        const int prow = item / pcols, pcol4 = item - prow * pcols;
+        pvalid[it] = prow < PH;
+        const int iy = y0 * STRIDE - p.pad + prow, ix = xorg + 4 * pcol4;
+        const bool rowok = pvalid[it] && (unsigned)iy < (unsigned)p.H;
+        const long long pix_off = (long long)(rowok ? iy : 0) * p.ldx + ix;
+        pdst[it] = (prow * PWL + 4 * pcol4) * PITCH + cg * 8;
+        const bool d0ok = rowok && (unsigned)ix < (unsigned)p.W, d1ok = rowok && (unsigned)(ix + 2) < (unsigned)p.W;
+        pmask0[it] = d0ok ? ~0u : 0u; pmask1[it] = d1ok ? ~0u : 0u;
+        lshift[it] = !d0ok && d1ok;                                                   // never touch bytes before a row 0
+        pvoff[it] = (d0ok || d1ok) ? (unsigned)(((long long)cg * 8 * p.H * p.ldx + pix_off + (lshift[it] ? 2 : 0)) * 2ll) : kOob;
+    }
+
+    unsigned preg[NITEM][8][2];
+    auto issue_patch = [&](int kc, bool live) __attribute__((always_inline)) {
+        const int cbase = kc * BK + cg * 8;
+        const int climit = live ? p.Cin : 0;
+#pragma unroll
+        for (int it = 0; it < NITEM; it++)
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+                const unsigned off = (cbase + c < climit) ? pvoff[it] : kOob;
+                const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(xrs, off, (kc * BK + c) * hw2, 0);
+                preg[it][c][0] = v.x; preg[it][c][1] = v.y;
+            }
+    };
+    auto write_patch = [&](int kc, T* dstbuf, int bufbase) __attribute__((always_inline)) {
+#pragma unroll
+        for (int it = 0; it < NITEM; it++) {
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+                const unsigned lo = lshift[it] ? 0u : (preg[it][c][0] & pmask0[it]);
+                const unsigned hi = (lshift[it] ? preg[it][c][0] : preg[it][c][1]) & pmask1[it];
+                preg[it][c][0] = lo; preg[it][c][1] = hi;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const unsigned sel = (e & 1) ? 0x07060302u : 0x05040100u;
+                uint4 v;
+                v.x = __builtin_amdgcn_perm(preg[it][1][e >> 1], preg[it][0][e >> 1], sel);
+                v.y = __builtin_amdgcn_perm(preg[it][3][e >> 1], preg[it][2][e >> 1], sel);
+                v.z = __builtin_amdgcn_perm(preg[it][5][e >> 1], preg[it][4][e >> 1], sel);
+                v.w = __builtin_amdgcn_perm(preg[it][7][e >> 1], preg[it][6][e >> 1], sel);
+                *(uint4*)(lds + (pvalid[it] ? bufbase + pdst[it] + e * PITCH : 2 * PMAX * PITCH)) = v;
+            }
+        }
+    };
+
+    frag_t ar[RING][MI];
+    issue_patch(0, true);
+#pragma unroll
+    for (int t = 0; t < RING; t++)
+#pragma unroll
+        for (int mi = 0; mi < MI; mi++) ar[t][mi] = load_a(0, t, mi);
+    write_patch(0, lds, 0);
+    __syncthreads();
+
+    const int last = p.nkc - 1;
+    for (int kc = 0; kc < p.nkc; kc++) {
+        const T* cur = lds + (kc & 1) * (PMAX * PITCH);
+        T* nxt = lds + ((kc + 1) & 1) * (PMAX * PITCH);
+        const bool more = kc < last;
+        // B fragments run one tap ahead of their MFMAs in the SAME registers: a tap's MFMAs go pixel-block by pixel-block, and
+        // as soon as block ti's fragment has been consumed the next tap's fragment for that block is read into it.  (Read, wait,
+        // multiply per tap left ~one LDS round trip exposed per 8 MFMAs with only the other workgroup's wave to cover it.)
+        frag_t b[NT];
+#pragma unroll
+        for (int ti = 0; ti < NT; ti++) b[ti] = *(const frag_t*)(cur + bbase[ti]);
+        issue_patch(kc + (int)more, more);
+        __builtin_amdgcn_sched_group_barrier(0x100, NT, 0);              // tap 0's fragments first, all in flight together
+        __builtin_amdgcn_sched_group_barrier(0x020, 8 * NITEM, 0);
+#pragma unroll
+        for (int tap = 0; tap < KK; tap++) {
+            const int nr = (tap + 1) / KS, ns = (tap + 1) - nr * KS;
+            const int tapoff_n = (nr * PWL + ns) * PITCH;                 // next tap's offset (unused on the last tap)
+            frag_t a[MI];
+#pragma unroll
+            for (int mi = 0; mi < MI; mi++) a[mi] = ar[tap % RING][mi];
+            // refill this ring slot with the fragments three taps ahead (clamped at the end: no branch around a load)
+            {
+                const int nt = (tap + RING) % KK;
+                const int nk = (tap + RING < KK) ? kc : (more ? kc + 1 : kc);
+#pragma unroll
+                for (int mi = 0; mi < MI; mi++) ar[tap % RING][mi] = load_a(nk, nt, mi);
+            }
+#pragma unroll
+            for (int ti = 0; ti < NT; ti++) {
+#pragma unroll
+                for (int mi = 0; mi < MI; mi++) {
+                    if constexpr (std::is_same<T, bf16_t>::value)
+                        acc[mi][ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ti], acc[mi][ti], 0, 0, 0);
+                    else
+                        acc[mi][ti] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mi], b[ti], acc[mi][ti], 0, 0, 0);
+                }
+                if (tap + 1 < KK) b[ti] = *(const frag_t*)(cur + bbase[ti] + tapoff_n);
+            }
+            if (tap == 5) {
+                // the other buffer (last read one chunk ago); on the last chunk this rewrites stale registers into a buffer
+                // nobody reads.  Interleave: one MFMA, then a handful of the transpose's vector instructions.
+                write_patch(kc + 1, nxt, ((kc + 1) & 1) * (PMAX * PITCH));
+                __builtin_amdgcn_sched_group_barrier(0x020, MI, 0);
+#pragma unroll
+                for (int ti = 0; ti < NT; ti++) {
+#pragma unroll
+                    for (int mi = 0; mi < MI; mi++) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, 20, 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x200, 4 * NITEM, 0);
+            } else {
+                // pin the issue order of the tap: the ring refill first (left alone, the scheduler sinks the loads next to
+                // their uses and the three-tap prefetch distance collapses), then per pixel block its MFMAs and the read ahead
+                __builtin_amdgcn_sched_group_barrier(0x020, MI, 0);
+#pragma unroll
+                for (int ti = 0; ti < NT; ti++) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, MI, 0);
+                    if (tap + 1 < KK) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: D[row = channel][col = pixel]; row = (reg&3) + 8*(reg>>2) + 4*h within the 32x32 tile.
+    if ((p.TW & 7) == 0 && (p.Q & 1) == 0) {        // (an odd output width -- possible at stride 2 -- puts rows on odd elements: element stores below)
+        // Tile rows that are multiples of 8 pixels: transpose through LDS (the patch buffers are free after the last barrier)
+        // and store 8 pixels = 16 bytes per lane.  A lane holds 16 channels of ONE pixel (4 runs of 4 consecutive channels), so
+        // it stages [pixel][32 channels] rows with four 8-byte writes per 32x32 tile, and the transposing read
+        // (ds_read_b64_tr_b16: a 16-lane group takes a 4-pixel x 16-channel block, lane i receives channel i of the 4 pixels)
+        // hands every lane 4 pixels of one channel.  Per thread and 32-channel pass: 32 packed conversions + 16 ds_write_b64 +
+        // 16 transposing reads + 8 stores (the first version staged [channel][pixel] with 64 two-byte writes per pass: the
+        // epilogue was 12 % of the whole conv time, 35 % on the 64-channel layers).
+        // Row = 64 bytes = eight 8-byte chunks; chunk c of pixel p lives at c ^ ((p >> 1) & 7): conflict-free for the writes
+        // (16 consecutive pixels x one chunk) and for the reads (a 32-lane half = both channel halves of 4 pixels).
+        typedef __attribute__((ext_vector_type(4))) short s16x4;
+        constexpr int EROW = 64;
+        unsigned char* ebuf = (unsigned char*)lds + wave * (PXW * EROW);
+        T* yn = (T*)p.y + (size_t)n * p.Cout * p.P * p.ldy;
+        const float* osn = p.oscale ? p.oscale + (size_t)n * p.Cout : nullptr;
+        const int pq = p.P * p.ldy;
+        // read side: lane = (half hh: granule parity, chalf: channel half, i16: channel / address role inside the 16-lane group)
+        const int i16 = lane & 15, chalf = (lane >> 4) & 1, hh = lane >> 5;
+        const int q4 = i16 >> 2, p4 = i16 & 3;
+        unsigned rd_off[2];
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            const int prow = 8 * hh + 4 * r + q4;                 // + 16 pixels per iteration: (prow >> 1) & 7 does not change
+            rd_off[r] = prow * EROW + (((chalf * 4 + p4) ^ ((prow >> 1) & 7)) << 3);
+        }
+        // this lane's 8 granules (8 pixels each, one tile row): plane offset, -1 = outside the image; bit it of gfullm = whole
+        int goff[2 * NT];
+        unsigned gfullm = 0;
+        int gxv[2 * NT];
+#pragma unroll
+        for (int it = 0; it < 2 * NT; it++) {
+            const int j0 = wpx * PXW + (2 * it + hh) * 8;
+            const int gpy = (int)__umulhi((unsigned)j0, p.magicTW), gpx = j0 - gpy * p.TW;
+            const int gy = y0 + gpy, gx = x0 + gpx;
+            goff[it] = (j0 < p.TH * p.TW && gy < p.P && gx < p.Q) ? gy * p.ldy + gx : -1;
+            gxv[it] = gx;
+            if (gx + 8 <= p.ldy) gfullm |= 1u << it;         // a pitched row has room for the whole granule (columns >= Q: padding)
+        }
+        const int wr_pix = r32;                                    // + 32 ti
+#pragma unroll
+        for (int mi = 0; mi < MI; mi++) {
+            float sc[16], ob[16];
+            const int obase = o0 + wo * (BM_O / 2) + mi * 32 + 4 * h;
+#pragma unroll
+            for (int reg = 0; reg < 16; reg++) { sc[reg] = 1.f; ob[reg] = 0.f; }
+            if (osn != nullptr) {
+#pragma unroll
+                for (int reg = 0; reg < 16; reg++) sc[reg] = osn[min(obase + (reg & 3) + 8 * (reg >> 2), p.Cout - 1)];
+            }
+            if (p.obias != nullptr) {
+#pragma unroll
+                for (int reg = 0; reg < 16; reg++) ob[reg] = p.obias[min(obase + (reg & 3) + 8 * (reg >> 2), p.Cout - 1)];
+            }
+#pragma unroll
+            for (int ti = 0; ti < NT; ti++) {
+                const int pix = ti * 32 + wr_pix;
+                const int sw = (pix >> 1) & 7;
+#pragma unroll
+                for (int k4 = 0; k4 < 4; k4++) {                   // registers 4 k4 .. 4 k4 + 3 = channels 4 h + 8 k4 + 0..3
+                    uint2 w;
+                    w.x = pack2<T>(acc[mi][ti][4 * k4 + 0] * sc[4 * k4 + 0] + ob[4 * k4 + 0], acc[mi][ti][4 * k4 + 1] * sc[4 * k4 + 1] + ob[4 * k4 + 1]);
+                    w.y = pack2<T>(acc[mi][ti][4 * k4 + 2] * sc[4 * k4 + 2] + ob[4 * k4 + 2], acc[mi][ti][4 * k4 + 3] * sc[4 * k4 + 3] + ob[4 * k4 + 3]);
+                    *(uint2*)(ebuf + pix * EROW + (((h + 2 * k4) ^ sw) << 3)) = w;
+                }
+            }
+            // same wave wrote and reads: LDS operations of a wave complete in order, no barrier needed
+            const int o = o0 + wo * (BM_O / 2) + mi * 32 + chalf * 16 + i16;
+            T* const yo = yn + (size_t)min(o, p.Cout - 1) * pq;
+#pragma unroll
+            for (int it = 0; it < 2 * NT; it++) {
+                union { s16x4 v[2]; uint4 q; } u;
+#pragma unroll
+                for (int r = 0; r < 2; r++)
+                    u.v[r] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ebuf + it * (16 * EROW) + rd_off[r]));
+                if (goff[it] >= 0 && o < p.Cout) {
+                    T* dst = yo + goff[it];
+                    if ((gfullm >> it) & 1) {
+                        *(uint4*)dst = u.q;
+                    } else {                                      // the granule straddles the right edge (even width: whole pairs)
+                        const unsigned vv[4] = {u.q.x, u.q.y, u.q.z, u.q.w};
+#pragma unroll
+                        for (int w2 = 0; w2 < 4; w2++)
+                            if (gxv[it] + 2 * w2 < p.Q) ((unsigned*)dst)[w2] = vv[w2];
+                    }
+                }
+            }
+        }
+        return;
+    }
+    T* yn = (T*)p.y + (size_t)n * p.Cout * p.P * p.ldy;
+    // per output-row block: all per-channel scales and biases first (clamped index, no branch around the loads: one wait
+    // instead of a round trip per row), then the stores
+    int poff[NT];                                    // pixel offset inside a plane, -1: not stored
+#pragma unroll
+    for (int ti = 0; ti < NT; ti++) poff[ti] = (pyv[ti] < p.P && pxv[ti] < p.Q) ? pyv[ti] * p.ldy + pxv[ti] : -1;
+    const float* osn = p.oscale ? p.oscale + (size_t)n * p.Cout : nullptr;
+    const int pq = p.P * p.ldy;
+#pragma unroll
+    for (int mi = 0; mi < MI; mi++) {
+        float sc[16], ob[16];
+        const int obase = o0 + wo * (BM_O / 2) + mi * 32 + 4 * h;
+#pragma unroll
+        for (int reg = 0; reg < 16; reg++) { sc[reg] = 1.f; ob[reg] = 0.f; }
+        if (osn != nullptr) {
+#pragma unroll
+            for (int reg = 0; reg < 16; reg++) sc[reg] = osn[min(obase + (reg & 3) + 8 * (reg >> 2), p.Cout - 1)];
+        }
+        if (p.obias != nullptr) {
+#pragma unroll
+            for (int reg = 0; reg < 16; reg++) ob[reg] = p.obias[min(obase + (reg & 3) + 8 * (reg >> 2), p.Cout - 1)];
+        }
+#pragma unroll
+        for (int reg = 0; reg < 16; reg++) {
+            const int o = obase + (reg & 3) + 8 * (reg >> 2);
+            if (o < p.Cout) {
+                T* yo = yn + (size_t)o * pq;
+#pragma unroll
+                for (int ti = 0; ti < NT; ti++)
+                    if (poff[ti] >= 0) yo[poff[ti]] = from_f32<T>(acc[mi][ti][reg] * sc[reg] + ob[reg]);
+            }
+        }
+    }
+}
+
 
 // ---------------------------------------------------------------------------------------------
 // 16-bit 3x3 forward / data-gradient kernel, r03 "direct" structure: NO LDS in the K loop.  conv2d_fwd16_kernel's measured limiter is
@@ -2556,6 +2887,24 @@ static void choose_tile(int P, int Q, int KS, int* TH, int* TW, int* PWL) {
     }
 }
 
+static void choose_tile_s2(int P, int Q, int* TH, int* TW, int* PWL) {
+    // stride-2 kernel: TH x TW output pixels with TH * TW <= 128 slots under a ((TH - 1) 2 + 3) x round4((TW - 1) 2 + 4) patch <= kPatchMaxS2
+    double best = -1;
+    for (int tw = 2; tw <= 64; tw += 2) {
+        int th = 128 / tw;
+        if (th > P) th = P;
+        for (; th >= 1; th--) {
+            const int pwl = round_up((tw - 1) * 2 + 4, 4);
+            if (((th - 1) * 2 + 3) * pwl > kPatchMaxS2) continue;
+            const double tiles = (double)cdiv(P, th) * cdiv(Q, tw);
+            const double util = (double)P * Q / (tiles * 128);
+            const double score = util + 1e-4 * tw + ((tw & 7) == 0 ? 0.03 : 0.0);
+            if (score > best) { best = score; *TH = th; *TW = tw; *PWL = pwl; }
+            break;
+        }
+    }
+}
+
 template <typename T, int BM_O>
 static int launch_conv(ConvParams p, int ks, hipStream_t st) {
     const long long blocks = (long long)p.tilesX * p.tilesY * p.N * cdiv(p.Cout, BM_O);
@@ -2670,6 +3019,33 @@ extern "C" int afcm_conv2d_pack_bank(const afcm_pack_entry* entries, int32_t cou
         case AFCM_F16: launch_pack_bank<f16_t>(b, tot, ks, st); break;
         default: launch_pack_bank<bf16_t>(b, tot, ks, st); break;
     }
+    return hip_status(hipGetLastError());
+}
+
+extern "C" int afcm_conv2d_stride2(void* y, const void* x, const void* wpacked, int32_t dtype, int32_t n, int32_t cin, int32_t cout, int32_t h,
+                                   int32_t w, int32_t pad, int32_t rows_pad, void* stream) {
+    AFCM_REQUIRE(y != nullptr && x != nullptr && wpacked != nullptr, "conv2d_stride2: null pointer");
+    AFCM_REQUIRE(dtype == AFCM_F16 || dtype == AFCM_BF16, "conv2d_stride2: 16-bit activations only");
+    AFCM_REQUIRE(n > 0 && cin > 0 && cout > 0 && h > 0 && w > 0 && (w % 2) == 0, "conv2d_stride2: empty x or odd width %d", w);
+    AFCM_REQUIRE(pad >= 0 && pad <= 2, "padding must be in [0, k-1]");
+    AFCM_REQUIRE(rows_pad >= cout && rows_pad % 128 == 0, "conv2d_stride2: rows_pad must be a multiple of 128 covering cout");
+    AFCM_REQUIRE(h + 2 * pad >= 3 && w + 2 * pad >= 3, "output must be at least 1x1");
+    ConvParams p;
+    p.x = x; p.y = y; p.wp = wpacked; p.oscale = nullptr; p.obias = nullptr;
+    p.N = n; p.Cin = cin; p.Cout = cout; p.H = h; p.W = w;
+    p.P = (h + 2 * pad - 3) / 2 + 1; p.Q = (w + 2 * pad - 3) / 2 + 1;
+    p.pad = pad;
+    p.ldx = w; p.ldy = p.Q;
+    choose_tile_s2(p.P, p.Q, &p.TH, &p.TW, &p.PWL);
+    p.tilesX = cdiv(p.Q, p.TW); p.tilesY = cdiv(p.P, p.TH);
+    p.magicTW = (unsigned)((0x100000000ull + (unsigned)p.TW - 1) / (unsigned)p.TW);
+    p.Opad = rows_pad;
+    p.nkc = cdiv(cin, afcm_conv2d_block_k(dtype));
+    const long long blocks = (long long)p.tilesX * p.tilesY * n * cdiv(cout, 128);
+    AFCM_REQUIRE(blocks > 0 && blocks < (1ll << 31), "conv2d_stride2: grid of %lld blocks is out of range", blocks);
+    AFCM_REQUIRE((long long)cin * h * w * 2ll < (1ll << 31), "conv2d_stride2: image out of range");
+    if (dtype == AFCM_F16) hipLaunchKernelGGL((conv2d_fwd16s2_kernel<f16_t, 128>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((conv2d_fwd16s2_kernel<bf16_t, 128>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
     return hip_status(hipGetLastError());
 }
 

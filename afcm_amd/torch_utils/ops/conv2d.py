@@ -290,6 +290,61 @@ class _ConvWgrad(torch.autograd.Function):
         return g_dy, g_x, None, None
 
 
+class _StridedConv2d(torch.autograd.Function):
+    """y = conv(x, w, pad) at stride 2, 16-bit 3x3 (C ABI afcm_conv2d_stride2): the even rows / columns of the stride-1 result, bit for
+    bit, at a quarter of its MFMAs.  The gradients of a strided correlation are stride-1 convolutions with the zero-stuffed dy: the
+    backward is written with the differentiable nodes above, so first- and higher-order graphs (the discriminator's R1 penalty) come
+    out the same way they did when the stride was a slice of the stride-1 result."""
+
+    @staticmethod
+    def forward(ctx, x, w, padding):
+        _lib.require_gpu(x, w)
+        lib = _lib.load()
+        n, cin, h, wd = x.shape
+        cout = int(w.shape[0])
+        x = x.contiguous()
+        code = _lib._DTYPES[x.dtype]
+        bk = lib.afcm_conv2d_block_k(code)
+        rows_pad = (cout + 127) // 128 * 128                       # the stride-2 kernel runs 128-row blocks only
+        w32 = w.detach().to(torch.float32).contiguous()
+        wp = torch.empty([(cin + bk - 1) // bk, 9, rows_pad, bk], dtype=x.dtype, device=x.device)
+        _lib.check(lib.afcm_conv2d_pack_weights(wp.data_ptr(), w32.data_ptr(), code, cout, cin, 3, 0, rows_pad, _lib.stream_ptr(x)), 'conv2d_pack_weights')
+        p, q = (h + 2 * padding - 3) // 2 + 1, (wd + 2 * padding - 3) // 2 + 1
+        y = torch.empty([n, cout, p, q], dtype=x.dtype, device=x.device)
+        span = profiling.span('conv2d', 2.0 * n * cout * cin * 9 * p * q)
+        _lib.check(lib.afcm_conv2d_stride2(y.data_ptr(), x.data_ptr(), wp.data_ptr(), code, n, cin, cout, h, wd, padding, rows_pad, _lib.stream_ptr(x)),
+                   'conv2d_stride2')
+        if span is not None:
+            span.end()
+        ctx.save_for_backward(x, w)
+        ctx.padding = padding
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        pad = ctx.padding
+        n, _, h, wd = x.shape
+        full = dy.new_zeros([n, dy.shape[1], h + 2 * pad - 2, wd + 2 * pad - 2])
+        full[:, :, ::2, ::2] = dy                                    # zero-stuffed: the gradient of the stride-1 result
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = _ScaledConv2d.apply(full, w.to(torch.float32).transpose(0, 1).flip([2, 3]).contiguous(), None, None, 2 - pad, False)
+        if ctx.needs_input_grad[1]:
+            dw = _ConvWgrad.apply(full, x, 3, pad).to(w.dtype)
+        return dx, dw, None
+
+
+def strided_conv2d_supported(x, w, padding):
+    return (x.is_cuda and x.dtype in (torch.bfloat16, torch.float16) and x.ndim == 4 and tuple(w.shape[2:]) == (3, 3) and x.shape[1] == w.shape[1]
+            and x.shape[3] % 2 == 0 and 0 <= padding <= 2 and x.shape[1] * x.shape[2] * x.shape[3] * 2 < (1 << 31))
+
+
+def strided_conv2d(x, w, padding=0):
+    """3x3 correlation at stride 2 of 16-bit activations (see _StridedConv2d); check ``strided_conv2d_supported`` first."""
+    return _StridedConv2d.apply(x.contiguous(), w.contiguous(), int(padding))
+
+
 def scaled_conv2d(x, w, in_scale=None, out_scale=None, padding=0, prescaled=False):
     # contiguity is established out here, under autograd, so that the node saves tensors that are still part of the graph
     # (a second-order backward differentiates through them)

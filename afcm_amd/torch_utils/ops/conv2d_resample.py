@@ -8,6 +8,8 @@ differentiable), the contraction is the framework's convolution exactly where th
 discriminator needs stride-2 convolutions and a double backward (R1, models/comodgan_model.py:143-147), neither of which the
 generator's MFMA conv kernels provide; padding is applied once at the beginning, not between the operations.
 """
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -15,6 +17,7 @@ from . import conv2d as _conv
 from . import upfirdn2d
 
 USE_MFMA_CONV = True      # module switch: False routes every convolution to the framework (A/B and debugging)
+NATIVE_STRIDE2 = os.environ.get('AFCM_NATIVE_STRIDE2', '1') != '0'     # 16-bit 3x3 stride-2 convolutions on the stride-2 MFMA kernel (False: the stride-1 result decimated, the r01/r02 route)
 MFMA_CONV_FP32 = False    # fp32 activations too: correct, but the stride-by-decimation waste makes it slower than the framework's
                           # fp32 convolution over the whole D update (151.7 vs 148 ms, batch 16); the 16-bit blocks gain 2x (69 vs 139 ms)
 
@@ -49,6 +52,8 @@ def _conv2d_wrapper(x, w, stride=1, padding=0, groups=1, transpose=False, flip_w
     if (USE_MFMA_CONV and not transpose and groups == 1 and x.device.type == 'cuda' and kh == kw and kh in (1, 3) and pad is not None
             and 0 <= pad <= kh - 1 and x.dtype in ((torch.float32, torch.bfloat16, torch.float16) if MFMA_CONV_FP32 else (torch.bfloat16, torch.float16))
             and (x.dtype == torch.float32 or (x.shape[3] % 2 == 0 and (x.shape[3] + 2 * pad - kh + 1) % 2 == 0))):
+        if stride == 2 and NATIVE_STRIDE2 and _conv.strided_conv2d_supported(x, w, pad):
+            return _conv.strided_conv2d(x, w.to(torch.float32), pad)     # csrc/conv2d.hip conv2d_fwd16s2_kernel: no full-resolution intermediate
         y = _conv.scaled_conv2d(x, w.to(torch.float32), None, None, pad)
         if stride != 1:
             y = y[:, :, ::stride, ::stride]

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define AFCM_ABI_VERSION 9   /* 9 (r03): + afcm_affine_bank_*, afcm_modulation_bank_*, afcm_conv2d_pack_bank (additions only; every v8 entry point and struct is unchanged) */
+#define AFCM_ABI_VERSION 9   /* 9 (r03): + afcm_affine_bank_*, afcm_modulation_bank_*, afcm_conv2d_pack_bank, afcm_conv2d_stride2 (additions only; every v8 entry point and struct is unchanged) */
 
 enum { AFCM_F32 = 0, AFCM_F16 = 1, AFCM_BF16 = 2 };
 enum { AFCM_OK = 0, AFCM_E_NOKERNEL = -1, AFCM_E_INVALID = -2 };
@@ -345,6 +345,16 @@ typedef struct afcm_pack_entry {
     int32_t cout, cin, rows_pad_fwd, rows_pad_dgrad;
 } afcm_pack_entry;
 int afcm_conv2d_pack_bank(const afcm_pack_entry* entries, int32_t count, int32_t dtype, int32_t ks, void* stream);
+
+/* ----------------------------------------------------------------------------------------
+ * 3x3 convolution at stride 2 (the discriminator's down-sampling convs, CoModGAN/generator.py:613-692, after the blur): 16-bit x
+ * [n][cin][h][w] (dense, w even), weights packed by afcm_conv2d_pack_weights(mode 0) with rows_pad a multiple of 128, y
+ * [n][cout][(h + 2 pad - 3) / 2 + 1][(w + 2 pad - 3) / 2 + 1] = the even rows / columns of afcm_conv2d's result, bit for bit, at a
+ * quarter of its MFMAs and without the full-resolution intermediate.  Forward only (the gradients are stride-1 convolutions with the
+ * zero-stuffed dy: afcm_conv2d / afcm_conv2d_wgrad).
+ * ---------------------------------------------------------------------------------------- */
+int afcm_conv2d_stride2(void* y, const void* x, const void* wpacked, int32_t dtype, int32_t n, int32_t cin, int32_t cout, int32_t h, int32_t w,
+                        int32_t pad, int32_t rows_pad, void* stream);
 
 #ifdef __cplusplus
 }

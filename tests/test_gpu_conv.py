@@ -313,3 +313,30 @@ def test_pack_weights_bank_is_bit_identical_to_the_layers_one_by_one(dtype, ks):
         assert (rp0, rp1) == (q0, q1)
         # rows past cout / cin inside the 64-row padding are never read by the conv kernels' valid outputs, but both routes zero them
         assert torch.equal(d0.view(torch.uint8), e0.view(torch.uint8)) and torch.equal(d1.view(torch.uint8), e1.view(torch.uint8)), tuple(w.shape)
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('n,cin,cout,h,w,pad', [(2, 32, 64, 34, 34, 0), (1, 37, 130, 67, 130, 0), (2, 16, 16, 20, 36, 1), (1, 64, 128, 130, 130, 0),
+                                               (3, 8, 200, 9, 12, 2)])
+def test_stride2_conv_equals_the_decimated_stride1_result(dtype, n, cin, cout, h, w, pad):
+    """conv2d.strided_conv2d (C ABI afcm_conv2d_stride2, csrc/conv2d.hip conv2d_fwd16s2_kernel: the discriminator's down-sampling convs,
+    CoModGAN/generator.py:613-692) against the route it replaces, the stride-1 MFMA result sliced [::2, ::2]: the forward bit for bit (same
+    packed weights, same K order), input and weight gradients bit for bit (both routes run the same stride-1 kernels on the same
+    zero-stuffed dy), and the double backward an R1 penalty takes (gradient of |dy/dx|^2 w.r.t. the weights) to 1e-3 of its scale.
+    Shapes: channel tails, several 128-row blocks, odd heights, tiles at all four image edges, paddings 0 / 1 / 2."""
+    from afcm_amd.torch_utils.ops import conv2d as C
+    torch.manual_seed(7)
+    x = torch.randn(n, cin, h, w, device='cuda').to(dtype).requires_grad_(True)
+    wt = (torch.randn(cout, cin, 3, 3, device='cuda') / (3 * cin ** 0.5)).requires_grad_(True)
+    assert C.strided_conv2d_supported(x, wt, pad)
+    got = C.strided_conv2d(x, wt, pad)
+    want = C.scaled_conv2d(x, wt, None, None, pad)[:, :, ::2, ::2]
+    assert got.shape == want.shape and torch.equal(got, want)
+    r = torch.randn_like(got)
+    gg = torch.autograd.grad((got.float() * r.float()).sum(), [x, wt], create_graph=True)
+    gw = torch.autograd.grad((want.float() * r.float()).sum(), [x, wt], create_graph=True)
+    assert torch.equal(gg[0], gw[0]) and torch.equal(gg[1], gw[1])
+    # second order: d/dw of |dL/dx|^2 (the R1 pattern)
+    hg, = torch.autograd.grad(gg[0].float().square().sum(), [wt])
+    hw, = torch.autograd.grad(gw[0].float().square().sum(), [wt])
+    assert (hg - hw).abs().max().item() <= 1e-3 * max(1e-6, hw.abs().max().item())
