@@ -207,6 +207,10 @@ __global__ __launch_bounds__(256, (DOWN == 2 && (TOH <= 32 || SIGN == AFCM_SIGNS
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, g = lane >> 4;
+#ifdef AFCM_WAVE_EXPERIMENT_LDS         // timing experiment only: LDS nobody uses, to run the same code at fewer waves per SIMD
+    __shared__ unsigned char lds_pad[AFCM_WAVE_EXPERIMENT_LDS];
+    if (p.total_tiles < 0) lds_pad[tid] = 1;
+#endif
     if (RD) {
         if (tid < 128) ((uint4*)lds_tab)[tid] = ((const uint4*)((const char*)p.ws + kWsTable))[tid];
         __syncthreads();
@@ -280,7 +284,11 @@ __global__ __launch_bounds__(256, (DOWN == 2 && (TOH <= 32 || SIGN == AFCM_SIGNS
         if (__builtin_expect(c0 >= 0 && c0 + 32 <= p.xw, 1)) {
 #pragma unroll
             for (int mb = 0; mb < G::NMB; mb++)
+#ifdef AFCM_WAVE_EXPERIMENT_CACHED_LOADS   // timing experiment only (wrong results): every piece is the strip's piece 0 or 1 -- real data, served by the L1 / L2
+                raw[mb] = __builtin_amdgcn_raw_buffer_load_b128(rsx, (unsigned)(xoff0 + 64 * (k & 1) + mb * xrow16), 0, AFCM_WAVE_LOAD_AUX);
+#else
                 raw[mb] = __builtin_amdgcn_raw_buffer_load_b128(rsx, (unsigned)(xoff0 + 64 * k + mb * xrow16), 0, AFCM_WAVE_LOAD_AUX);
+#endif
         } else {
             // the piece crosses the left or right edge of the plane: dword by dword, columns outside it read as zero
             // (even plane widths: the two elements of a dword are in or out together; rows outside: as above, except that a
@@ -342,6 +350,9 @@ __global__ __launch_bounds__(256, (DOWN == 2 && (TOH <= 32 || SIGN == AFCM_SIGNS
     // READ: the sign dwords of a group's two column blocks, fetched one group ahead like the input window (consumed right after
     // the up-y products: fetched in place, every column block exposed a full memory round trip)
     auto load_signs = [&](int nb, unsigned (&sg)[RA ? 1 : 2][NL]) __attribute__((always_inline)) {
+#ifdef AFCM_WAVE_EXPERIMENT_CACHED_LOADS   // timing experiment only (wrong results): the codes of the strip's first two column blocks, again and again
+        nb &= 1;
+#endif
         const int blo = sgr_lo + nb * blkbytes, bhi = sgr_hi + nb * blkbytes;
 #pragma unroll
         for (int i = 0; i < NL; i++) {
@@ -363,7 +374,11 @@ __global__ __launch_bounds__(256, (DOWN == 2 && (TOH <= 32 || SIGN == AFCM_SIGNS
 #ifdef AFCM_WAVE_EXPERIMENT_NOSTORE   // timing experiment only: every output store falls outside the descriptor
     const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc((void*)yp, 0, 0, 0x00020000);
 #else
+#ifdef AFCM_WAVE_EXPERIMENT_STORE_ALIAS   // timing experiment only (wrong results): every plane's stores land in plane 0's first 64 KB
+    const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, p.yh * p.yld * 2, 0x00020000);
+#else
     const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc((void*)yp, 0, p.yh * p.yld * 2, 0x00020000);
+#endif
 #endif
     const bool has_skip = (EPI & 2) && p.skip != nullptr;
     const __amdgpu_buffer_rsrc_t rsk = __builtin_amdgcn_make_buffer_rsrc(
@@ -506,6 +521,17 @@ __global__ __launch_bounds__(256, (DOWN == 2 && (TOH <= 32 || SIGN == AFCM_SIGNS
                 for (int k = 0; k < NA; k++)
                     four[nbl][k] = __builtin_amdgcn_alignbyte(k + 1 < NL ? sg[nbl][0][k + 1] : 0u, sg[nbl][0][k], sgr_sl);
             }
+#ifndef AFCM_WAVE_NO_PIN_SIGNS
+            // ... and pinned here: left to the scheduler the funnel shifts sank below the flush, so the wait for the codes (vmcnt is in
+            // order and the count must hold on the path without a flush: 0) also drained the four output stores issued a moment
+            // before, every fourth group, and the next request left half a group late.  (An empty asm with a memory clobber: the
+            // shifts are done above it, every store and load of the group stays below it; sched_barrier alone binds one scheduler)
+#pragma unroll
+            for (int nbl = 0; nbl < G::NBG; nbl++)
+#pragma unroll
+                for (int k = 0; k < NA; k++) asm volatile("" : "+v"(four[nbl][k]) : : "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#endif
         }
         // the window of group PGRP (k - 1) + 1 is the first to reach into piece k: park it (requested PGRP groups ago, or before
         // the loop) and request piece k + 1 into the same registers; then this group's fragments; then the stores of the 64-column
@@ -537,6 +563,9 @@ __global__ __launch_bounds__(256, (DOWN == 2 && (TOH <= 32 || SIGN == AFCM_SIGNS
             // register copies that wait for the window just requested)
             load_signs((gi + 1) * G::NBG, sg[0]);
             load_signs((gi + 1) * G::NBG + 1, sg[1]);
+#ifndef AFCM_WAVE_NO_PIN_SIGNS
+            __builtin_amdgcn_sched_barrier(0);
+#endif
         }
 #pragma unroll
         for (int nbl = 0; nbl < G::NBG; nbl++) {
@@ -598,15 +627,26 @@ __global__ __launch_bounds__(256, (DOWN == 2 && (TOH <= 32 || SIGN == AFCM_SIGNS
             __amdgpu_buffer_rsrc_t rsw = rsx;
             if (SIGN == AFCM_SIGNS_WRITE) {
                 const int blk = (U0x >> 4) + nb;
+#ifdef AFCM_WAVE_EXPERIMENT_STORE_ALIAS   // (... and every block's codes in the tensor's first block)
+                rsw = __builtin_amdgcn_make_buffer_rsrc((void*)p.s, 0, blk < nblk ? v4_end * 256 : 0, 0x00020000);
+#else
                 rsw = __builtin_amdgcn_make_buffer_rsrc((void*)(splane + (size_t)blk * blkbytes), 0, blk < nblk ? v4_end * 256 : 0, 0x00020000);
+#endif
             }
 
             // up-y + activation.  Fast path: relu(X2) (forward) / keep-mask & X2 (backward) is the only operand kept; the linear
             // part comes from X1 through the composite operator.  Exact path: the activated value itself.
             u32x4 rv[G::NPAIR];
-            unsigned wc[4 * NA];          // WRITE: per tile the sign bits (fast path: bits 0, 4, 16, 20 = rows 0, 2, 1, 3) / the code byte (exact)
+            unsigned wc[4 * NA];          // WRITE, exact path: per tile the code byte
+            // WRITE, fast path: per PAIR of tiles (2 i, 2 i + 1) the sign bytes (0xff = negative) of rows 0, 1 (sa) and 2, 3 (sb) as
+            // [even tile, odd tile][row]: ONE v_perm_b32 with the sign-extending selectors (8 .. 11) per packed dword pair -- r03
+            // shifted the sign bits out per dword (two v_pk_lshrrev + a v_lshl_or per tile) and then folded bytes pairwise
+            // (perm, shift, or): 19 vector instructions per code dword against 12 now
+            unsigned sa[2 * NA], sb[2 * NA], ev0 = 0, ev1 = 0;
 #pragma unroll
             for (int i = 0; i < 4 * NA; i++) wc[i] = 0;
+#pragma unroll
+            for (int i = 0; i < 2 * NA; i++) sa[i] = sb[i] = 0;
 #pragma unroll
             for (int vb = 0; vb < 2 * G::NPAIR; vb++) {
                 unsigned r0 = 0, r1 = 0;
@@ -637,7 +677,20 @@ __global__ __launch_bounds__(256, (DOWN == 2 && (TOH <= 32 || SIGN == AFCM_SIGNS
                         const unsigned d0 = pack2<T>(x2[0], x2[1]), d1 = pack2<T>(x2[2], x2[3]);
                         r0 = relu_pk(d0);
                         r1 = relu_pk(d1);
-                        if (SIGN == AFCM_SIGNS_WRITE && vb < NVW) wc[vb] = (signs_pk(d1) << 4) | signs_pk(d0);
+                        if (SIGN == AFCM_SIGNS_WRITE && vb < NVW) {
+                            // selectors: 8 / 9 = sign of the low / high half of the second operand, 10 / 11 = of the first
+                            if ((vb & 1) == 0) {
+                                ev0 = d0;
+                                ev1 = d1;
+                                if (vb == NVW - 1) {
+                                    sa[vb >> 1] = __builtin_amdgcn_perm(0u, d0, 0x0c090c08u);
+                                    sb[vb >> 1] = __builtin_amdgcn_perm(0u, d1, 0x0c090c08u);
+                                }
+                            } else {
+                                sa[vb >> 1] = __builtin_amdgcn_perm(d0, ev0, 0x0b090a08u);
+                                sb[vb >> 1] = __builtin_amdgcn_perm(d1, ev1, 0x0b090a08u);
+                            }
+                        }
                     } else {
                         unsigned wcode = 0;
 #pragma unroll
@@ -663,17 +716,12 @@ __global__ __launch_bounds__(256, (DOWN == 2 && (TOH <= 32 || SIGN == AFCM_SIGNS
                 for (int d = 0; d < cdiv(NVW, 4); d++) {
                     unsigned dw;
                     if (!EXACT) {
-                        // sign bits -> code bytes, two tiles at a time: bytes (b0, b2) of a tile hold rows (0, 2) and (1, 3) at bits
-                        // (0, 4); gathered pairwise, x | x >> 6 drops rows (1, 3) onto bits (2, 6) of the bytes of rows (0, 2)
-                        const unsigned p01 = __builtin_amdgcn_perm(wc[4 * d + 1], wc[4 * d], 0x06040200u);
-                        const unsigned q01 = p01 | (p01 >> 6);
-                        if (4 * d + 2 < NVW) {
-                            const unsigned p23 = __builtin_amdgcn_perm(wc[4 * d + 3], wc[4 * d + 2], 0x06040200u);
-                            const unsigned q23 = p23 | (p23 >> 6);
-                            dw = __builtin_amdgcn_perm(q23, q01, 0x06040200u);
-                        } else {
-                            dw = __builtin_amdgcn_perm(0u, q01, 0x0c0c0200u);
-                        }
+                        // sa / sb of the tile pairs (2 d, 2 d + 1): [tile][row] -> one dword per row with a byte per tile, then bit 2 r
+                        // of every byte from row r (code 1 = negative)
+                        const unsigned a0 = sa[2 * d], a1 = sa[2 * d + 1], b0 = sb[2 * d], b1 = sb[2 * d + 1];
+                        const unsigned r0 = __builtin_amdgcn_perm(a1, a0, 0x05040100u), r1 = __builtin_amdgcn_perm(a1, a0, 0x07060302u);
+                        const unsigned r2 = __builtin_amdgcn_perm(b1, b0, 0x05040100u), r3 = __builtin_amdgcn_perm(b1, b0, 0x07060302u);
+                        dw = (r0 & 0x01010101u) | (r1 & 0x04040404u) | (r2 & 0x10101010u) | (r3 & 0x40404040u);
                     } else {
                         const unsigned p01 = __builtin_amdgcn_perm(wc[4 * d + 1], wc[4 * d], 0x0c0c0400u);
                         const unsigned p23 = __builtin_amdgcn_perm(wc[4 * d + 3], wc[4 * d + 2], 0x0c0c0400u);
@@ -751,14 +799,29 @@ __global__ __launch_bounds__(256, (DOWN == 2 && (TOH <= 32 || SIGN == AFCM_SIGNS
         // the first down-x pass runs in group NDVK - 1 >= 1: when that is group 1 its skip rows are requested here (group 0 does
         // it itself for later ones)
         static_assert(G::NDVK - 1 >= 1, "the first down-x pass must not be in group 0");
+        if constexpr (G::NHIST == 1) {
+            // down 2: the pair a group produces is the next group's history -- two groups per iteration with the two register sets
+            // trading places instead of a copy per group (8 v_mov), and the parity of gi (which groups park a piece) static
+            typedef u32x4 (&as_hist)[G::NOB][1];
+            u32x4 alt[G::NOB];
+#pragma unroll
+            for (int ob = 0; ob < G::NOB; ob++) alt[ob] = hist[ob][0];
 #pragma unroll 1
-        for (int gi = 0; gi < ng; gi++) {
-            group(gi, exact_c, lasty_c, raw, sg, hist, cur, skw, amax, anyc);
+            for (int gi = 0; gi < ng; gi += 2) {
+                group(gi, exact_c, lasty_c, raw, sg, reinterpret_cast<as_hist>(alt), cur, skw, amax, anyc);
+                if (gi + 1 >= ng) break;
+                group(gi + 1, exact_c, lasty_c, raw, sg, reinterpret_cast<as_hist>(cur), alt, skw, amax, anyc);
+            }
+        } else {
+#pragma unroll 1
+            for (int gi = 0; gi < ng; gi++) {
+                group(gi, exact_c, lasty_c, raw, sg, hist, cur, skw, amax, anyc);
 #pragma unroll
-            for (int ob = 0; ob < G::NOB; ob++) {
+                for (int ob = 0; ob < G::NOB; ob++) {
 #pragma unroll
-                for (int h = 0; h + 1 < G::NHIST; h++) hist[ob][h] = hist[ob][h + 1];
-                hist[ob][G::NHIST - 1] = cur[ob];
+                    for (int h = 0; h + 1 < G::NHIST; h++) hist[ob][h] = hist[ob][h + 1];
+                    hist[ob][G::NHIST - 1] = cur[ob];
+                }
             }
         }
         flush(ncb - 1);                                   // the last group completed the last column block
