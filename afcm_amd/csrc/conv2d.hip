@@ -988,206 +988,6 @@ __global__ __launch_bounds__(256, 2) void conv2d_fwd16s2_kernel(ConvParams p) {
 
 
 // ---------------------------------------------------------------------------------------------
-// 16-bit 3x3 forward / data-gradient kernel, r03 "direct" structure: NO LDS in the K loop.  conv2d_fwd16_kernel's measured limiter is
-// the register -> LDS transpose NCHW forces on the activation patch (ablations above: +19 % without the four transposing
-// ds_write_b128, +38 % without the activation path).  An MFMA B fragment wants 8 consecutive CHANNELS of one pixel per lane; NCHW
-// hands a lane consecutive PIXELS of one channel.  Here a lane owns a PAIR of horizontally adjacent output pixels (2p, 2p + 1):
-// per tap row ky and channel it loads the two aligned dwords covering input pixels 2p - pad .. 2p - pad + 3, and v_perm_b32 of the
-// dwords of channels (c, c + 1) yields the fragment dword (c, c + 1) of any of the four pixel "phases" q = 0..3.  The MFMA of tap
-// (ky, kx) on the even pixels takes phase kx, the one on the odd pixels phase kx + 1: 16 dword loads and 16 perms feed the 6 (kx,
-// parity) x MI MFMAs of a tap row, no barrier, no LDS queue to wait on, no bank conflicts; the patch's reuse across taps and waves
-// is left to the L1 (a wave re-requests each input row once per ky).  Accumulator column blocks = (pair block ti, parity e);
-// the epilogue packs the two parities of a lane into the dword it stores.  Same tile (BM_O x 256 pixels = 128 pairs, waves
-// 2(o) x 2(pair halves)), same packed weights and 3-tap register ring as conv2d_fwd16_kernel.  Needs an even pad (0 / 2: every
-// conv of the generator) and even widths.
-template <typename T, int BM_O>
-__global__ __launch_bounds__(256, 2) void conv2d_fwd16d_kernel(ConvParams p) {
-    static_assert(sizeof(T) == 2, "16-bit types only");
-    typedef ConvCfg<T> C;
-    constexpr int KS = 3, KK = 9, BK = C::BK, MI = BM_O / 64, RING = 3;
-    typedef typename std::conditional<std::is_same<T, bf16_t>::value, bf16x8, f16x8>::type frag_t;
-    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wo = wave & 1, wpx = wave >> 1;
-    const int r32 = lane & 31, h = lane >> 5;
-
-    int bid = blockIdx.x;
-    {
-        const int total = gridDim.x;
-        bid = xcd_order(bid, total);
-    }
-    const int tx = __builtin_amdgcn_readfirstlane(bid % p.tilesX); bid /= p.tilesX;
-    const int ty = __builtin_amdgcn_readfirstlane(bid % p.tilesY); bid /= p.tilesY;
-    const int n = __builtin_amdgcn_readfirstlane(bid % p.N);
-    const int ob = __builtin_amdgcn_readfirstlane(bid / p.N);
-    const int y0 = ty * p.TH, x0 = tx * p.TW;
-    const int o0 = ob * BM_O;
-    const int TWP = p.TW >> 1;
-
-    const T* xn = (const T*)p.x + (size_t)n * p.Cin * p.H * p.ldx;
-    const long long img_bytes = (long long)p.Cin * p.H * p.ldx * 2ll;
-    const int hw2 = p.H * p.ldx * 2;                                    // bytes per channel plane
-    constexpr unsigned kOob = 0x80000000u;
-
-    // this lane's two pixel pairs (ti = 0, 1): byte offsets of the dwords (A: pixels ix, ix + 1; B: ix + 2, ix + 3) of channel 8 h,
-    // per tap row; rows / column pairs outside the image and slots outside the tile get the out-of-range offset (zeros, no traffic)
-    unsigned offA[2][KS], offB[2][KS];
-    int opix[2];                                                          // output dword's element offset inside a plane, -1: not stored
-#pragma unroll
-    for (int ti = 0; ti < 2; ti++) {
-        const int js = wpx * 64 + ti * 32 + r32;
-        const int py = js / TWP, pxp = js - py * TWP;
-        const bool valid = py < p.TH;
-        const int oy = y0 + py, ox = x0 + 2 * pxp;
-        const int ix = ox - p.pad;
-        const bool aok = valid && (unsigned)ix < (unsigned)p.W, bok = valid && (unsigned)(ix + 2) < (unsigned)p.W;
-        opix[ti] = (valid && oy < p.P && ox < p.Q) ? oy * p.ldy + ox : -1;
-#pragma unroll
-        for (int ky = 0; ky < KS; ky++) {
-            const int iy = oy - p.pad + ky;
-            const bool rowok = (unsigned)iy < (unsigned)p.H;
-            const unsigned base = (unsigned)(((h * 8 * p.H + (rowok ? iy : 0)) * p.ldx + ix) * 2);
-            offA[ti][ky] = (rowok && aok) ? base : kOob;
-            offB[ti][ky] = (rowok && bok) ? base + 4u : kOob;
-        }
-    }
-
-    f32x16 acc[MI][4];                                                    // [mi][2 ti + parity]
-#pragma unroll
-    for (int mi = 0; mi < MI; mi++)
-#pragma unroll
-        for (int nb = 0; nb < 4; nb++)
-#pragma unroll
-            for (int e = 0; e < 16; e++) acc[mi][nb][e] = 0.f;
-
-    const T* wlane = (const T*)p.wp + (size_t)(o0 + wo * (BM_O / 2) + r32) * BK + h * 8;
-    const size_t wtap = (size_t)p.Opad * BK;
-    auto load_a = [&](int kc, int tap, int mi) __attribute__((always_inline)) {
-        return *(const frag_t*)(wlane + ((size_t)kc * KK + tap) * wtap + mi * 32 * BK);
-    };
-
-    // loads of one tap row of chunk kc: 8 channels x 2 dwords per pixel pair.  The chunk's first channel rides in the descriptor's
-    // base, the channel inside the lane's eight in the scalar offset (no vector arithmetic per load); the scalar offset is outside
-    // the descriptor's range check, so channels past Cin (last chunk of a layer whose Cin is not a multiple of 16) get the
-    // out-of-range offset instead (one compare per channel and row, one select per load).
-    unsigned raw[2][8][2];
-    auto issue_row = [&](int kc, int ky) __attribute__((always_inline)) {
-        const long long skip = (long long)kc * BK * hw2;
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)xn + skip), 0, (int)(img_bytes - skip), 0x00020000);
-        const int rem = p.Cin - kc * BK - h * 8;
-#pragma unroll
-        for (int ti = 0; ti < 2; ti++)
-#pragma unroll
-            for (int c = 0; c < 8; c++) {
-                raw[ti][c][0] = __builtin_amdgcn_raw_buffer_load_b32(rs, c < rem ? offA[ti][ky] : kOob, c * hw2, 0);
-                raw[ti][c][1] = __builtin_amdgcn_raw_buffer_load_b32(rs, c < rem ? offB[ti][ky] : kOob, c * hw2, 0);
-            }
-    };
-    // fragments of the four pixel phases of a pair: dword r of phase q = channels (2r, 2r + 1) at pixel q
-    union FragU { u32x4 u; frag_t f; };
-    auto build = [&](int ti, FragU (&bf)[4]) __attribute__((always_inline)) {
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const unsigned sel = (q & 1) ? 0x07060302u : 0x05040100u;
-#pragma unroll
-            for (int r = 0; r < 4; r++) bf[q].u[r] = __builtin_amdgcn_perm(raw[ti][2 * r + 1][q >> 1], raw[ti][2 * r][q >> 1], sel);
-        }
-    };
-
-    frag_t ar[RING][MI];
-    issue_row(0, 0);
-#pragma unroll
-    for (int t = 0; t < RING; t++)
-#pragma unroll
-        for (int mi = 0; mi < MI; mi++) ar[t][mi] = load_a(0, t, mi);
-
-    const int last = p.nkc - 1;
-    for (int kc = 0; kc < p.nkc; kc++) {
-        const bool more = kc < last;
-#pragma unroll
-        for (int ky = 0; ky < KS; ky++) {
-            FragU bf[2][4];
-            build(0, bf[0]);
-            build(1, bf[1]);
-            __builtin_amdgcn_sched_group_barrier(0x002, 32, 0);
-            // next tap row (past the last chunk: the same chunk again, results unused -- no branch around loads in the loop)
-            if (ky + 1 < KS) issue_row(kc, ky + 1);
-            else issue_row(more ? kc + 1 : kc, 0);
-#pragma unroll
-            for (int kx = 0; kx < KS; kx++) {
-                const int tap = ky * KS + kx;
-#pragma unroll
-                for (int ti = 0; ti < 2; ti++)
-#pragma unroll
-                    for (int e = 0; e < 2; e++)
-#pragma unroll
-                        for (int mi = 0; mi < MI; mi++) {
-                            if constexpr (std::is_same<T, bf16_t>::value)
-                                acc[mi][2 * ti + e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[kx][mi], bf[ti][kx + e].f, acc[mi][2 * ti + e], 0, 0, 0);
-                            else
-                                acc[mi][2 * ti + e] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ar[kx][mi], bf[ti][kx + e].f, acc[mi][2 * ti + e], 0, 0, 0);
-                        }
-                // the slot's next occupant (three taps ahead), requested as soon as the slot's last MFMA has issued
-                {
-                    const int nt = (tap + RING) % KK;
-                    const int nk = (tap + RING < KK) ? kc : (more ? kc + 1 : kc);
-#pragma unroll
-                    for (int mi = 0; mi < MI; mi++) ar[kx][mi] = load_a(nk, nt, mi);
-                }
-                // pin the issue order (left alone, the scheduler sinks the ring refills next to their uses: every tap then waits a
-                // full L2 round trip): the tap's MFMAs with the next tap row's loads and their offset selects (32 + 32 per step)
-                // spread under the first two taps, then the refill
-                if (kx < 2) {
-#pragma unroll
-                    for (int j = 0; j < 4 * MI; j++) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x002, 4 / MI, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x020, 4 / MI, 0);
-                    }
-                } else {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 4 * MI, 0);
-                }
-                __builtin_amdgcn_sched_group_barrier(0x020, MI, 0);
-            }
-        }
-    }
-
-    // ---- epilogue: D[row = channel][col = pixel pair slot]; row = (reg & 3) + 8 (reg >> 2) + 4 h within the 32-row block.  A lane
-    // holds both pixels of its pair (the two parity accumulators): one dword store per channel and pair.
-    T* yn = (T*)p.y + (size_t)n * p.Cout * p.P * p.ldy;
-    const float* osn = p.oscale ? p.oscale + (size_t)n * p.Cout : nullptr;
-    const int pq = p.P * p.ldy;
-#pragma unroll
-    for (int mi = 0; mi < MI; mi++) {
-        float sc[16], obv[16];
-        const int obase = o0 + wo * (BM_O / 2) + mi * 32 + 4 * h;
-#pragma unroll
-        for (int reg = 0; reg < 16; reg++) { sc[reg] = 1.f; obv[reg] = 0.f; }
-        if (osn != nullptr) {
-#pragma unroll
-            for (int reg = 0; reg < 16; reg++) sc[reg] = osn[min(obase + (reg & 3) + 8 * (reg >> 2), p.Cout - 1)];
-        }
-        if (p.obias != nullptr) {
-#pragma unroll
-            for (int reg = 0; reg < 16; reg++) obv[reg] = p.obias[min(obase + (reg & 3) + 8 * (reg >> 2), p.Cout - 1)];
-        }
-#pragma unroll
-        for (int reg = 0; reg < 16; reg++) {
-            const int o = obase + (reg & 3) + 8 * (reg >> 2);
-            if (o < p.Cout) {
-                T* yo = yn + (size_t)o * pq;
-#pragma unroll
-                for (int ti = 0; ti < 2; ti++)
-                    if (opix[ti] >= 0)
-                        *(unsigned*)(yo + opix[ti]) = pack2<T>(acc[mi][2 * ti][reg] * sc[reg] + obv[reg], acc[mi][2 * ti + 1][reg] * sc[reg] + obv[reg]);
-            }
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
 // Weight packing: w[O][I][KS][KS] (fp32) -> [nkc][KK][Opad][BK] of T, zero padded.
 //   mode 0 (forward):        dst[kc][r*KS+s][o][kk]  = w[o][kc*BK+kk][r][s]
 //   mode 1 (data gradient):  roles of O and I swap and taps flip:
@@ -1863,372 +1663,6 @@ __device__ __forceinline__ i32x4 make_rsrc(const void* base, int num_records) {
     return r;
 }
 
-// ---------------------------------------------------------------------------------------------
-// 16-bit 3x3 forward / data-gradient kernel, r03 "gather" structure: the activation patch reaches LDS by LDS-DMA, the wave's own
-// instruction stream never touches it on the way in.  conv2d_fwd16_kernel loads the patch into registers, transposes it there
-// (NCHW hands a lane consecutive pixels of one channel, an MFMA B fragment wants 8 channels of one pixel) and writes it with four
-// ds_write_b128 per thread and chunk -- the measured limiter (ablations above).  LDS-DMA cannot transpose, but the transposition
-// can be split: the DMA brings 16-byte pieces (4 pixel PAIRS of one channel) with lane = (channel c of 16, piece ql of 4), so one
-// instruction lays down [channel][4 pieces][4 pairs] = 1 KB of a patch row; a lane that needs pair P of 8 channels reads 8 dwords
-// 64 bytes apart (four ds_read2_b32: dwords of channels (c, c + 1) land in adjacent registers), and the last step, 2 pixels x (c,
-// c + 1) -> (c, c + 1) of one pixel, is one v_perm_b32 per fragment dword -- the "pixel phase" scheme of conv2d_fwd16d_kernel: a
-// lane owns an output pixel pair, reads the two input pairs that cover the four pixels 2p - pad .. 2p - pad + 3 of a tap row, builds
-// the four phase fragments (16 perms) and feeds the tap row's 3 (kx) x 2 (parity) x MI MFMAs.  Rows outside the image and channels
-// past Cin are out-of-range offsets (the DMA writes zeros); the patch starts 8 pixels left of the tile, so at the left image edge
-// whole pieces fall outside; the one piece column that straddles the RIGHT edge is trimmed in LDS by the wave that fetched it
-// (tiles of the last tile column only).  Per chunk and wave: <= 6 DMA instructions, 48 ds_read2_b32, 96 v_perm (the ~20 staging
-// instructions, 8 global loads and 4 ds_write_b128 are gone), ONE barrier, placed three taps before the chunk ends so that the
-// next chunk's first tap row is read and permuted under the last MFMAs.  Blocks of 4 pieces x 16 channels (1 KB) sit 1088 B
-// apart: 32 lanes with consecutive pairs hit 32 different banks.
-// (First version: dword pieces, lane = (pair, channel), [pair][channel] rows read by ds_read_b128 -- 16 instructions per wave and
-// chunk, each touching 16 cache lines: 35 % of the kernel's time, 0.88-1.01 PF/s against 1.35-1.56 without the DMA.)
-constexpr int kGatherNI = 6;                         // DMA instructions per wave and chunk (blocks: 4 x 6 = 24 per buffer)
-constexpr int kGatherBlock = 1088;                   // bytes between blocks of [16 channels][4 pieces][16 B]
-constexpr int kGatherBuf = 4 * kGatherNI * kGatherBlock;
-__host__ __device__ inline int gather_quads(int TW, int pad) { return (TW + 9 - pad) / 8 + 1; }   // 8-pixel pieces per patch row
-template <typename T, int BM_O>
-__global__ __launch_bounds__(256, 2) void conv2d_fwd16g_kernel(ConvParams p) {
-    static_assert(sizeof(T) == 2 && BM_O == 128, "16-bit types, 128-row blocks");
-    typedef ConvCfg<T> C;
-    constexpr int KS = 3, KK = 9, BK = C::BK, MI = BM_O / 64, RING = 3, NI = kGatherNI;
-    typedef typename std::conditional<std::is_same<T, bf16_t>::value, bf16x8, f16x8>::type frag_t;
-    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * kGatherBuf];
-    const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) void*)lds;
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wo = wave & 1, wpx = wave >> 1;
-    const int r32 = lane & 31, h = lane >> 5;
-
-    int bid = blockIdx.x;
-    {
-        const int total = gridDim.x;
-        bid = xcd_order(bid, total);
-    }
-    const int tx = __builtin_amdgcn_readfirstlane(bid % p.tilesX); bid /= p.tilesX;
-    const int ty = __builtin_amdgcn_readfirstlane(bid % p.tilesY); bid /= p.tilesY;
-    const int n = __builtin_amdgcn_readfirstlane(bid % p.N);
-    const int ob = __builtin_amdgcn_readfirstlane(bid / p.N);
-    const int y0 = ty * p.TH, x0 = tx * p.TW;
-    const int o0 = ob * BM_O;
-    const int TWP = p.TW >> 1;
-    const int PH = p.TH + KS - 1;
-    const int NB = (gather_quads(p.TW, p.pad) + 3) >> 2;                  // blocks of 4 pieces per patch row
-    const int px_org = x0 - 8;                                            // first patch pixel
-    const int PB = (8 - p.pad) >> 1;                                      // patch pair of the first input pixel of output pair 0
-
-    const T* xn = (const T*)p.x + (size_t)n * p.Cin * p.H * p.ldx;
-    const long long img_bytes = (long long)p.Cin * p.H * p.ldx * 2ll;
-    const int hw2 = p.H * p.ldx * 2;
-    constexpr unsigned kOob = 0x80000000u;
-
-    // DMA lane offsets (fixed for the kernel): instruction i of wave w fills block 4 i + w = (row, block of the row); lane = (channel
-    // c, piece ql); the piece that straddles the right image edge keeps `cut` = its number of valid pairs (4: nothing to trim)
-    unsigned voff[NI];
-    bool any_cut = false;
-    const int dc = lane >> 2, dql = lane & 3;
-#pragma unroll
-    for (int i = 0; i < NI; i++) {
-        const int idx = 4 * i + wave;
-        const int row = idx / NB, blk = idx - row * NB;
-        const int iy = y0 - p.pad + row, ix = px_org + 8 * (4 * blk + dql);
-        const bool ok = row < PH && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-        voff[i] = ok ? (unsigned)(((dc * p.H + iy) * p.ldx + ix) * 2) : kOob;
-        any_cut |= ok && ix + 8 > p.W;
-    }
-    const bool edge_tile = __builtin_amdgcn_readfirstlane(__ballot(any_cut) != 0ull) != 0;   // wave-uniform
-    // chunk kc -> buffer kc & 1; channels past Cin (and every chunk past the last) fall outside the descriptor
-    auto issue_dma = [&](int kc) __attribute__((always_inline)) {
-        const long long skip = (long long)kc * BK * hw2;
-        const long long left = img_bytes - skip;
-        const i32x4 rs = make_rsrc((const char*)xn + skip, left > 0 ? (int)left : 0);
-        const unsigned dst = lds0 + (kc & 1) * kGatherBuf + wave * kGatherBlock;
-#pragma unroll
-        for (int i = 0; i < NI; i++) lds_dma_b128(rs, voff[i], dst + i * (4 * kGatherBlock));
-    };
-    // pairs right of the image inside this wave's straddling pieces (next row's head or padding in memory) -> zero.  Runs after the
-    // wave's own DMA has landed and before the barrier that publishes the buffer; tiles of the last tile column only.
-    auto trim = [&](int buf) __attribute__((always_inline)) {
-        if (edge_tile) {
-#pragma unroll
-            for (int i = 0; i < NI; i++) {
-                const int idx = 4 * i + wave;
-                const int blk = idx % NB;
-                const int ix = px_org + 8 * (4 * blk + dql);
-                const int valid = (p.W - ix) >> 1;                        // pairs of the piece inside the row
-                if (voff[i] != kOob && valid < 4) {
-                    unsigned* piece = (unsigned*)(lds + buf * kGatherBuf + idx * kGatherBlock + lane * 16);
-#pragma unroll
-                    for (int k = 1; k < 4; k++)
-                        if (k >= valid) piece[k] = 0u;
-                }
-            }
-        }
-    };
-
-    // B reads: this lane's two pixel pairs (ti = 0, 1), each needs the patch pairs pxp + PB and pxp + PB + 1 of rows py + ky: byte
-    // offset of the dword of channel 8 h in those pairs at ky = 0 (channels: + 64 bytes each)
-    unsigned boff[2][2];
-    int jslot[2];
-#pragma unroll
-    for (int ti = 0; ti < 2; ti++) {
-        const int js = wpx * 64 + ti * 32 + r32;
-        int py = js / TWP, pxp = js - py * TWP;
-        if (py >= p.TH) { py = 0; pxp = 0; }                            // slots outside the tile: any valid address, never stored
-        jslot[ti] = js;
-#pragma unroll
-        for (int j = 0; j < 2; j++) {
-            const int pp = pxp + PB + j, q = pp >> 2;
-            boff[ti][j] = (unsigned)((py * NB + (q >> 2)) * kGatherBlock + h * 512 + (q & 3) * 16 + (pp & 3) * 4);
-        }
-    }
-    const unsigned rowstride = (unsigned)(NB * kGatherBlock);
-
-    f32x16 acc[MI][4];                                                    // [mi][2 ti + parity]
-#pragma unroll
-    for (int mi = 0; mi < MI; mi++)
-#pragma unroll
-        for (int nb = 0; nb < 4; nb++)
-#pragma unroll
-            for (int e = 0; e < 16; e++) acc[mi][nb][e] = 0.f;
-
-    const T* wlane = (const T*)p.wp + (size_t)(o0 + wo * (BM_O / 2) + r32) * BK + h * 8;
-    const size_t wtap = (size_t)p.Opad * BK;
-    auto load_a = [&](int kc, int tap, int mi) __attribute__((always_inline)) {
-        return *(const frag_t*)(wlane + ((size_t)kc * KK + tap) * wtap + mi * 32 * BK);
-    };
-
-    // Rolling operand pipeline, one tap = 4 MI MFMAs + 8 v_perm (+ 4 ds_read_b128 on two taps of three):
-    //   phase q of a tap row is used by tap kx = q (even pixels) and kx = q - 1 (odd pixels); it is rebuilt for the NEXT row as soon
-    //   as its last tap has issued: phases 0 / 1 (from pair j = 0 of the next row) under taps kx = 1 / 2, phases 2 / 3 (pair j = 1 of
-    //   the row itself) under taps kx = 0 / 1 of that row; the raw pair j = 0 of the next row is read under tap kx = 0, pair j = 1
-    //   under tap kx = 2, each one tap before its first perm.  32 fragment + 32 raw registers, nothing waits on LDS.
-    unsigned raw[2][2][8];                                                // [pair j][ti][channel of the lane's eight]: 2 pixels each
-    auto read_pair = [&](int buf, int ky, int j) __attribute__((always_inline)) {
-        const unsigned char* b = lds + buf * kGatherBuf;
-        const unsigned ro = (unsigned)ky * rowstride;
-#pragma unroll
-        for (int ti = 0; ti < 2; ti++)
-#pragma unroll
-            for (int c = 0; c < 8; c++) {
-#ifdef AFCM_GATHER_EXPERIMENT_NOREAD
-                asm volatile("" : "+v"(raw[j][ti][c]) : "v"(b + (boff[ti][j] + ro)));
-#else
-                raw[j][ti][c] = *(const unsigned*)(b + (boff[ti][j] + ro) + 64 * c);
-#endif
-            }
-    };
-    union FragU { u32x4 u; frag_t f; };
-    FragU bf[2][4];                                                       // [ti][phase]
-    auto build = [&](int q) __attribute__((always_inline)) {
-        const unsigned sel = (q & 1) ? 0x07060302u : 0x05040100u;
-#pragma unroll
-        for (int ti = 0; ti < 2; ti++)
-#pragma unroll
-            for (int r = 0; r < 4; r++)
-#ifdef AFCM_GATHER_EXPERIMENT_NOPERM
-                bf[ti][q].u[r] = raw[q >> 1][ti][2 * r + (q & 1)];
-#else
-                bf[ti][q].u[r] = __builtin_amdgcn_perm(raw[q >> 1][ti][2 * r + 1], raw[q >> 1][ti][2 * r], sel);
-#endif
-    };
-
-    issue_dma(0);
-    frag_t ar[RING][MI];
-#pragma unroll
-    for (int t = 0; t < RING; t++)
-#pragma unroll
-        for (int mi = 0; mi < MI; mi++) ar[t][mi] = load_a(0, t, mi);
-    asm volatile("s_waitcnt vmcnt(0)");
-    trim(0);
-    __syncthreads();
-    read_pair(0, 0, 0);
-    read_pair(0, 0, 1);
-    build(0);
-    build(1);
-
-    const int last = p.nkc - 1;
-    for (int kc = 0; kc < p.nkc; kc++) {
-        const bool more = kc < last;
-#ifndef AFCM_GATHER_EXPERIMENT_NODMA   // timing experiments only (wrong results)
-        issue_dma(kc + 1);                                                // into the buffer everyone left at the last barrier
-#endif
-        static_for<0, KK>([&](auto tapc) __attribute__((always_inline)) {
-            constexpr int tap = decltype(tapc)::value, ky = tap / KS, kx = tap % KS;
-            if constexpr (tap == 6) {
-                // the next chunk's patch: every wave's DMA has landed (issued before this chunk's first ring refill, so all but the
-                // loads of the last taps are younger) and nobody reads its old contents any more
-                asm volatile("s_waitcnt vmcnt(%0)" : : "n"(3 * MI));
-                trim((kc + 1) & 1);
-                __syncthreads();
-            }
-            frag_t a[MI];
-#pragma unroll
-            for (int mi = 0; mi < MI; mi++) a[mi] = ar[kx][mi];
-            {
-                constexpr int nt = (tap + RING) % KK;
-                const int nk = (tap + RING < KK) ? kc : (more ? kc + 1 : kc);
-#pragma unroll
-                for (int mi = 0; mi < MI; mi++) ar[kx][mi] = load_a(nk, nt, mi);
-            }
-            // the next row's raw pairs (ky = 2: the next chunk's first row, from the other buffer)
-            if constexpr (kx == 0) read_pair(ky == 2 ? (kc + 1) & 1 : kc & 1, (ky + 1) % KS, 0);
-#pragma unroll
-            for (int ti = 0; ti < 2; ti++)
-#pragma unroll
-                for (int e = 0; e < 2; e++)
-#pragma unroll
-                    for (int mi = 0; mi < MI; mi++) {
-                        if constexpr (std::is_same<T, bf16_t>::value)
-                            acc[mi][2 * ti + e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], bf[ti][kx + e].f, acc[mi][2 * ti + e], 0, 0, 0);
-                        else
-                            acc[mi][2 * ti + e] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mi], bf[ti][kx + e].f, acc[mi][2 * ti + e], 0, 0, 0);
-                    }
-            if constexpr (kx == 0) build(2);
-            if constexpr (kx == 1) { build(3); build(0); }
-            if constexpr (kx == 2) { build(1); read_pair(ky == 2 ? (kc + 1) & 1 : kc & 1, (ky + 1) % KS, 1); }
-            // issue order of the tap: ring refill, then the MFMAs with the LDS reads and permutes between them
-            __builtin_amdgcn_sched_group_barrier(0x020, MI, 0);
-            if constexpr (kx == 0) {
-#pragma unroll
-                for (int j = 0; j < 4 * MI; j++) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                }
-            } else if constexpr (kx == 1) {
-#pragma unroll
-                for (int j = 0; j < 4 * MI; j++) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 16 / (4 * MI), 0);
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4 * MI; j++) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                }
-            }
-        });
-    }
-    asm volatile("s_waitcnt vmcnt(0)");
-    __syncthreads();                                                      // the patch buffers become the epilogue's staging area
-
-    // ---- epilogue: as conv2d_fwd16_kernel; accumulator column block (ti, e) holds the tile's pixel slots 2 (wpx 64 + 32 ti + r32) + e
-    T* yn = (T*)p.y + (size_t)n * p.Cout * p.P * p.ldy;
-    const float* osn = p.oscale ? p.oscale + (size_t)n * p.Cout : nullptr;
-    const int pq = p.P * p.ldy;
-    if ((p.TW & 7) == 0) {
-        typedef __attribute__((ext_vector_type(4))) short s16x4;
-        constexpr int EROW = 64;
-        unsigned char* ebuf = lds + wave * (128 * EROW);
-        const int i16 = lane & 15, chalf = (lane >> 4) & 1, hh = lane >> 5;
-        const int q4 = i16 >> 2, p4 = i16 & 3;
-        unsigned rd_off[2];
-#pragma unroll
-        for (int r = 0; r < 2; r++) {
-            const int prow = 8 * hh + 4 * r + q4;
-            rd_off[r] = prow * EROW + (((chalf * 4 + p4) ^ ((prow >> 1) & 7)) << 3);
-        }
-        int goff[8];
-        unsigned gfullm = 0;
-        int gxv[8];
-#pragma unroll
-        for (int it = 0; it < 8; it++) {
-            const int j0 = wpx * 128 + (2 * it + hh) * 8;
-            const int gpy = (int)__umulhi((unsigned)j0, p.magicTW), gpx = j0 - gpy * p.TW;
-            const int gy = y0 + gpy, gx = x0 + gpx;
-            goff[it] = (j0 < p.TH * p.TW && gy < p.P && gx < p.Q) ? gy * p.ldy + gx : -1;
-            gxv[it] = gx;
-            if (gx + 8 <= p.ldy) gfullm |= 1u << it;
-        }
-#pragma unroll
-        for (int mi = 0; mi < MI; mi++) {
-            float sc[16], obv[16];
-            const int obase = o0 + wo * (BM_O / 2) + mi * 32 + 4 * h;
-#pragma unroll
-            for (int reg = 0; reg < 16; reg++) { sc[reg] = 1.f; obv[reg] = 0.f; }
-            if (osn != nullptr) {
-#pragma unroll
-                for (int reg = 0; reg < 16; reg++) sc[reg] = osn[min(obase + (reg & 3) + 8 * (reg >> 2), p.Cout - 1)];
-            }
-            if (p.obias != nullptr) {
-#pragma unroll
-                for (int reg = 0; reg < 16; reg++) obv[reg] = p.obias[min(obase + (reg & 3) + 8 * (reg >> 2), p.Cout - 1)];
-            }
-#pragma unroll
-            for (int nb = 0; nb < 4; nb++) {
-                const int pix = 2 * ((nb >> 1) * 32 + r32) + (nb & 1);
-                const int sw = (pix >> 1) & 7;
-#pragma unroll
-                for (int k4 = 0; k4 < 4; k4++) {
-                    uint2 w;
-                    w.x = pack2<T>(acc[mi][nb][4 * k4 + 0] * sc[4 * k4 + 0] + obv[4 * k4 + 0], acc[mi][nb][4 * k4 + 1] * sc[4 * k4 + 1] + obv[4 * k4 + 1]);
-                    w.y = pack2<T>(acc[mi][nb][4 * k4 + 2] * sc[4 * k4 + 2] + obv[4 * k4 + 2], acc[mi][nb][4 * k4 + 3] * sc[4 * k4 + 3] + obv[4 * k4 + 3]);
-                    *(uint2*)(ebuf + pix * EROW + (((h + 2 * k4) ^ sw) << 3)) = w;
-                }
-            }
-            const int o = o0 + wo * (BM_O / 2) + mi * 32 + chalf * 16 + i16;
-            T* const yo = yn + (size_t)min(o, p.Cout - 1) * pq;
-#pragma unroll
-            for (int it = 0; it < 8; it++) {
-                union { s16x4 v[2]; uint4 q; } u;
-#pragma unroll
-                for (int r = 0; r < 2; r++)
-                    u.v[r] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ebuf + it * (16 * EROW) + rd_off[r]));
-                if (goff[it] >= 0 && o < p.Cout) {
-                    T* dst = yo + goff[it];
-                    if ((gfullm >> it) & 1) {
-                        *(uint4*)dst = u.q;
-                    } else {
-                        const unsigned vv[4] = {u.q.x, u.q.y, u.q.z, u.q.w};
-#pragma unroll
-                        for (int w2 = 0; w2 < 4; w2++)
-                            if (gxv[it] + 2 * w2 < p.Q) ((unsigned*)dst)[w2] = vv[w2];
-                    }
-                }
-            }
-        }
-        return;
-    }
-    // tile rows that are not whole 8-pixel granules: a lane holds both pixels of its pairs, one dword store per channel and pair
-    int opix[2];
-#pragma unroll
-    for (int ti = 0; ti < 2; ti++) {
-        const int py = jslot[ti] / TWP, pxp = jslot[ti] - py * TWP;
-        const int oy = y0 + py, ox = x0 + 2 * pxp;
-        opix[ti] = (py < p.TH && oy < p.P && ox < p.Q) ? oy * p.ldy + ox : -1;
-    }
-#pragma unroll
-    for (int mi = 0; mi < MI; mi++) {
-        float sc[16], obv[16];
-        const int obase = o0 + wo * (BM_O / 2) + mi * 32 + 4 * h;
-#pragma unroll
-        for (int reg = 0; reg < 16; reg++) { sc[reg] = 1.f; obv[reg] = 0.f; }
-        if (osn != nullptr) {
-#pragma unroll
-            for (int reg = 0; reg < 16; reg++) sc[reg] = osn[min(obase + (reg & 3) + 8 * (reg >> 2), p.Cout - 1)];
-        }
-        if (p.obias != nullptr) {
-#pragma unroll
-            for (int reg = 0; reg < 16; reg++) obv[reg] = p.obias[min(obase + (reg & 3) + 8 * (reg >> 2), p.Cout - 1)];
-        }
-#pragma unroll
-        for (int reg = 0; reg < 16; reg++) {
-            const int o = obase + (reg & 3) + 8 * (reg >> 2);
-            if (o < p.Cout) {
-                T* yo = yn + (size_t)o * pq;
-#pragma unroll
-                for (int ti = 0; ti < 2; ti++)
-                    if (opix[ti] >= 0)
-                        *(unsigned*)(yo + opix[ti]) = pack2<T>(acc[mi][2 * ti][reg] * sc[reg] + obv[reg], acc[mi][2 * ti + 1][reg] * sc[reg] + obv[reg]);
-            }
-        }
-    }
-}
-
 template <typename T, int KS, int XOFF, int NBUF>
 __global__ __launch_bounds__(512, 1) void conv2d_wgrad16_kernel(WgradParams p) {
     static_assert(sizeof(T) == 2, "16-bit types only");
@@ -2869,7 +2303,7 @@ static void choose_tile(int P, int Q, int KS, int* TH, int* TW, int* PWL) {
     // Tile of TH x TW output pixels with TH*TW <= 256 slots and an LDS patch (TH+KS-1) x round4(TW+KS) <= kPatchMax,
     // chosen to maximise the fraction of useful slots.
     double best = -1;
-    static const double gran_bonus = getenv("AFCM_CONV_GRAN_BONUS") ? atof(getenv("AFCM_CONV_GRAN_BONUS")) : 0.03;   // tuning aid
+    constexpr double gran_bonus = 0.03;
     for (int tw = 2; tw <= 128; tw += 2) {
         int th = kSlots / tw;
         if (th > P) th = P;
@@ -2911,25 +2345,7 @@ static int launch_conv(ConvParams p, int ks, hipStream_t st) {
     AFCM_REQUIRE(blocks > 0 && blocks < (1ll << 31), "conv2d: grid of %lld blocks is out of range", blocks);
     dim3 grid((unsigned)blocks), block(256);
     if constexpr (sizeof(T) == 2) {
-        static const bool legacy = getenv("AFCM_CONV_LEGACY") != nullptr;     // tuning aid: the r01 LDS-staged-weights kernel
-        static const char* direct_s = getenv("AFCM_CONV_DIRECT");             // experiment: 1 = the no-LDS kernel (slower, see its header)
-        const bool direct = (direct_s != nullptr && atoi(direct_s) != 0) && (p.pad & 1) == 0 && (p.W & 1) == 0 && (p.Q & 1) == 0 &&
-                            ((p.ldx | p.ldy) & 1) == 0 && (long long)p.Cin * p.H * p.ldx * 2ll < (1ll << 31);
-        static const char* gather_s = getenv("AFCM_CONV_GATHER");             // experiment: 1 = the LDS-DMA gather kernel
-        const int gather_rows = (p.TH + 2) * ((gather_quads(p.TW, p.pad) + 3) >> 2);   // 1 KB blocks in the patch
-        const bool gather = (gather_s != nullptr && atoi(gather_s) != 0) && BM_O == 128 && (p.pad & 1) == 0 && (p.W & 1) == 0 && (p.Q & 1) == 0 &&
-                            ((p.ldx | p.ldy) & 1) == 0 && (long long)p.Cin * p.H * p.ldx * 2ll < (1ll << 31) && gather_rows <= 4 * kGatherNI;
-        if constexpr (BM_O == 128) {
-            if (ks == 3 && !legacy && gather) {
-                hipLaunchKernelGGL((conv2d_fwd16g_kernel<T, BM_O>), grid, block, 0, st, p);
-                return hip_status(hipGetLastError());
-            }
-        }
-        if (ks == 3 && !legacy && direct) {
-            hipLaunchKernelGGL((conv2d_fwd16d_kernel<T, BM_O>), grid, block, 0, st, p);
-            return hip_status(hipGetLastError());
-        }
-        if (ks == 3 && !legacy) {
+        if (ks == 3) {
             hipLaunchKernelGGL((conv2d_fwd16_kernel<T, BM_O>), grid, block, 0, st, p);
             return hip_status(hipGetLastError());
         }
@@ -3072,8 +2488,7 @@ extern "C" int afcm_conv2d_ld(void* y, const void* x, const void* wpacked, const
     p.pad = pad;
     p.ldx = x_pitch ? x_pitch : w; p.ldy = y_pitch ? y_pitch : p.Q;
     if (p.ldx != w || p.ldy != p.Q) {
-        static const bool legacy16 = getenv("AFCM_CONV_LEGACY") != nullptr;
-        AFCM_REQUIRE(dtype != AFCM_F32 && ks == 3 && !legacy16, "conv2d: row pitches need the 16-bit 3x3 kernel");
+        AFCM_REQUIRE(dtype != AFCM_F32 && ks == 3, "conv2d: row pitches need the 16-bit 3x3 kernel");
         AFCM_REQUIRE(p.ldx >= w && p.ldy >= p.Q && ((p.ldx | p.ldy) & 1) == 0, "conv2d: row pitches %d / %d must be even and cover the widths %d / %d", p.ldx, p.ldy, w, p.Q);
         AFCM_REQUIRE((long long)cout * p.P * p.ldy < (1ll << 30), "conv2d: pitched output image is out of range");
     }
@@ -3084,8 +2499,7 @@ extern "C" int afcm_conv2d_ld(void* y, const void* x, const void* wpacked, const
     p.nkc = cdiv(cin, afcm_conv2d_block_k(dtype));
     hipStream_t st = (hipStream_t)stream;
     // 64-row blocks when they waste fewer padded rows than 128-row blocks
-    static const char* force = getenv("AFCM_CONV_BM");   // tuning aid: force the 64- or 128-row block
-    const bool small = force ? (atoi(force) == 64) : ((rows_pad % 128 != 0) || cout <= 64);
+    const bool small = (rows_pad % 128 != 0) || cout <= 64;
     switch (dtype) {
         case AFCM_F32: return small ? launch_conv<float, 64>(p, ks, st) : launch_conv<float, 128>(p, ks, st);
         case AFCM_F16: return small ? launch_conv<f16_t, 64>(p, ks, st) : launch_conv<f16_t, 128>(p, ks, st);
@@ -3102,8 +2516,7 @@ extern "C" int afcm_conv2d_wgrad_splits(int32_t n, int32_t cout, int32_t cin, in
     // One workgroup per CU is resident (LDS ring), so aim for ONE full round of the 256 CUs and never one workgroup more:
     // rounding up (258 workgroups = two rounds) halves the throughput, and every extra split costs a 36 x 64 x 64 x 4 B
     // partial tile written and read back (at 768 workgroups the partials of a 64 -> 64 layer were 2/3 of its time).
-    static const char* tgt = getenv("AFCM_WGRAD_WGS");            // tuning aid: workgroups to aim for
-    int splits = (tgt ? atoi(tgt) : 256) / tiles;
+    int splits = 256 / tiles;
     const long long ksteps = (long long)n * p_rows;   // upper bound on the macro-steps of any dtype
     if (splits > ksteps) splits = (int)ksteps;
     if (splits < 1) splits = 1;
@@ -3152,18 +2565,16 @@ extern "C" int afcm_conv2d_wgrad_ld(float* dw, float* workspace, const void* dy,
                             else if (small) hipLaunchKernelGGL((conv2d_wgrad16g_kernel<T, 1, NB, true>), grid, block, 0, st, p); \
                             else if (ks == 3) hipLaunchKernelGGL((conv2d_wgrad16g_kernel<T, 3, NB, false>), grid, block, 0, st, p); \
                             else hipLaunchKernelGGL((conv2d_wgrad16g_kernel<T, 1, NB, false>), grid, block, 0, st, p); } while (0)
-    static const char* wdesc = getenv("AFCM_WGRAD_DESC");           // tuning aid: "piece" = a descriptor per LDS-DMA piece (the general form)
-    const bool small = !(wdesc && !strcmp(wdesc, "piece")) && (long long)n * cout * p.P * p.lddy * 2 < (1ll << 31) - 65536 &&
+    // tensors below 2 GB: one descriptor per tensor; larger ones: a descriptor per LDS-DMA piece (the general form)
+    const bool small = (long long)n * cout * p.P * p.lddy * 2 < (1ll << 31) - 65536 &&
                        (long long)n * cin * h * p.ldx * 2 < (1ll << 31) - 65536;
-    static const char* wsel = getenv("AFCM_WGRAD_KERNEL");                 // tuning aid: "regs" (register-staged) or "dword" (4-byte LDS-DMA)
-    const bool legacy = wsel && !strcmp(wsel, "regs");
-    const bool granule = !(wsel && !strcmp(wsel, "dword")) && ((ks == 3 && pad == 2) || (ks == 1 && pad == 0));
+    const bool granule = (ks == 3 && pad == 2) || (ks == 1 && pad == 0);     // 16-byte LDS-DMA pieces; other paddings: 4-byte pieces
     // rows by pitch: the 16-byte LDS-DMA kernel only (a granule straddling x's right edge is zeroed in LDS whatever follows it)
-    AFCM_REQUIRE(!pitched || (dtype != AFCM_F32 && granule && !legacy), "conv2d_wgrad: row pitches need the 16-bit granule kernel (3x3 pad 2 or 1x1 pad 0)");
+    AFCM_REQUIRE(!pitched || (dtype != AFCM_F32 && granule), "conv2d_wgrad: row pitches need the 16-bit granule kernel (3x3 pad 2 or 1x1 pad 0)");
     switch (dtype) {
         case AFCM_F32: AFCM_WG(float, 1); break;
-        case AFCM_F16: if (legacy) AFCM_WG(f16_t, 2); else if (granule) AFCM_WG16G(f16_t); else AFCM_WG16(f16_t); break;
-        default: if (legacy) AFCM_WG(bf16_t, 2); else if (granule) AFCM_WG16G(bf16_t); else AFCM_WG16(bf16_t); break;
+        case AFCM_F16: if (granule) AFCM_WG16G(f16_t); else AFCM_WG16(f16_t); break;
+        default: if (granule) AFCM_WG16G(bf16_t); else AFCM_WG16(bf16_t); break;
     }
 #undef AFCM_WG16G
 #undef AFCM_WG16
@@ -3211,8 +2622,7 @@ extern "C" int afcm_plane_dot(float* out, const void* a, const void* b, int32_t 
     AFCM_REQUIRE((((uintptr_t)a | (uintptr_t)b) & 15) == 0, "plane_dot: operands must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     const int esize = dtype == AFCM_F32 ? 4 : 2;
-    static const char* force = getenv("AFCM_PLANE_DOT_WAVE");     // tuning aid: 0 = always one workgroup per plane
-    const bool per_wave = (long long)hw * esize <= 16384 && !(force && atoi(force) == 0);
+    const bool per_wave = (long long)hw * esize <= 16384;
     dim3 grid((unsigned)(per_wave ? (planes + 3) / 4 : planes)), block(256);
 #define AFCM_PD(T) do { \
         if (per_wave) hipLaunchKernelGGL((plane_dot_wave_kernel<T>), grid, block, 0, st, out, (const T*)a, (const T*)b, (long long)planes, hw); \

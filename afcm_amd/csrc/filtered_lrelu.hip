@@ -655,8 +655,9 @@ __global__ __launch_bounds__(256) void flrelu_strip_kernel(FlreluParams p, const
                             }
                             unsigned nib = 0u;
                             if (SIGN != AFCM_SIGNS_READ && FASTACT) {
-                                // 0 <= slope <= 1: leaky ReLU = max(v, slope v) and the clamp a med3 -- the same values bit for bit
-                                // (act_elem: select on the sign bit, compare, select), two instructions fewer per element
+                                // 0 <= slope <= 1: leaky ReLU = max(v, slope v); the clamp is a select on the compare the code needs anyway
+                                // (NOT a med3: v_med3_f32 turns a NaN into -clamp, act_elem and the reference kernel hand it on) -- the
+                                // same values as act_elem bit for bit, NaN included, one instruction fewer per element
 #pragma unroll
                                 for (int a2 = 0; a2 < UP / 2; a2++) {
                                     const f32x2 g2 = (f32x2){v[2 * a2], v[2 * a2 + 1]} * (f32x2){p.gain, p.gain};
@@ -666,8 +667,9 @@ __global__ __launch_bounds__(256) void flrelu_strip_kernel(FlreluParams p, const
                                         const int ax = 2 * a2 + e;
                                         const float w = fmaxf(g2[e], t2[e]);
                                         unsigned code = __float_as_uint(g2[e]) >> 31;
-                                        if (fabsf(w) > p.clamp) code = 2u;
-                                        v[ax] = __builtin_amdgcn_fmed3f(w, -p.clamp, p.clamp);
+                                        const bool big = fabsf(w) > p.clamp;            // (false for a NaN)
+                                        if (big) code = 2u;
+                                        v[ax] = big ? __builtin_copysignf(p.clamp, w) : w;
                                         nib |= code << (2 * ax);
                                     }
                                 }
@@ -763,8 +765,7 @@ static int launch_sep(const afcm_filtered_lrelu_args* a, FlreluParams p, hipStre
 template <typename T, int UP, int DOWN, int CPL>
 static int launch_strip(const afcm_filtered_lrelu_args* a, FlreluParams p, hipStream_t st) {
     p.tilesX = a->sign_mode == AFCM_SIGNS_WRITE ? cdiv(a->yw, StripGeom<UP, DOWN, CPL, AFCM_SIGNS_WRITE>::SW) : cdiv(a->yw, StripGeom<UP, DOWN, CPL, AFCM_SIGNS_NONE>::SW);
-    static const char* rows_s = getenv("AFCM_FLRELU_STRIP_ROWS");       // tuning aid: output rows per segment
-    const int rows = rows_s ? atoi(rows_s) : 96;
+    constexpr int rows = 96;                                            // output rows per segment (profiles/r03_flrelu_fp32_strip_rows_sweep.txt)
     p.tilesY = a->yh <= rows ? 1 : (a->yh + rows / 2) / rows;
     p.planes = a->n * a->c;
     const long long waves = (long long)p.tilesX * p.tilesY * p.planes;
@@ -806,8 +807,7 @@ static int dispatch(const afcm_filtered_lrelu_args* a, const FlreluParams& p, hi
     const bool sep = (a->fuh == 0 && a->fdh == 0);
     if constexpr (sizeof(T) == 4) {
         // fp32: the strip kernel (planes below 2^31 elements; the tile kernel stays for the 16-bit calls with a bias operand)
-        static const char* strip_s = getenv("AFCM_FLRELU_STRIP");       // tuning aid: 0 = tile kernel only
-        const bool strip = sep && !(strip_s != nullptr && atoi(strip_s) == 0) && (long long)a->xw * a->xh < (1ll << 30) && (long long)a->yw * a->yh < (1ll << 30);
+        const bool strip = sep && (long long)a->xw * a->xh < (1ll << 30) && (long long)a->yw * a->yh < (1ll << 30);
         if (strip && a->up == 2 && a->down == 2 && a->fuw == 12 && a->fdw == 12) return launch_strip<T, 2, 2, 1>(a, p, st);
         if (strip && a->up == 2 && a->down == 4 && a->fuw == 12 && a->fdw == 24) return launch_strip<T, 2, 4, 2>(a, p, st);
         if (strip && a->up == 4 && a->down == 2 && a->fuw == 24 && a->fdw == 12) return launch_strip<T, 4, 2, 1>(a, p, st);
@@ -817,24 +817,19 @@ static int dispatch(const afcm_filtered_lrelu_args* a, const FlreluParams& p, hi
         // Tile height by mode (measured, fp32, batch 16): the sign-writing forward runs 10 % faster on 20-row tiles (53 KB of LDS:
         // three workgroups per CU instead of two cover its five LDS stages), the sign-reading backward 12 % slower (its staged sign
         // window grows with the halo); planes of <= 40 rows take the 20-row tile both ways (36 rows: 40 computed instead of 70).
-        static const char* force = getenv("AFCM_FLRELU_SEP_TOH");       // tuning aid: 20 or 35 for every launch
-        const int toh = force ? atoi(force) : ((a->sign_mode != AFCM_SIGNS_READ || a->yh <= 40) ? 20 : 35);
+        const int toh = (a->sign_mode != AFCM_SIGNS_READ || a->yh <= 40) ? 20 : 35;
         if (toh == 20) return launch_sep<T, 2, 2, 6, 12, 64, 20, 5, 384>(a, p, st);
         return launch_sep<T, 2, 2, 6, 12, 64, 35, 5, 384>(a, p, st);
     }
     if (sep && a->up == 2 && a->down == 4 && a->fuw == 12 && a->fdw == 24) {
         // 16-column tiles (46 KB of LDS) only where they also cut the padded columns: planes of <= 40 columns (36 / 38: 48 computed
         // instead of 64).  On the larger planes the 1.31x halo of a 16-column tile costs more than the third workgroup per CU wins.
-        static const char* force = getenv("AFCM_FLRELU_SEP_TOW24");     // tuning aid: 16 or 32 output columns per tile
-        const int tow = force ? atoi(force) : (a->yw <= 40 ? 16 : 32);
+        const int tow = a->yw <= 40 ? 16 : 32;
         if (tow == 16) return launch_sep<T, 2, 4, 6, 24, 16, 12, 4, 384>(a, p, st);
         return launch_sep<T, 2, 4, 6, 24, 32, 12, 4, 384>(a, p, st);
     }
     if (sep && a->up == 4 && a->down == 2 && a->fuw == 24 && a->fdw == 12) {
-        static const char* force = getenv("AFCM_FLRELU_SEP_TOH42");     // tuning aid: 20 or 35 (20 is faster in every mode: 47 KB of LDS)
-        const int toh = force ? atoi(force) : 20;
-        if (toh == 20) return launch_sep<T, 4, 2, 6, 12, 64, 20, 5, 384>(a, p, st);
-        return launch_sep<T, 4, 2, 6, 12, 64, 35, 5, 384>(a, p, st);
+        return launch_sep<T, 4, 2, 6, 12, 64, 20, 5, 384>(a, p, st);      // (20-row tiles: 47 KB of LDS, faster than 35 rows in every mode)
     }
     return AFCM_E_NOKERNEL;
 }

@@ -616,8 +616,6 @@ int prepare_wave(const afcm_filtered_lrelu_args* a, int py0_frag, int dshift, hi
 
 constexpr int kWavePitchSlack = 128;        // elements a row pitch may exceed the plane width by (wave kernels)
 static bool wave_family(const afcm_filtered_lrelu_args* a) {
-    static const char* e = getenv("AFCM_FLRELU_WAVE");          // tuning aid: 0 = LDS-tile kernels only
-    if (e != nullptr && atoi(e) == 0) return false;
     if (a->sign_mode == AFCM_SIGNS_READ) return a->sign_layout == 2;
     // no bias operand; offsets + out-of-range markers stay below 2^31.  Decided on the plane sizes plus the largest pitch overhead
     // launch_wave() accepts -- NOT on the pitches themselves: afcm_filtered_lrelu_shapes() runs before the caller has chosen them,
@@ -643,8 +641,7 @@ static int wave_toh(int up, int down, int rows) {
 static bool wave_read_origin(const afcm_filtered_lrelu_args* a, int* oy0, int* dshift) {
     *oy0 = 0;
     *dshift = 0;
-    static const char* e = getenv("AFCM_FLRELU_READ_ALIGNED");          // tuning aid: 0 = general READ kernels only
-    if (a->sign_mode != AFCM_SIGNS_READ || a->sign_layout != 2 || (e != nullptr && atoi(e) == 0)) return false;
+    if (a->sign_mode != AFCM_SIGNS_READ || a->sign_layout != 2) return false;
     const int m = pos_mod(a->sy, 16);
     *oy0 = -(m / a->down);
     *dshift = m % a->down;
@@ -659,10 +656,8 @@ static int wave_rows(const afcm_filtered_lrelu_args* a) {
 
 static bool tall_tile(int up, int down, int yh, int sign_mode, bool wave) {
     if (wave) return wave_toh(up, down, yh) == kTallTOH;                    // (callers pass wave_rows())
-    static const char* force = getenv("AFCM_FLRELU_TALL");      // tuning aid: 0 = never, 1 = rules below (default), 2 = 33..48-row planes only
-    const int mode = force ? atoi(force) : 1;
     (void)down;
-    if (mode == 0 || up != 2) return false;
+    if (up != 2) return false;
     if (yh > 32 && yh <= kTallTOH) return true;
     // The sign-WRITING kernels (forward) also gain on larger planes whenever 48-row tiles cover the plane with no more padded rows
     // than 32-row tiles (276 rows: 6 x 48 = 9 x 32; 84 rows: 2 x 48 = 3 x 32): 7 % fewer halo rows, a third fewer workgroups --
@@ -670,9 +665,8 @@ static bool tall_tile(int up, int down, int yh, int sign_mode, bool wave) {
     // (their staged sign window and keep-mask table scale with the tile), so the transposed op keeps 32 rows.
     // up to 7 % more padded rows still pay (the 532- and 512-row planes of the 512^2 generator: 576 vs 544, 528 vs 512 rows --
     // filtered_lrelu 10.0 -> 9.8 ms per step there); at 12.5 % (256 rows) the gain is gone
-    static const char* slack_s = getenv("AFCM_FLRELU_TALL_SLACK");        // tuning aid: extra padded rows tolerated, in percent
-    const int slack = slack_s ? atoi(slack_s) : 7;
-    if (mode == 1 && sign_mode != AFCM_SIGNS_READ && 100 * cdiv(yh, kTallTOH) * kTallTOH <= (100 + slack) * cdiv(yh, 32) * 32) return true;
+    constexpr int slack = 7;                                                   // extra padded rows tolerated, in percent
+    if (sign_mode != AFCM_SIGNS_READ && 100 * cdiv(yh, kTallTOH) * kTallTOH <= (100 + slack) * cdiv(yh, 32) * 32) return true;
     return false;
 }
 

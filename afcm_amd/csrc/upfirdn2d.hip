@@ -210,8 +210,7 @@ extern "C" int afcm_upfirdn2d(void* y, const void* x, const float* f, int32_t dt
     if (nblk > 256 * 64) nblk = 256 * 64;
     dim3 grid((unsigned)nblk), block(256);
     hipStream_t st = (hipStream_t)stream;
-    static const bool no_tile = getenv("AFCM_UPFIRDN_GATHER") != nullptr;       // tuning aid: always the gather kernel
-    if (!no_tile) {
+    {
         const bool done = dtype == AFCM_F32 ? launch_tile<float>(p, f, st) : dtype == AFCM_F16 ? launch_tile<f16_t>(p, f, st) : launch_tile<bf16_t>(p, f, st);
         if (done) return hip_status(hipGetLastError());
     }

@@ -432,7 +432,8 @@ class SynthesisNetwork(torch.nn.Module):
         enc_layers = [getattr(self, f'encoder_{idx}') for idx in range(self.num_layers)]
         enc_packs = [None] * len(enc_layers)
         if bank16 and all(layer.conv_kernel == 3 for layer in enc_layers) and len(enc_layers) <= _conv_ops.PACK_MAX:
-            enc_packs = _conv_ops.pack_weights_bank([layer.weight for layer in enc_layers], self.compute_dtype)
+            # (the data-gradient images only where a backward can follow)
+            enc_packs = _conv_ops.pack_weights_bank([layer.weight for layer in enc_layers], self.compute_dtype, need_dgrad=torch.is_grad_enabled())
 
         E_features = {}
         for idx in range(self.num_layers):
@@ -474,7 +475,7 @@ class SynthesisNetwork(torch.nn.Module):
         if bank16 and fuse and mods[0] is not None:
             k3 = [i for i, layer in enumerate(layers) if layer.conv_kernel == 3]
             if 0 < len(k3) <= _conv_ops.PACK_MAX:
-                for i, pk in zip(k3, _conv_ops.pack_weights_bank([mods[i][0] for i in k3], self.compute_dtype)):
+                for i, pk in zip(k3, _conv_ops.pack_weights_bank([mods[i][0] for i in k3], self.compute_dtype, need_dgrad=torch.is_grad_enabled())):
                     dec_packs[i] = pk
         prescaled = False
         for idx, (layer, w) in enumerate(zip(layers, ws[1:])):

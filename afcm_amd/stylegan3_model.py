@@ -134,13 +134,25 @@ class StyleGAN3GeneratorStep:
         None keeps the current blur_sigma."""
         if cur_nimg is not None:
             self.blur_sigma = (max(1 - cur_nimg / (self.blur_fade_kimg * 1e3), 0) * self.blur_init_sigma) if self.blur_fade_kimg > 0 else 0.0
+        ev = getattr(self, 'phase_events', None)      # a dict: record CUDA events at the phase boundaries of THIS step (bench.py's bucket timeline)
+        mark = (lambda k: ev.__setitem__(k, _recorded_event())) if ev is not None else (lambda k: None)
         self.optimizer_G.zero_grad(set_to_none=True)
+        mark('forward')
         self.forward(update_emas=False)
+        mark('backward')
         self.backward_G()
+        mark('finish')
         grads, scale = (None, 1.0) if self.buckets is None else self.buckets.finish_flat()
         # averaging (1 / world), the NaN/Inf scrub and the Adam update all happen inside the optimizer kernel; with buckets the
         # reduced gradients are read where the all-reduce left them
         self.optimizer_G.step(grads=grads, grad_scale=scale)
+        mark('end')
+
+
+def _recorded_event():
+    e = torch.cuda.Event(enable_timing=True)
+    e.record()
+    return e
 
 
 @torch.no_grad()

@@ -57,9 +57,10 @@ def pack_weights_both(w, dtype):
 PACK_MAX = _lib.PACK_MAX
 
 
-def pack_weights_bank(ws, dtype):
+def pack_weights_bank(ws, dtype, need_dgrad=True):
     """``pack_weights_both`` for a list of same-kernel-size weights in ONE launch (C ABI afcm_conv2d_pack_bank): a list of
-    ((packed, rows_pad), (packed_t, rows_pad_t)), bit-identical to the per-layer calls."""
+    ((packed, rows_pad), (packed_t, rows_pad_t)), bit-identical to the per-layer calls.  ``need_dgrad=False`` (no gradient will be
+    taken: inference, torch.no_grad()) builds the forward images only: (packed_t, rows_pad_t) is None."""
     lib = _lib.load()
     assert 0 < len(ws) <= _lib.PACK_MAX
     ks = int(ws[0].shape[2])
@@ -74,10 +75,10 @@ def pack_weights_bank(ws, dtype):
         keep.append(w32)
         rp0, rp1 = _pad64(o), _pad64(i)
         d0 = torch.empty([(i + bk - 1) // bk, ks * ks, rp0, bk], dtype=dtype, device=w.device)
-        d1 = torch.empty([(o + bk - 1) // bk, ks * ks, rp1, bk], dtype=dtype, device=w.device)
-        e.dst_fwd, e.dst_dgrad, e.w = d0.data_ptr(), d1.data_ptr(), w32.data_ptr()
+        d1 = torch.empty([(o + bk - 1) // bk, ks * ks, rp1, bk], dtype=dtype, device=w.device) if need_dgrad else None
+        e.dst_fwd, e.dst_dgrad, e.w = d0.data_ptr(), (d1.data_ptr() if need_dgrad else 0), w32.data_ptr()
         e.cout, e.cin, e.rows_pad_fwd, e.rows_pad_dgrad = o, i, rp0, rp1
-        out.append(((d0, rp0), (d1, rp1)))
+        out.append(((d0, rp0), ((d1, rp1) if need_dgrad else None)))
     _lib.check(lib.afcm_conv2d_pack_bank(table, len(ws), code, ks, _lib.stream_ptr(ws[0])), 'conv2d_pack_bank')
     return out
 

@@ -32,10 +32,14 @@ class _ConvFilteredLRelu(torch.autograd.Function):
         cout, cin, ks, _ = w.shape
         xs = _conv.scale_planes(x, in_scale) if (in_scale is not None and not prescaled) else x
         ctx.wpt = None
-        if packed is not None and packed[0][0].dtype == x.dtype:
-            # both weight images come from the caller's multi-layer pack (conv2d.pack_weights_bank)
+        need_wpt = ctx.needs_input_grad[0] or (ctx.needs_input_grad[2] and not prescaled)
+        if packed is not None and packed[0][0].dtype == x.dtype and (packed[1] is not None or not need_wpt):
+            # both weight images come from the caller's multi-layer pack (conv2d.pack_weights_bank); the image must be THIS weight's
             (wp, rows_pad), ctx.wpt = packed
-        elif ctx.needs_input_grad[0] or (ctx.needs_input_grad[2] and not prescaled):
+            bk = wp.shape[3]
+            assert tuple(wp.shape) == ((cin + bk - 1) // bk, ks * ks, rows_pad, bk) and rows_pad == (cout + 63) // 64 * 64, \
+                f'packed weight image {tuple(wp.shape)} does not belong to a {tuple(w.shape)} weight'
+        elif need_wpt:
             (wp, rows_pad), ctx.wpt = _conv.pack_weights_both(w, x.dtype)      # the backward's weight image from the same launch
         else:
             wp, rows_pad = _conv.pack_weights(w, x.dtype, 0)

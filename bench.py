@@ -37,6 +37,8 @@ def parse():
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp16', 'fp32'])
     ap.add_argument('--cpu-baseline', default='auto', choices=['auto', 'off'])
     ap.add_argument('--cpu-baseline-worker', action='store_true', help=argparse.SUPPRESS)
+    ap.add_argument('--cpu-threads', type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument('--cpu-timed', type=int, default=2, help=argparse.SUPPRESS)
     ap.add_argument('--no-kernel-timing', action='store_true', help='skip the HIP-event spans around the hot kernels')
     ap.add_argument('--kernel-timing-every', type=int, default=4,
                     help='bracket the hot launches with HIP events in every n-th timed step only (every event fences its launch: all steps '
@@ -59,13 +61,13 @@ def _cpu_model():
     return 'unknown CPU'
 
 
-def cpu_baseline_worker(res, batch=2, timed=2):
+def cpu_baseline_worker(res, batch=2, timed=2, threads=0):
     """Child process: time the CPU oracle (pure-aten restatement of the reference's impl='ref' path, oracle/) as SURVEY.md
     section 8(d) / BASELINE.md section 4 plan it: full-width generator, batch 2, fwd + L1 loss + bwd on the same synthetic tensors
-    the GPU run uses (afcm_amd.synthetic, seed 0), all host cores, 1 warm-up + 2 timed iterations."""
+    the GPU run uses (afcm_amd.synthetic, seed 0), `threads` host threads (0 = every core), 1 warm-up + `timed` timed iterations."""
     import torch
     from oracle import generator as ogen
-    threads = min(os.cpu_count() or 1, 32)      # the oracle's small aten ops stop scaling (and thrash) beyond a few dozen threads
+    threads = threads or (os.cpu_count() or 1)
     torch.set_num_threads(threads)
     from afcm_amd import synthetic
     pl = ogen.plan(res, 4, 1, {})
@@ -87,28 +89,42 @@ def cpu_baseline_worker(res, batch=2, timed=2):
                           cpu=_cpu_model(), res=res)))
 
 
-def run_cpu_baseline(res, budget=(120, 200)):
-    """Bounded CPU samples, config-1 shape first (128^2, BASELINE.json configs[0]: the reference's own CPU-runnable case), then the
-    bench resolution; each in a child process under its own time limit so the GPU number is never blocked.  `value` is the point
-    at the bench resolution when it finished inside its limit, else the 128^2 point (said in `sample`)."""
+def run_cpu_baseline(res, budget=200.0):
+    """Bounded CPU samples, each in a child process under its own time limit so the GPU number is never blocked: the bench resolution
+    on EVERY host core ("all cores"; 1 warm-up + 1 timed iteration) and on 32 threads (the oracle's small aten ops stop
+    scaling beyond a few dozen threads; 1 + 2), then config-1's shape (128^2, BASELINE.json configs[0]: the reference's own CPU-runnable
+    case) on the faster of the two thread counts while the budget lasts.  `value` is the FASTER point at the bench resolution; every
+    point is listed with its thread count."""
     points, notes = [], []
-    for r, limit in zip(sorted({128, res}), budget):
+    t_start = time.time()
+    ncores = os.cpu_count() or 1
+
+    def sample(r, threads, timed, limit):
         try:
-            out = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-baseline-worker', '--res', str(r)],
-                                 capture_output=True, text=True, timeout=limit, cwd=ROOT)
+            out = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-baseline-worker', '--res', str(r), '--cpu-threads', str(threads),
+                                  '--cpu-timed', str(timed)], capture_output=True, text=True, timeout=limit, cwd=ROOT)
             d = json.loads([l for l in out.stdout.splitlines() if l.startswith('{"seconds"')][-1])
             points.append(dict(resolution=r, batch=d['batch'], images_per_sec=d['images'] / d['seconds'], s_per_iteration=d['seconds'],
                                warmup_s=d['warmup_seconds'], timed_iterations=d['timed'], cores=d['cores'], cpu=d['cpu']))
         except Exception as e:  # timeout or failure: say so, keep what was measured
-            notes.append(f'{r}x{r}: {type(e).__name__} (limit {limit} s)')
+            notes.append(f'{r}x{r} on {threads} threads: {type(e).__name__} (limit {limit:.0f} s)')
+
+    sample(res, ncores, 1, min(90.0, budget))
+    if ncores > 32:
+        sample(res, 32, 2, max(30.0, min(120.0, budget - (time.time() - t_start))))
+    at_res = [p for p in points if p['resolution'] == res]
+    best_threads = max(at_res, key=lambda p: p['images_per_sec'])['cores'] if at_res else min(ncores, 32)
+    left = budget - (time.time() - t_start)
+    if res != 128 and left > 30.0:
+        sample(128, best_threads, 1, left)
     if not points:
-        return dict(value=None, unit='images/sec', cores=min(os.cpu_count() or 1, 32), kind='port', sample='not measured: ' + '; '.join(notes))
-    head = [p for p in points if p['resolution'] == res] or points[-1:]
-    h = head[0]
+        return dict(value=None, unit='images/sec', cores=ncores, kind='port', sample='not measured: ' + '; '.join(notes))
+    h = max(at_res, key=lambda p: p['images_per_sec']) if at_res else points[-1]
     return dict(value=h['images_per_sec'], unit='images/sec', cores=h['cores'], kind='port',
                 sample=f'oracle/ (aten restatement of the reference impl=ref path), full-width {h["resolution"]}x{h["resolution"]} generator, '
                        f'batch {h["batch"]}, fwd + L1 + bwd on the GPU run\'s synthetic tensors, 1 warm-up ({h["warmup_s"]:.1f} s) + '
-                       f'{h["timed_iterations"]} timed iterations ({h["s_per_iteration"]:.1f} s each) on {h["cores"]} threads of {h["cpu"]}'
+                       f'{h["timed_iterations"]} timed iteration(s) ({h["s_per_iteration"]:.1f} s each) on {h["cores"]} threads of {h["cpu"]} '
+                       f'({ncores} cores; the faster of the thread counts in `points`)'
                        + ('' if not notes else '; not finished: ' + '; '.join(notes)),
                 points=points)
 
@@ -117,12 +133,10 @@ def self_launch(n):
     """`python bench.py --gpus N` without a launcher: start `python -m torch.distributed.run --nproc-per-node N bench.py <same
     arguments>` as a CHILD process -- this parent has made no GPU call (torch is not even imported yet) and only relays the child's
     output and exit code; rank 0's JSON line is the last line the child prints to stdout."""
-    import socket
-    with socket.socket() as s:
-        s.bind(('127.0.0.1', 0))
-        port = s.getsockname()[1]
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
-           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    # --standalone: the launcher picks a free rendezvous port itself and holds it (a port found by bind-and-close here could be taken
+    # by another process before the ranks connect); 127.0.0.1 because the container's hostname may not resolve
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--standalone', '--local-addr', '127.0.0.1', '--nnodes=1', f'--nproc-per-node={n}',
+           os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or n) // n)))
@@ -133,7 +147,7 @@ def self_launch(n):
 def main():
     args = parse()
     if args.cpu_baseline_worker:
-        cpu_baseline_worker(args.res)
+        cpu_baseline_worker(args.res, timed=args.cpu_timed, threads=args.cpu_threads)
         return
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(self_launch(args.gpus))
@@ -204,12 +218,20 @@ def main():
     timed_with_events = 0
     if not args.no_kernel_timing:
         profiling.start()
+    host_wall = host_cpu = 0.0
     t0 = time.perf_counter()
     for i in range(args.steps):
         if not args.no_kernel_timing:
             profiling.enabled = (i % max(1, args.kernel_timing_every) == 0)
             timed_with_events += int(profiling.enabled)
+        if use_dist and step.buckets is not None and i == args.steps - 1:
+            # the LAST timed step carries the bucket timeline: CUDA events at the phase boundaries and at every bucket's launch
+            # (records only, nothing waits on them)
+            step.buckets.trace, step.phase_events = [], {}
+        h0, c0 = time.perf_counter(), time.process_time()
         one_step()
+        host_wall += time.perf_counter() - h0      # wall time of the Python call: the host's own work while it does not run ahead into a full queue
+        host_cpu += time.process_time() - c0       # CPU time of this process (all its threads) inside the call
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -222,26 +244,16 @@ def main():
         elapsed = t.item()
 
     bucket_timeline = None
-    if use_dist and step.buckets is not None:
-        # one more (untimed) step with the bucket launches time-stamped on the GPU timeline: where in the backward pass each
-        # gradient bucket's all-reduce is issued (a one-rank run has no peer to exchange with; the N-rank runs overlap from here)
-        ev0, ev1, ev2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
-        step.buckets.trace = []
-        step.set_input(real_A, real_B, z, c)
-        step.optimizer_G.zero_grad(set_to_none=True)
-        step.forward(update_emas=False)
-        ev0.record()
-        step.backward_G()
-        ev1.record()
-        grads, scale = step.buckets.finish_flat()
-        step.optimizer_G.step(grads=grads, grad_scale=scale)
-        ev2.record()
-        torch.cuda.synchronize()
-        bwd_ms = ev0.elapsed_time(ev1)
-        bucket_timeline = dict(backward_ms=bwd_ms, optimizer_ms=ev1.elapsed_time(ev2),
-                               buckets=[dict(bucket=i, mbytes=round(nb / 1e6, 1), issued_at_ms=round(ev0.elapsed_time(e), 2),
-                                             backward_left_ms=round(bwd_ms - ev0.elapsed_time(e), 2)) for i, nb, e in step.buckets.trace])
-        step.buckets.trace = None
+    if use_dist and step.buckets is not None and getattr(step, 'phase_events', None):
+        # where in the backward pass of the last TIMED step each gradient bucket's all-reduce was issued (GPU timeline of this rank;
+        # a one-rank run has no peer to exchange with, the N-rank runs overlap from these points on)
+        pe = step.phase_events
+        bwd_ms = pe['backward'].elapsed_time(pe['finish'])
+        bucket_timeline = dict(step='last timed step', forward_ms=pe['forward'].elapsed_time(pe['backward']), backward_ms=bwd_ms,
+                               finish_and_optimizer_ms=pe['finish'].elapsed_time(pe['end']),
+                               buckets=[dict(bucket=i, mbytes=round(nb / 1e6, 1), issued_at_ms=round(pe['backward'].elapsed_time(e), 2),
+                                             backward_left_ms=round(bwd_ms - pe['backward'].elapsed_time(e), 2)) for i, nb, e in step.buckets.trace])
+        step.buckets.trace = step.phase_events = None
     if rank == 0:
         fams = profiling.summary()
         kernels = {}
@@ -285,6 +297,14 @@ def main():
             'steps': args.steps,
             'warmup': args.warmup,
             'ms_per_step': elapsed / args.steps * 1e3,
+            # host side of a step (rank 0): wall time of the Python call that issues it and the CPU time the process spent in it;
+            # both well below ms_per_step = the GPU is the limiter and the host runs ahead
+            'host_ms_per_step': host_wall / args.steps * 1e3,
+            'host_cpu_ms_per_step': host_cpu / args.steps * 1e3,
+            'host_threads': dict(omp_num_threads=os.environ.get('OMP_NUM_THREADS'), torch_num_threads=torch.get_num_threads(),
+                                 cpu_count=os.cpu_count(), ranks_on_host=world),
+            # every AFCM_* variable set in this process's environment (they select libraries / layouts: a stray one changes what is measured)
+            'env': {k: v for k, v in sorted(os.environ.items()) if k.startswith('AFCM_')},
             'higher_is_better': True,
             'scaling': 'weak',
             'vs_baseline': None,

@@ -359,3 +359,46 @@ def test_finish_never_leaves_an_unreduced_gradient_on_one_rank(tmp_path):
         if s0[it] is not None:
             assert torch.equal(s0[it], s1[it])
     assert s0[0] is None and s0[1] is None and s0[3] is not None
+
+
+def _worker_ragged(rank, world, port, sizes, out_dir):
+    _init(rank, world, port)
+    from afcm_amd.distributed import GradientBuckets
+    m = _model()
+    buckets = GradientBuckets(m.parameters(), bucket_bytes=8192)
+    buckets.broadcast_parameters(m)
+    torch.manual_seed(321)
+    total = sum(sizes)
+    x, y = torch.randn(total, 16), torch.randn(total, 4)
+    lo = sum(sizes[:rank])
+    xs, ys = x[lo:lo + sizes[rank]], y[lo:lo + sizes[rank]]
+    for it in range(3):                # three iterations: the bucket rebuild after the first one must keep working with four ranks
+        for p in m.parameters():
+            p.grad = None
+        # the buckets average over RANKS (1 / world); a rank holding n_r of the N samples weighs its mean loss by n_r world / N so that
+        # the result is the mean over SAMPLES, whatever the split (the last, short batch of an epoch: data/cmsr_dataset.py has no drop_last)
+        loss = (m(xs) - ys).abs().mean() * (sizes[rank] * world / total)
+        loss.backward()
+        buckets.finish()
+    torch.save({n: p.grad.clone() for n, p in m.named_parameters()}, os.path.join(out_dir, f'g{rank}.pt'))
+    torch.save(buckets.num_buckets, os.path.join(out_dir, f'nb{rank}.pt'))
+    dist.destroy_process_group()
+
+
+def test_four_ranks_with_ragged_per_rank_batches_match_the_full_batch(tmp_path):
+    """World size 4, per-rank batches 3 / 2 / 2 / 1: after finish() every rank holds the gradient of the mean loss
+    over all 8 samples -- the loss of a rank is weighted by its share of the samples, the buckets average over ranks."""
+    world, sizes = 4, (3, 2, 2, 1)
+    port = _free_port()
+    mp.spawn(_worker_ragged, args=(world, port, sizes, str(tmp_path)), nprocs=world, join=True)
+    m = _model()
+    torch.manual_seed(321)
+    x, y = torch.randn(sum(sizes), 16), torch.randn(sum(sizes), 4)
+    (m(x) - y).abs().mean().backward()
+    want = {n: p.grad for n, p in m.named_parameters()}
+    g = [torch.load(tmp_path / f'g{r}.pt') for r in range(world)]
+    for n, w in want.items():
+        for r in range(world):
+            assert torch.allclose(g[r][n], w, rtol=1e-5, atol=1e-7), (n, r, (g[r][n] - w).abs().max().item())
+            assert torch.equal(g[r][n], g[0][n]), f'{n}: rank {r} differs from rank 0'
+    assert torch.load(tmp_path / 'nb0.pt') > 1

@@ -281,22 +281,6 @@ def test_pack_weights_layout(dtype, cout, cin, ks):
         assert torch.equal(single, want), f'mode {mode}: single-mode image differs from the layout definition'
 
 
-@pytest.mark.parametrize('flag', ['AFCM_CONV_GATHER', 'AFCM_CONV_DIRECT'])
-def test_experimental_conv_kernels_parity(flag):
-    """The two opt-in 16-bit 3x3 kernels of round 3 (csrc/conv2d.hip: conv2d_fwd16g_kernel = patch by LDS-DMA gather, conv2d_fwd16d_kernel =
-    no LDS) against an fp32 torch conv of the same 16-bit operands, bf16 2e-2 / fp16 3e-3 of the output's maximum: 128-row blocks, channel
-    tails, edge tiles, pad 2 (forward) and 0 (data gradient).  The kernel choice is read from the environment once per process, so the
-    check (tools/conv_kernel_parity.py) runs in ONE child process per kernel."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, **{flag: '1'})
-    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'conv_kernel_parity.py')], env=env, capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert 'worst' in r.stdout
-
-
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16, torch.float32])
 @pytest.mark.parametrize('ks', [3, 1])
 def test_pack_weights_bank_is_bit_identical_to_the_layers_one_by_one(dtype, ks):

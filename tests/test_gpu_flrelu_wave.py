@@ -118,8 +118,7 @@ def test_wave_kernels_clamp(lname, dtype, tol):
 
 
 def test_wave_and_lds_tile_kernels_agree(monkeypatch):
-    """Same call through both matrix-core families (AFCM_FLRELU_WAVE is read once per process, so the LDS-tile family is reached
-    through its bias operand: b = 0): outputs and input gradients agree to 16-bit rounding; epilogue operands (skip, per-plane
+    """Same call through both matrix-core families (the LDS-tile family is reached through its bias operand: b = 0): outputs and input gradients agree to 16-bit rounding; epilogue operands (skip, per-plane
     factors, per-tile output sums) behave identically."""
     from afcm_amd.torch_utils.ops import filtered_lrelu as flr
     L = _layer('L9_148_181')

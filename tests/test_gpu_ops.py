@@ -698,3 +698,24 @@ def test_fp32_strip_kernel_on_ragged_planes(layer, h, w, flip):
     ggot = torch.autograd.grad((got * r.cuda()).sum(), [xg, bg])
     _close(ggot[0], gref[0], what=f'{layer} {h}x{w} dx')
     _close(ggot[1], gref[1], tol=1e-4, what=f'{layer} {h}x{w} db')
+
+
+@pytest.mark.parametrize('layer', ['enc1', 'enc4', 'dec3'])
+def test_fp32_strip_kernel_hands_a_nan_on(layer):
+    """a NaN activation must stay a NaN (the reference kernel and the aten path propagate it, filtered_lrelu.cu:484-572); the
+    fast activation of the fp32 strip kernel clamped through v_med3_f32, which returns -clamp for a NaN operand.  One NaN input sample: the
+    output is NaN exactly where the oracle's is, and equal to it everywhere else."""
+    from afcm_amd.torch_utils.ops import filtered_lrelu as flr
+    from oracle import aten_ops as ops
+    from oracle import generator as ogen
+    pl = ogen.plan(256, 4, 1, {})
+    L = {'enc1': pl['enc'][1], 'enc4': pl['enc'][4], 'dec3': pl['dec'][3]}[layer]
+    torch.manual_seed(7)
+    x = torch.randn(1, 2, 70, 66)
+    x[0, 1, 33, 29] = float('nan')
+    kw = dict(up=L['up'], down=L['down'], padding=L['padding'], gain=float(np.sqrt(2)), slope=0.2, clamp=256.0)
+    ref = ops.filtered_lrelu(x, fu=L['fu'], fd=L['fd'], b=None, **kw)
+    got = flr.filtered_lrelu(x.cuda(), fu=L['fu'].cuda(), fd=L['fd'].cuda(), b=None, **kw).cpu()
+    assert ref.isnan().any() and not ref[0, 0].isnan().any()
+    assert torch.equal(got.isnan(), ref.isnan()), f'{layer}: {int(got.isnan().sum())} NaN outputs, the oracle has {int(ref.isnan().sum())}'
+    _close(torch.nan_to_num(got), torch.nan_to_num(ref), what=f'{layer} y beside the NaN')

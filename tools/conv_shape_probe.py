@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Forward conv on a few hand-picked shapes: tools/conv_shape_probe.py [cin cout size]...  (run under AFCM_CONV_DIRECT=0/1 to compare the
-LDS-patch and the direct 16-bit kernels; sizes whose output width is a multiple of 32 give the direct kernel whole 16-lane runs)."""
+"""Forward conv on a few hand-picked shapes: tools/conv_shape_probe.py [cin cout size]...  (duration of the 16-bit forward kernel per shape; used with a
+rocprofv3 --pmc pass for MFMA-busy share and effective clock)."""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

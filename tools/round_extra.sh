@@ -1,22 +1,30 @@
 #!/bin/bash
-# usage: tools/round_extra.sh <tag>   -- the other BASELINE configurations and dtypes, one JSON line each (GPU box, repo root)
+# usage: tools/round_extra.sh <tag>   -- the other BASELINE configurations and dtypes, one JSON line each (GPU box, repo root).
+# Every configuration keeps its stderr (<tag>_bench_other_configs.err) and reports its exit code; a failed one leaves no line behind.
 tag=$1
 out=gpurun_out/${tag}_bench_other_configs.jsonl
-: > $out
-python bench.py --cpu-baseline off --dtype fp16 2>/dev/null < /dev/null | tail -n 1 >> $out                       # fp16: the scored dtype (evaluation copy)
-python bench.py --cpu-baseline off --batch 32 --steps 4 2>/dev/null < /dev/null | tail -n 1 >> $out               # configs[3]'s per-GPU workload
-python bench.py --cpu-baseline off --res 512 --batch 8 --dtype fp16 --steps 4 2>/dev/null < /dev/null | tail -n 1 >> $out   # configs[4]'s per-GPU workload
-python bench.py --cpu-baseline off --with-discriminator --steps 4 2>/dev/null < /dev/null | tail -n 1 >> $out     # row f1: full D + G iteration
-python bench.py --cpu-baseline off --dtype fp32 --steps 3 --warmup 1 2>/dev/null < /dev/null | tail -n 1 >> $out  # the reference's own dtype
-python bench.py --cpu-baseline off --force-dist 2>/dev/null < /dev/null | tail -n 1 >> $out                       # one-rank RCCL: bucket hooks + reduced-gradient Adam
-AFCM_FLRELU_READ_ALIGNED=0 python bench.py --cpu-baseline off 2>/dev/null < /dev/null | tail -n 1 >> $out          # ablation: general sign-reading kernels
-for f in $out; do python - <<PY
+err=gpurun_out/${tag}_bench_other_configs.err
+: > $out; : > $err
+run() {   # run <label> <bench.py arguments...>
+  local label=$1; shift
+  echo "== $label: bench.py $*" >> $err
+  timeout -k 10 400 python bench.py --cpu-baseline off "$@" 2>> $err < /dev/null | tail -n 1 > /tmp/extra_line.json
+  local rc=${PIPESTATUS[0]}
+  if [ $rc -eq 0 ] && head -c 1 /tmp/extra_line.json | grep -q '{'; then cat /tmp/extra_line.json >> $out; fi
+  echo "$label: rc $rc"
+}
+run fp16 --dtype fp16                                              # fp16: the scored dtype (evaluation copy)
+run batch32 --batch 32 --steps 4                                   # configs[3]'s per-GPU workload
+run res512 --res 512 --batch 8 --dtype fp16 --steps 4              # configs[4]'s per-GPU workload
+run d_plus_g --with-discriminator --steps 4                        # row f1: full D + G iteration
+run fp32 --dtype fp32 --steps 3 --warmup 1                         # the reference's own dtype
+run one_rank_rccl --force-dist                                     # one-rank RCCL: bucket hooks + reduced-gradient Adam
+python - <<PY
 import json
-for l in open("$f"):
+for l in open("$out"):
     l = l.strip()
     if not l.startswith("{"): continue
     d = json.loads(l)
     k = d.get("kernels", {})
     print(f"{d['value']:8.1f} {d['unit']:10s} {d['ms_per_step']:7.1f} ms  {d['dtype']:5s} batch {d['config']['per_gpu_batch']:3d} res {d['config']['resolution']}  " + "  ".join(f"{n} {v['ms_per_step']:.1f} ms ({v['frac']:.3f})" for n, v in k.items()) + ("  [D+G]" if "FULL" in d['config']['workload'] else "") + ("  [dist]" if d['config'].get('backend') else ""))
 PY
-done

@@ -22,5 +22,10 @@ echo pmc done
 python tools/bench_conv.py --dtype bf16 > gpurun_out/${tag}_conv_layers_bf16.txt 2>&1 < /dev/null || true
 python tools/bench_flrelu.py --dtype bf16 --no-bias --raw pitched > gpurun_out/${tag}_flrelu_layers_bf16.txt 2>&1 < /dev/null || true
 python tools/bench_flrelu.py --dtype fp32 > gpurun_out/${tag}_flrelu_layers_fp32.txt 2>&1 < /dev/null || true
-timeout -k 5 120 tools/ubench/strip_read.bin > gpurun_out/${tag}_strip_read.txt 2>&1 || true
+# load-only replica of the wave kernels' access pattern: built here from its source (binaries are not tracked)
+if [ -x /opt/rocm/bin/hipcc ]; then
+  /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -Wno-unused-value tools/ubench/strip_read.hip -o /tmp/strip_read.bin > /dev/null 2>&1 && timeout -k 5 120 /tmp/strip_read.bin > gpurun_out/${tag}_strip_read.txt 2>&1 || echo "strip_read: not built / failed (skipped)"
+else
+  echo "strip_read: no hipcc on this box (skipped)"
+fi
 echo ALLDONE
