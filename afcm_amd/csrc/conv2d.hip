@@ -61,7 +61,10 @@ struct ConvParams {
     int TH, TW, PWL, tilesX, tilesY;
     int Opad, nkc;
     unsigned magicTW;     // ceil(2^32 / TW): j / TW = umulhi(j, magicTW) for the tile-local pixel indices (j < 2^16)
+    unsigned magicTX, magicTY, magicN, magicPC;   // ... / tilesX, tilesY, N (block index decode: dividend x divisor < 2^32), / (PWL / 4)
 };
+__host__ __device__ inline unsigned magic_u32(unsigned d) { return (unsigned)((0x100000000ull + d - 1) / d); }   // 0 for d = 1 (see udiv_magic)
+__device__ __forceinline__ unsigned udiv_magic(unsigned n, unsigned magic) { return magic ? __umulhi(n, magic) : n; }
 
 template <typename T, int BM_O, int KS>
 __global__ __launch_bounds__(256, (sizeof(T) == 4 ? 1 : 2)) void conv2d_fwd_kernel(ConvParams p) {
@@ -338,15 +341,43 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? 1 : 2)) void conv2d_fwd_kern
 // register -> LDS transpose that NCHW forces is the limiter; LDS-DMA + ds_read_b64_tr_b16 cannot replace it because the
 // transposing read ignores the low three address bits (tools/ubench/tr_align_probe.hip) and the tap columns shift by
 // 1 and 2 pixels.
-template <typename T, int BM_O>
-__global__ __launch_bounds__(256, 2) void conv2d_fwd16_kernel(ConvParams p) {
+#ifdef AFCM_CONV_STAMPS        // diagnostic build only: shader-clock stamps per workgroup (entry, K loop start, K loop end, exit)
+__device__ unsigned long long afcm_conv_stamps_buf[4 * 65536];
+__device__ unsigned long long afcm_conv_bar_buf[4 * 65536];    // per wave: cycles spent at the K loop's barriers
+#define AFCM_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 65536) afcm_conv_stamps_buf[4 * blockIdx.x + (k)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define AFCM_STAMP(k) do { } while (0)
+#endif
+// ring depth / patch register sets of the 64-row blocks (see the loop)
+#ifndef AFCM_CONV_BM64_RING
+#define AFCM_CONV_BM64_RING 3
+#endif
+#ifndef AFCM_CONV_BM64_NP
+#define AFCM_CONV_BM64_NP 1
+#endif
+// tap under whose MFMAs the next chunk's patch is transposed into LDS (deep rings: the later, the longer the patch may take)
+#ifndef AFCM_CONV_BM64_WTAP
+#define AFCM_CONV_BM64_WTAP 5
+#endif
+#ifndef AFCM_CONV_BM64_OCC
+#define AFCM_CONV_BM64_OCC 2
+#endif
+// taps the B fragments run ahead of their MFMAs (64-row blocks: a tap is 4 MFMAs = 128 pipe cycles, less than an LDS round trip
+// under 12 waves per CU; 128-row blocks: 8 MFMAs cover it)
+#ifndef AFCM_CONV_BM64_BD
+#define AFCM_CONV_BM64_BD 1
+#endif
+template <typename T, int BM_O, int RING = 3, int NP = 1, int BD = 1>
+__global__ __launch_bounds__(256, (BM_O == 64 ? AFCM_CONV_BM64_OCC : 2)) void conv2d_fwd16_kernel(ConvParams p) {
     static_assert(sizeof(T) == 2, "16-bit types only");
     typedef ConvCfg<T> C;
-    constexpr int KS = 3, KK = 9, BK = C::BK, PITCH = C::PITCH, MI = BM_O / 64, RING = 3;
+    constexpr int KS = 3, KK = 9, BK = C::BK, PITCH = C::PITCH, MI = BM_O / 64;
+    static_assert(KK % RING == 0 && (NP == 1 || NP == 2), "ring depth divides the taps; one or two patch register sets");
     typedef typename std::conditional<std::is_same<T, bf16_t>::value, bf16x8, f16x8>::type frag_t;
     typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
     __shared__ __attribute__((aligned(16))) T lds[2 * kPatchMax * PITCH + 4 * PITCH];      // + a sink for lanes outside the patch
 
+    AFCM_STAMP(0);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wo = wave & 1, wpx = wave >> 1;
@@ -357,29 +388,21 @@ __global__ __launch_bounds__(256, 2) void conv2d_fwd16_kernel(ConvParams p) {
         const int total = gridDim.x;
         bid = xcd_order(bid, total);
     }
-    // integer division runs on the vector pipe even for uniform operands: pin the results to SGPRs, or everything derived
-    // from them (image base, buffer descriptor) sits in VGPRs and every buffer load gets a waterfall loop around it
-    const int tx = __builtin_amdgcn_readfirstlane(bid % p.tilesX); bid /= p.tilesX;
-    const int ty = __builtin_amdgcn_readfirstlane(bid % p.tilesY); bid /= p.tilesY;
-    const int n = __builtin_amdgcn_readfirstlane(bid % p.N);
-    const int ob = __builtin_amdgcn_readfirstlane(bid / p.N);
+    // block index -> (tile x, tile y, image, row block): multiplications by host-made reciprocals on the scalar unit (an integer division,
+    // even of uniform operands, is ~30 vector instructions, and everything derived from a VGPR result -- image base, buffer
+    // descriptor -- would sit in VGPRs with a waterfall loop around every buffer load)
+    unsigned q0 = udiv_magic((unsigned)bid, p.magicTX);
+    const int tx = __builtin_amdgcn_readfirstlane(bid - (int)q0 * p.tilesX);
+    unsigned q1 = udiv_magic(q0, p.magicTY);
+    const int ty = __builtin_amdgcn_readfirstlane((int)q0 - (int)q1 * p.tilesY);
+    unsigned q2 = udiv_magic(q1, p.magicN);
+    const int n = __builtin_amdgcn_readfirstlane((int)q1 - (int)q2 * p.N);
+    const int ob = __builtin_amdgcn_readfirstlane((int)q2);
     const int y0 = ty * p.TH, x0 = tx * p.TW;
     const int o0 = ob * BM_O;
     const int PH = p.TH + KS - 1, PWL = p.PWL;
     const int xorg = (x0 - p.pad) & ~1;
     const int xoff = (x0 - p.pad) - xorg;
-
-    int bbase[4], pyv[4], pxv[4];
-#pragma unroll
-    for (int ti = 0; ti < 4; ti++) {
-        const int j = wpx * 128 + ti * 32 + r32;
-        int py = j / p.TW, px = j - py * p.TW;
-        const bool valid = j < p.TH * p.TW;
-        if (!valid) { py = 0; px = 0; }
-        pyv[ti] = valid ? y0 + py : p.P;             // invalid slots fall outside the image -> never stored
-        pxv[ti] = x0 + px;
-        bbase[ti] = (py * PWL + px + xoff) * PITCH + h * 8;
-    }
 
     f32x16 acc[MI][4];
 #pragma unroll
@@ -399,7 +422,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_fwd16_kernel(ConvParams p) {
     // ---- patch staging (one item = 4 pixels x 8 channels), as in conv2d_fwd_kernel
     const int cg = (tid >> 5) & 1, pg = (tid & 31) + 32 * (tid >> 6);
     const int pcols = PWL >> 2;
-    const int prow = pg / pcols, pcol4 = pg - prow * pcols;
+    const int prow = (int)udiv_magic((unsigned)pg, p.magicPC), pcol4 = pg - prow * pcols;
     const bool pvalid = prow < PH;
     const int iy = y0 - p.pad + prow, ix = xorg + 4 * pcol4;
     const bool rowok = pvalid && (unsigned)iy < (unsigned)p.H;
@@ -415,77 +438,116 @@ __global__ __launch_bounds__(256, 2) void conv2d_fwd16_kernel(ConvParams p) {
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)xn, 0, (int)(img_bytes > 0x7fffffffll ? 0x7fffffffll : img_bytes), 0x00020000);
     const int hw2 = p.H * p.ldx * 2;
 
-    unsigned preg[8][2];
+    unsigned preg[NP][8][2];
     // Channels past Cin exist only in the last chunk of a layer whose Cin is not a multiple of 16; the chunk's channel offset
     // rides in the scalar offset, which the descriptor's range check does not cover, so those lanes get the out-of-range
     // vector offset instead (zeros).  Decided here, at the chunk boundary, to keep the tap loop free of branches.
     // Branch-free, and issued on EVERY chunk (past the last one with the out-of-range offset: zeros, no memory traffic): a
     // conditional issue makes the compiler's s_waitcnt for the weight ring assume the path without these eight loads, and on
     // the path with them that count waits for all eight -- a full memory round trip exposed at the top of every chunk.
-    auto issue_patch = [&](int kc, bool live) __attribute__((always_inline)) {
+    auto issue_patch = [&](int kc, bool live, auto set_c) __attribute__((always_inline)) {
+        constexpr int SET = decltype(set_c)::value;
         const int cbase = kc * BK + cg * 8;
         const int climit = live ? p.Cin : 0;              // one scalar select; `live && ...` per load comes back as branches
 #pragma unroll
         for (int c = 0; c < 8; c++) {
             const unsigned off = (cbase + c < climit) ? pvoff : kOob;
             const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(xrs, off, (kc * BK + c) * hw2, 0);
-            preg[c][0] = v.x; preg[c][1] = v.y;
+            preg[SET][c][0] = v.x; preg[SET][c][1] = v.y;
         }
     };
     // Branch-free on purpose: any branch here (even a wave-uniform one) cuts the tap loop into basic blocks, the ~60
     // transpose instructions then run as one serial block with no MFMA in flight (measured: the register -> LDS transpose
     // cost 38 % of the kernel that way).  Channels past Cin are zeroed by issue_patch; lanes outside the patch
     // write to a sink; edge masks are applied unconditionally.
-    auto write_patch = [&](int kc, T* dstbuf, int bufbase) __attribute__((always_inline)) {
+    auto write_patch = [&](int kc, T* dstbuf, int bufbase, auto set_c) __attribute__((always_inline)) {
+        constexpr int SET = decltype(set_c)::value;
 #pragma unroll
         for (int c = 0; c < 8; c++) {
-            const unsigned lo = lshift ? 0u : (preg[c][0] & pmask0);
-            const unsigned hi = (lshift ? preg[c][0] : preg[c][1]) & pmask1;
-            preg[c][0] = lo; preg[c][1] = hi;
+            const unsigned lo = lshift ? 0u : (preg[SET][c][0] & pmask0);
+            const unsigned hi = (lshift ? preg[SET][c][0] : preg[SET][c][1]) & pmask1;
+            preg[SET][c][0] = lo; preg[SET][c][1] = hi;
         }
 #pragma unroll
         for (int e = 0; e < 4; e++) {
             const unsigned sel = (e & 1) ? 0x07060302u : 0x05040100u;
             uint4 v;
-            v.x = __builtin_amdgcn_perm(preg[1][e >> 1], preg[0][e >> 1], sel);
-            v.y = __builtin_amdgcn_perm(preg[3][e >> 1], preg[2][e >> 1], sel);
-            v.z = __builtin_amdgcn_perm(preg[5][e >> 1], preg[4][e >> 1], sel);
-            v.w = __builtin_amdgcn_perm(preg[7][e >> 1], preg[6][e >> 1], sel);
+            v.x = __builtin_amdgcn_perm(preg[SET][1][e >> 1], preg[SET][0][e >> 1], sel);
+            v.y = __builtin_amdgcn_perm(preg[SET][3][e >> 1], preg[SET][2][e >> 1], sel);
+            v.z = __builtin_amdgcn_perm(preg[SET][5][e >> 1], preg[SET][4][e >> 1], sel);
+            v.w = __builtin_amdgcn_perm(preg[SET][7][e >> 1], preg[SET][6][e >> 1], sel);
             *(uint4*)(lds + (pvalid ? bufbase + pdst + e * PITCH : 2 * kPatchMax * PITCH)) = v;
         }
     };
 
+    // Ring depth and patch sets.  vmcnt is ONE in-order counter: a wait for a weight fragment also waits for every load issued
+    // before it, so a patch request (an HBM round trip) stalls the first tap whose fragments were requested behind it -- with
+    // RING = 3 that is three taps after the request, whatever the distance to the transposing writes.  <RING = 9, NP = 2> (the
+    // 64-row blocks: 32 accumulator registers leave room): a chunk's fragments are all requested one chunk ahead and the patch of
+    // chunk k + 2 is requested at the top of chunk k into the second register set, so the fragments waited for during chunk k
+    // are all OLDER than that request and the patch has a whole chunk to arrive.
     frag_t ar[RING][MI];
-    issue_patch(0, true);
+    typedef std::integral_constant<int, 0> set0_t;
+    typedef std::integral_constant<int, NP - 1> set1_t;
+    issue_patch(0, true, set0_t{});
 #pragma unroll
     for (int t = 0; t < RING; t++)
 #pragma unroll
         for (int mi = 0; mi < MI; mi++) ar[t][mi] = load_a(0, t, mi);
-    write_patch(0, lds, 0);
+    if (NP == 2) issue_patch(p.nkc > 1 ? 1 : 0, p.nkc > 1, set1_t{});
+    // (tile-local pixel coordinates of this lane's four B fragments: computed under the first requests' round trip)
+    int bbase[4], pyv[4], pxv[4];
+#pragma unroll
+    for (int ti = 0; ti < 4; ti++) {
+        const int j = wpx * 128 + ti * 32 + r32;
+        int py = (int)__umulhi((unsigned)j, p.magicTW), px = j - py * p.TW;
+        const bool valid = j < p.TH * p.TW;
+        if (!valid) { py = 0; px = 0; }
+        pyv[ti] = valid ? y0 + py : p.P;             // invalid slots fall outside the image -> never stored
+        pxv[ti] = x0 + px;
+        bbase[ti] = (py * PWL + px + xoff) * PITCH + h * 8;
+    }
+
+    write_patch(0, lds, 0, set0_t{});
     __syncthreads();
+    AFCM_STAMP(1);
 
     const int last = p.nkc - 1;
-    for (int kc = 0; kc < p.nkc; kc++) {
+#ifdef AFCM_CONV_STAMPS
+    unsigned long long bar_cycles = 0;
+#endif
+    // one K-chunk; PAR = kc & 1 (NP = 2: the register set that takes the request of chunk kc + 2; the other one holds chunk kc + 1)
+    auto chunk = [&](int kc, auto par_c) __attribute__((always_inline)) {
+        constexpr int PAR = decltype(par_c)::value;
+        typedef std::integral_constant<int, NP == 2 ? PAR : 0> req_t;
+        typedef std::integral_constant<int, NP == 2 ? 1 - PAR : 0> wr_t;
         const T* cur = lds + (kc & 1) * (kPatchMax * PITCH);
         T* nxt = lds + ((kc + 1) & 1) * (kPatchMax * PITCH);
         const bool more = kc < last;
         // B fragments run one tap ahead of their MFMAs in the SAME registers: a tap's MFMAs go pixel-block by pixel-block, and
         // as soon as block ti's fragment has been consumed the next tap's fragment for that block is read into it.  (Read, wait,
         // multiply per tap left ~one LDS round trip exposed per 8 MFMAs with only the other workgroup's wave to cover it.)
-        frag_t b[4];
+        frag_t b[BD][4];
 #pragma unroll
-        for (int ti = 0; ti < 4; ti++) b[ti] = *(const frag_t*)(cur + bbase[ti]);
-        issue_patch(kc + (int)more, more);
-        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);               // tap 0's fragments first, all four in flight together
+        for (int d = 0; d < BD; d++)
+#pragma unroll
+            for (int ti = 0; ti < 4; ti++) b[d][ti] = *(const frag_t*)(cur + bbase[ti] + ((d / KS) * PWL + (d % KS)) * PITCH);
+        if (NP == 2) {
+            const bool more2 = kc + 2 <= last;
+            issue_patch(more2 ? kc + 2 : kc, more2, req_t{});
+        } else {
+            issue_patch(kc + (int)more, more, req_t{});
+        }
+        __builtin_amdgcn_sched_group_barrier(0x100, 4 * BD, 0);          // the first fragments first, all in flight together
         __builtin_amdgcn_sched_group_barrier(0x020, 8, 0);
 #pragma unroll
         for (int tap = 0; tap < KK; tap++) {
-            const int nr = (tap + 1) / KS, ns = (tap + 1) - nr * KS;
-            const int tapoff_n = (nr * PWL + ns) * PITCH;                 // next tap's offset (unused on the last tap)
+            const int nr = (tap + BD) / KS, ns = (tap + BD) - nr * KS;
+            const int tapoff_n = (nr * PWL + ns) * PITCH;                 // offset of the tap BD ahead (unused on the last BD taps)
             frag_t a[MI];
 #pragma unroll
             for (int mi = 0; mi < MI; mi++) a[mi] = ar[tap % RING][mi];
-            // refill this ring slot with the fragments three taps ahead (clamped at the end: no branch around a load)
+            // refill this ring slot with the fragments RING taps ahead (clamped at the end: no branch around a load)
             {
                 const int nt = (tap + RING) % KK;
                 const int nk = (tap + RING < KK) ? kc : (more ? kc + 1 : kc);
@@ -497,16 +559,20 @@ __global__ __launch_bounds__(256, 2) void conv2d_fwd16_kernel(ConvParams p) {
 #pragma unroll
                 for (int mi = 0; mi < MI; mi++) {
                     if constexpr (std::is_same<T, bf16_t>::value)
-                        acc[mi][ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ti], acc[mi][ti], 0, 0, 0);
+                        acc[mi][ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[tap % BD][ti], acc[mi][ti], 0, 0, 0);
                     else
-                        acc[mi][ti] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mi], b[ti], acc[mi][ti], 0, 0, 0);
+                        acc[mi][ti] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mi], b[tap % BD][ti], acc[mi][ti], 0, 0, 0);
                 }
-                if (tap + 1 < KK) b[ti] = *(const frag_t*)(cur + bbase[ti] + tapoff_n);
+#ifdef AFCM_CONV_EXPERIMENT_HALFB      // timing experiment only (wrong results): every other tap keeps the previous tap's B fragments
+                if (tap + BD < KK && (tap & 1) == 0) b[tap % BD][ti] = *(const frag_t*)(cur + bbase[ti] + tapoff_n);
+#else
+                if (tap + BD < KK) b[tap % BD][ti] = *(const frag_t*)(cur + bbase[ti] + tapoff_n);
+#endif
             }
-            if (tap == 5) {
+            if (tap == ((BM_O == 64 && RING == 9) ? AFCM_CONV_BM64_WTAP : 5)) {
                 // the other buffer (last read one chunk ago); on the last chunk this rewrites stale registers into a buffer
                 // nobody reads.  Interleave: one MFMA, then a handful of the transpose's vector instructions.
-                write_patch(kc + 1, nxt, ((kc + 1) & 1) * (kPatchMax * PITCH));
+                write_patch(kc + 1, nxt, ((kc + 1) & 1) * (kPatchMax * PITCH), wr_t{});
                 __builtin_amdgcn_sched_group_barrier(0x020, MI, 0);
 #pragma unroll
                 for (int ti = 0; ti < 4; ti++) {
@@ -520,35 +586,86 @@ __global__ __launch_bounds__(256, 2) void conv2d_fwd16_kernel(ConvParams p) {
                 __builtin_amdgcn_sched_group_barrier(0x200, 4, 0);
             } else {
                 // pin the issue order of the tap: the ring refill first (left alone, the scheduler sinks the loads next to
-                // their uses and the three-tap prefetch distance collapses), then per pixel block its MFMAs and the read ahead
+                // their uses and the prefetch distance collapses), then per pixel block its MFMAs and the read ahead
                 __builtin_amdgcn_sched_group_barrier(0x020, MI, 0);
 #pragma unroll
                 for (int ti = 0; ti < 4; ti++) {
                     __builtin_amdgcn_sched_group_barrier(0x008, MI, 0);
-                    if (tap + 1 < KK) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    if (tap + BD < KK) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                 }
             }
         }
+#ifdef AFCM_CONV_STAMPS
+        const unsigned long long tb0 = __builtin_readcyclecounter();
         __syncthreads();
+        bar_cycles += __builtin_readcyclecounter() - tb0;
+#else
+        __syncthreads();
+#endif
+    };
+    if constexpr (NP == 2) {
+        for (int kc = 0; kc < p.nkc; kc += 2) {
+            chunk(kc, std::integral_constant<int, 0>{});
+            if (kc + 1 >= p.nkc) break;
+            chunk(kc + 1, std::integral_constant<int, 1>{});
+        }
+    } else {
+        for (int kc = 0; kc < p.nkc; kc++) chunk(kc, std::integral_constant<int, 0>{});
     }
 
+    AFCM_STAMP(2);
+#ifdef AFCM_CONV_STAMPS
+    if ((threadIdx.x & 63) == 0 && blockIdx.x < 65536) afcm_conv_bar_buf[4 * blockIdx.x + (threadIdx.x >> 6)] = bar_cycles;
+#endif
     // ---- epilogue: D[row = channel][col = pixel]; row = (reg&3) + 8*(reg>>2) + 4*h within the 32x32 tile.
     if ((p.TW & 7) == 0) {
         // Tile rows that are multiples of 8 pixels: transpose through LDS (the patch buffers are free after the last barrier)
         // and store 8 pixels = 16 bytes per lane.  A lane holds 16 channels of ONE pixel (4 runs of 4 consecutive channels), so
         // it stages [pixel][32 channels] rows with four 8-byte writes per 32x32 tile, and the transposing read
         // (ds_read_b64_tr_b16: a 16-lane group takes a 4-pixel x 16-channel block, lane i receives channel i of the 4 pixels)
-        // hands every lane 4 pixels of one channel.  Per thread and 32-channel pass: 32 packed conversions + 16 ds_write_b64 +
-        // 16 transposing reads + 8 stores (the first version staged [channel][pixel] with 64 two-byte writes per pass: the
-        // epilogue was 12 % of the whole conv time, 35 % on the 64-channel layers).
+        // hands every lane 4 pixels of one channel.
         // Row = 64 bytes = eight 8-byte chunks; chunk c of pixel p lives at c ^ ((p >> 1) & 7): conflict-free for the writes
         // (16 consecutive pixels x one chunk) and for the reads (a 32-lane half = both channel halves of 4 pixels).
+        // r04: this block retired ~650 vector instructions per 32-row pass (PMC: 1324 per wave on a 64 -> 64 layer whose K loop
+        // needs 436) -- a min + sign-extend + 64-bit add in front of EVERY per-row scale / bias load (32 of them), the swizzled
+        // LDS address of every write, a 64-bit pointer and two predicates per store -- and the SIMD issues those at ~4.6 cycles
+        // each whatever the number of waves (tools/ubench/issue_mix.hip): on the 64-row layers the vector issue port, not the matrix
+        // pipe, was the limit.  Now everything position-dependent is an immediate offset or one of a few registers computed once:
+        // scales / biases come as 16-byte buffer loads (range-checked: rows past Cout read 0), the writes use four per-lane
+        // addresses + immediates, the stores are buffer stores whose byte offset is one add of two precomputed registers (an
+        // out-of-image granule or an out-of-range channel carries a marker that pushes the sum past the descriptor's range).
         typedef __attribute__((ext_vector_type(4))) short s16x4;
+        typedef __attribute__((ext_vector_type(4))) float ef32x4;
+        typedef __attribute__((ext_vector_type(4))) unsigned eu32x4;
         constexpr int EROW = 64;
-        unsigned char* ebuf = (unsigned char*)lds + wave * (128 * EROW);
-        T* yn = (T*)p.y + (size_t)n * p.Cout * p.P * p.ldy;
-        const float* osn = p.oscale ? p.oscale + (size_t)n * p.Cout : nullptr;
+        unsigned char* const ebuf = (unsigned char*)lds + wave * (128 * EROW);
         const int pq = p.P * p.ldy;
+        // output image n as one buffer (host: Cout * P * ldy * 2 bytes < 2^30, so the markers below cannot wrap back into range)
+        const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void*)((T*)p.y + (size_t)n * p.Cout * pq), 0, p.Cout * pq * 2, 0x00020000);
+        const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.oscale ? p.oscale + (size_t)n * p.Cout : (const float*)p.y), 0, p.oscale ? p.Cout * 4 : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.obias ? p.obias : (const float*)p.y), 0, p.obias ? p.Cout * 4 : 0, 0x00020000);
+        constexpr unsigned kGOut = 0x80000000u, kOOut = 0xc0000000u;
+        // per-row scales and biases of BOTH row passes first (rows of a lane's 16 accumulator registers: rowbase + 4 h + (reg & 3) +
+        // 8 (reg >> 2): four 16-byte loads each), so that the address arithmetic below runs under their round trip
+        const bool has_sc = p.oscale != nullptr, has_ob = p.obias != nullptr;
+        ef32x4 sc[MI][4], ob[MI][4];
+#pragma unroll
+        for (int mi = 0; mi < MI; mi++) {
+            const unsigned sboff = (unsigned)((o0 + wo * (BM_O / 2) + mi * 32 + 4 * h) * 4);
+#pragma unroll
+            for (int k4 = 0; k4 < 4; k4++) {
+                sc[mi][k4] = (ef32x4){1.f, 1.f, 1.f, 1.f};
+                ob[mi][k4] = (ef32x4){0.f, 0.f, 0.f, 0.f};
+            }
+            if (has_sc) {
+#pragma unroll
+                for (int k4 = 0; k4 < 4; k4++) sc[mi][k4] = __builtin_bit_cast(ef32x4, __builtin_amdgcn_raw_buffer_load_b128(srs, sboff + 32u * k4, 0, 0));
+            }
+            if (has_ob) {
+#pragma unroll
+                for (int k4 = 0; k4 < 4; k4++) ob[mi][k4] = __builtin_bit_cast(ef32x4, __builtin_amdgcn_raw_buffer_load_b128(brs, sboff + 32u * k4, 0, 0));
+            }
+        }
         // read side: lane = (half hh: granule parity, chalf: channel half, i16: channel / address role inside the 16-lane group)
         const int i16 = lane & 15, chalf = (lane >> 4) & 1, hh = lane >> 5;
         const int q4 = i16 >> 2, p4 = i16 & 3;
@@ -558,68 +675,56 @@ __global__ __launch_bounds__(256, 2) void conv2d_fwd16_kernel(ConvParams p) {
             const int prow = 8 * hh + 4 * r + q4;                 // + 16 pixels per iteration: (prow >> 1) & 7 does not change
             rd_off[r] = prow * EROW + (((chalf * 4 + p4) ^ ((prow >> 1) & 7)) << 3);
         }
-        // this lane's 8 granules (8 pixels each, one tile row): plane offset, -1 = outside the image; bit it of gfullm = whole
-        int goff[8];
-        unsigned gfullm = 0;
+        // write side: pixel 32 ti + r32 (its swizzle (pix >> 1) & 7 does not depend on ti), chunks h + 2 k4
+        unsigned wr_off[4];
+#pragma unroll
+        for (int k4 = 0; k4 < 4; k4++) wr_off[k4] = (unsigned)(r32 * EROW + (((h + 2 * k4) ^ ((r32 >> 1) & 7)) << 3));
+        // this lane's 8 granules (8 pixels each, one tile row): byte offset inside a channel plane, or the marker; bit `it` of gfullm =
+        // the whole granule fits the row (a pitched row: up to the pitch, columns >= Q are padding)
+        unsigned gbyte[8], gfullm = 0;
         int gxv[8];
 #pragma unroll
         for (int it = 0; it < 8; it++) {
             const int j0 = wpx * 128 + (2 * it + hh) * 8;
             const int gpy = (int)__umulhi((unsigned)j0, p.magicTW), gpx = j0 - gpy * p.TW;
             const int gy = y0 + gpy, gx = x0 + gpx;
-            goff[it] = (j0 < p.TH * p.TW && gy < p.P && gx < p.Q) ? gy * p.ldy + gx : -1;
+            gbyte[it] = (j0 < p.TH * p.TW && gy < p.P && gx < p.Q) ? (unsigned)((gy * p.ldy + gx) * 2) : kGOut;
             gxv[it] = gx;
-            if (gx + 8 <= p.ldy) gfullm |= 1u << it;         // a pitched row has room for the whole granule (columns >= Q: padding)
+            if (gx + 8 <= p.ldy) gfullm |= 1u << it;
         }
-        const int wr_pix = r32;                                    // + 32 ti
 #pragma unroll
         for (int mi = 0; mi < MI; mi++) {
-            float sc[16], ob[16];
-            const int obase = o0 + wo * (BM_O / 2) + mi * 32 + 4 * h;
-#pragma unroll
-            for (int reg = 0; reg < 16; reg++) { sc[reg] = 1.f; ob[reg] = 0.f; }
-            if (osn != nullptr) {
-#pragma unroll
-                for (int reg = 0; reg < 16; reg++) sc[reg] = osn[min(obase + (reg & 3) + 8 * (reg >> 2), p.Cout - 1)];
-            }
-            if (p.obias != nullptr) {
-#pragma unroll
-                for (int reg = 0; reg < 16; reg++) ob[reg] = p.obias[min(obase + (reg & 3) + 8 * (reg >> 2), p.Cout - 1)];
-            }
+            const int rowbase = o0 + wo * (BM_O / 2) + mi * 32;
 #pragma unroll
             for (int ti = 0; ti < 4; ti++) {
-                const int pix = ti * 32 + wr_pix;
-                const int sw = (pix >> 1) & 7;
 #pragma unroll
                 for (int k4 = 0; k4 < 4; k4++) {                   // registers 4 k4 .. 4 k4 + 3 = channels 4 h + 8 k4 + 0..3
                     uint2 w;
-                    w.x = pack2<T>(acc[mi][ti][4 * k4 + 0] * sc[4 * k4 + 0] + ob[4 * k4 + 0], acc[mi][ti][4 * k4 + 1] * sc[4 * k4 + 1] + ob[4 * k4 + 1]);
-                    w.y = pack2<T>(acc[mi][ti][4 * k4 + 2] * sc[4 * k4 + 2] + ob[4 * k4 + 2], acc[mi][ti][4 * k4 + 3] * sc[4 * k4 + 3] + ob[4 * k4 + 3]);
-                    *(uint2*)(ebuf + pix * EROW + (((h + 2 * k4) ^ sw) << 3)) = w;
+                    w.x = pack2<T>(acc[mi][ti][4 * k4 + 0] * sc[mi][k4][0] + ob[mi][k4][0], acc[mi][ti][4 * k4 + 1] * sc[mi][k4][1] + ob[mi][k4][1]);
+                    w.y = pack2<T>(acc[mi][ti][4 * k4 + 2] * sc[mi][k4][2] + ob[mi][k4][2], acc[mi][ti][4 * k4 + 3] * sc[mi][k4][3] + ob[mi][k4][3]);
+                    *(uint2*)(ebuf + wr_off[k4] + ti * (32 * EROW)) = w;
                 }
             }
             // same wave wrote and reads: LDS operations of a wave complete in order, no barrier needed
-            const int o = o0 + wo * (BM_O / 2) + mi * 32 + chalf * 16 + i16;
-            T* const yo = yn + (size_t)min(o, p.Cout - 1) * pq;
+            const int o = rowbase + chalf * 16 + i16;
+            const unsigned obyte = o < p.Cout ? (unsigned)(o * pq * 2) : kOOut;
 #pragma unroll
             for (int it = 0; it < 8; it++) {
-                union { s16x4 v[2]; uint4 q; } u;
+                union { s16x4 v[2]; eu32x4 q; } u;
 #pragma unroll
                 for (int r = 0; r < 2; r++)
                     u.v[r] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ebuf + it * (16 * EROW) + rd_off[r]));
-                if (goff[it] >= 0 && o < p.Cout) {
-                    T* dst = yo + goff[it];
-                    if ((gfullm >> it) & 1) {
-                        *(uint4*)dst = u.q;
-                    } else {                                      // the granule straddles the right edge (even width: whole pairs)
-                        const unsigned vv[4] = {u.q.x, u.q.y, u.q.z, u.q.w};
+                const unsigned off = obyte + gbyte[it];
+                if ((gfullm >> it) & 1) {
+                    __builtin_amdgcn_raw_buffer_store_b128(u.q, yrs, off, 0, 0);
+                } else {                                          // the granule straddles the right edge (even width: whole pairs)
 #pragma unroll
-                        for (int w2 = 0; w2 < 4; w2++)
-                            if (gxv[it] + 2 * w2 < p.Q) ((unsigned*)dst)[w2] = vv[w2];
-                    }
+                    for (int w2 = 0; w2 < 4; w2++)
+                        __builtin_amdgcn_raw_buffer_store_b32(u.q[w2], yrs, (gxv[it] + 2 * w2 < p.Q) ? off + 4u * w2 : kGOut, 0, 0);
                 }
             }
         }
+        AFCM_STAMP(3);
         return;
     }
     T* yn = (T*)p.y + (size_t)n * p.Cout * p.P * p.ldy;
@@ -2346,7 +2451,8 @@ static int launch_conv(ConvParams p, int ks, hipStream_t st) {
     dim3 grid((unsigned)blocks), block(256);
     if constexpr (sizeof(T) == 2) {
         if (ks == 3) {
-            hipLaunchKernelGGL((conv2d_fwd16_kernel<T, BM_O>), grid, block, 0, st, p);
+            if constexpr (BM_O == 64) hipLaunchKernelGGL((conv2d_fwd16_kernel<T, BM_O, AFCM_CONV_BM64_RING, AFCM_CONV_BM64_NP, AFCM_CONV_BM64_BD>), grid, block, 0, st, p);
+            else hipLaunchKernelGGL((conv2d_fwd16_kernel<T, BM_O>), grid, block, 0, st, p);
             return hip_status(hipGetLastError());
         }
     }
@@ -2359,6 +2465,20 @@ static int launch_conv(ConvParams p, int ks, hipStream_t st) {
 
 using namespace afcm;
 
+#ifdef AFCM_CONV_STAMPS
+extern "C" int afcm_debug_conv_stamps(void* dst, int n_blocks) {
+    return hip_status(hipMemcpyFromSymbol(dst, HIP_SYMBOL(afcm_conv_stamps_buf), (size_t)n_blocks * 32, 0, hipMemcpyDeviceToHost));
+}
+extern "C" int afcm_debug_conv_barrier_cycles(void* dst, int n_blocks) {
+    return hip_status(hipMemcpyFromSymbol(dst, HIP_SYMBOL(afcm_conv_bar_buf), (size_t)n_blocks * 32, 0, hipMemcpyDeviceToHost));
+}
+extern "C" int afcm_debug_conv_stamps_clear() {
+    void* a; void* b;
+    if (hipGetSymbolAddress(&a, HIP_SYMBOL(afcm_conv_stamps_buf)) != hipSuccess || hipGetSymbolAddress(&b, HIP_SYMBOL(afcm_conv_bar_buf)) != hipSuccess) return AFCM_E_INVALID;
+    (void)hipMemset(a, 0, sizeof(afcm_conv_stamps_buf));
+    return hip_status(hipMemset(b, 0, sizeof(afcm_conv_bar_buf)));
+}
+#endif
 extern "C" int afcm_conv2d_block_k(int32_t dtype) { return dtype == AFCM_F32 ? ConvCfg<float>::BK : ConvCfg<bf16_t>::BK; }
 
 template <typename T>
@@ -2455,6 +2575,7 @@ extern "C" int afcm_conv2d_stride2(void* y, const void* x, const void* wpacked, 
     choose_tile_s2(p.P, p.Q, &p.TH, &p.TW, &p.PWL);
     p.tilesX = cdiv(p.Q, p.TW); p.tilesY = cdiv(p.P, p.TH);
     p.magicTW = (unsigned)((0x100000000ull + (unsigned)p.TW - 1) / (unsigned)p.TW);
+    p.magicTX = magic_u32((unsigned)p.tilesX); p.magicTY = magic_u32((unsigned)p.tilesY); p.magicN = magic_u32((unsigned)p.N); p.magicPC = magic_u32((unsigned)(p.PWL >> 2));
     p.Opad = rows_pad;
     p.nkc = cdiv(cin, afcm_conv2d_block_k(dtype));
     const long long blocks = (long long)p.tilesX * p.tilesY * n * cdiv(cout, 128);
@@ -2492,9 +2613,11 @@ extern "C" int afcm_conv2d_ld(void* y, const void* x, const void* wpacked, const
         AFCM_REQUIRE(p.ldx >= w && p.ldy >= p.Q && ((p.ldx | p.ldy) & 1) == 0, "conv2d: row pitches %d / %d must be even and cover the widths %d / %d", p.ldx, p.ldy, w, p.Q);
         AFCM_REQUIRE((long long)cout * p.P * p.ldy < (1ll << 30), "conv2d: pitched output image is out of range");
     }
+    AFCM_REQUIRE(dtype == AFCM_F32 || ks != 3 || (long long)cout * p.P * p.ldy * 2 < (1ll << 30), "conv2d: 16-bit output image of %lld bytes is out of range (< 2^30)", (long long)cout * p.P * p.ldy * 2);
     choose_tile(p.P, p.Q, ks, &p.TH, &p.TW, &p.PWL);
     p.tilesX = cdiv(p.Q, p.TW); p.tilesY = cdiv(p.P, p.TH);
     p.magicTW = (unsigned)((0x100000000ull + (unsigned)p.TW - 1) / (unsigned)p.TW);
+    p.magicTX = magic_u32((unsigned)p.tilesX); p.magicTY = magic_u32((unsigned)p.tilesY); p.magicN = magic_u32((unsigned)p.N); p.magicPC = magic_u32((unsigned)(p.PWL >> 2));
     p.Opad = rows_pad;
     p.nkc = cdiv(cin, afcm_conv2d_block_k(dtype));
     hipStream_t st = (hipStream_t)stream;

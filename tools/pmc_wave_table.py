@@ -1,15 +1,17 @@
 #!/usr/bin/env python3
-"""Per-kernel table from tools/pmc_wave.sh output: counters per WAVE (counter / SQ_WAVES), quad-cycle counters x 4."""
+"""Per-kernel table from tools/pmc_wave.sh output: counters per WAVE (counter / SQ_WAVES), quad-cycle counters x 4.
+tools/pmc_wave_table.py <dir> [kernel-name substring, default flrelu_wave_kernel]"""
 import csv, glob, re, sys, collections
 d = sys.argv[1]
+want = sys.argv[2] if len(sys.argv) > 2 else 'flrelu_wave_kernel'
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in sorted(glob.glob(d + '/**/*counter_collection.csv', recursive=True)):
     for row in csv.DictReader(open(f)):
         k = row['Kernel_Name']
-        if 'flrelu_wave_kernel' not in k:
+        if want not in k:
             continue
         m = re.search(r'flrelu_wave_kernelI(DF16b|DF16_)Li(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E', k) or re.search(r'flrelu_wave_kernel<([^,]+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+)>', k)
-        key = '<%s>' % ','.join(m.groups()[1:]) + ' grid %s' % row['Grid_Size'] if m else k[:60]
+        key = ('<%s>' % ','.join(m.groups()[1:]) if m else k[:70]) + ' grid %s' % row['Grid_Size']
         acc[key][row['Counter_Name']].append(float(row['Counter_Value']))
 QUAD = ('SQ_WAVE_CYCLES', 'SQ_BUSY_CYCLES', 'SQ_WAIT_ANY', 'SQ_WAIT_INST_ANY', 'SQ_WAIT_INST_LDS', 'SQ_ACTIVE_INST_ANY', 'SQ_ACTIVE_INST_VALU', 'SQ_ACTIVE_INST_LDS',
         'SQ_ACTIVE_INST_VMEM', 'SQ_ACTIVE_INST_SCA', 'SQ_ACTIVE_INST_MISC')
