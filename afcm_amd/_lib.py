@@ -30,6 +30,7 @@ class FilteredLReluArgs(C.Structure):
         ('workspace', C.c_void_p), ('sign_layout', C.c_int32), ('plane_sum_slots', C.c_int32),
         ('plane_sum', C.c_void_p), ('oscale', C.c_void_p), ('skip', C.c_void_p), ('oscale2', C.c_void_p),
         ('x_pitch', C.c_int32), ('y_pitch', C.c_int32), ('skip_pitch', C.c_int32), ('row_pitch_ok', C.c_int32),
+        ('clamp_flags', C.c_void_p),
     ]
 
 
@@ -93,6 +94,7 @@ SIGNATURES = {
     'afcm_scale_planes': (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i64, _i32, _vp]),
     'afcm_plane_dot': (C.c_int, [_vp, _vp, _vp, _i32, _i64, _i32, _vp]),
     'afcm_plane_dot_ld': (C.c_int, [_vp, _vp, _vp, _i32, _i64, _i32, _i32, _i32, _i32, _vp]),
+    'afcm_plane_dot_gated_ld': (C.c_int, [_vp, _vp, _vp, _i32, _i64, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
     'afcm_weight_norm_fwd': (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     'afcm_weight_norm_bwd': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     'afcm_style_coefs_fwd': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
@@ -124,8 +126,8 @@ def load():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
-        if lib.afcm_abi_version() != 9:
-            raise RuntimeError(f'libafcm_hip.so ABI version {lib.afcm_abi_version()} does not match this package (9); rebuild it')
+        if lib.afcm_abi_version() != 10:
+            raise RuntimeError(f'libafcm_hip.so ABI version {lib.afcm_abi_version()} does not match this package (10); rebuild it')
         _lib = lib
     return _lib
 

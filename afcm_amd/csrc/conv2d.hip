@@ -1392,9 +1392,17 @@ constexpr int kWgKQ = 64;        // pixels of one output row per K macro-step
 // section 3): 16-byte vectors within a row; the last vector of a row is shifted back to END at column w (no access past the row,
 // the re-read elements are selected out), so nothing depends on what the padding holds.  PER_WAVE: one wave per plane, four
 // planes per workgroup (small planes, as plane_dot_wave_kernel).  Needs w >= 16 / sizeof(T).
+// Gate of the "dot product by homogeneity" (afcm_plane_dot_gated_ld): a plane none of whose strips could reach the clamp takes
+//     out = osc (gz - nsc gsk)                     (nsc, gsk may be NULL: 1, 0)
+// and its wave / workgroup leaves without touching a or b; a flagged plane gets the real dot product.
+struct PlaneGate {
+    const int* flags;     // [planes][slots], NULL: no gate
+    int slots;
+    const float *osc, *gz, *nsc, *gsk;
+};
 template <typename T, bool PER_WAVE>
 __global__ __launch_bounds__(256) void plane_dot_rows_kernel(float* __restrict__ out, const T* __restrict__ a, const T* __restrict__ b,
-                                                             long long planes, int h, int w, int lda, int ldb) {
+                                                             long long planes, int h, int w, int lda, int ldb, PlaneGate gate) {
     constexpr int E = 16 / (int)sizeof(T);
     union V16 { uint4 u; T v[E]; };
     __shared__ float part[4];
@@ -1402,6 +1410,14 @@ __global__ __launch_bounds__(256) void plane_dot_rows_kernel(float* __restrict__
     const int t = PER_WAVE ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
     const long long plane = PER_WAVE ? (long long)blockIdx.x * 4 + (threadIdx.x >> 6) : (long long)blockIdx.x;
     if (plane >= planes) return;                               // PER_WAVE: a whole wave leaves (no barrier below in that mode)
+    if (gate.flags != nullptr) {
+        int any = 0;                                           // (wave- / workgroup-uniform: every thread reads the same words)
+        for (int i = 0; i < gate.slots; i++) any |= gate.flags[plane * gate.slots + i];
+        if (!any) {
+            if (t == 0) out[plane] = gate.osc[plane] * (gate.gz[plane] - (gate.nsc ? gate.nsc[plane] : 1.f) * (gate.gsk ? gate.gsk[plane] : 0.f));
+            return;
+        }
+    }
     const int nvec = (w + E - 1) / E, total = h * nvec;
     const unsigned magic = (unsigned)((0x100000000ull + (unsigned)nvec - 1) / (unsigned)nvec);
     const T* ap = a + plane * h * lda;
@@ -2760,8 +2776,8 @@ extern "C" int afcm_plane_dot(float* out, const void* a, const void* b, int32_t 
     return hip_status(hipGetLastError());
 }
 
-extern "C" int afcm_plane_dot_ld(float* out, const void* a, const void* b, int32_t dtype, int64_t planes, int32_t h, int32_t w,
-                                 int32_t a_pitch, int32_t b_pitch, void* stream) {
+static int plane_dot_rows(float* out, const void* a, const void* b, int32_t dtype, int64_t planes, int32_t h, int32_t w,
+                          int32_t a_pitch, int32_t b_pitch, const PlaneGate& gate, void* stream) {
     AFCM_REQUIRE(out != nullptr && a != nullptr && planes > 0 && h > 0 && w > 0, "plane_dot: empty input");
     AFCM_REQUIRE(planes < (1ll << 31), "plane_dot: too many planes");
     const int esize = dtype == AFCM_F32 ? 4 : 2;
@@ -2774,8 +2790,8 @@ extern "C" int afcm_plane_dot_ld(float* out, const void* a, const void* b, int32
     const bool per_wave = (long long)h * w * esize <= 16384;
     dim3 grid((unsigned)(per_wave ? (planes + 3) / 4 : planes)), block(256);
 #define AFCM_PDR(T) do { \
-        if (per_wave) hipLaunchKernelGGL((plane_dot_rows_kernel<T, true>), grid, block, 0, st, out, (const T*)a, (const T*)b, (long long)planes, h, w, lda, ldb); \
-        else hipLaunchKernelGGL((plane_dot_rows_kernel<T, false>), grid, block, 0, st, out, (const T*)a, (const T*)b, (long long)planes, h, w, lda, ldb); } while (0)
+        if (per_wave) hipLaunchKernelGGL((plane_dot_rows_kernel<T, true>), grid, block, 0, st, out, (const T*)a, (const T*)b, (long long)planes, h, w, lda, ldb, gate); \
+        else hipLaunchKernelGGL((plane_dot_rows_kernel<T, false>), grid, block, 0, st, out, (const T*)a, (const T*)b, (long long)planes, h, w, lda, ldb, gate); } while (0)
     switch (dtype) {
         case AFCM_F32: AFCM_PDR(float); break;
         case AFCM_F16: AFCM_PDR(f16_t); break;
@@ -2784,4 +2800,16 @@ extern "C" int afcm_plane_dot_ld(float* out, const void* a, const void* b, int32
     }
 #undef AFCM_PDR
     return hip_status(hipGetLastError());
+}
+
+extern "C" int afcm_plane_dot_ld(float* out, const void* a, const void* b, int32_t dtype, int64_t planes, int32_t h, int32_t w,
+                                 int32_t a_pitch, int32_t b_pitch, void* stream) {
+    return plane_dot_rows(out, a, b, dtype, planes, h, w, a_pitch, b_pitch, PlaneGate{nullptr, 0, nullptr, nullptr, nullptr, nullptr}, stream);
+}
+
+extern "C" int afcm_plane_dot_gated_ld(float* out, const void* a, const void* b, int32_t dtype, int64_t planes, int32_t h, int32_t w,
+                                       int32_t a_pitch, int32_t b_pitch, const int32_t* flags, int32_t slots, const float* out_scale,
+                                       const float* gz, const float* next_scale, const float* gskip, void* stream) {
+    AFCM_REQUIRE(flags != nullptr && slots > 0 && out_scale != nullptr && gz != nullptr && b != nullptr, "plane_dot_gated: null pointer");
+    return plane_dot_rows(out, a, b, dtype, planes, h, w, a_pitch, b_pitch, PlaneGate{flags, slots, out_scale, gz, next_scale, gskip}, stream);
 }

@@ -679,6 +679,7 @@ static void launch_one(const FlreluMfmaParams& p, bool bias, dim3 grid, dim3 blo
 static int fill_params(const afcm_filtered_lrelu_args* a, FlreluMfmaParams& p, int tilesX, int tilesY) {
     p.x = a->x; p.y = a->y; p.b = a->b; p.s = a->signs; p.ws = a->workspace; p.plane_sum = a->plane_sum;
     p.oscale = a->oscale; p.oscale2 = a->oscale2; p.skip = a->skip;
+    p.clamp_flags = nullptr;                    // (wave kernels only: launch_wave sets it)
     p.xw = a->xw; p.xh = a->xh; p.yw = a->yw; p.yh = a->yh; p.C = a->c;
     p.xld = a->x_pitch ? a->x_pitch : a->xw; p.yld = a->y_pitch ? a->y_pitch : a->yw; p.kld = a->skip_pitch ? a->skip_pitch : a->yw;
     p.px0 = a->px0; p.py0 = a->py0;
@@ -730,6 +731,7 @@ static int launch_wave(const afcm_filtered_lrelu_args* a, hipStream_t st) {
     p.read_aligned = wave_read_origin(a, &p.oy0, &dshift) ? 1 : 0;
     p.py0 += dshift;                 // the fragments were prepared for this origin (prepare_mfma)
     p.sy -= dshift;
+    p.clamp_flags = a->sign_mode == AFCM_SIGNS_READ ? nullptr : a->clamp_flags;
     if constexpr (UP == 2 && DOWN == 2) {
         if (toh == kTallTOH) return launch_wave_tile<T, 2, 2, 64, kTallTOH>(a, p, st);
     }

@@ -829,11 +829,17 @@ __global__ __launch_bounds__(256, (DOWN == 2 && (TOH <= 32 || SIGN == AFCM_SIGNS
         return __builtin_amdgcn_ballot_w64(!(amax <= cthr1)) != 0;                                        // NaN takes the exact path
     };
     // (READ never writes codes: one LASTY variant suffices)
+    bool exact;
     if (SIGN == AFCM_SIGNS_WRITE && lastY) {
-        if (__builtin_expect(run_strip(std::false_type{}, std::true_type{}), 0)) run_strip(std::true_type{}, std::true_type{});
+        exact = run_strip(std::false_type{}, std::true_type{});
+        if (__builtin_expect(exact, 0)) run_strip(std::true_type{}, std::true_type{});
     } else {
-        if (__builtin_expect(run_strip(std::false_type{}, std::false_type{}), 0)) run_strip(std::true_type{}, std::false_type{});
+        exact = run_strip(std::false_type{}, std::false_type{});
+        if (__builtin_expect(exact, 0)) run_strip(std::true_type{}, std::false_type{});
     }
+    // optional per-strip flag: the strip's activations could reach the clamp (a plane with no flagged strip is positively homogeneous
+    // of degree 1 in its input: the caller derives <dL/dy, y> from <g, z>, afcm_plane_dot_gated_ld).  Every slot is written.
+    if (!RD && p.clamp_flags != nullptr && lane == 0) p.clamp_flags[(size_t)plane * (p.tilesX * p.tilesY) + ty * p.tilesX + tx] = exact ? 1 : 0;
 
     if ((EPI & 4) && p.plane_sum != nullptr) {
         // one plain store into this tile's slot (no atomics: deterministic)

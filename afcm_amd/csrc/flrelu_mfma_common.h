@@ -34,6 +34,7 @@ struct FlreluMfmaParams {
     int sx, sy, shq, swq;  // sign tensor: rows of quads, bytes per row
     int total_tiles;       // wave kernels: tilesX * tilesY * planes (one wave per tile)
     int oy0, read_aligned; // wave kernels, READ: strips start at output row ty * TOH + oy0 (oy0 <= 0) so that they fall on 16-row blocks of the sign tensor
+    int* clamp_flags;      // wave kernels, WRITE / NONE: optional [planes][tilesX * tilesY]: 1 if the strip took the exact (clamp-capable) path
 };
 
 constexpr int kFUT = 6;            // taps per polyphase branch of the up filter (filter_size of the model)

@@ -136,6 +136,29 @@ def plane_dot(a, b=None):
     return out
 
 
+def plane_dot_gated(a, b, flags, out_scale, gz, next_scale=None, gskip=None):
+    """[N, C] fp32: out_scale * (gz - next_scale * gskip) for the planes whose ``flags`` ([N, C, slots] int32, afcm_filtered_lrelu_args.
+    clamp_flags) are all zero, the real sum over H, W of a * b for the others (C ABI afcm_plane_dot_gated_ld).  Operands outside the
+    row kernel's preconditions: the plain dot product."""
+    lib = _lib.load()
+    assert b.shape == a.shape and b.dtype == a.dtype
+    lda, ldb = _rows.pitch_of(a), _rows.pitch_of(b)
+    n, c, h, w = a.shape
+    ok = (lda is not None and ldb is not None and w * a.element_size() >= 16 and (a.element_size() == 4 or w % 2 == 0)
+          and a.data_ptr() % 4 == 0 and b.data_ptr() % 4 == 0 and flags.dtype == torch.int32 and flags.is_contiguous()
+          and tuple(flags.shape[:2]) == (n, c))
+    if not ok:
+        return plane_dot(a, b)
+    f32 = torch.float32
+    for t in (out_scale, gz, next_scale, gskip):
+        assert t is None or (t.dtype == f32 and t.is_contiguous() and t.numel() == n * c)
+    out = torch.empty([n, c], dtype=f32, device=a.device)
+    _lib.check(lib.afcm_plane_dot_gated_ld(out.data_ptr(), a.data_ptr(), b.data_ptr(), _lib.dtype_code(a), n * c, h, w, lda, ldb,
+                                           flags.data_ptr(), int(flags.shape[2]), out_scale.data_ptr(), gz.data_ptr(), _lib.ptr(next_scale),
+                                           _lib.ptr(gskip), _lib.stream_ptr(a)), 'plane_dot_gated')
+    return out
+
+
 def _pitch_conv(dtype, ks):
     """Does the conv kernel for this case address rows by pitch?  (The 16-bit 3x3 kernel; C ABI afcm_conv2d_ld.)"""
     return dtype in (torch.bfloat16, torch.float16) and ks == 3

@@ -114,11 +114,13 @@ class NoFusedKernel(Exception):
 
 
 def _run(x, fu, fd, b, si, cfg, write_signs, want_plane_sum=False, oscale=None, skip=None, oscale2=None, allow_mfma=True, no_fallback=False,
-         pitched_out=False):
+         pitched_out=False, clamp_flags_out=None):
     """One launch of the op (C ABI afcm_filtered_lrelu, or the generic GPU path when there is no fused kernel).
     Returns (y, signs written or None, sign layout, per-plane output sums or None).  x / skip may be row-pitched views (_rows.py):
     kernels that take a pitch read them in place, the others get a contiguous copy; ``pitched_out``: y comes back row-pitched
-    when the selected kernel can write one (callers that hand y to pitch-aware kernels only)."""
+    when the selected kernel can write one (callers that hand y to pitch-aware kernels only); ``clamp_flags_out``: a list that
+    receives the per-strip "could reach the clamp" flags (int32 [N, C, slots]) of a sign-writing call of the wave kernels (C ABI
+    afcm_filtered_lrelu_args.clamp_flags) -- left empty when another kernel family runs."""
     up, down, px0, px1, py0, py1, gain, slope, clamp, flip_filter, sx, sy, si_layout = cfg
     assert isinstance(x, torch.Tensor) and x.ndim == 4
     _lib.require_gpu(x, fu, fd, b, si)
@@ -196,6 +198,10 @@ def _run(x, fu, fd, b, si, cfg, write_signs, want_plane_sum=False, oscale=None, 
     if ws is not None and want_plane_sum and a.plane_sum_slots > 0:
         psum = torch.empty([a.n, a.c, a.plane_sum_slots], dtype=torch.float32, device=x.device)   # every slot is written
         a.plane_sum = psum.data_ptr()
+    flags = None
+    if clamp_flags_out is not None and ws is not None and write_signs and b is None and a.plane_sum_slots > 0:
+        flags = torch.empty([a.n, a.c, a.plane_sum_slots], dtype=torch.int32, device=x.device)       # every slot is written (layout 2 only: checked below)
+        a.clamp_flags = flags.data_ptr()
     a.fu, a.fd = _lib.ptr(fu_t), _lib.ptr(fd_t)
     span = profiling.span('filtered_lrelu', (x.numel() + y.numel()) * x.element_size()
                           + (so.numel() if so is not None else (si.numel() if si is not None else 0)))
@@ -203,6 +209,8 @@ def _run(x, fu, fd, b, si, cfg, write_signs, want_plane_sum=False, oscale=None, 
     if span is not None:
         span.end()
     layout = a.sign_layout
+    if flags is not None and layout == 2 and rc == 0:
+        clamp_flags_out.append(flags)
 
     if rc == _lib.E_NOKERNEL and no_fallback:
         raise NoFusedKernel()

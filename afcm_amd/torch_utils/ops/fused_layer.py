@@ -47,17 +47,22 @@ class _ConvFilteredLRelu(torch.autograd.Function):
         # node and of its neighbours (_rows.py)
         y = _conv._conv_raw(xs, wp, rows_pad, out_scale, cout, ks, conv_pad, obias=bias, pitched_out=True)
         need_grad = any(ctx.needs_input_grad[:5]) or ctx.needs_input_grad[7] or ctx.needs_input_grad[8]
-        z, signs, layout, _ = _flr._run(y, fu, fd, None, None, cfg, need_grad, oscale=next_scale, skip=skip, pitched_out=True)
         keep_y = out_scale is not None and ctx.needs_input_grad[3]
-        keep_z = next_scale is not None and ctx.needs_input_grad[8]
-        ctx.save_for_backward(xs, w, in_scale, out_scale, bias, fu, fd, signs, next_scale, y if keep_y else None, z if keep_z else None)
+        flags = [] if (keep_y and need_grad and HOMOGENEOUS_DOT) else None
+        z, signs, layout, _ = _flr._run(y, fu, fd, None, None, cfg, need_grad, oscale=next_scale, skip=skip, pitched_out=True, clamp_flags_out=flags)
+        flags = flags[0] if flags else None
+        # the demodulation gradient needs <dys, y>: with the flags it comes from <g, z> (and <g, skip>) by homogeneity, y is read
+        # for flagged planes only (see backward); z is this node's output, keeping it costs nothing
+        keep_z = (next_scale is not None and ctx.needs_input_grad[8]) or flags is not None
+        ctx.save_for_backward(xs, w, in_scale, out_scale, bias, fu, fd, signs, next_scale, y if keep_y else None, z if keep_z else None,
+                              flags, skip if (flags is not None and skip is not None) else None)
         ctx.meta = (conv_pad, cfg, bool(prescaled), layout, tuple(y.shape), tuple(z.shape), skip is not None)
         return z
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, g):
-        xs, w, in_scale, out_scale, bias, fu, fd, signs, next_scale, y, z = ctx.saved_tensors
+        xs, w, in_scale, out_scale, bias, fu, fd, signs, next_scale, y, z, flags, skip = ctx.saved_tensors
         conv_pad, cfg, prescaled, layout, y_shape, z_shape, has_skip = ctx.meta
         cout, cin, ks, _ = w.shape
         f32 = torch.float32
@@ -71,16 +76,25 @@ class _ConvFilteredLRelu(torch.autograd.Function):
         want_db, want_next, want_out = ctx.needs_input_grad[4], ctx.needs_input_grad[8], ctx.needs_input_grad[3]
         if want_db or want_next or want_out:
             lib = _lib.load()
-            gz = _conv.plane_dot(g, z) if want_next else None
-            dysy = _conv.plane_dot(dys, y) if want_out else None
+            gz = _conv.plane_dot(g, z) if (want_next or (want_out and flags is not None)) else None
+            osc = None if out_scale is None else out_scale.to(f32).contiguous()
+            nsc = None if next_scale is None else next_scale.to(f32).contiguous()
+            if want_out and flags is not None:
+                # <dys, y> = d <dL/dy, y> = d (<g, z> - s_next <g, skip>): without an active clamp the fused filtered_lrelu is positively
+                # homogeneous of degree 1 (linear filters around a leaky ReLU), so J(y) y = F(y) = z / s_next - skip.  The forward
+                # kernels flagged every strip whose activations could reach the clamp; a flagged plane gets the real dot product,
+                # on the device (C ABI afcm_plane_dot_gated_ld) -- 14 full-plane dot products per step become 14 launches that read a
+                # few flags per plane
+                gsk = _conv.plane_dot(g, skip) if skip is not None else None
+                dysy = _conv.plane_dot_gated(dys, y, flags, osc, gz, nsc, gsk)
+            else:
+                dysy = _conv.plane_dot(dys, y) if want_out else None
             db32 = torch.empty([o], dtype=f32, device=g.device) if want_db else None
             dn32 = torch.empty([n, o], dtype=f32, device=g.device) if want_next else None
             do32 = torch.empty([n, o], dtype=f32, device=g.device) if want_out else None
-            osc = None if out_scale is None else out_scale.to(f32).contiguous()
-            nsc = None if next_scale is None else next_scale.to(f32).contiguous()
             b32 = None if bias is None else bias.to(f32).contiguous()
             _lib.check(lib.afcm_layer_bwd_coefs(_lib.ptr(db32), _lib.ptr(dn32), _lib.ptr(do32), psum.data_ptr(), int(psum.shape[2]), _lib.ptr(osc),
-                                                _lib.ptr(nsc), _lib.ptr(b32), _lib.ptr(gz), _lib.ptr(dysy), n, o, _lib.stream_ptr(g)),
+                                                _lib.ptr(nsc), _lib.ptr(b32), _lib.ptr(gz if want_next else None), _lib.ptr(dysy), n, o, _lib.stream_ptr(g)),
                        'layer_bwd_coefs')
             db = None if db32 is None else db32.to(bias.dtype)
             d_next = None if dn32 is None else dn32.to(next_scale.dtype)
@@ -97,6 +111,10 @@ class _ConvFilteredLRelu(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             dw = _conv._wgrad_raw(dys, xs, cout, cin, ks, conv_pad).to(w.dtype)
         return dx, dw, d_in, d_out, db, None, None, d_skip, d_next, None, None, None, None
+
+
+# the demodulation gradient's <dys, y> from <g, z> where no strip of a plane could reach the clamp (tests switch it off to compare)
+HOMOGENEOUS_DOT = True
 
 
 def _cfg(up, down, padding, gain, slope, clamp):

@@ -45,6 +45,8 @@ def parse():
                          'instrumented cost 0.9-1.0 ms of a 41 ms step, measured; every 4th: 0.25 ms)')
     ap.add_argument('--force-dist', action='store_true', help='initialise RCCL and run the gradient buckets even with one rank (path check)')
     ap.add_argument('--comm-dtype', default='fp32', choices=['fp32', 'bf16'], help='dtype of the gradient buckets on the wire')
+    ap.add_argument('--no-homogeneous-dot', action='store_true', help='ablation: the demodulation gradient from real plane dot products everywhere '
+                                                                      '(torch_utils/ops/fused_layer.py HOMOGENEOUS_DOT)')
     ap.add_argument('--with-discriminator', action='store_true',
                     help='time the FULL iteration (D update with R1, then G update with the GAN term; SURVEY.md row f1) instead of the '
                          'generator step that BASELINE.json\'s metric names')
@@ -189,6 +191,9 @@ def main():
         else:
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
+    if args.no_homogeneous_dot:
+        from afcm_amd.torch_utils.ops import fused_layer
+        fused_layer.HOMOGENEOUS_DOT = False
     dtype = {'bf16': torch.bfloat16, 'fp16': torch.float16, 'fp32': torch.float32}[args.dtype]
     comm_dtype = torch.bfloat16 if args.comm_dtype == 'bf16' else None
     torch.manual_seed(0)      # identical init on every rank (the step also broadcasts from rank 0)
@@ -325,7 +330,7 @@ def main():
                        'world_size': dist.get_world_size() if use_dist else 1,
                        'backend': dist.get_backend() if use_dist else None,
                        'gradient_buckets': step.buckets.num_buckets if step.buckets is not None else 0,
-                       'comm_dtype': args.comm_dtype},
+                       'comm_dtype': args.comm_dtype, 'homogeneous_dot': not args.no_homogeneous_dot},
             'roofline': roofline,
             'kernels': kernels,
             'cpu_baseline': cpu,

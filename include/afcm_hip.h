@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define AFCM_ABI_VERSION 9   /* 9 (r03): + afcm_affine_bank_*, afcm_modulation_bank_*, afcm_conv2d_pack_bank, afcm_conv2d_stride2 (additions only; every v8 entry point and struct is unchanged) */
+#define AFCM_ABI_VERSION 10  /* 10 (r04): + afcm_filtered_lrelu_args.clamp_flags (appended), afcm_plane_dot_gated_ld; the runtime getenv switches are gone.  9 (r03): + afcm_affine_bank_*, afcm_modulation_bank_*, afcm_conv2d_pack_bank, afcm_conv2d_stride2 (additions only; every v8 entry point and struct is unchanged) */
 
 enum { AFCM_F32 = 0, AFCM_F16 = 1, AFCM_BF16 = 2 };
 enum { AFCM_OK = 0, AFCM_E_NOKERNEL = -1, AFCM_E_INVALID = -2 };
@@ -103,6 +103,11 @@ typedef struct afcm_filtered_lrelu_args {
                                and with y_pitch set they write finite values to every column of y up to the pitch (columns
                                >= yw are padding).                                                                              */
     int32_t row_pitch_ok;   /* set by afcm_filtered_lrelu_shapes(): 1 if the kernel selected for these arguments accepts pitches */
+    int32_t* clamp_flags;   /* NULL, or int32 [N*C][plane_sum_slots] (sign-writing calls of the wave kernels, i.e. plane_sum_slots > 0 and
+                               no bias operand): slot = 1 if that strip's activations could reach the clamp (it then took the exact
+                               per-element path), else 0.  Every slot is written.  A plane whose slots are all 0 went through linear
+                               filters around a pure leaky ReLU: there filtered_lrelu is positively homogeneous of degree 1, which
+                               the caller may use to derive <dL/dy, y> from <g, z> (afcm_plane_dot_gated_ld).                      */
 } afcm_filtered_lrelu_args;
 
 /* Output / sign-tensor geometry for the arguments above (filtered_lrelu.cpp:61-94). Fills yh, yw
@@ -214,6 +219,13 @@ int afcm_plane_dot(float* out, const void* a, const void* b, int32_t dtype, int6
 /* The same over planes of h rows x w columns with row pitches (elements; 0 = dense); padding columns are never read. */
 int afcm_plane_dot_ld(float* out, const void* a, const void* b, int32_t dtype, int64_t planes, int32_t h, int32_t w,
                       int32_t a_pitch, int32_t b_pitch, void* stream);
+/* The demodulation gradient's dot product by homogeneity (fused layer node, NET:41-57 backward): for a plane whose clamp_flags
+ * (afcm_filtered_lrelu_args, [planes][slots]) are all 0,  out = out_scale * (gz - next_scale * gskip)  -- <dys, y> = d <dL/dy, y> =
+ * d (<g, z> - s_next <g, skip>) by Euler's identity for the degree-1 homogeneous filtered_lrelu -- and neither a nor b is read;
+ * a flagged plane gets the real dot product sum a * b.  next_scale / gskip may be NULL (1 / 0). */
+int afcm_plane_dot_gated_ld(float* out, const void* a, const void* b, int32_t dtype, int64_t planes, int32_t h, int32_t w,
+                            int32_t a_pitch, int32_t b_pitch, const int32_t* flags, int32_t slots, const float* out_scale,
+                            const float* gz, const float* next_scale, const float* gskip, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * The small-tensor half of modulated_conv2d (NET:41-57), fp32, forward and exact backward.  The reference runs it as

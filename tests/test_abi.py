@@ -39,7 +39,7 @@ def test_binding_table_matches_header(lib):
 
 
 def test_abi_version(lib):
-    assert lib.afcm_abi_version() == 9
+    assert lib.afcm_abi_version() == 10
 
 
 def test_shapes_helper_is_pure_host(lib):
@@ -66,8 +66,9 @@ def test_struct_layout_matches_c():
 #include <stdio.h>
 #include <stddef.h>
 #include "afcm_hip.h"
-int main(void){ printf("%zu %zu %zu %zu %zu\n", sizeof(afcm_filtered_lrelu_args), offsetof(afcm_filtered_lrelu_args, dtype),
-  offsetof(afcm_filtered_lrelu_args, up), offsetof(afcm_filtered_lrelu_args, gain), offsetof(afcm_filtered_lrelu_args, sign_mode)); return 0; }
+int main(void){ printf("%zu %zu %zu %zu %zu %zu\n", sizeof(afcm_filtered_lrelu_args), offsetof(afcm_filtered_lrelu_args, dtype),
+  offsetof(afcm_filtered_lrelu_args, up), offsetof(afcm_filtered_lrelu_args, gain), offsetof(afcm_filtered_lrelu_args, sign_mode),
+  offsetof(afcm_filtered_lrelu_args, clamp_flags)); return 0; }
 '''
     import tempfile
     with tempfile.TemporaryDirectory() as d:
@@ -75,7 +76,7 @@ int main(void){ printf("%zu %zu %zu %zu %zu\n", sizeof(afcm_filtered_lrelu_args)
         subprocess.check_call(['gcc', '-I', os.path.join(ROOT, 'include'), '-o', os.path.join(d, 't'), os.path.join(d, 't.c')])
         out = subprocess.check_output([os.path.join(d, 't')]).decode().split()
     S = _lib.FilteredLReluArgs
-    assert [int(v) for v in out] == [ctypes.sizeof(S), S.dtype.offset, S.up.offset, S.gain.offset, S.sign_mode.offset]
+    assert [int(v) for v in out] == [ctypes.sizeof(S), S.dtype.offset, S.up.offset, S.gain.offset, S.sign_mode.offset, S.clamp_flags.offset]
 
 
 def test_ops_refuse_cpu_tensors():

@@ -197,6 +197,63 @@ def test_fused_layer_node_matches_op_by_op(case, dtype, tol):
         _close_rel(gx, gref['x'] / s[:, :, None, None], 3 * tol, 'prescaled dxs')
 
 
+@pytest.mark.parametrize('dtype,tol', [(torch.bfloat16, 4e-2), (torch.float16, 8e-3)])
+def test_demodulation_gradient_by_homogeneity_falls_back_on_clamped_planes(dtype, tol):
+    """The fused node's <dys, y> (the demodulation gradient, NET:50-52 backward) comes from <g, z> - s_next <g, skip> where no strip of
+    a plane could reach the clamp (filtered_lrelu is then positively homogeneous of degree 1) and from the real dot product on the
+    others, decided on the device from the flags the sign-writing kernels emit (C ABI afcm_filtered_lrelu_args.clamp_flags,
+    afcm_plane_dot_gated_ld).  Half of the planes are scaled far below the clamp, the other half far into it: the flags say so, the
+    flagged planes' gradient is bit-identical to the all-real-dot-products path, the others agree to 16-bit rounding, and both match
+    the fp32 oracle (which clamps, filtered_lrelu.cu:484-572)."""
+    from afcm_amd.torch_utils.ops import filtered_lrelu as flr
+    from afcm_amd.torch_utils.ops import fused_layer
+    from oracle import aten_ops as ops
+    from oracle import generator as ogen
+    pl = ogen.plan(256, 4, 1, {})
+    L = [l for l in pl['dec'] if l['name'] == 'L9_148_181'][0]
+    torch.manual_seed(11)
+    n, cin, cout, h = 2, 16, 8, L['in_size']
+    x = torch.randn(n, cin, h, h)
+    w = torch.randn(cout, cin, 3, 3) / np.sqrt(cin * 9)
+    s = torch.rand(n, cin) + 0.5
+    d = torch.where(torch.arange(n * cout).reshape(n, cout) % 2 == 0, torch.full([n, cout], 0.05), torch.full([n, cout], 40.0)) * (torch.rand(n, cout) + 0.5)
+    b = torch.randn(cout) * 0.01
+    oh = L['out_size']
+    skip = torch.randn(n, cout, oh, oh)
+    ns = torch.rand(n, cout) + 0.5
+    act = dict(up=L['up'], down=L['down'], padding=L['padding'], gain=float(np.sqrt(2)), slope=0.2, clamp=4.0)
+    xq, skq = x.to(dtype).float(), skip.to(dtype).float()
+    lv = [t.clone().requires_grad_(True) for t in (xq, w, s, d, b, skq, ns)]
+    y = torch.nn.functional.conv2d(lv[0] * lv[2][:, :, None, None], lv[1], padding=2) * lv[3][:, :, None, None]
+    z = (ops.filtered_lrelu(y, fu=L['fu'], fd=L['fd'], b=lv[4], **act) + lv[5]) * lv[6][:, :, None, None]
+    r = torch.randn_like(z).to(dtype).float()
+    gd_ref, gns_ref = torch.autograd.grad((z * r).sum(), [lv[3], lv[6]])
+
+    def run(homog):
+        fused_layer.HOMOGENEOUS_DOT = homog
+        try:
+            dev = [t.detach().cuda().requires_grad_(True) for t in (x.to(dtype), w, s, d, b, skip.to(dtype), ns)]
+            got = fused_layer.conv_filtered_lrelu(dev[0], dev[1], dev[2], dev[3], dev[4], L['fu'].cuda(), L['fd'].cuda(), conv_pad=2,
+                                                  skip=dev[5], next_scale=dev[6], **act)
+            flags = got.grad_fn.saved_tensors[11]
+            gd, gns = torch.autograd.grad((got.float() * r.cuda()).sum(), [dev[3], dev[6]])
+            return got, flags, gd.cpu(), gns.cpu()
+        finally:
+            fused_layer.HOMOGENEOUS_DOT = True
+    got, flags, gd_h, gns_h = run(True)
+    _, flags0, gd_r, gns_r = run(False)
+    assert flags0 is None and flags is not None and flags.dtype == torch.int32 and tuple(flags.shape[:2]) == (n, cout)
+    flagged = (flags.sum(dim=2) > 0).cpu()
+    small = (torch.arange(n * cout).reshape(n, cout) % 2 == 0)
+    assert flagged[~small].all(), 'every strongly driven plane must be flagged'
+    assert not flagged[small].any(), 'planes far below the clamp must not be flagged'
+    assert torch.equal(gd_h[flagged], gd_r[flagged]), 'flagged planes take the real dot product'
+    assert torch.equal(gns_h, gns_r)
+    _close_rel(gd_h[~flagged], gd_r[~flagged], tol, 'homogeneity vs real dot products, planes below the clamp')
+    _close_rel(gd_h, gd_ref, 3 * tol, 'dd vs the oracle')
+    _close_rel(gns_h, gns_ref, 3 * tol, 'd(next styles) vs the oracle')
+
+
 def _close_rel(a, b, tol, what):
     a = a.detach().float().cpu()
     b = b.detach().float().cpu()
