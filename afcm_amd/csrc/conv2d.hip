@@ -348,31 +348,16 @@ __device__ unsigned long long afcm_conv_bar_buf[4 * 65536];    // per wave: cycl
 #else
 #define AFCM_STAMP(k) do { } while (0)
 #endif
-// ring depth / patch register sets of the 64-row blocks (see the loop)
-#ifndef AFCM_CONV_BM64_RING
-#define AFCM_CONV_BM64_RING 3
-#endif
-#ifndef AFCM_CONV_BM64_NP
-#define AFCM_CONV_BM64_NP 1
-#endif
-// tap under whose MFMAs the next chunk's patch is transposed into LDS (deep rings: the later, the longer the patch may take)
-#ifndef AFCM_CONV_BM64_WTAP
-#define AFCM_CONV_BM64_WTAP 5
-#endif
-#ifndef AFCM_CONV_BM64_OCC
-#define AFCM_CONV_BM64_OCC 2
-#endif
-// taps the B fragments run ahead of their MFMAs (64-row blocks: a tap is 4 MFMAs = 128 pipe cycles, less than an LDS round trip
-// under 12 waves per CU; 128-row blocks: 8 MFMAs cover it)
-#ifndef AFCM_CONV_BM64_BD
-#define AFCM_CONV_BM64_BD 1
-#endif
-template <typename T, int BM_O, int RING = 3, int NP = 1, int BD = 1>
-__global__ __launch_bounds__(256, (BM_O == 64 ? AFCM_CONV_BM64_OCC : 2)) void conv2d_fwd16_kernel(ConvParams p) {
+template <typename T, int BM_O>
+__global__ __launch_bounds__(256, 2) void conv2d_fwd16_kernel(ConvParams p) {
     static_assert(sizeof(T) == 2, "16-bit types only");
     typedef ConvCfg<T> C;
     constexpr int KS = 3, KK = 9, BK = C::BK, PITCH = C::PITCH, MI = BM_O / 64;
-    static_assert(KK % RING == 0 && (NP == 1 || NP == 2), "ring depth divides the taps; one or two patch register sets");
+    // RING: taps the weight fragments run ahead; NP: patch register sets (2 = the patch of chunk k + 2 requested at the top of chunk
+    // k); BD: taps the B fragments run ahead.  r04 built and measured the deeper forms on the 64-row blocks (RING 9 at two waves per
+    // SIMD or with 9-11 spilled registers at three, NP 2, BD 2, the transposing write at tap 7 / 8): 0-8 % slower on every layer
+    // (profiles/r04_conv_ring_depth.txt) -- the chunk does not wait for any ONE of these round trips.
+    constexpr int RING = 3, NP = 1, BD = 1;
     typedef typename std::conditional<std::is_same<T, bf16_t>::value, bf16x8, f16x8>::type frag_t;
     typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
     __shared__ __attribute__((aligned(16))) T lds[2 * kPatchMax * PITCH + 4 * PITCH];      // + a sink for lanes outside the patch
@@ -569,7 +554,7 @@ __global__ __launch_bounds__(256, (BM_O == 64 ? AFCM_CONV_BM64_OCC : 2)) void co
                 if (tap + BD < KK) b[tap % BD][ti] = *(const frag_t*)(cur + bbase[ti] + tapoff_n);
 #endif
             }
-            if (tap == ((BM_O == 64 && RING == 9) ? AFCM_CONV_BM64_WTAP : 5)) {
+            if (tap == 5) {
                 // the other buffer (last read one chunk ago); on the last chunk this rewrites stale registers into a buffer
                 // nobody reads.  Interleave: one MFMA, then a handful of the transpose's vector instructions.
                 write_patch(kc + 1, nxt, ((kc + 1) & 1) * (kPatchMax * PITCH), wr_t{});
@@ -2467,8 +2452,7 @@ static int launch_conv(ConvParams p, int ks, hipStream_t st) {
     dim3 grid((unsigned)blocks), block(256);
     if constexpr (sizeof(T) == 2) {
         if (ks == 3) {
-            if constexpr (BM_O == 64) hipLaunchKernelGGL((conv2d_fwd16_kernel<T, BM_O, AFCM_CONV_BM64_RING, AFCM_CONV_BM64_NP, AFCM_CONV_BM64_BD>), grid, block, 0, st, p);
-            else hipLaunchKernelGGL((conv2d_fwd16_kernel<T, BM_O>), grid, block, 0, st, p);
+            hipLaunchKernelGGL((conv2d_fwd16_kernel<T, BM_O>), grid, block, 0, st, p);
             return hip_status(hipGetLastError());
         }
     }
