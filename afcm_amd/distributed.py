@@ -72,6 +72,7 @@ class GradientBuckets:
         self._armed = True
         self._next = 0              # first bucket whose collective has not been issued yet (collectives go out in bucket order)
         self._warned = False
+        self._warned_dropped = False
         self.trace = None           # set to a list to record (bucket index, bytes, CUDA event at the point the collective was issued)
         self._used = None           # per parameter (bucket order): some rank produced a gradient
         self._flag_check = None     # (pinned host flags, event) of the previous iteration, verified lazily
@@ -307,6 +308,13 @@ class GradientBuckets:
                     else:
                         p.grad.copy_(red)
                 else:
+                    if p.grad is not None and not self._warned_dropped:
+                        # said in the iteration in which it happens (the lazy check of _resolve_used() reports the changed set one
+                        # iteration later): this rank produced a gradient for a parameter outside the used set
+                        self._warned_dropped = True
+                        warnings.warn('GradientBuckets: a parameter outside the used set (static_graph=True: the set of the previous '
+                                      'iteration) received a gradient on this rank; it is dropped this iteration and the set is corrected '
+                                      'from the next one on (construct with static_graph=False to follow the set exactly).', RuntimeWarning)
                     p.grad = None
                 i += 1
 

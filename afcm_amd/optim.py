@@ -44,6 +44,7 @@ class FusedScrubAdam(torch.optim.Optimizer):
         for gi, group in enumerate(self.param_groups):
             beta1, beta2 = group['betas']
             rows = []
+            touched = []
             chunks = 0
             step_t = None
             for p in group['params']:
@@ -66,6 +67,7 @@ class FusedScrubAdam(torch.optim.Optimizer):
                     step_t = int(max(float(self._state(q)['step']) for q in group['params'])) + 1
                 st['step'].fill_(step_t)
                 rows.append((p.data_ptr(), g.data_ptr(), st['exp_avg'].data_ptr(), st['exp_avg_sq'].data_ptr(), p.numel(), chunks))
+                touched.extend((p, st['exp_avg'], st['exp_avg_sq']))
                 chunks += (p.numel() + chunk - 1) // chunk
             if not rows:
                 continue
@@ -86,4 +88,7 @@ class FusedScrubAdam(torch.optim.Optimizer):
             _lib.check(lib.afcm_adam_multi(ctypes.c_void_p(table.data_ptr()), len(rows), chunks, group['lr'] / bc1, beta1, beta2,
                                            1.0 - beta1, 1.0 - beta2, math.sqrt(bc2), group['eps'], float(grad_scale), int(self.scrub), self.posinf, self.neginf,
                                            int(self.write_grad), _lib.stream_ptr(table)), 'adam_multi')
+            # the kernel wrote through raw pointers: tell autograd (version counters), so that anything keyed on a parameter's version --
+            # saved-tensor checks, caches of derived tensors such as packed weight images -- sees the update
+            torch.autograd.graph.increment_version(touched)
         return loss

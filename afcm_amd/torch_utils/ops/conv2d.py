@@ -314,6 +314,9 @@ class _ConvWgrad(torch.autograd.Function):
         return g_dy, g_x, None, None
 
 
+_S2_PACKS = {}          # (weight storage, version, shape, dtype, device) -> packed image of the stride-2 kernel
+
+
 class _StridedConv2d(torch.autograd.Function):
     """y = conv(x, w, pad) at stride 2, 16-bit 3x3 (C ABI afcm_conv2d_stride2): the even rows / columns of the stride-1 result, bit for
     bit, at a quarter of its MFMAs.  The gradients of a strided correlation are stride-1 convolutions with the zero-stuffed dy: the
@@ -330,9 +333,17 @@ class _StridedConv2d(torch.autograd.Function):
         code = _lib._DTYPES[x.dtype]
         bk = lib.afcm_conv2d_block_k(code)
         rows_pad = (cout + 127) // 128 * 128                       # the stride-2 kernel runs 128-row blocks only
-        w32 = w.detach().to(torch.float32).contiguous()
-        wp = torch.empty([(cin + bk - 1) // bk, 9, rows_pad, bk], dtype=x.dtype, device=x.device)
-        _lib.check(lib.afcm_conv2d_pack_weights(wp.data_ptr(), w32.data_ptr(), code, cout, cin, 3, 0, rows_pad, _lib.stream_ptr(x)), 'conv2d_pack_weights')
+        # the packed image is reused while the weight tensor is unchanged (a D iteration runs every down-conv three times --
+        # fake, real, R1 -- on the same weights: ADVICE r03); keyed on storage, version counter and dtype
+        key = (w.data_ptr(), w._version, tuple(w.shape), x.dtype, x.device)
+        wp = _S2_PACKS.get(key)
+        if wp is None:
+            w32 = w.detach().to(torch.float32).contiguous()
+            wp = torch.empty([(cin + bk - 1) // bk, 9, rows_pad, bk], dtype=x.dtype, device=x.device)
+            _lib.check(lib.afcm_conv2d_pack_weights(wp.data_ptr(), w32.data_ptr(), code, cout, cin, 3, 0, rows_pad, _lib.stream_ptr(x)), 'conv2d_pack_weights')
+            if len(_S2_PACKS) >= 64:
+                _S2_PACKS.clear()
+            _S2_PACKS[key] = wp
         p, q = (h + 2 * padding - 3) // 2 + 1, (wd + 2 * padding - 3) // 2 + 1
         y = torch.empty([n, cout, p, q], dtype=x.dtype, device=x.device)
         span = profiling.span('conv2d', 2.0 * n * cout * cin * 9 * p * q)

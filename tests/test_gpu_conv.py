@@ -381,3 +381,27 @@ def test_stride2_conv_equals_the_decimated_stride1_result(dtype, n, cin, cout, h
     hg, = torch.autograd.grad(gg[0].float().square().sum(), [wt])
     hw, = torch.autograd.grad(gw[0].float().square().sum(), [wt])
     assert (hg - hw).abs().max().item() <= 1e-3 * max(1e-6, hw.abs().max().item())
+
+
+def test_stride2_conv_repacks_after_an_optimizer_step():
+    """The stride-2 conv keeps its packed weight image while the weight tensor is unchanged (keyed on storage and version counter);
+    the fused Adam kernel writes parameters through raw pointers and therefore bumps the version counters itself (afcm_amd/optim.py):
+    after a step the conv must run on the NEW weights, and an in-place torch update must be seen as well."""
+    from afcm_amd.optim import FusedScrubAdam
+    from afcm_amd.torch_utils.ops import conv2d as C
+    torch.manual_seed(3)
+    x = torch.randn(2, 16, 20, 20, device='cuda').to(torch.bfloat16)
+    wt = torch.nn.Parameter(torch.randn(24, 16, 3, 3, device='cuda') / 12)
+    opt = FusedScrubAdam([wt], lr=0.05, betas=(0.0, 0.99))
+    y0 = C.strided_conv2d(x, wt, 1)
+    assert torch.equal(y0, C.strided_conv2d(x, wt, 1))                 # (second call: the cached image)
+    v0 = wt._version
+    y0.float().square().sum().backward()
+    opt.step()
+    assert wt._version > v0, 'the optimizer kernel must bump the version counter of what it wrote'
+    y1 = C.strided_conv2d(x, wt, 1)
+    want = C.scaled_conv2d(x, wt.detach(), None, None, 1)[:, :, ::2, ::2]
+    assert torch.equal(y1, want) and not torch.equal(y1, y0)
+    with torch.no_grad():
+        wt.mul_(0.5)
+    assert torch.equal(C.strided_conv2d(x, wt, 1), C.scaled_conv2d(x, wt.detach(), None, None, 1)[:, :, ::2, ::2])
