@@ -62,6 +62,9 @@ struct ConvParams {
     int Opad, nkc;
     unsigned magicTW;     // ceil(2^32 / TW): j / TW = umulhi(j, magicTW) for the tile-local pixel indices (j < 2^16)
     unsigned magicTX, magicTY, magicN, magicPC;   // ... / tilesX, tilesY, N (block index decode: dividend x divisor < 2^32), / (PWL / 4)
+    // split-precision form (conv2d_fwd16_kernel<bf16, BM, true>): x holds `parts` bf16 tensors [N, Cin, H, ldx] part_bytes apart,
+    // the K loop runs over terms x nkc_real chunks, term t reads part (term_parts >> 4 t) & 15; y is fp32
+    int nkc_real; unsigned magicNK, term_parts; int part_bytes, last_part_bytes;   // last_part_bytes: offset of the highest part any term reads
 };
 __host__ __device__ inline unsigned magic_u32(unsigned d) { return (unsigned)((0x100000000ull + d - 1) / d); }   // 0 for d = 1 (see udiv_magic)
 __device__ __forceinline__ unsigned udiv_magic(unsigned n, unsigned magic) { return magic ? __umulhi(n, magic) : n; }
@@ -348,10 +351,11 @@ __device__ unsigned long long afcm_conv_bar_buf[4 * 65536];    // per wave: cycl
 #else
 #define AFCM_STAMP(k) do { } while (0)
 #endif
-template <typename T, int BM_O>
+template <typename T, int BM_O, bool SPLIT = false>
 __global__ __launch_bounds__(256, 2) void conv2d_fwd16_kernel(ConvParams p) {
     static_assert(sizeof(T) == 2, "16-bit types only");
     typedef ConvCfg<T> C;
+    typedef typename std::conditional<SPLIT, float, T>::type TO;      // output element
     constexpr int KS = 3, KK = 9, BK = C::BK, PITCH = C::PITCH, MI = BM_O / 64;
     // RING: taps the weight fragments run ahead; NP: patch register sets (2 = the patch of chunk k + 2 requested at the top of chunk
     // k); BD: taps the B fragments run ahead.  r04 built and measured the deeper forms on the 64-row blocks (RING 9 at two waves per
@@ -419,25 +423,36 @@ __global__ __launch_bounds__(256, 2) void conv2d_fwd16_kernel(ConvParams p) {
     const unsigned pmask0 = d0ok ? ~0u : 0u, pmask1 = d1ok ? ~0u : 0u;
     const bool lshift = !d0ok && d1ok;                                                // never touch bytes before a row 0
     const unsigned pvoff = (d0ok || d1ok) ? (unsigned)(((long long)cg * 8 * p.H * p.ldx + pix_off + (lshift ? 2 : 0)) * 2ll) : kOob;
-    const long long img_bytes = (long long)p.Cin * p.H * p.ldx * 2ll;
+    // (split form: one descriptor from this image in part 0 to its end in the highest part read -- the part offset rides in the scalar
+    // offset, and the range check covers vector + scalar offset (tools/ubench/buffer_range_probe.hip).  It has to end exactly there: the
+    // 8-byte loads of a row's last columns run up to 4 bytes past the row, which for the last row of the last image of the last part is
+    // past the allocation; host: that end lies below 2^31 bytes)
+    const long long img_bytes = (long long)p.Cin * p.H * p.ldx * 2ll + (SPLIT ? (long long)p.last_part_bytes : 0ll);
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)xn, 0, (int)(img_bytes > 0x7fffffffll ? 0x7fffffffll : img_bytes), 0x00020000);
     const int hw2 = p.H * p.ldx * 2;
 
     unsigned preg[NP][8][2];
-    // Channels past Cin exist only in the last chunk of a layer whose Cin is not a multiple of 16; the chunk's channel offset
-    // rides in the scalar offset, which the descriptor's range check does not cover, so those lanes get the out-of-range
-    // vector offset instead (zeros).  Decided here, at the chunk boundary, to keep the tap loop free of branches.
+    // Channels past Cin exist only in the last chunk of a layer whose Cin is not a multiple of 16.  In the plain form the descriptor
+    // ends with the image and the range check (vector + scalar offset) zeroes them; in the split form the descriptor runs on into the
+    // next part, so those lanes get the out-of-range vector offset.  Decided here, at the chunk boundary, to keep the tap loop free of
+    // branches.
     // Branch-free, and issued on EVERY chunk (past the last one with the out-of-range offset: zeros, no memory traffic): a
     // conditional issue makes the compiler's s_waitcnt for the weight ring assume the path without these eight loads, and on
     // the path with them that count waits for all eight -- a full memory round trip exposed at the top of every chunk.
     auto issue_patch = [&](int kc, bool live, auto set_c) __attribute__((always_inline)) {
         constexpr int SET = decltype(set_c)::value;
-        const int cbase = kc * BK + cg * 8;
+        int kcr = kc, sbase = 0;                           // chunk inside its term, byte offset of the term's part (scalar unit)
+        if constexpr (SPLIT) {
+            const int term = (int)udiv_magic((unsigned)kc, p.magicNK);
+            kcr = kc - term * p.nkc_real;
+            sbase = (int)((p.term_parts >> (4 * term)) & 15u) * p.part_bytes;
+        }
+        const int cbase = kcr * BK + cg * 8;
         const int climit = live ? p.Cin : 0;              // one scalar select; `live && ...` per load comes back as branches
 #pragma unroll
         for (int c = 0; c < 8; c++) {
             const unsigned off = (cbase + c < climit) ? pvoff : kOob;
-            const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(xrs, off, (kc * BK + c) * hw2, 0);
+            const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(xrs, off, sbase + (kcr * BK + c) * hw2, 0);
             preg[SET][c][0] = v.x; preg[SET][c][1] = v.y;
         }
     };
@@ -603,7 +618,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_fwd16_kernel(ConvParams p) {
     if ((threadIdx.x & 63) == 0 && blockIdx.x < 65536) afcm_conv_bar_buf[4 * blockIdx.x + (threadIdx.x >> 6)] = bar_cycles;
 #endif
     // ---- epilogue: D[row = channel][col = pixel]; row = (reg&3) + 8*(reg>>2) + 4*h within the 32x32 tile.
-    if ((p.TW & 7) == 0) {
+    if (!SPLIT && (p.TW & 7) == 0) {
         // Tile rows that are multiples of 8 pixels: transpose through LDS (the patch buffers are free after the last barrier)
         // and store 8 pixels = 16 bytes per lane.  A lane holds 16 channels of ONE pixel (4 runs of 4 consecutive channels), so
         // it stages [pixel][32 channels] rows with four 8-byte writes per 32x32 tile, and the transposing read
@@ -712,7 +727,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_fwd16_kernel(ConvParams p) {
         AFCM_STAMP(3);
         return;
     }
-    T* yn = (T*)p.y + (size_t)n * p.Cout * p.P * p.ldy;
+    TO* yn = (TO*)p.y + (size_t)n * p.Cout * p.P * p.ldy;
     // per output-row block: all per-channel scales and biases first (clamped index, no branch around the loads: one wait
     // instead of a round trip per row), then the stores
     int poff[4];                                     // pixel offset inside a plane, -1: not stored
@@ -738,10 +753,10 @@ __global__ __launch_bounds__(256, 2) void conv2d_fwd16_kernel(ConvParams p) {
         for (int reg = 0; reg < 16; reg++) {
             const int o = obase + (reg & 3) + 8 * (reg >> 2);
             if (o < p.Cout) {
-                T* yo = yn + (size_t)o * pq;
+                TO* yo = yn + (size_t)o * pq;
 #pragma unroll
                 for (int ti = 0; ti < 4; ti++)
-                    if (poff[ti] >= 0) yo[poff[ti]] = from_f32<T>(acc[mi][ti][reg] * sc[reg] + ob[reg]);
+                    if (poff[ti] >= 0) yo[poff[ti]] = from_f32<TO>(acc[mi][ti][reg] * sc[reg] + ob[reg]);
             }
         }
     }
@@ -1231,6 +1246,56 @@ __global__ __launch_bounds__(256) void scale_planes_kernel(TO* __restrict__ y, c
 #pragma unroll
             for (int e = 0; e < 4; e++)
                 if (i0 + e < hw) yp[e] = from_f32<TO>(to_f32(xp[e]) * sc);
+        }
+    }
+}
+
+// Split-precision operands: v = scale * x as a sum of `parts` bfloat16 numbers, v ~ a + b (+ c) with a = bf16(v), b = bf16(v - a),
+// c = bf16(v - a - b) (round to nearest even; the differences are exact in fp32).  Two parts carry 16 significand bits, three carry
+// all 24.  parts[k] is a dense bf16 tensor of the input's shape, part_stride elements after parts[k - 1].  A non-finite v keeps
+// its class in part a and zeros in the others (inf - inf would make NaNs of infinities).
+template <int PARTS>
+__global__ __launch_bounds__(256) void split_bf16_kernel(bf16_t* __restrict__ parts, const float* __restrict__ x, const float* __restrict__ scale,
+                                                         long long planes, int hw, long long part_stride) {
+    const int per = (hw + 3) >> 2;
+    const long long total = planes * per;
+    const bool vec = (hw & 3) == 0;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const long long plane = idx / per;
+        const int i0 = (int)(idx - plane * per) << 2;
+        const float sc = scale ? scale[plane] : 1.f;
+        const float* xp = x + plane * hw + i0;
+        bf16_t* yp = parts + plane * hw + i0;
+        float v[4];
+        if (vec) {
+            const Vec4<float> in = *(const Vec4<float>*)xp;
+#pragma unroll
+            for (int e = 0; e < 4; e++) v[e] = in.v[e] * sc;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; e++) v[e] = (i0 + e < hw) ? xp[e] * sc : 0.f;
+        }
+        Vec4<bf16_t> out[PARTS];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            float r = v[e];
+#pragma unroll
+            for (int k = 0; k < PARTS; k++) {
+                const bf16_t q = (bf16_t)r;
+                out[k].v[e] = q;
+                const float qf = (float)q;
+                r = (__builtin_fabsf(qf) <= 3.4028234664e38f) ? r - qf : 0.f;      // inf / nan: nothing left for the lower parts
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < PARTS; k++) {
+            if (vec) {
+                *(Vec4<bf16_t>*)(yp + k * part_stride) = out[k];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; e++)
+                    if (i0 + e < hw) yp[k * part_stride + e] = out[k].v[e];
+            }
         }
     }
 }
@@ -2578,6 +2643,7 @@ extern "C" int afcm_conv2d_stride2(void* y, const void* x, const void* wpacked, 
     p.magicTX = magic_u32((unsigned)p.tilesX); p.magicTY = magic_u32((unsigned)p.tilesY); p.magicN = magic_u32((unsigned)p.N); p.magicPC = magic_u32((unsigned)(p.PWL >> 2));
     p.Opad = rows_pad;
     p.nkc = cdiv(cin, afcm_conv2d_block_k(dtype));
+    p.nkc_real = p.nkc; p.magicNK = 0; p.term_parts = 0; p.part_bytes = 0; p.last_part_bytes = 0;
     const long long blocks = (long long)p.tilesX * p.tilesY * n * cdiv(cout, 128);
     AFCM_REQUIRE(blocks > 0 && blocks < (1ll << 31), "conv2d_stride2: grid of %lld blocks is out of range", blocks);
     AFCM_REQUIRE((long long)cin * h * w * 2ll < (1ll << 31), "conv2d_stride2: image out of range");
@@ -2620,6 +2686,7 @@ extern "C" int afcm_conv2d_ld(void* y, const void* x, const void* wpacked, const
     p.magicTX = magic_u32((unsigned)p.tilesX); p.magicTY = magic_u32((unsigned)p.tilesY); p.magicN = magic_u32((unsigned)p.N); p.magicPC = magic_u32((unsigned)(p.PWL >> 2));
     p.Opad = rows_pad;
     p.nkc = cdiv(cin, afcm_conv2d_block_k(dtype));
+    p.nkc_real = p.nkc; p.magicNK = 0; p.term_parts = 0; p.part_bytes = 0; p.last_part_bytes = 0;
     hipStream_t st = (hipStream_t)stream;
     // 64-row blocks when they waste fewer padded rows than 128-row blocks
     const bool small = (rows_pad % 128 != 0) || cout <= 64;
@@ -2630,6 +2697,64 @@ extern "C" int afcm_conv2d_ld(void* y, const void* x, const void* wpacked, const
     }
 }
 
+
+extern "C" int afcm_split_bf16(void* parts, const float* x, const float* scale, int64_t planes, int32_t hw, int32_t nparts, int64_t part_stride,
+                               void* stream) {
+    AFCM_REQUIRE(parts != nullptr && x != nullptr && planes > 0 && hw > 0, "split_bf16: empty input");
+    AFCM_REQUIRE(nparts == 2 || nparts == 3, "split_bf16: 2 or 3 parts (got %d)", nparts);
+    AFCM_REQUIRE(part_stride >= planes * (long long)hw && part_stride % 4 == 0, "split_bf16: part stride %lld must cover the tensor and be a multiple of 4", (long long)part_stride);
+    AFCM_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)parts & 7) == 0, "split_bf16: x must be 16-byte, parts 8-byte aligned");
+    long long blocks = (planes * ((hw + 3) >> 2) + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    dim3 grid((unsigned)blocks), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (nparts == 2) hipLaunchKernelGGL((split_bf16_kernel<2>), grid, block, 0, st, (bf16_t*)parts, x, scale, (long long)planes, hw, (long long)part_stride);
+    else hipLaunchKernelGGL((split_bf16_kernel<3>), grid, block, 0, st, (bf16_t*)parts, x, scale, (long long)planes, hw, (long long)part_stride);
+    return hip_status(hipGetLastError());
+}
+
+extern "C" int afcm_conv2d_split(float* y, const void* x_parts, const void* wpacked, const float* oscale, const float* obias, int32_t n, int32_t cin,
+                                 int32_t cout, int32_t h, int32_t w, int32_t pad, int32_t rows_pad, int32_t terms, uint32_t term_parts,
+                                 int64_t part_stride, void* stream) {
+    const int ks = 3;
+    AFCM_REQUIRE(y != nullptr && x_parts != nullptr && wpacked != nullptr, "conv2d_split: null pointer");
+    AFCM_REQUIRE(n > 0 && cin > 0 && cout > 0 && h > 0 && w > 0, "x is empty");
+    AFCM_REQUIRE(pad >= 0 && pad <= ks - 1, "padding must be in [0, k-1]");
+    AFCM_REQUIRE(w % 2 == 0, "conv2d_split needs an even input width (got %d)", w);
+    AFCM_REQUIRE(rows_pad >= cout && rows_pad % 64 == 0, "rows_pad must be a multiple of 64 covering cout");
+    AFCM_REQUIRE(terms >= 1 && terms <= 8, "conv2d_split: 1..8 terms (got %d)", terms);
+    int max_part = 0;
+    for (int t = 0; t < terms; t++) max_part = std::max(max_part, (int)((term_parts >> (4 * t)) & 15u));
+    AFCM_REQUIRE(max_part <= 2, "conv2d_split: parts 0..2");
+    AFCM_REQUIRE(part_stride >= (long long)n * cin * h * w && (long long)max_part * part_stride * 2 < (1ll << 31) - (long long)cin * h * w * 2,
+                 "conv2d_split: part stride %lld out of range", (long long)part_stride);
+    ConvParams p;
+    p.x = x_parts; p.y = y; p.wp = wpacked; p.oscale = oscale; p.obias = obias;
+    p.N = n; p.Cin = cin; p.Cout = cout; p.H = h; p.W = w;
+    p.P = h + 2 * pad - ks + 1; p.Q = w + 2 * pad - ks + 1;
+    AFCM_REQUIRE(p.P >= 1 && p.Q >= 1, "output must be at least 1x1");
+    p.pad = pad;
+    p.ldx = w; p.ldy = p.Q;
+    choose_tile(p.P, p.Q, ks, &p.TH, &p.TW, &p.PWL);
+    p.tilesX = cdiv(p.Q, p.TW); p.tilesY = cdiv(p.P, p.TH);
+    p.magicTW = (unsigned)((0x100000000ull + (unsigned)p.TW - 1) / (unsigned)p.TW);
+    p.magicTX = magic_u32((unsigned)p.tilesX); p.magicTY = magic_u32((unsigned)p.tilesY); p.magicN = magic_u32((unsigned)p.N); p.magicPC = magic_u32((unsigned)(p.PWL >> 2));
+    p.Opad = rows_pad;
+    p.nkc_real = cdiv(cin, ConvCfg<bf16_t>::BK);
+    p.nkc = terms * p.nkc_real;
+    p.magicNK = magic_u32((unsigned)p.nkc_real);
+    p.term_parts = term_parts;
+    p.part_bytes = (int)(part_stride * 2);
+    p.last_part_bytes = max_part * p.part_bytes;
+    const bool small = (rows_pad % 128 != 0) || cout <= 64;
+    const long long blocks = (long long)p.tilesX * p.tilesY * p.N * cdiv(p.Cout, small ? 64 : 128);
+    AFCM_REQUIRE(blocks > 0 && blocks < (1ll << 31), "conv2d_split: grid of %lld blocks is out of range", blocks);
+    dim3 grid((unsigned)blocks), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (small) hipLaunchKernelGGL((conv2d_fwd16_kernel<bf16_t, 64, true>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((conv2d_fwd16_kernel<bf16_t, 128, true>), grid, block, 0, st, p);
+    return hip_status(hipGetLastError());
+}
 
 // Split count for the weight gradient: enough workgroups to fill the chip, bounded by the K macro-steps.
 static int wgrad_rows_per_step(int dtype) { return dtype == AFCM_F32 ? 1 : 2; }

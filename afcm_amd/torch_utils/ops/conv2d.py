@@ -159,6 +159,101 @@ def plane_dot_gated(a, b, flags, out_scale, gz, next_scale=None, gskip=None):
     return out
 
 
+# ---- fp32 3x3 convolutions on the bf16 matrix pipe (split operands: include/afcm_hip.h, afcm_split_bf16 / afcm_conv2d_split) --------
+# (forward terms, data-gradient terms, weight-gradient terms) of an fp32 3x3 conv, each 3 or 6; None: the native fp32 MFMA kernels
+# (0.157 PFLOP/s peak against 2.5 for bf16).  Six terms of a three-way split reproduce the fp32 product to 6e-9 of the output scale
+# (an fp32 dot product of the same length rounds to 4e-7), three terms of a two-way split to 4e-6.
+FP32_SPLIT = (6, 6, 3)
+_SPLIT_TERMS = {           # (part of the activations, part of the weights) per term, smallest products first
+    3: ((1, 0), (0, 1), (0, 0)),
+    6: ((2, 0), (0, 2), (1, 1), (1, 0), (0, 1), (0, 0)),
+}
+
+
+def _split_plan(x, ks):
+    """The split-operand route takes fp32 tensors on the GPU, 3x3 kernels, even widths and parts inside the kernel's 2^31-byte
+    scalar offsets."""
+    if FP32_SPLIT is None or x.dtype != torch.float32 or ks != 3 or x.device.type != 'cuda' or x.ndim != 4 or x.shape[3] % 2:
+        return None
+    if (x.numel() + 3) // 4 * 4 * 2 * 2 + x[0].numel() * 2 >= (1 << 31):
+        return None
+    return FP32_SPLIT
+
+
+def split_bf16(x, scale=None, nparts=3):
+    """[nparts, N, C, H, W] bfloat16: scale[n, c] * x[n, c] as a sum of `nparts` bfloat16 tensors (C ABI afcm_split_bf16); every part
+    is dense, ``.stride(0)`` is the part stride."""
+    lib = _lib.load()
+    x = x.contiguous()
+    assert x.dtype == torch.float32 and x.ndim == 4 and nparts in (2, 3)
+    n, c, h, w = x.shape
+    total = x.numel()
+    stride = (total + 3) // 4 * 4
+    buf = torch.empty([nparts, stride], dtype=torch.bfloat16, device=x.device)
+    if scale is not None:
+        scale = scale.to(torch.float32).contiguous()
+        assert scale.numel() == n * c
+    _lib.check(lib.afcm_split_bf16(buf.data_ptr(), x.data_ptr(), _lib.ptr(scale), n * c, h * w, nparts, stride, _lib.stream_ptr(x)), 'split_bf16')
+    return buf[:, :total].view(nparts, n, c, h, w)
+
+
+def _nparts(*term_counts):
+    return 1 + max(max(a, b) for t in term_counts for a, b in _SPLIT_TERMS[t])
+
+
+def pack_weights_split(w, terms, transposed=False):
+    """The packed bf16 image of the stacked weight parts of `w` ([O, I, 3, 3] fp32; ``transposed``: of the data gradient's
+    [I, O, 3, 3] flipped kernel) for a `terms`-term split conv: channel block t holds the weight part of term t, zero-padded to a multiple of 16 channels."""
+    w = w.detach().to(torch.float32)
+    if transposed:
+        w = w.transpose(0, 1).flip([2, 3])
+    table = _SPLIT_TERMS[terms]
+    parts, r = [], w
+    for _ in range(1 + max(b for _, b in table)):
+        q = r.to(torch.bfloat16).to(torch.float32)
+        parts.append(q)
+        r = r - q
+    o, i = int(w.shape[0]), int(w.shape[1])
+    i16 = (i + 15) // 16 * 16
+    cat = torch.zeros([o, terms * i16, 3, 3], dtype=torch.float32, device=w.device)
+    for t, (_, b) in enumerate(table):
+        cat[:, t * i16:t * i16 + i] = parts[b]
+    return pack_weights(cat, torch.bfloat16, 0)
+
+
+def _conv_split(parts, wp, rows_pad, terms, oscale, cout, pad, obias=None):
+    """fp32 y = oscale * conv(w, x) + obias from the bf16 parts of x (split_bf16) and the stacked weight image (pack_weights_split)."""
+    lib = _lib.load()
+    nparts, n, cin, h, w = parts.shape
+    table = _SPLIT_TERMS[terms]
+    assert nparts > max(a for a, _ in table) and parts.dtype == torch.bfloat16 and parts.stride(1) == cin * h * w
+    assert tuple(wp.shape) == (terms * ((cin + 15) // 16), 9, rows_pad, 16), 'the weight image does not belong to this split'
+    p, q = h + 2 * pad - 2, w + 2 * pad - 2
+    y = torch.empty([n, cout, p, q], dtype=torch.float32, device=parts.device)
+    if oscale is not None:
+        oscale = oscale.to(torch.float32).contiguous()
+        assert oscale.numel() == n * cout
+    if obias is not None:
+        obias = obias.to(torch.float32).contiguous()
+        assert obias.numel() == cout
+    code = sum(a << (4 * t) for t, (a, _) in enumerate(table))
+    span = profiling.span('conv2d', 2.0 * n * cout * cin * 9 * p * q)
+    _lib.check(lib.afcm_conv2d_split(y.data_ptr(), parts.data_ptr(), wp.data_ptr(), _lib.ptr(oscale), _lib.ptr(obias), n, cin, cout, h, w, pad,
+                                     rows_pad, terms, code, parts.stride(0), _lib.stream_ptr(parts)), 'conv2d_split')
+    if span is not None:
+        span.end()
+    return y
+
+
+def _wgrad_split(dy_parts, x_parts, cout, cin, pad, terms):
+    """fp32 weight gradient of a 3x3 conv from the bf16 parts of dy and x: one 16-bit weight-gradient launch per term, summed."""
+    dw = None
+    for a, b in _SPLIT_TERMS[terms]:
+        d = _wgrad_raw(dy_parts[b], x_parts[a], cout, cin, 3, pad)
+        dw = d if dw is None else dw.add_(d)
+    return dw
+
+
 def _pitch_conv(dtype, ks):
     """Does the conv kernel for this case address rows by pitch?  (The 16-bit 3x3 kernel; C ABI afcm_conv2d_ld.)"""
     return dtype in (torch.bfloat16, torch.float16) and ks == 3
@@ -240,6 +335,14 @@ class _ScaledConv2d(torch.autograd.Function):
         xs = scale_planes(x, in_scale) if (in_scale is not None and not prescaled) else x
         # a backward that will need the data gradient gets its (transposed, flipped) weight image from the same launch
         ctx.wpt = None
+        plan = _split_plan(xs, ks)
+        if plan is not None:
+            wp, rows_pad = pack_weights_split(w, plan[0])
+            y = _conv_split(split_bf16(xs, None, _nparts(plan[0])), wp, rows_pad, plan[0], out_scale, cout, padding)
+            ctx.save_for_backward(xs, w, in_scale, out_scale, y if (out_scale is not None and ctx.needs_input_grad[3]) else None)
+            ctx.padding = padding
+            ctx.prescaled = bool(prescaled)
+            return y
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[2]:
             (wp, rows_pad), ctx.wpt = pack_weights_both(w, x.dtype)
         else:
@@ -272,6 +375,23 @@ class _ScaledConv2d(torch.autograd.Function):
         cout, cin, ks, _ = w.shape
         dy = dy.contiguous()
         dx = dw = d_in = d_out = None
+        plan = _split_plan(dy, ks) if _split_plan(xs, ks) is not None else None
+        if plan is not None:
+            # fp32 on the bf16 pipe: dy's parts (with the demodulation factor applied while splitting) feed both gradients
+            need_dx = ctx.needs_input_grad[0] or ctx.needs_input_grad[2]
+            terms = [plan[1]] * bool(need_dx) + [plan[2]] * bool(ctx.needs_input_grad[1])
+            dparts = split_bf16(dy, out_scale, _nparts(*terms)) if terms else None
+            if need_dx:
+                wpt, rows_pad = pack_weights_split(w, plan[1], transposed=True)
+                dx = _conv_split(dparts, wpt, rows_pad, plan[1], in_scale, cin, ks - 1 - pad)
+                if ctx.needs_input_grad[2] and in_scale is not None:
+                    s2 = in_scale.to(torch.float32).square()
+                    d_in = torch.where(s2 > 0, plane_dot(xs, dx) / s2.clamp_min(1e-30), torch.zeros_like(s2)).to(in_scale.dtype)
+            if ctx.needs_input_grad[1]:
+                dw = _wgrad_split(dparts, split_bf16(xs, None, _nparts(plan[2])), cout, cin, pad, plan[2]).to(w.dtype)
+            if ctx.needs_input_grad[3]:
+                d_out = (plane_dot(dy, y) / out_scale.to(torch.float32)).to(out_scale.dtype)
+            return dx, dw, d_in, d_out, None, None
         dys = scale_planes(dy, out_scale) if out_scale is not None else dy
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[2]:
             wpt, rows_pad = ctx.wpt if (ctx.wpt is not None and ctx.wpt[0].dtype == dy.dtype) else pack_weights(w, dy.dtype, 1)
@@ -300,6 +420,10 @@ class _ConvWgrad(torch.autograd.Function):
         cout, cin = int(dy.shape[1]), int(x.shape[1])
         ctx.save_for_backward(dy, x)
         ctx.cfg = (ks, pad)
+        plan = _split_plan(dy, ks) if _split_plan(x, ks) is not None else None
+        if plan is not None:
+            k = _nparts(plan[2])
+            return _wgrad_split(split_bf16(dy, None, k), split_bf16(x, None, k), cout, cin, pad, plan[2])
         return _wgrad_raw(dy, x, cout, cin, ks, pad)
 
     @staticmethod

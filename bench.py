@@ -47,6 +47,9 @@ def parse():
     ap.add_argument('--comm-dtype', default='fp32', choices=['fp32', 'bf16'], help='dtype of the gradient buckets on the wire')
     ap.add_argument('--no-homogeneous-dot', action='store_true', help='ablation: the demodulation gradient from real plane dot products everywhere '
                                                                       '(torch_utils/ops/fused_layer.py HOMOGENEOUS_DOT)')
+    ap.add_argument('--fp32-conv', default='split663', choices=['split6', 'split663', 'split633', 'split3', 'native'],
+                    help='--dtype fp32 only: the 3x3 convs on the bf16 matrix pipe from split operands (6 terms: fp32-exact products; '
+                         '663: 3 in the weight gradient only; 633: 3 in both gradients; 3 everywhere) or on the native fp32 MFMA kernels')
     ap.add_argument('--with-discriminator', action='store_true',
                     help='time the FULL iteration (D update with R1, then G update with the GAN term; SURVEY.md row f1) instead of the '
                          'generator step that BASELINE.json\'s metric names')
@@ -194,6 +197,8 @@ def main():
     if args.no_homogeneous_dot:
         from afcm_amd.torch_utils.ops import fused_layer
         fused_layer.HOMOGENEOUS_DOT = False
+    from afcm_amd.torch_utils.ops import conv2d as conv_ops
+    conv_ops.FP32_SPLIT = {'split6': (6, 6, 6), 'split663': (6, 6, 3), 'split633': (6, 3, 3), 'split3': (3, 3, 3), 'native': None}[args.fp32_conv]
     dtype = {'bf16': torch.bfloat16, 'fp16': torch.float16, 'fp32': torch.float32}[args.dtype]
     comm_dtype = torch.bfloat16 if args.comm_dtype == 'bf16' else None
     torch.manual_seed(0)      # identical init on every rank (the step also broadcasts from rank 0)
@@ -330,7 +335,8 @@ def main():
                        'world_size': dist.get_world_size() if use_dist else 1,
                        'backend': dist.get_backend() if use_dist else None,
                        'gradient_buckets': step.buckets.num_buckets if step.buckets is not None else 0,
-                       'comm_dtype': args.comm_dtype, 'homogeneous_dot': not args.no_homogeneous_dot},
+                       'comm_dtype': args.comm_dtype, 'homogeneous_dot': not args.no_homogeneous_dot,
+                       **({'fp32_conv': args.fp32_conv} if args.dtype == 'fp32' else {})},
             'roofline': roofline,
             'kernels': kernels,
             'cpu_baseline': cpu,

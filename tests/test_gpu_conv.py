@@ -405,3 +405,74 @@ def test_stride2_conv_repacks_after_an_optimizer_step():
     with torch.no_grad():
         wt.mul_(0.5)
     assert torch.equal(C.strided_conv2d(x, wt, 1), C.scaled_conv2d(x, wt.detach(), None, None, 1)[:, :, ::2, ::2])
+
+
+# ---- fp32 on the bf16 matrix pipe: split operands (C ABI afcm_split_bf16 / afcm_conv2d_split) ----------------------------------
+def test_split_bf16_parts_sum_back_to_the_fp32_value():
+    from afcm_amd.torch_utils.ops import conv2d as C
+    g = torch.Generator().manual_seed(3)
+    x = (torch.randn([2, 5, 6, 10], generator=g) * torch.logspace(-20, 20, 600).view(2, 5, 6, 10)).cuda()
+    x[0, 0, 0, :4] = torch.tensor([float('inf'), -float('inf'), float('nan'), 0.0])
+    sc = torch.rand([2, 5], generator=g).cuda() + 0.5
+    for scale in (None, sc):
+        v = x if scale is None else x * scale[:, :, None, None]
+        fin = torch.isfinite(v)
+        for k in (2, 3):
+            parts = C.split_bf16(x, scale, k)
+            assert parts.shape == (k, 2, 5, 6, 10) and parts.dtype == torch.bfloat16
+            tot = parts.double().sum(0)
+            # round-to-nearest parts: k parts leave at most 2^-(8 k + 1) of the value (three parts: 2^-25 -- below half an fp32 ulp)
+            err = ((tot - v.double()).abs() / v.double().abs().clamp_min(1e-300))[fin]
+            assert float(err.max()) <= 2.0 ** -(8 * k + 1) * 1.01, (k, float(err.max()))
+            assert torch.equal(parts[0][~fin].float().isnan(), v[~fin].isnan()) and torch.equal(parts[0][~fin].float().isinf(), v[~fin].isinf())
+            assert float(parts[1:][:, ~fin].float().abs().max()) == 0.0       # inf / nan stay in the leading part only
+
+
+@pytest.mark.parametrize('terms,tol', [(3, 2e-5), (6, 1.5e-6)])
+@pytest.mark.parametrize('case', [(2, 4, 64, 30, 30, 2), (2, 64, 91, 22, 26, 2), (1, 181, 128, 20, 20, 2), (2, 72, 72, 36, 36, 1),
+                                  (1, 40, 48, 70, 150, 2), (1, 512, 512, 36, 36, 2)], ids=str)
+def test_fp32_conv_on_split_bf16_operands(case, terms, tol):
+    """The fp32 3x3 conv, its data gradient and its weight gradient through the split-operand route against float64 aten on the
+    CPU.  Six terms: as good as an fp32 dot product (tolerance = fp32 accumulation over K = 9 Cin); three terms: ~16 bits."""
+    from afcm_amd.torch_utils.ops import conv2d as C
+    n, i, o, h, w, pad = case
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn([n, i, h, w], generator=g)
+    wt = torch.randn([o, i, 3, 3], generator=g) / (3 * i ** 0.5)
+    si, so = torch.rand([n, i], generator=g) + 0.5, torch.rand([n, o], generator=g) + 0.5
+    xd, wd = x.double().requires_grad_(True), wt.double().requires_grad_(True)
+    yd = torch.nn.functional.conv2d(xd * si.double()[:, :, None, None], wd, padding=pad) * so.double()[:, :, None, None]
+    r = torch.randn(yd.shape, generator=g)
+    dxd, dwd = torch.autograd.grad((yd * r.double()).sum(), [xd, wd])
+    old = C.FP32_SPLIT
+    C.FP32_SPLIT = (terms, terms, terms)
+    try:
+        xg, wg = x.cuda().requires_grad_(True), wt.cuda().requires_grad_(True)
+        y = C._ScaledConv2d.apply(xg, wg, si.cuda(), so.cuda(), pad, False)
+        dx, dw = torch.autograd.grad((y * r.cuda()).sum(), [xg, wg])
+    finally:
+        C.FP32_SPLIT = old
+    assert y.dtype == torch.float32
+    _close(y, yd.float(), tol, 'y')
+    _close(dx, dxd.float(), tol, 'dx')
+    _close(dw, dwd.float(), 3 * tol, 'dw')
+
+
+def test_fp32_split_route_is_the_default_and_native_kernels_remain():
+    from afcm_amd.torch_utils.ops import conv2d as C
+    assert C.FP32_SPLIT is not None
+    g = torch.Generator().manual_seed(5)
+    x, wt = torch.randn([1, 32, 18, 20], generator=g).cuda(), (torch.randn([48, 32, 3, 3], generator=g) / 17).cuda()
+    y_split = C._ScaledConv2d.apply(x, wt, None, None, 2, False)
+    old, C.FP32_SPLIT = C.FP32_SPLIT, None
+    try:
+        y_native = C._ScaledConv2d.apply(x, wt, None, None, 2, False)
+    finally:
+        C.FP32_SPLIT = old
+    ref = torch.nn.functional.conv2d(x.double().cpu(), wt.double().cpu(), padding=2).float()
+    _close(y_native, ref, 2e-6, 'native fp32 MFMA')
+    _close(y_split, ref, 2e-6, 'split bf16')
+    assert not torch.equal(y_split, y_native)          # different kernels, different summation order
+    # odd widths keep the native kernel
+    xo = torch.randn([1, 32, 18, 21], generator=g).cuda()
+    _close(C._ScaledConv2d.apply(xo, wt, None, None, 2, False), torch.nn.functional.conv2d(xo.double().cpu(), wt.double().cpu(), padding=2).float(), 2e-6, 'odd width')
