@@ -94,8 +94,8 @@ SIGNATURES = {
     'afcm_scale_planes': (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i64, _i32, _vp]),
     'afcm_plane_dot': (C.c_int, [_vp, _vp, _vp, _i32, _i64, _i32, _vp]),
     'afcm_plane_dot_ld': (C.c_int, [_vp, _vp, _vp, _i32, _i64, _i32, _i32, _i32, _i32, _vp]),
-    'afcm_split_bf16': (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _i64, _vp]),
-    'afcm_conv2d_split': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, C.c_uint32, _i64, _vp]),
+    'afcm_split16': (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _i64, _vp]),
+    'afcm_conv2d_split': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, C.c_uint32, _i64, _vp]),
     'afcm_plane_dot_gated_ld': (C.c_int, [_vp, _vp, _vp, _i32, _i64, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
     'afcm_weight_norm_fwd': (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     'afcm_weight_norm_bwd': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),

@@ -1250,22 +1250,25 @@ __global__ __launch_bounds__(256) void scale_planes_kernel(TO* __restrict__ y, c
     }
 }
 
-// Split-precision operands: v = scale * x as a sum of `parts` bfloat16 numbers, v ~ a + b (+ c) with a = bf16(v), b = bf16(v - a),
-// c = bf16(v - a - b) (round to nearest even; the differences are exact in fp32).  Two parts carry 16 significand bits, three carry
-// all 24.  parts[k] is a dense bf16 tensor of the input's shape, part_stride elements after parts[k - 1].  A non-finite v keeps
-// its class in part a and zeros in the others (inf - inf would make NaNs of infinities).
-template <int PARTS>
-__global__ __launch_bounds__(256) void split_bf16_kernel(bf16_t* __restrict__ parts, const float* __restrict__ x, const float* __restrict__ scale,
-                                                         long long planes, int hw, long long part_stride) {
+// Split-precision operands: v = gscale * scale[plane] * x as a sum of `parts` 16-bit numbers, v ~ a + b (+ c) with a = r16(v), b = r16(v - a),
+// c = r16(v - a - b) (round to nearest even; the differences are exact in fp32).  bfloat16: two parts carry 16 significand bits, three
+// carry all 24.  float16: two parts carry 22 bits wherever b is a normal number, i.e. for |v| >= 2^-3; below that the error is at most
+// 2^-25 ABSOLUTE, so with gscale a power of two that brings the tensor's largest magnitude near 2^15 it is 2^-40 of that magnitude.
+// parts[k] is a dense tensor of the input's shape, part_stride elements after parts[k - 1].  A non-finite v keeps its class in part a
+// and zeros in the others (inf - inf would make NaNs of infinities).
+template <typename TP, int PARTS>
+__global__ __launch_bounds__(256) void split16_kernel(TP* __restrict__ parts, const float* __restrict__ x, const float* __restrict__ scale,
+                                                      const float* __restrict__ gscale, long long planes, int hw, long long part_stride) {
     const int per = (hw + 3) >> 2;
     const long long total = planes * per;
     const bool vec = (hw & 3) == 0;
+    const float gs = gscale ? *gscale : 1.f;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
         const long long plane = idx / per;
         const int i0 = (int)(idx - plane * per) << 2;
-        const float sc = scale ? scale[plane] : 1.f;
+        const float sc = (scale ? scale[plane] : 1.f) * gs;
         const float* xp = x + plane * hw + i0;
-        bf16_t* yp = parts + plane * hw + i0;
+        TP* yp = parts + plane * hw + i0;
         float v[4];
         if (vec) {
             const Vec4<float> in = *(const Vec4<float>*)xp;
@@ -1275,13 +1278,13 @@ __global__ __launch_bounds__(256) void split_bf16_kernel(bf16_t* __restrict__ pa
 #pragma unroll
             for (int e = 0; e < 4; e++) v[e] = (i0 + e < hw) ? xp[e] * sc : 0.f;
         }
-        Vec4<bf16_t> out[PARTS];
+        Vec4<TP> out[PARTS];
 #pragma unroll
         for (int e = 0; e < 4; e++) {
             float r = v[e];
 #pragma unroll
             for (int k = 0; k < PARTS; k++) {
-                const bf16_t q = (bf16_t)r;
+                const TP q = (TP)r;
                 out[k].v[e] = q;
                 const float qf = (float)q;
                 r = (__builtin_fabsf(qf) <= 3.4028234664e38f) ? r - qf : 0.f;      // inf / nan: nothing left for the lower parts
@@ -1290,7 +1293,7 @@ __global__ __launch_bounds__(256) void split_bf16_kernel(bf16_t* __restrict__ pa
 #pragma unroll
         for (int k = 0; k < PARTS; k++) {
             if (vec) {
-                *(Vec4<bf16_t>*)(yp + k * part_stride) = out[k];
+                *(Vec4<TP>*)(yp + k * part_stride) = out[k];
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; e++)
@@ -2698,26 +2701,30 @@ extern "C" int afcm_conv2d_ld(void* y, const void* x, const void* wpacked, const
 }
 
 
-extern "C" int afcm_split_bf16(void* parts, const float* x, const float* scale, int64_t planes, int32_t hw, int32_t nparts, int64_t part_stride,
-                               void* stream) {
-    AFCM_REQUIRE(parts != nullptr && x != nullptr && planes > 0 && hw > 0, "split_bf16: empty input");
-    AFCM_REQUIRE(nparts == 2 || nparts == 3, "split_bf16: 2 or 3 parts (got %d)", nparts);
-    AFCM_REQUIRE(part_stride >= planes * (long long)hw && part_stride % 4 == 0, "split_bf16: part stride %lld must cover the tensor and be a multiple of 4", (long long)part_stride);
-    AFCM_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)parts & 7) == 0, "split_bf16: x must be 16-byte, parts 8-byte aligned");
+extern "C" int afcm_split16(void* parts, const float* x, const float* scale, const float* gscale, int32_t dtype, int64_t planes, int32_t hw,
+                            int32_t nparts, int64_t part_stride, void* stream) {
+    AFCM_REQUIRE(parts != nullptr && x != nullptr && planes > 0 && hw > 0, "split16: empty input");
+    AFCM_REQUIRE(dtype == AFCM_BF16 || dtype == AFCM_F16, "split16: parts are bfloat16 or float16");
+    AFCM_REQUIRE(nparts == 2 || nparts == 3, "split16: 2 or 3 parts (got %d)", nparts);
+    AFCM_REQUIRE(part_stride >= planes * (long long)hw && part_stride % 4 == 0, "split16: part stride %lld must cover the tensor and be a multiple of 4", (long long)part_stride);
+    AFCM_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)parts & 7) == 0, "split16: x must be 16-byte, parts 8-byte aligned");
     long long blocks = (planes * ((hw + 3) >> 2) + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     dim3 grid((unsigned)blocks), block(256);
     hipStream_t st = (hipStream_t)stream;
-    if (nparts == 2) hipLaunchKernelGGL((split_bf16_kernel<2>), grid, block, 0, st, (bf16_t*)parts, x, scale, (long long)planes, hw, (long long)part_stride);
-    else hipLaunchKernelGGL((split_bf16_kernel<3>), grid, block, 0, st, (bf16_t*)parts, x, scale, (long long)planes, hw, (long long)part_stride);
+#define AFCM_SPLIT(T, K) hipLaunchKernelGGL((split16_kernel<T, K>), grid, block, 0, st, (T*)parts, x, scale, gscale, (long long)planes, hw, (long long)part_stride)
+    if (dtype == AFCM_BF16) { if (nparts == 2) AFCM_SPLIT(bf16_t, 2); else AFCM_SPLIT(bf16_t, 3); }
+    else { if (nparts == 2) AFCM_SPLIT(f16_t, 2); else AFCM_SPLIT(f16_t, 3); }
+#undef AFCM_SPLIT
     return hip_status(hipGetLastError());
 }
 
-extern "C" int afcm_conv2d_split(float* y, const void* x_parts, const void* wpacked, const float* oscale, const float* obias, int32_t n, int32_t cin,
-                                 int32_t cout, int32_t h, int32_t w, int32_t pad, int32_t rows_pad, int32_t terms, uint32_t term_parts,
+extern "C" int afcm_conv2d_split(float* y, const void* x_parts, const void* wpacked, const float* oscale, const float* obias, int32_t dtype, int32_t n,
+                                 int32_t cin, int32_t cout, int32_t h, int32_t w, int32_t pad, int32_t rows_pad, int32_t terms, uint32_t term_parts,
                                  int64_t part_stride, void* stream) {
     const int ks = 3;
     AFCM_REQUIRE(y != nullptr && x_parts != nullptr && wpacked != nullptr, "conv2d_split: null pointer");
+    AFCM_REQUIRE(dtype == AFCM_BF16 || dtype == AFCM_F16, "conv2d_split: parts are bfloat16 or float16");
     AFCM_REQUIRE(n > 0 && cin > 0 && cout > 0 && h > 0 && w > 0, "x is empty");
     AFCM_REQUIRE(pad >= 0 && pad <= ks - 1, "padding must be in [0, k-1]");
     AFCM_REQUIRE(w % 2 == 0, "conv2d_split needs an even input width (got %d)", w);
@@ -2751,8 +2758,13 @@ extern "C" int afcm_conv2d_split(float* y, const void* x_parts, const void* wpac
     AFCM_REQUIRE(blocks > 0 && blocks < (1ll << 31), "conv2d_split: grid of %lld blocks is out of range", blocks);
     dim3 grid((unsigned)blocks), block(256);
     hipStream_t st = (hipStream_t)stream;
-    if (small) hipLaunchKernelGGL((conv2d_fwd16_kernel<bf16_t, 64, true>), grid, block, 0, st, p);
-    else hipLaunchKernelGGL((conv2d_fwd16_kernel<bf16_t, 128, true>), grid, block, 0, st, p);
+    if (dtype == AFCM_BF16) {
+        if (small) hipLaunchKernelGGL((conv2d_fwd16_kernel<bf16_t, 64, true>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((conv2d_fwd16_kernel<bf16_t, 128, true>), grid, block, 0, st, p);
+    } else {
+        if (small) hipLaunchKernelGGL((conv2d_fwd16_kernel<f16_t, 64, true>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((conv2d_fwd16_kernel<f16_t, 128, true>), grid, block, 0, st, p);
+    }
     return hip_status(hipGetLastError());
 }
 

@@ -159,11 +159,13 @@ def plane_dot_gated(a, b, flags, out_scale, gz, next_scale=None, gskip=None):
     return out
 
 
-# ---- fp32 3x3 convolutions on the bf16 matrix pipe (split operands: include/afcm_hip.h, afcm_split_bf16 / afcm_conv2d_split) --------
-# (forward terms, data-gradient terms, weight-gradient terms) of an fp32 3x3 conv, each 3 or 6; None: the native fp32 MFMA kernels
-# (0.157 PFLOP/s peak against 2.5 for bf16).  Six terms of a three-way split reproduce the fp32 product to 6e-9 of the output scale
-# (an fp32 dot product of the same length rounds to 4e-7), three terms of a two-way split to 4e-6.
-FP32_SPLIT = (6, 6, 3)
+# ---- fp32 3x3 convolutions on the 16-bit matrix pipe (split operands: include/afcm_hip.h, afcm_split16 / afcm_conv2d_split) --------
+# (part dtype, forward terms, data-gradient terms, weight-gradient terms) of an fp32 3x3 conv; None: the native fp32 MFMA kernels
+# (0.157 PFLOP/s peak against 2.5 for the 16-bit types).
+#   float16, 3 terms of a two-way split, operands scaled by a power of two to just below 2^15: 22 significand bits -- measured equal to
+#     an fp32 dot product of the same length (3e-7 of the output scale at K = 4608).  The default.
+#   bfloat16 (no scaling, any range): 3 terms keep ~16 bits (4e-6), the 6 terms of order <= 2 of a three-way split all 24 (2e-7).
+FP32_SPLIT = (torch.float16, 3, 3, 3)
 _SPLIT_TERMS = {           # (part of the activations, part of the weights) per term, smallest products first
     3: ((1, 0), (0, 1), (0, 0)),
     6: ((2, 0), (0, 2), (1, 1), (1, 0), (0, 1), (0, 0)),
@@ -180,37 +182,71 @@ def _split_plan(x, ks):
     return FP32_SPLIT
 
 
-def split_bf16(x, scale=None, nparts=3):
-    """[nparts, N, C, H, W] bfloat16: scale[n, c] * x[n, c] as a sum of `nparts` bfloat16 tensors (C ABI afcm_split_bf16); every part
-    is dense, ``.stride(0)`` is the part stride."""
+def _magnitude(t):
+    """0-dim tensor: max |t| (one pass)."""
+    lo, hi = torch.aminmax(t)
+    return torch.maximum(-lo, hi)
+
+
+def _pow2_scale(bound):
+    """The power of two that brings `bound` (0-dim device tensor, an upper bound of the magnitudes) into [2^14, 2^15): float16 parts of the
+    scaled values cannot overflow (max 65504) and the second part of everything above 2^-18 of the bound is a normal number.  The bound
+    may be loose by many binades before precision suffers (an element's error floor is 2^-40 of the bound).  On the device: no host
+    round trip."""
+    e = torch.frexp(bound.to(torch.float32).clamp_min(1e-30))[1]           # bound = f * 2^e, f in [0.5, 1)
+    return torch.ldexp(torch.ones_like(bound, dtype=torch.float32), 15 - e)
+
+
+def split16(x, scale=None, nparts=2, dtype=torch.float16, gscale=None):
+    """[nparts, N, C, H, W] of `dtype`: gscale * scale[n, c] * x[n, c] as a sum of `nparts` 16-bit tensors (C ABI afcm_split16); every part
+    is dense, ``.stride(0)`` is the part stride.  ``gscale``: 0-dim fp32 device tensor or None."""
     lib = _lib.load()
     x = x.contiguous()
-    assert x.dtype == torch.float32 and x.ndim == 4 and nparts in (2, 3)
+    assert x.dtype == torch.float32 and x.ndim == 4 and nparts in (2, 3) and dtype in (torch.float16, torch.bfloat16)
     n, c, h, w = x.shape
     total = x.numel()
     stride = (total + 3) // 4 * 4
-    buf = torch.empty([nparts, stride], dtype=torch.bfloat16, device=x.device)
+    buf = torch.empty([nparts, stride], dtype=dtype, device=x.device)
     if scale is not None:
         scale = scale.to(torch.float32).contiguous()
         assert scale.numel() == n * c
-    _lib.check(lib.afcm_split_bf16(buf.data_ptr(), x.data_ptr(), _lib.ptr(scale), n * c, h * w, nparts, stride, _lib.stream_ptr(x)), 'split_bf16')
+    if gscale is not None:
+        assert gscale.dtype == torch.float32 and gscale.numel() == 1 and gscale.device == x.device
+    _lib.check(lib.afcm_split16(buf.data_ptr(), x.data_ptr(), _lib.ptr(scale), _lib.ptr(gscale), _lib._DTYPES[dtype], n * c, h * w, nparts, stride,
+                                _lib.stream_ptr(x)), 'split16')
     return buf[:, :total].view(nparts, n, c, h, w)
+
+
+def _split_operand(x, scale, terms, dtype):
+    """(parts, gscale): the parts of scale * x for a `terms`-term product; float16 parts carry the power-of-two factor ``gscale``."""
+    gs = None
+    if dtype == torch.float16:
+        bound = _magnitude(x)
+        if scale is not None:
+            bound = bound * scale.detach().abs().max().to(torch.float32)
+        gs = _pow2_scale(bound)
+    return split16(x, scale, _nparts(terms), dtype, gs), gs
 
 
 def _nparts(*term_counts):
     return 1 + max(max(a, b) for t in term_counts for a, b in _SPLIT_TERMS[t])
 
 
-def pack_weights_split(w, terms, transposed=False):
-    """The packed bf16 image of the stacked weight parts of `w` ([O, I, 3, 3] fp32; ``transposed``: of the data gradient's
-    [I, O, 3, 3] flipped kernel) for a `terms`-term split conv: channel block t holds the weight part of term t, zero-padded to a multiple of 16 channels."""
+def pack_weights_split(w, terms, dtype, transposed=False):
+    """(packed, rows_pad, gscale): the packed 16-bit image of the stacked weight parts of `w` ([O, I, 3, 3] fp32; ``transposed``: of the
+    data gradient's [I, O, 3, 3] flipped kernel) for a `terms`-term split conv -- channel block t holds the weight part of term t,
+    zero-padded to a multiple of 16 channels; float16 parts are those of gscale * w."""
     w = w.detach().to(torch.float32)
     if transposed:
         w = w.transpose(0, 1).flip([2, 3])
+    gs = None
+    if dtype == torch.float16:
+        gs = _pow2_scale(w.abs().max())
+        w = w * gs
     table = _SPLIT_TERMS[terms]
     parts, r = [], w
     for _ in range(1 + max(b for _, b in table)):
-        q = r.to(torch.bfloat16).to(torch.float32)
+        q = r.to(dtype).to(torch.float32)
         parts.append(q)
         r = r - q
     o, i = int(w.shape[0]), int(w.shape[1])
@@ -218,40 +254,54 @@ def pack_weights_split(w, terms, transposed=False):
     cat = torch.zeros([o, terms * i16, 3, 3], dtype=torch.float32, device=w.device)
     for t, (_, b) in enumerate(table):
         cat[:, t * i16:t * i16 + i] = parts[b]
-    return pack_weights(cat, torch.bfloat16, 0)
+    return pack_weights(cat, dtype, 0) + (gs,)
 
 
-def _conv_split(parts, wp, rows_pad, terms, oscale, cout, pad, obias=None):
-    """fp32 y = oscale * conv(w, x) + obias from the bf16 parts of x (split_bf16) and the stacked weight image (pack_weights_split)."""
+def _inv_scale(*gscales):
+    """Product of the reciprocals of the operands' power-of-two factors (exact; the product of the factors themselves could overflow
+    for a tensor of tiny magnitudes), or None."""
+    gs = [g.reciprocal() for g in gscales if g is not None]
+    if not gs:
+        return None
+    prod = gs[0]
+    for g in gs[1:]:
+        prod = prod * g
+    return prod
+
+
+def _conv_split(parts, wp, rows_pad, terms, oscale, cout, pad, obias=None, inv=None):
+    """fp32 y = inv * oscale * conv(w, x) + obias from the 16-bit parts of x (split16) and the stacked weight image (pack_weights_split)."""
     lib = _lib.load()
     nparts, n, cin, h, w = parts.shape
     table = _SPLIT_TERMS[terms]
-    assert nparts > max(a for a, _ in table) and parts.dtype == torch.bfloat16 and parts.stride(1) == cin * h * w
+    assert nparts > max(a for a, _ in table) and parts.dtype == wp.dtype and parts.stride(1) == cin * h * w
     assert tuple(wp.shape) == (terms * ((cin + 15) // 16), 9, rows_pad, 16), 'the weight image does not belong to this split'
     p, q = h + 2 * pad - 2, w + 2 * pad - 2
     y = torch.empty([n, cout, p, q], dtype=torch.float32, device=parts.device)
     if oscale is not None:
         oscale = oscale.to(torch.float32).contiguous()
         assert oscale.numel() == n * cout
+    if inv is not None:
+        oscale = (oscale * inv) if oscale is not None else inv.expand(n, cout).contiguous()
     if obias is not None:
         obias = obias.to(torch.float32).contiguous()
         assert obias.numel() == cout
     code = sum(a << (4 * t) for t, (a, _) in enumerate(table))
     span = profiling.span('conv2d', 2.0 * n * cout * cin * 9 * p * q)
-    _lib.check(lib.afcm_conv2d_split(y.data_ptr(), parts.data_ptr(), wp.data_ptr(), _lib.ptr(oscale), _lib.ptr(obias), n, cin, cout, h, w, pad,
-                                     rows_pad, terms, code, parts.stride(0), _lib.stream_ptr(parts)), 'conv2d_split')
+    _lib.check(lib.afcm_conv2d_split(y.data_ptr(), parts.data_ptr(), wp.data_ptr(), _lib.ptr(oscale), _lib.ptr(obias), _lib._DTYPES[parts.dtype], n, cin,
+                                     cout, h, w, pad, rows_pad, terms, code, parts.stride(0), _lib.stream_ptr(parts)), 'conv2d_split')
     if span is not None:
         span.end()
     return y
 
 
-def _wgrad_split(dy_parts, x_parts, cout, cin, pad, terms):
-    """fp32 weight gradient of a 3x3 conv from the bf16 parts of dy and x: one 16-bit weight-gradient launch per term, summed."""
+def _wgrad_split(dy_parts, x_parts, cout, cin, pad, terms, inv=None):
+    """fp32 weight gradient of a 3x3 conv from the 16-bit parts of dy and x: one 16-bit weight-gradient launch per term, summed."""
     dw = None
     for a, b in _SPLIT_TERMS[terms]:
         d = _wgrad_raw(dy_parts[b], x_parts[a], cout, cin, 3, pad)
         dw = d if dw is None else dw.add_(d)
-    return dw
+    return dw if inv is None else dw.mul_(inv)
 
 
 def _pitch_conv(dtype, ks):
@@ -332,17 +382,23 @@ class _ScaledConv2d(torch.autograd.Function):
         cout, cin, ks, _ = w.shape
         x = x.contiguous()
         # prescaled: the producer of x already applied in_scale (fused into its epilogue) and owns the gradient of in_scale
-        xs = scale_planes(x, in_scale) if (in_scale is not None and not prescaled) else x
         # a backward that will need the data gradient gets its (transposed, flipped) weight image from the same launch
         ctx.wpt = None
-        plan = _split_plan(xs, ks)
+        plan = _split_plan(x, ks)
         if plan is not None:
-            wp, rows_pad = pack_weights_split(w, plan[0])
-            y = _conv_split(split_bf16(xs, None, _nparts(plan[0])), wp, rows_pad, plan[0], out_scale, cout, padding)
-            ctx.save_for_backward(xs, w, in_scale, out_scale, y if (out_scale is not None and ctx.needs_input_grad[3]) else None)
+            # fp32 on the 16-bit matrix pipe.  The style factor is applied while splitting; the unscaled x is what the backward keeps
+            dt, tf = plan[0], plan[1]
+            eff_in = in_scale if (in_scale is not None and not prescaled) else None
+            parts, gsx = _split_operand(x, eff_in, tf, dt)
+            wp, rows_pad, gsw = pack_weights_split(w, tf, dt)
+            y = _conv_split(parts, wp, rows_pad, tf, out_scale, cout, padding, inv=_inv_scale(gsx, gsw))
+            ctx.save_for_backward(x, w, in_scale, out_scale, y if (out_scale is not None and ctx.needs_input_grad[3]) else None)
             ctx.padding = padding
             ctx.prescaled = bool(prescaled)
+            ctx.split = plan
             return y
+        ctx.split = None
+        xs = scale_planes(x, in_scale) if (in_scale is not None and not prescaled) else x
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[2]:
             (wp, rows_pad), ctx.wpt = pack_weights_both(w, x.dtype)
         else:
@@ -375,20 +431,24 @@ class _ScaledConv2d(torch.autograd.Function):
         cout, cin, ks, _ = w.shape
         dy = dy.contiguous()
         dx = dw = d_in = d_out = None
-        plan = _split_plan(dy, ks) if _split_plan(xs, ks) is not None else None
-        if plan is not None:
-            # fp32 on the bf16 pipe: dy's parts (with the demodulation factor applied while splitting) feed both gradients
+        if ctx.split is not None:
+            # fp32 on the 16-bit matrix pipe: dy's parts (the demodulation factor applied while splitting) feed both gradients; here
+            # xs is the UNSCALED x
+            dt, td, tw = ctx.split[0], ctx.split[2], ctx.split[3]
             need_dx = ctx.needs_input_grad[0] or ctx.needs_input_grad[2]
-            terms = [plan[1]] * bool(need_dx) + [plan[2]] * bool(ctx.needs_input_grad[1])
-            dparts = split_bf16(dy, out_scale, _nparts(*terms)) if terms else None
+            terms = [td] * bool(need_dx) + [tw] * bool(ctx.needs_input_grad[1])
+            if terms:
+                dparts, gsd = _split_operand(dy, out_scale, max(terms), dt)
             if need_dx:
-                wpt, rows_pad = pack_weights_split(w, plan[1], transposed=True)
-                dx = _conv_split(dparts, wpt, rows_pad, plan[1], in_scale, cin, ks - 1 - pad)
+                wpt, rows_pad, gsw = pack_weights_split(w, td, dt, transposed=True)
+                dx = _conv_split(dparts, wpt, rows_pad, td, in_scale, cin, ks - 1 - pad, inv=_inv_scale(gsd, gsw))
                 if ctx.needs_input_grad[2] and in_scale is not None:
-                    s2 = in_scale.to(torch.float32).square()
-                    d_in = torch.where(s2 > 0, plane_dot(xs, dx) / s2.clamp_min(1e-30), torch.zeros_like(s2)).to(in_scale.dtype)
+                    # d in_scale[n,i] = <x, g> with dx = s * g  =>  <x, dx> / s
+                    s1 = in_scale.to(torch.float32)
+                    d_in = torch.where(s1 != 0, plane_dot(xs, dx) / torch.where(s1 != 0, s1, torch.ones_like(s1)), torch.zeros_like(s1)).to(in_scale.dtype)
             if ctx.needs_input_grad[1]:
-                dw = _wgrad_split(dparts, split_bf16(xs, None, _nparts(plan[2])), cout, cin, pad, plan[2]).to(w.dtype)
+                xparts, gsx = _split_operand(xs, in_scale, tw, dt)
+                dw = _wgrad_split(dparts, xparts, cout, cin, pad, tw, inv=_inv_scale(gsd, gsx)).to(w.dtype)
             if ctx.needs_input_grad[3]:
                 d_out = (plane_dot(dy, y) / out_scale.to(torch.float32)).to(out_scale.dtype)
             return dx, dw, d_in, d_out, None, None
@@ -422,8 +482,8 @@ class _ConvWgrad(torch.autograd.Function):
         ctx.cfg = (ks, pad)
         plan = _split_plan(dy, ks) if _split_plan(x, ks) is not None else None
         if plan is not None:
-            k = _nparts(plan[2])
-            return _wgrad_split(split_bf16(dy, None, k), split_bf16(x, None, k), cout, cin, pad, plan[2])
+            (dparts, gsd), (xparts, gsx) = _split_operand(dy, None, plan[3], plan[0]), _split_operand(x, None, plan[3], plan[0])
+            return _wgrad_split(dparts, xparts, cout, cin, pad, plan[3], inv=_inv_scale(gsd, gsx))
         return _wgrad_raw(dy, x, cout, cin, ks, pad)
 
     @staticmethod

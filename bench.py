@@ -47,9 +47,10 @@ def parse():
     ap.add_argument('--comm-dtype', default='fp32', choices=['fp32', 'bf16'], help='dtype of the gradient buckets on the wire')
     ap.add_argument('--no-homogeneous-dot', action='store_true', help='ablation: the demodulation gradient from real plane dot products everywhere '
                                                                       '(torch_utils/ops/fused_layer.py HOMOGENEOUS_DOT)')
-    ap.add_argument('--fp32-conv', default='split663', choices=['split6', 'split663', 'split633', 'split3', 'native'],
-                    help='--dtype fp32 only: the 3x3 convs on the bf16 matrix pipe from split operands (6 terms: fp32-exact products; '
-                         '663: 3 in the weight gradient only; 633: 3 in both gradients; 3 everywhere) or on the native fp32 MFMA kernels')
+    ap.add_argument('--fp32-conv', default='f16x3', choices=['f16x3', 'bf16x6', 'bf16x663', 'bf16x633', 'bf16x3', 'native'],
+                    help='--dtype fp32 only: the 3x3 convs on the 16-bit matrix pipe from split operands (f16x3: scaled float16 parts, 3 terms, '
+                         'fp32-grade; bf16x6: 6 terms, fp32-grade; bf16x663 / 633: 3 terms in the weight / both gradients; bf16x3: ~16 bits) '
+                         'or on the native fp32 MFMA kernels')
     ap.add_argument('--with-discriminator', action='store_true',
                     help='time the FULL iteration (D update with R1, then G update with the GAN term; SURVEY.md row f1) instead of the '
                          'generator step that BASELINE.json\'s metric names')
@@ -198,7 +199,9 @@ def main():
         from afcm_amd.torch_utils.ops import fused_layer
         fused_layer.HOMOGENEOUS_DOT = False
     from afcm_amd.torch_utils.ops import conv2d as conv_ops
-    conv_ops.FP32_SPLIT = {'split6': (6, 6, 6), 'split663': (6, 6, 3), 'split633': (6, 3, 3), 'split3': (3, 3, 3), 'native': None}[args.fp32_conv]
+    bf = torch.bfloat16
+    conv_ops.FP32_SPLIT = {'f16x3': (torch.float16, 3, 3, 3), 'bf16x6': (bf, 6, 6, 6), 'bf16x663': (bf, 6, 6, 3), 'bf16x633': (bf, 6, 3, 3),
+                           'bf16x3': (bf, 3, 3, 3), 'native': None}[args.fp32_conv]
     dtype = {'bf16': torch.bfloat16, 'fp16': torch.float16, 'fp32': torch.float32}[args.dtype]
     comm_dtype = torch.bfloat16 if args.comm_dtype == 'bf16' else None
     torch.manual_seed(0)      # identical init on every rank (the step also broadcasts from rank 0)

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define AFCM_ABI_VERSION 11  /* 11 (r04): + afcm_split_bf16, afcm_conv2d_split (additions only).  10 (r04): + afcm_filtered_lrelu_args.clamp_flags (appended), afcm_plane_dot_gated_ld; the runtime getenv switches are gone.  9 (r03): + afcm_affine_bank_*, afcm_modulation_bank_*, afcm_conv2d_pack_bank, afcm_conv2d_stride2 (additions only; every v8 entry point and struct is unchanged) */
+#define AFCM_ABI_VERSION 11  /* 11 (r04): + afcm_split16, afcm_conv2d_split (additions only).  10 (r04): + afcm_filtered_lrelu_args.clamp_flags (appended), afcm_plane_dot_gated_ld; the runtime getenv switches are gone.  9 (r03): + afcm_affine_bank_*, afcm_modulation_bank_*, afcm_conv2d_pack_bank, afcm_conv2d_stride2 (additions only; every v8 entry point and struct is unchanged) */
 
 enum { AFCM_F32 = 0, AFCM_F16 = 1, AFCM_BF16 = 2 };
 enum { AFCM_OK = 0, AFCM_E_NOKERNEL = -1, AFCM_E_INVALID = -2 };
@@ -359,25 +359,29 @@ typedef struct afcm_pack_entry {
 int afcm_conv2d_pack_bank(const afcm_pack_entry* entries, int32_t count, int32_t dtype, int32_t ks, void* stream);
 
 /* ----------------------------------------------------------------------------------------
- * fp32 convolution on the bf16 matrix pipe by split operands ("bf16x3" / "bf16x6").  The reference's fp32 conv is cuDNN's
- * (SG3OPS/conv2d_gradfix.py:37-58 behind NET:25-64); gfx950 multiplies bf16 16x faster than fp32 (2.5 vs 0.157 PFLOP/s), so an fp32
- * operand v is written as a sum of bfloat16 parts, a = bf16(v), b = bf16(v - a), c = bf16(v - a - b) (exact differences), and the
- * product of two such sums is accumulated term by term in the fp32 MFMA accumulators: terms (a a') + (a b') + (b a') keep ~16
- * significand bits (measured 4e-6 of the output scale on a K = 4608 conv), the six terms of order <= 2 of a three-way split keep all 24
- * (6e-9: below the rounding of an fp32 dot product of that length).
+ * fp32 convolution on the 16-bit matrix pipe by split operands.  The reference's fp32 conv is cuDNN's (SG3OPS/conv2d_gradfix.py:37-58
+ * behind NET:25-64); gfx950 multiplies bf16 / f16 16x faster than fp32 (2.5 vs 0.157 PFLOP/s), so an fp32 operand v is written as a
+ * sum of 16-bit parts, a = r16(v), b = r16(v - a), c = r16(v - a - b) (exact differences), and the product of two such sums is
+ * accumulated term by term in the fp32 MFMA accumulators.
+ *   float16, 2 parts, terms (b a') + (a b') + (a a'): 22 significand bits -- with both operands first multiplied by a power of two that
+ *     brings their largest magnitude near 2^15 (so that b is a normal number wherever it matters; the callers fold the inverse into
+ *     oscale), the result is as accurate as an fp32 dot product of the same length (3e-7 of the output scale at K = 4608).
+ *   bfloat16 (no range limit, no scaling): 2 parts / the same 3 terms keep ~16 bits (4e-6 of the output scale), 3 parts / the six
+ *     terms of order <= 2 keep all 24 (2e-7).
  *
- * afcm_split_bf16: parts[k] (k < nparts in {2, 3}) = part k of scale[plane] * x[plane, :] (scale NULL: 1), each a dense bf16 tensor
- *   of x's shape, part_stride ELEMENTS apart (>= planes * hw, a multiple of 4).
+ * afcm_split16: parts[k] (k < nparts in {2, 3}) = part k of gscale[0] * scale[plane] * x[plane, :] (either may be NULL: 1; gscale is a
+ *   DEVICE scalar so that a magnitude bound computed on the device needs no host round trip), dtype AFCM_F16 or AFCM_BF16, each a
+ *   dense tensor of x's shape, part_stride ELEMENTS apart (>= planes * hw, a multiple of 4).
  * afcm_conv2d_split: y[n][cout][P][Q] fp32 = oscale[n,o] * sum_t conv(W_t, part_{x(t)}) + obias[o], 3x3, stride 1, 0 <= pad <= 2, w even.
- *   x_parts as written by afcm_split_bf16 on the [n][cin][h][w] tensor; term t (t < terms <= 8) reads part (term_parts >> 4 t) & 15 and
- *   the channel block [t * cin16, (t + 1) * cin16) of the packed weights, cin16 = cin rounded up to 16 -- i.e. wpacked is
- *   afcm_conv2d_pack_weights(AFCM_BF16, mode 0) of the [cout][terms * cin16][3][3] tensor that stacks the weight part of every
- *   term (values exactly representable in bf16, zero rows for the padding channels).
+ *   x_parts as written by afcm_split16 on the [n][cin][h][w] tensor (it must hold every part a term names); term t (t < terms <= 8) reads
+ *   part (term_parts >> 4 t) & 15 and the channel block [t * cin16, (t + 1) * cin16) of the packed weights, cin16 = cin rounded up
+ *   to 16 -- i.e. wpacked is afcm_conv2d_pack_weights(dtype, mode 0) of the [cout][terms * cin16][3][3] tensor that stacks the weight
+ *   part of every term (values exactly representable in dtype, zero rows for the padding channels).
  * ---------------------------------------------------------------------------------------- */
-int afcm_split_bf16(void* parts, const float* x, const float* scale, int64_t planes, int32_t hw, int32_t nparts, int64_t part_stride,
-                    void* stream);
-int afcm_conv2d_split(float* y, const void* x_parts, const void* wpacked, const float* oscale, const float* obias, int32_t n, int32_t cin,
-                      int32_t cout, int32_t h, int32_t w, int32_t pad, int32_t rows_pad, int32_t terms, uint32_t term_parts,
+int afcm_split16(void* parts, const float* x, const float* scale, const float* gscale, int32_t dtype, int64_t planes, int32_t hw,
+                 int32_t nparts, int64_t part_stride, void* stream);
+int afcm_conv2d_split(float* y, const void* x_parts, const void* wpacked, const float* oscale, const float* obias, int32_t dtype, int32_t n,
+                      int32_t cin, int32_t cout, int32_t h, int32_t w, int32_t pad, int32_t rows_pad, int32_t terms, uint32_t term_parts,
                       int64_t part_stride, void* stream);
 
 /* ----------------------------------------------------------------------------------------

@@ -407,8 +407,8 @@ def test_stride2_conv_repacks_after_an_optimizer_step():
     assert torch.equal(C.strided_conv2d(x, wt, 1), C.scaled_conv2d(x, wt.detach(), None, None, 1)[:, :, ::2, ::2])
 
 
-# ---- fp32 on the bf16 matrix pipe: split operands (C ABI afcm_split_bf16 / afcm_conv2d_split) ----------------------------------
-def test_split_bf16_parts_sum_back_to_the_fp32_value():
+# ---- fp32 on the 16-bit matrix pipe: split operands (C ABI afcm_split16 / afcm_conv2d_split) -------------------------------------
+def test_split16_parts_sum_back_to_the_fp32_value():
     from afcm_amd.torch_utils.ops import conv2d as C
     g = torch.Generator().manual_seed(3)
     x = (torch.randn([2, 5, 6, 10], generator=g) * torch.logspace(-20, 20, 600).view(2, 5, 6, 10)).cuda()
@@ -418,7 +418,7 @@ def test_split_bf16_parts_sum_back_to_the_fp32_value():
         v = x if scale is None else x * scale[:, :, None, None]
         fin = torch.isfinite(v)
         for k in (2, 3):
-            parts = C.split_bf16(x, scale, k)
+            parts = C.split16(x, scale, k, torch.bfloat16)
             assert parts.shape == (k, 2, 5, 6, 10) and parts.dtype == torch.bfloat16
             tot = parts.double().sum(0)
             # round-to-nearest parts: k parts leave at most 2^-(8 k + 1) of the value (three parts: 2^-25 -- below half an fp32 ulp)
@@ -426,36 +426,55 @@ def test_split_bf16_parts_sum_back_to_the_fp32_value():
             assert float(err.max()) <= 2.0 ** -(8 * k + 1) * 1.01, (k, float(err.max()))
             assert torch.equal(parts[0][~fin].float().isnan(), v[~fin].isnan()) and torch.equal(parts[0][~fin].float().isinf(), v[~fin].isinf())
             assert float(parts[1:][:, ~fin].float().abs().max()) == 0.0       # inf / nan stay in the leading part only
+    # float16 parts under the power-of-two factor of the magnitude bound: 22 bits where the second part is a normal number
+    # (|gs v| >= 2^-3), an absolute 2^-25 (in scaled units) below -- 2^-40 of the bound
+    y = (torch.randn([2, 5, 6, 10], generator=g) * torch.logspace(-12, 3, 600).view(2, 5, 6, 10)).cuda()
+    for scale in (None, sc):
+        v = (y if scale is None else y * scale[:, :, None, None]).double()
+        gs = C._pow2_scale(C._magnitude(y) * (1.0 if scale is None else scale.abs().max()))
+        top = float((v.abs().max() * gs.double()).item())
+        assert 2.0 ** 13 <= top < 2.0 ** 15 and float(torch.frexp(gs)[0]) == 0.5          # a power of two; the bound may be loose by the scale's spread
+        parts = C.split16(y, scale, 2, torch.float16, gs)
+        assert parts.dtype == torch.float16 and bool(torch.isfinite(parts.float()).all())
+        err = (parts.double().sum(0) - v * gs.double()).abs()
+        big = (v * gs.double()).abs() >= 2.0 ** -3
+        assert float((err[big] / (v * gs.double()).abs()[big]).max()) <= 2.0 ** -22 and float(err[~big].max()) <= 2.0 ** -25
 
 
-@pytest.mark.parametrize('terms,tol', [(3, 2e-5), (6, 1.5e-6)])
+_SPLIT_MODES = [((torch.float16, 3, 3, 3), 1.5e-6), ((torch.bfloat16, 6, 6, 6), 1.5e-6), ((torch.bfloat16, 3, 3, 3), 2e-5)]
+
+
+@pytest.mark.parametrize('mode,tol', _SPLIT_MODES, ids=['f16x3', 'bf16x6', 'bf16x3'])
 @pytest.mark.parametrize('case', [(2, 4, 64, 30, 30, 2), (2, 64, 91, 22, 26, 2), (1, 181, 128, 20, 20, 2), (2, 72, 72, 36, 36, 1),
                                   (1, 40, 48, 70, 150, 2), (1, 512, 512, 36, 36, 2)], ids=str)
-def test_fp32_conv_on_split_bf16_operands(case, terms, tol):
+def test_fp32_conv_on_split_16bit_operands(case, mode, tol):
     """The fp32 3x3 conv, its data gradient and its weight gradient through the split-operand route against float64 aten on the
-    CPU.  Six terms: as good as an fp32 dot product (tolerance = fp32 accumulation over K = 9 Cin); three terms: ~16 bits."""
+    CPU.  Scaled float16 x 3 terms and bfloat16 x 6 terms: as good as an fp32 dot product (tolerance = fp32 accumulation over
+    K = 9 Cin); bfloat16 x 3 terms: ~16 bits."""
     from afcm_amd.torch_utils.ops import conv2d as C
     n, i, o, h, w, pad = case
     g = torch.Generator().manual_seed(11)
-    x = torch.randn([n, i, h, w], generator=g)
+    x = torch.randn([n, i, h, w], generator=g) * torch.exp(1.5 * torch.randn([n, i, 1, 1], generator=g))      # planes of very different size
     wt = torch.randn([o, i, 3, 3], generator=g) / (3 * i ** 0.5)
     si, so = torch.rand([n, i], generator=g) + 0.5, torch.rand([n, o], generator=g) + 0.5
     xd, wd = x.double().requires_grad_(True), wt.double().requires_grad_(True)
-    yd = torch.nn.functional.conv2d(xd * si.double()[:, :, None, None], wd, padding=pad) * so.double()[:, :, None, None]
-    r = torch.randn(yd.shape, generator=g)
-    dxd, dwd = torch.autograd.grad((yd * r.double()).sum(), [xd, wd])
+    sid, sod = si.double().requires_grad_(True), so.double().requires_grad_(True)
+    yd = torch.nn.functional.conv2d(xd * sid[:, :, None, None], wd, padding=pad) * sod[:, :, None, None]
+    r = torch.randn(yd.shape, generator=g) * 1e-3                                                               # small gradients
+    ref = torch.autograd.grad((yd * r.double()).sum(), [xd, wd, sid, sod])
     old = C.FP32_SPLIT
-    C.FP32_SPLIT = (terms, terms, terms)
+    C.FP32_SPLIT = mode
     try:
         xg, wg = x.cuda().requires_grad_(True), wt.cuda().requires_grad_(True)
-        y = C._ScaledConv2d.apply(xg, wg, si.cuda(), so.cuda(), pad, False)
-        dx, dw = torch.autograd.grad((y * r.cuda()).sum(), [xg, wg])
+        sig, sog = si.cuda().requires_grad_(True), so.cuda().requires_grad_(True)
+        y = C._ScaledConv2d.apply(xg, wg, sig, sog, pad, False)
+        got = torch.autograd.grad((y * r.cuda()).sum(), [xg, wg, sig, sog])
     finally:
         C.FP32_SPLIT = old
     assert y.dtype == torch.float32
     _close(y, yd.float(), tol, 'y')
-    _close(dx, dxd.float(), tol, 'dx')
-    _close(dw, dwd.float(), 3 * tol, 'dw')
+    for nm, a, b, f in zip(('dx', 'dw', 'd in_scale', 'd out_scale'), got, ref, (1, 3, 3, 3)):
+        _close(a, b.float(), f * tol, nm)
 
 
 def test_fp32_split_route_is_the_default_and_native_kernels_remain():
@@ -471,8 +490,15 @@ def test_fp32_split_route_is_the_default_and_native_kernels_remain():
         C.FP32_SPLIT = old
     ref = torch.nn.functional.conv2d(x.double().cpu(), wt.double().cpu(), padding=2).float()
     _close(y_native, ref, 2e-6, 'native fp32 MFMA')
-    _close(y_split, ref, 2e-6, 'split bf16')
+    _close(y_split, ref, 2e-6, 'split operands')
     assert not torch.equal(y_split, y_native)          # different kernels, different summation order
     # odd widths keep the native kernel
     xo = torch.randn([1, 32, 18, 21], generator=g).cuda()
     _close(C._ScaledConv2d.apply(xo, wt, None, None, 2, False), torch.nn.functional.conv2d(xo.double().cpu(), wt.double().cpu(), padding=2).float(), 2e-6, 'odd width')
+    # an all-zero and a non-finite input go through (zeros; NaN where the window touches the NaN, nothing else)
+    z = C._ScaledConv2d.apply(torch.zeros_like(x), wt, None, None, 2, False)
+    assert float(z.abs().max()) == 0.0
+    xn = x.clone()
+    xn[0, 3, 9, 10] = float('nan')
+    yn = C._ScaledConv2d.apply(xn, wt, None, None, 2, False)
+    assert bool(yn[0, :, 9:12, 10:13].isnan().all())
