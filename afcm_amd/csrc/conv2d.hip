@@ -65,7 +65,17 @@ struct ConvParams {
     // split-precision form (conv2d_fwd16_kernel<bf16, BM, true>): x holds `parts` bf16 tensors [N, Cin, H, ldx] part_bytes apart,
     // the K loop runs over terms x nkc_real chunks, term t reads part (term_parts >> 4 t) & 15; y is fp32
     int nkc_real; unsigned magicNK, term_parts; int part_bytes, last_part_bytes;   // last_part_bytes: offset of the highest part any term reads
+    const unsigned* bound_a; const unsigned* bound_b;   // magnitude-bound words of the two operands (or null): their power-of-two factors are undone in the epilogue
 };
+// the power of two g with g * bound in [2^14, 2^15) for a magnitude-bound word (amax_bits_kernel); *inverse = 1 / g
+__device__ __forceinline__ float pow2_factor(unsigned bound_bits, float* inverse = nullptr) {
+    const float b = __uint_as_float(bound_bits);
+    int e = 15;                                              // non-finite bound (a NaN fails the comparison): g = 1
+    if (b <= 3.4028234664e38f) frexpf(fmaxf(b, 1e-30f), &e); // b = f * 2^e, f in [0.5, 1)
+    if (inverse) *inverse = ldexpf(1.f, e - 15);
+    return ldexpf(1.f, 15 - e);
+}
+
 __host__ __device__ inline unsigned magic_u32(unsigned d) { return (unsigned)((0x100000000ull + d - 1) / d); }   // 0 for d = 1 (see udiv_magic)
 __device__ __forceinline__ unsigned udiv_magic(unsigned n, unsigned magic) { return magic ? __umulhi(n, magic) : n; }
 
@@ -749,6 +759,14 @@ __global__ __launch_bounds__(256, 2) void conv2d_fwd16_kernel(ConvParams p) {
 #pragma unroll
             for (int reg = 0; reg < 16; reg++) ob[reg] = p.obias[min(obase + (reg & 3) + 8 * (reg >> 2), p.Cout - 1)];
         }
+        if constexpr (SPLIT) {
+            float ia = 1.f, ib = 1.f;
+            if (p.bound_a) pow2_factor(p.bound_a[0], &ia);
+            if (p.bound_b) pow2_factor(p.bound_b[0], &ib);
+            const float inv = ia * ib;
+#pragma unroll
+            for (int reg = 0; reg < 16; reg++) sc[reg] *= inv;
+        }
 #pragma unroll
         for (int reg = 0; reg < 16; reg++) {
             const int o = obase + (reg & 3) + 8 * (reg >> 2);
@@ -1250,19 +1268,104 @@ __global__ __launch_bounds__(256) void scale_planes_kernel(TO* __restrict__ y, c
     }
 }
 
-// Split-precision operands: v = gscale * scale[plane] * x as a sum of `parts` 16-bit numbers, v ~ a + b (+ c) with a = r16(v), b = r16(v - a),
+// Magnitude bound of a tensor, for the float16 split (split16_kernel): out[0] = max(out[0], bits of max |scale[plane] * x[plane, :]|).
+// Magnitudes compare as their bit patterns (a NaN ranks above inf).  The consumers turn the bound into the power of two g with
+// g * bound in [2^14, 2^15) (pow2_factor): float16 parts of g * v cannot overflow (65504) and the second part of every element above
+// 2^-18 of the bound is a normal number; a non-finite bound gives g = 1, so an inf / NaN tensor goes through the split as it is.
+// One atomic per workgroup, and only from workgroups that would raise the value (2048 unconditional atomics on one word cost 50 us).
+__global__ __launch_bounds__(256) void amax_bits_kernel(unsigned* __restrict__ out, const float* __restrict__ x, long long planes, int hw,
+                                                        const float* __restrict__ scale) {
+    __shared__ unsigned red[4];
+    unsigned m = 0;
+    const long long numel = planes * hw;
+    const bool vec = (((uintptr_t)x & 15) == 0) && (hw & 3) == 0;
+    const long long n4 = vec ? (numel >> 2) : 0;
+    const int per = hw >> 2;                                 // 16-byte groups per plane (vec only)
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    auto fold = [&](const uint4 v, long long g) {
+        unsigned a = max(max(v.x & 0x7fffffffu, v.y & 0x7fffffffu), max(v.z & 0x7fffffffu, v.w & 0x7fffffffu));
+        if (scale) a = __float_as_uint(__uint_as_float(a) * __builtin_fabsf(scale[g / per]));      // |s| max|x| = max|s x| (NaN stays NaN)
+        m = max(m, a);
+    };
+    // four independent 16-byte loads in flight per lane
+    for (; i + 3 * stride < n4; i += 4 * stride) {
+        const uint4 v0 = ((const uint4*)x)[i], v1 = ((const uint4*)x)[i + stride], v2 = ((const uint4*)x)[i + 2 * stride], v3 = ((const uint4*)x)[i + 3 * stride];
+        fold(v0, i); fold(v1, i + stride); fold(v2, i + 2 * stride); fold(v3, i + 3 * stride);
+    }
+    for (; i < n4; i += stride) fold(((const uint4*)x)[i], i);
+    for (long long j = 4 * n4 + (long long)blockIdx.x * blockDim.x + threadIdx.x; j < numel; j += stride) {
+        const float v = x[j] * (scale ? scale[j / hw] : 1.f);
+        m = max(m, __float_as_uint(v) & 0x7fffffffu);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = max(max(red[0], red[1]), max(red[2], red[3]));
+        if (m > __atomic_load_n(out, __ATOMIC_RELAXED)) atomicMax(out, m);
+    }
+}
+
+// t *= 1 / (g_a g_b): the power-of-two factors of two split operands undone (weight gradient of split parts).
+__global__ __launch_bounds__(256) void unscale_kernel(float* __restrict__ t, long long numel, const unsigned* __restrict__ bound_a, const unsigned* __restrict__ bound_b) {
+    float ia = 1.f, ib = 1.f;
+    if (bound_a) pow2_factor(bound_a[0], &ia);
+    if (bound_b) pow2_factor(bound_b[0], &ib);
+    const float inv = ia * ib;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < numel; i += (long long)gridDim.x * blockDim.x) t[i] *= inv;
+}
+
+// The packed image of a split conv's stacked weight parts (afcm_conv2d_split): channel block t (cin16 = 16 nkc_real channels) holds part
+// (term_wparts >> 4 t) & 15 of g * w (g: pow2_factor of the bound word, 1 without one) -- part 0 = r16(v), part 1 = r16(v - part 0), ... -- in the layout of conv2d_pack_kernel
+// (mode 1: the data gradient's transposed, flipped kernel).
+template <typename T>
+__global__ __launch_bounds__(256) void conv2d_pack_split_kernel(T* __restrict__ dst, const float* __restrict__ w, const unsigned* __restrict__ bound,
+                                                                int O, int I, int rows, int cols, int rows_pad, int nkc_real, int terms,
+                                                                unsigned term_wparts, int mode) {
+    constexpr int KS = 3, KK = 9, BK = 16;
+    const float gs = bound ? pow2_factor(bound[0]) : 1.f;
+    const long long total = (long long)terms * nkc_real * KK * rows_pad * BK;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int kk = (int)(idx % BK);
+        long long t = idx / BK;
+        const int row = (int)(t % rows_pad); t /= rows_pad;
+        const int tap = (int)(t % KK);
+        const int kc = (int)(t / KK);
+        const int term = kc / nkc_real;
+        const int col = (kc - term * nkc_real) * BK + kk;
+        float r = 0.f;
+        if (row < rows && col < cols) {
+            const int rr = tap / KS, ss = tap - rr * KS;
+            if (mode == 0) r = w[(((size_t)row * I + col) * KS + rr) * KS + ss];
+            else r = w[(((size_t)col * I + row) * KS + (KS - 1 - rr)) * KS + (KS - 1 - ss)];
+        }
+        r *= gs;
+        const int part = (int)((term_wparts >> (4 * term)) & 15u);
+        T q = (T)r;
+        for (int k = 0; k < part; k++) {
+            const float qf = (float)q;
+            r = (__builtin_fabsf(qf) <= 3.4028234664e38f) ? r - qf : 0.f;
+            q = (T)r;
+        }
+        dst[idx] = q;
+    }
+}
+
+// Split-precision operands: v = g * scale[plane] * x (g: pow2_factor of the bound word, 1 without one) as a sum of `parts` 16-bit numbers, v ~ a + b (+ c) with a = r16(v), b = r16(v - a),
 // c = r16(v - a - b) (round to nearest even; the differences are exact in fp32).  bfloat16: two parts carry 16 significand bits, three
 // carry all 24.  float16: two parts carry 22 bits wherever b is a normal number, i.e. for |v| >= 2^-3; below that the error is at most
-// 2^-25 ABSOLUTE, so with gscale a power of two that brings the tensor's largest magnitude near 2^15 it is 2^-40 of that magnitude.
+// 2^-25 ABSOLUTE, so with g the power of two that brings the tensor's largest magnitude near 2^15 it is 2^-40 of that magnitude.
 // parts[k] is a dense tensor of the input's shape, part_stride elements after parts[k - 1].  A non-finite v keeps its class in part a
 // and zeros in the others (inf - inf would make NaNs of infinities).
 template <typename TP, int PARTS>
 __global__ __launch_bounds__(256) void split16_kernel(TP* __restrict__ parts, const float* __restrict__ x, const float* __restrict__ scale,
-                                                      const float* __restrict__ gscale, long long planes, int hw, long long part_stride) {
+                                                      const unsigned* __restrict__ bound, long long planes, int hw, long long part_stride) {
     const int per = (hw + 3) >> 2;
     const long long total = planes * per;
     const bool vec = (hw & 3) == 0;
-    const float gs = gscale ? *gscale : 1.f;
+    const float gs = bound ? pow2_factor(bound[0]) : 1.f;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
         const long long plane = idx / per;
         const int i0 = (int)(idx - plane * per) << 2;
@@ -2646,7 +2749,7 @@ extern "C" int afcm_conv2d_stride2(void* y, const void* x, const void* wpacked, 
     p.magicTX = magic_u32((unsigned)p.tilesX); p.magicTY = magic_u32((unsigned)p.tilesY); p.magicN = magic_u32((unsigned)p.N); p.magicPC = magic_u32((unsigned)(p.PWL >> 2));
     p.Opad = rows_pad;
     p.nkc = cdiv(cin, afcm_conv2d_block_k(dtype));
-    p.nkc_real = p.nkc; p.magicNK = 0; p.term_parts = 0; p.part_bytes = 0; p.last_part_bytes = 0;
+    p.nkc_real = p.nkc; p.magicNK = 0; p.term_parts = 0; p.part_bytes = 0; p.last_part_bytes = 0; p.bound_a = p.bound_b = nullptr;
     const long long blocks = (long long)p.tilesX * p.tilesY * n * cdiv(cout, 128);
     AFCM_REQUIRE(blocks > 0 && blocks < (1ll << 31), "conv2d_stride2: grid of %lld blocks is out of range", blocks);
     AFCM_REQUIRE((long long)cin * h * w * 2ll < (1ll << 31), "conv2d_stride2: image out of range");
@@ -2689,7 +2792,7 @@ extern "C" int afcm_conv2d_ld(void* y, const void* x, const void* wpacked, const
     p.magicTX = magic_u32((unsigned)p.tilesX); p.magicTY = magic_u32((unsigned)p.tilesY); p.magicN = magic_u32((unsigned)p.N); p.magicPC = magic_u32((unsigned)(p.PWL >> 2));
     p.Opad = rows_pad;
     p.nkc = cdiv(cin, afcm_conv2d_block_k(dtype));
-    p.nkc_real = p.nkc; p.magicNK = 0; p.term_parts = 0; p.part_bytes = 0; p.last_part_bytes = 0;
+    p.nkc_real = p.nkc; p.magicNK = 0; p.term_parts = 0; p.part_bytes = 0; p.last_part_bytes = 0; p.bound_a = p.bound_b = nullptr;
     hipStream_t st = (hipStream_t)stream;
     // 64-row blocks when they waste fewer padded rows than 128-row blocks
     const bool small = (rows_pad % 128 != 0) || cout <= 64;
@@ -2701,7 +2804,7 @@ extern "C" int afcm_conv2d_ld(void* y, const void* x, const void* wpacked, const
 }
 
 
-extern "C" int afcm_split16(void* parts, const float* x, const float* scale, const float* gscale, int32_t dtype, int64_t planes, int32_t hw,
+extern "C" int afcm_split16(void* parts, const float* x, const float* scale, const uint32_t* bound, int32_t dtype, int64_t planes, int32_t hw,
                             int32_t nparts, int64_t part_stride, void* stream) {
     AFCM_REQUIRE(parts != nullptr && x != nullptr && planes > 0 && hw > 0, "split16: empty input");
     AFCM_REQUIRE(dtype == AFCM_BF16 || dtype == AFCM_F16, "split16: parts are bfloat16 or float16");
@@ -2712,16 +2815,52 @@ extern "C" int afcm_split16(void* parts, const float* x, const float* scale, con
     if (blocks > 4096) blocks = 4096;
     dim3 grid((unsigned)blocks), block(256);
     hipStream_t st = (hipStream_t)stream;
-#define AFCM_SPLIT(T, K) hipLaunchKernelGGL((split16_kernel<T, K>), grid, block, 0, st, (T*)parts, x, scale, gscale, (long long)planes, hw, (long long)part_stride)
+#define AFCM_SPLIT(T, K) hipLaunchKernelGGL((split16_kernel<T, K>), grid, block, 0, st, (T*)parts, x, scale, (const unsigned*)bound, (long long)planes, hw, (long long)part_stride)
     if (dtype == AFCM_BF16) { if (nparts == 2) AFCM_SPLIT(bf16_t, 2); else AFCM_SPLIT(bf16_t, 3); }
     else { if (nparts == 2) AFCM_SPLIT(f16_t, 2); else AFCM_SPLIT(f16_t, 3); }
 #undef AFCM_SPLIT
     return hip_status(hipGetLastError());
 }
 
+extern "C" int afcm_amax_bits(uint32_t* out, const float* x, int64_t planes, int32_t hw, const float* scale, void* stream) {
+    AFCM_REQUIRE(out != nullptr && x != nullptr && planes > 0 && hw > 0, "amax_bits: empty input");
+    AFCM_REQUIRE(((uintptr_t)out & 3) == 0 && ((uintptr_t)x & 3) == 0, "amax_bits: misaligned pointer");
+    long long blocks = (planes * hw / 16 + 255) / 256;          // >= 4 16-byte groups per lane
+    blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+    hipLaunchKernelGGL(amax_bits_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (unsigned*)out, x, (long long)planes, hw, scale);
+    return hip_status(hipGetLastError());
+}
+
+extern "C" int afcm_unscale(float* t, int64_t numel, const uint32_t* bound_a, const uint32_t* bound_b, void* stream) {
+    AFCM_REQUIRE(t != nullptr && numel > 0, "unscale: empty input");
+    long long blocks = (numel + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(unscale_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, t, (long long)numel, (const unsigned*)bound_a, (const unsigned*)bound_b);
+    return hip_status(hipGetLastError());
+}
+
+extern "C" int afcm_conv2d_pack_split(void* dst, const float* w, const uint32_t* bound, int32_t dtype, int32_t cout, int32_t cin, int32_t mode,
+                                      int32_t rows_pad, int32_t terms, uint32_t term_wparts, void* stream) {
+    AFCM_REQUIRE(dst != nullptr && w != nullptr, "conv2d_pack_split: null pointer");
+    AFCM_REQUIRE(dtype == AFCM_BF16 || dtype == AFCM_F16, "conv2d_pack_split: parts are bfloat16 or float16");
+    AFCM_REQUIRE(mode == 0 || mode == 1, "mode must be 0 (forward) or 1 (data gradient)");
+    AFCM_REQUIRE(terms >= 1 && terms <= 8 && cout > 0 && cin > 0, "conv2d_pack_split: 1..8 terms");
+    const int rows = mode == 0 ? cout : cin, cols = mode == 0 ? cin : cout;
+    AFCM_REQUIRE(rows_pad >= rows && rows_pad % 64 == 0, "rows_pad must be a multiple of 64 covering the rows");
+    for (int t = 0; t < terms; t++) AFCM_REQUIRE(((term_wparts >> (4 * t)) & 15u) <= 2, "conv2d_pack_split: parts 0..2");
+    const int nkc_real = cdiv(cols, 16);
+    const long long total = (long long)terms * nkc_real * 9 * rows_pad * 16;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == AFCM_BF16) hipLaunchKernelGGL((conv2d_pack_split_kernel<bf16_t>), dim3((unsigned)blocks), dim3(256), 0, st, (bf16_t*)dst, w, (const unsigned*)bound, cout, cin, rows, cols, rows_pad, nkc_real, terms, term_wparts, mode);
+    else hipLaunchKernelGGL((conv2d_pack_split_kernel<f16_t>), dim3((unsigned)blocks), dim3(256), 0, st, (f16_t*)dst, w, (const unsigned*)bound, cout, cin, rows, cols, rows_pad, nkc_real, terms, term_wparts, mode);
+    return hip_status(hipGetLastError());
+}
+
 extern "C" int afcm_conv2d_split(float* y, const void* x_parts, const void* wpacked, const float* oscale, const float* obias, int32_t dtype, int32_t n,
                                  int32_t cin, int32_t cout, int32_t h, int32_t w, int32_t pad, int32_t rows_pad, int32_t terms, uint32_t term_parts,
-                                 int64_t part_stride, void* stream) {
+                                 int64_t part_stride, const uint32_t* bound_a, const uint32_t* bound_b, void* stream) {
     const int ks = 3;
     AFCM_REQUIRE(y != nullptr && x_parts != nullptr && wpacked != nullptr, "conv2d_split: null pointer");
     AFCM_REQUIRE(dtype == AFCM_BF16 || dtype == AFCM_F16, "conv2d_split: parts are bfloat16 or float16");
@@ -2753,6 +2892,7 @@ extern "C" int afcm_conv2d_split(float* y, const void* x_parts, const void* wpac
     p.term_parts = term_parts;
     p.part_bytes = (int)(part_stride * 2);
     p.last_part_bytes = max_part * p.part_bytes;
+    p.bound_a = (const unsigned*)bound_a; p.bound_b = (const unsigned*)bound_b;
     const bool small = (rows_pad % 128 != 0) || cout <= 64;
     const long long blocks = (long long)p.tilesX * p.tilesY * p.N * cdiv(p.Cout, small ? 64 : 128);
     AFCM_REQUIRE(blocks > 0 && blocks < (1ll << 31), "conv2d_split: grid of %lld blocks is out of range", blocks);

@@ -182,24 +182,49 @@ def _split_plan(x, ks):
     return FP32_SPLIT
 
 
-def _magnitude(t):
-    """0-dim tensor: max |t| (one pass)."""
-    lo, hi = torch.aminmax(t)
-    return torch.maximum(-lo, hi)
+_BOUND_POOL = {}       # device -> [zeroed int32 words, next free index]
 
 
-def _pow2_scale(bound):
-    """The power of two that brings `bound` (0-dim device tensor, an upper bound of the magnitudes) into [2^14, 2^15): float16 parts of the
-    scaled values cannot overflow (max 65504) and the second part of everything above 2^-18 of the bound is a normal number.  The bound
-    may be loose by many binades before precision suffers (an element's error floor is 2^-40 of the bound).  On the device: no host
-    round trip."""
-    e = torch.frexp(bound.to(torch.float32).clamp_min(1e-30))[1]           # bound = f * 2^e, f in [0.5, 1)
-    return torch.ldexp(torch.ones_like(bound, dtype=torch.float32), 15 - e)
+def _bound_word(device):
+    """A zeroed int32 word on `device` (a view of a pooled zeros tensor: one fill launch per 1024 words)."""
+    slot = _BOUND_POOL.get(device)
+    if slot is None or slot[1] >= slot[0].numel():
+        slot = _BOUND_POOL[device] = [torch.zeros([1024], dtype=torch.int32, device=device), 0]
+    word = slot[0][slot[1]:slot[1] + 1]
+    slot[1] += 1
+    return word
 
 
-def split16(x, scale=None, nparts=2, dtype=torch.float16, gscale=None):
-    """[nparts, N, C, H, W] of `dtype`: gscale * scale[n, c] * x[n, c] as a sum of `nparts` 16-bit tensors (C ABI afcm_split16); every part
-    is dense, ``.stride(0)`` is the part stride.  ``gscale``: 0-dim fp32 device tensor or None."""
+def amax_bits(x, scale=None, out=None):
+    """One int32 word on the device holding the bit pattern of max |scale[n, c] * x[n, c]| (C ABI afcm_amax_bits; ``out``: a word to
+    raise instead of a fresh one).  split16 / pack_weights_split / the split conv turn it into the power of two g that brings that
+    magnitude into [2^14, 2^15) -- float16 parts of g * v cannot overflow (max 65504) and the second part of everything above 2^-18 of
+    the largest magnitude is a normal number.  One pass over x, no host round trip."""
+    lib = _lib.load()
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    word = _bound_word(x.device) if out is None else out
+    if x.ndim == 4:
+        planes, hw = x.shape[0] * x.shape[1], x.shape[2] * x.shape[3]
+    else:
+        planes, hw = 1, x.numel()
+    if scale is not None:
+        scale = scale.detach().to(torch.float32).contiguous()
+        assert scale.numel() == planes
+    _lib.check(lib.afcm_amax_bits(word.data_ptr(), x.data_ptr(), planes, hw, _lib.ptr(scale), _lib.stream_ptr(x)), 'amax_bits')
+    return word
+
+
+def pow2_factor(word):
+    """The factor the kernels derive from a bound word (host-side mirror, for tests): 2^(15 - e) with bound = f 2^e, f in [0.5, 1)."""
+    b = word.view(torch.float32).double().cpu()
+    if not bool(torch.isfinite(b).all()):
+        return 1.0
+    return float(2.0 ** (15 - torch.frexp(b.clamp_min(1e-30))[1].item()))
+
+
+def split16(x, scale=None, nparts=2, dtype=torch.float16, bound=None):
+    """[nparts, N, C, H, W] of `dtype`: g * scale[n, c] * x[n, c] as a sum of `nparts` 16-bit tensors (C ABI afcm_split16); every
+    part is dense, ``.stride(0)`` is the part stride.  ``bound``: the word of ``amax_bits`` (g: its power of two) or None (g = 1)."""
     lib = _lib.load()
     x = x.contiguous()
     assert x.dtype == torch.float32 and x.ndim == 4 and nparts in (2, 3) and dtype in (torch.float16, torch.bfloat16)
@@ -210,22 +235,20 @@ def split16(x, scale=None, nparts=2, dtype=torch.float16, gscale=None):
     if scale is not None:
         scale = scale.to(torch.float32).contiguous()
         assert scale.numel() == n * c
-    if gscale is not None:
-        assert gscale.dtype == torch.float32 and gscale.numel() == 1 and gscale.device == x.device
-    _lib.check(lib.afcm_split16(buf.data_ptr(), x.data_ptr(), _lib.ptr(scale), _lib.ptr(gscale), _lib._DTYPES[dtype], n * c, h * w, nparts, stride,
+    if bound is not None:
+        assert bound.dtype == torch.int32 and bound.numel() == 1 and bound.device == x.device
+    _lib.check(lib.afcm_split16(buf.data_ptr(), x.data_ptr(), _lib.ptr(scale), _lib.ptr(bound), _lib._DTYPES[dtype], n * c, h * w, nparts, stride,
                                 _lib.stream_ptr(x)), 'split16')
     return buf[:, :total].view(nparts, n, c, h, w)
 
 
-def _split_operand(x, scale, terms, dtype):
-    """(parts, gscale): the parts of scale * x for a `terms`-term product; float16 parts carry the power-of-two factor ``gscale``."""
-    gs = None
-    if dtype == torch.float16:
-        bound = _magnitude(x)
-        if scale is not None:
-            bound = bound * scale.detach().abs().max().to(torch.float32)
-        gs = _pow2_scale(bound)
-    return split16(x, scale, _nparts(terms), dtype, gs), gs
+def _split_operand(x, scale, terms, dtype, bound=None):
+    """(parts, bound): the parts of scale * x for a `terms`-term product; float16 parts carry the power of two of the magnitude word
+    ``bound`` (given: the same tensor and scale were measured before)."""
+    x = x.contiguous()
+    if dtype == torch.float16 and bound is None:
+        bound = amax_bits(x, scale)
+    return split16(x, scale, _nparts(terms), dtype, bound if dtype == torch.float16 else None), (bound if dtype == torch.float16 else None)
 
 
 def _nparts(*term_counts):
@@ -233,44 +256,27 @@ def _nparts(*term_counts):
 
 
 def pack_weights_split(w, terms, dtype, transposed=False):
-    """(packed, rows_pad, gscale): the packed 16-bit image of the stacked weight parts of `w` ([O, I, 3, 3] fp32; ``transposed``: of the
-    data gradient's [I, O, 3, 3] flipped kernel) for a `terms`-term split conv -- channel block t holds the weight part of term t,
-    zero-padded to a multiple of 16 channels; float16 parts are those of gscale * w."""
-    w = w.detach().to(torch.float32)
-    if transposed:
-        w = w.transpose(0, 1).flip([2, 3])
-    gs = None
-    if dtype == torch.float16:
-        gs = _pow2_scale(w.abs().max())
-        w = w * gs
-    table = _SPLIT_TERMS[terms]
-    parts, r = [], w
-    for _ in range(1 + max(b for _, b in table)):
-        q = r.to(dtype).to(torch.float32)
-        parts.append(q)
-        r = r - q
+    """(packed, rows_pad, bound): the packed 16-bit image of the stacked weight parts of `w` ([O, I, 3, 3] fp32; ``transposed``: of the
+    data gradient's [I, O, 3, 3] flipped kernel) for a `terms`-term split conv (C ABI afcm_conv2d_pack_split) -- channel block t holds
+    the weight part of term t, zero-padded to a multiple of 16 channels; float16 parts are those of g * w, g from the magnitude word ``bound``."""
+    lib = _lib.load()
+    w = w.detach().to(torch.float32).contiguous()
     o, i = int(w.shape[0]), int(w.shape[1])
-    i16 = (i + 15) // 16 * 16
-    cat = torch.zeros([o, terms * i16, 3, 3], dtype=torch.float32, device=w.device)
-    for t, (_, b) in enumerate(table):
-        cat[:, t * i16:t * i16 + i] = parts[b]
-    return pack_weights(cat, dtype, 0) + (gs,)
+    assert tuple(w.shape[2:]) == (3, 3)
+    rows, cols = (i, o) if transposed else (o, i)
+    rows_pad = _pad64(rows)
+    bound = amax_bits(w) if dtype == torch.float16 else None
+    table = _SPLIT_TERMS[terms]
+    dst = torch.empty([terms * ((cols + 15) // 16), 9, rows_pad, 16], dtype=dtype, device=w.device)
+    code = sum(b << (4 * t) for t, (_, b) in enumerate(table))
+    _lib.check(lib.afcm_conv2d_pack_split(dst.data_ptr(), w.data_ptr(), _lib.ptr(bound), _lib._DTYPES[dtype], o, i, 1 if transposed else 0, rows_pad,
+                                          terms, code, _lib.stream_ptr(w)), 'conv2d_pack_split')
+    return dst, rows_pad, bound
 
 
-def _inv_scale(*gscales):
-    """Product of the reciprocals of the operands' power-of-two factors (exact; the product of the factors themselves could overflow
-    for a tensor of tiny magnitudes), or None."""
-    gs = [g.reciprocal() for g in gscales if g is not None]
-    if not gs:
-        return None
-    prod = gs[0]
-    for g in gs[1:]:
-        prod = prod * g
-    return prod
-
-
-def _conv_split(parts, wp, rows_pad, terms, oscale, cout, pad, obias=None, inv=None):
-    """fp32 y = inv * oscale * conv(w, x) + obias from the 16-bit parts of x (split16) and the stacked weight image (pack_weights_split)."""
+def _conv_split(parts, wp, rows_pad, terms, oscale, cout, pad, obias=None, bounds=(None, None)):
+    """fp32 y = oscale * conv(w, x) + obias from the 16-bit parts of x (split16) and the stacked weight image (pack_weights_split);
+    ``bounds``: the two operands' magnitude words, their factors undone in the kernel's epilogue."""
     lib = _lib.load()
     nparts, n, cin, h, w = parts.shape
     table = _SPLIT_TERMS[terms]
@@ -281,27 +287,28 @@ def _conv_split(parts, wp, rows_pad, terms, oscale, cout, pad, obias=None, inv=N
     if oscale is not None:
         oscale = oscale.to(torch.float32).contiguous()
         assert oscale.numel() == n * cout
-    if inv is not None:
-        oscale = (oscale * inv) if oscale is not None else inv.expand(n, cout).contiguous()
     if obias is not None:
         obias = obias.to(torch.float32).contiguous()
         assert obias.numel() == cout
     code = sum(a << (4 * t) for t, (a, _) in enumerate(table))
     span = profiling.span('conv2d', 2.0 * n * cout * cin * 9 * p * q)
     _lib.check(lib.afcm_conv2d_split(y.data_ptr(), parts.data_ptr(), wp.data_ptr(), _lib.ptr(oscale), _lib.ptr(obias), _lib._DTYPES[parts.dtype], n, cin,
-                                     cout, h, w, pad, rows_pad, terms, code, parts.stride(0), _lib.stream_ptr(parts)), 'conv2d_split')
+                                     cout, h, w, pad, rows_pad, terms, code, parts.stride(0), _lib.ptr(bounds[0]), _lib.ptr(bounds[1]),
+                                     _lib.stream_ptr(parts)), 'conv2d_split')
     if span is not None:
         span.end()
     return y
 
 
-def _wgrad_split(dy_parts, x_parts, cout, cin, pad, terms, inv=None):
+def _wgrad_split(dy_parts, x_parts, cout, cin, pad, terms, bounds=(None, None)):
     """fp32 weight gradient of a 3x3 conv from the 16-bit parts of dy and x: one 16-bit weight-gradient launch per term, summed."""
     dw = None
     for a, b in _SPLIT_TERMS[terms]:
         d = _wgrad_raw(dy_parts[b], x_parts[a], cout, cin, 3, pad)
         dw = d if dw is None else dw.add_(d)
-    return dw if inv is None else dw.mul_(inv)
+    if bounds[0] is not None or bounds[1] is not None:
+        _lib.check(_lib.load().afcm_unscale(dw.data_ptr(), dw.numel(), _lib.ptr(bounds[0]), _lib.ptr(bounds[1]), _lib.stream_ptr(dw)), 'unscale')
+    return dw
 
 
 def _pitch_conv(dtype, ks):
@@ -391,11 +398,12 @@ class _ScaledConv2d(torch.autograd.Function):
             eff_in = in_scale if (in_scale is not None and not prescaled) else None
             parts, gsx = _split_operand(x, eff_in, tf, dt)
             wp, rows_pad, gsw = pack_weights_split(w, tf, dt)
-            y = _conv_split(parts, wp, rows_pad, tf, out_scale, cout, padding, inv=_inv_scale(gsx, gsw))
+            y = _conv_split(parts, wp, rows_pad, tf, out_scale, cout, padding, bounds=(gsx, gsw))
             ctx.save_for_backward(x, w, in_scale, out_scale, y if (out_scale is not None and ctx.needs_input_grad[3]) else None)
             ctx.padding = padding
             ctx.prescaled = bool(prescaled)
             ctx.split = plan
+            ctx.x_bound = gsx                 # the same x and style factor are split again for the weight gradient
             return y
         ctx.split = None
         xs = scale_planes(x, in_scale) if (in_scale is not None and not prescaled) else x
@@ -441,14 +449,14 @@ class _ScaledConv2d(torch.autograd.Function):
                 dparts, gsd = _split_operand(dy, out_scale, max(terms), dt)
             if need_dx:
                 wpt, rows_pad, gsw = pack_weights_split(w, td, dt, transposed=True)
-                dx = _conv_split(dparts, wpt, rows_pad, td, in_scale, cin, ks - 1 - pad, inv=_inv_scale(gsd, gsw))
+                dx = _conv_split(dparts, wpt, rows_pad, td, in_scale, cin, ks - 1 - pad, bounds=(gsd, gsw))
                 if ctx.needs_input_grad[2] and in_scale is not None:
                     # d in_scale[n,i] = <x, g> with dx = s * g  =>  <x, dx> / s
                     s1 = in_scale.to(torch.float32)
                     d_in = torch.where(s1 != 0, plane_dot(xs, dx) / torch.where(s1 != 0, s1, torch.ones_like(s1)), torch.zeros_like(s1)).to(in_scale.dtype)
             if ctx.needs_input_grad[1]:
-                xparts, gsx = _split_operand(xs, in_scale, tw, dt)
-                dw = _wgrad_split(dparts, xparts, cout, cin, pad, tw, inv=_inv_scale(gsd, gsx)).to(w.dtype)
+                xparts, gsx = _split_operand(xs, in_scale, tw, dt, bound=ctx.x_bound)
+                dw = _wgrad_split(dparts, xparts, cout, cin, pad, tw, bounds=(gsd, gsx)).to(w.dtype)
             if ctx.needs_input_grad[3]:
                 d_out = (plane_dot(dy, y) / out_scale.to(torch.float32)).to(out_scale.dtype)
             return dx, dw, d_in, d_out, None, None
@@ -483,7 +491,7 @@ class _ConvWgrad(torch.autograd.Function):
         plan = _split_plan(dy, ks) if _split_plan(x, ks) is not None else None
         if plan is not None:
             (dparts, gsd), (xparts, gsx) = _split_operand(dy, None, plan[3], plan[0]), _split_operand(x, None, plan[3], plan[0])
-            return _wgrad_split(dparts, xparts, cout, cin, pad, plan[3], inv=_inv_scale(gsd, gsx))
+            return _wgrad_split(dparts, xparts, cout, cin, pad, plan[3], bounds=(gsd, gsx))
         return _wgrad_raw(dy, x, cout, cin, ks, pad)
 
     @staticmethod

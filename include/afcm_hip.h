@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define AFCM_ABI_VERSION 11  /* 11 (r04): + afcm_split16, afcm_conv2d_split (additions only).  10 (r04): + afcm_filtered_lrelu_args.clamp_flags (appended), afcm_plane_dot_gated_ld; the runtime getenv switches are gone.  9 (r03): + afcm_affine_bank_*, afcm_modulation_bank_*, afcm_conv2d_pack_bank, afcm_conv2d_stride2 (additions only; every v8 entry point and struct is unchanged) */
+#define AFCM_ABI_VERSION 11  /* 11 (r04): + afcm_amax_bits, afcm_split16, afcm_conv2d_pack_split, afcm_conv2d_split, afcm_unscale (additions only).  10 (r04): + afcm_filtered_lrelu_args.clamp_flags (appended), afcm_plane_dot_gated_ld; the runtime getenv switches are gone.  9 (r03): + afcm_affine_bank_*, afcm_modulation_bank_*, afcm_conv2d_pack_bank, afcm_conv2d_stride2 (additions only; every v8 entry point and struct is unchanged) */
 
 enum { AFCM_F32 = 0, AFCM_F16 = 1, AFCM_BF16 = 2 };
 enum { AFCM_OK = 0, AFCM_E_NOKERNEL = -1, AFCM_E_INVALID = -2 };
@@ -369,20 +369,32 @@ int afcm_conv2d_pack_bank(const afcm_pack_entry* entries, int32_t count, int32_t
  *   bfloat16 (no range limit, no scaling): 2 parts / the same 3 terms keep ~16 bits (4e-6 of the output scale), 3 parts / the six
  *     terms of order <= 2 keep all 24 (2e-7).
  *
- * afcm_split16: parts[k] (k < nparts in {2, 3}) = part k of gscale[0] * scale[plane] * x[plane, :] (either may be NULL: 1; gscale is a
- *   DEVICE scalar so that a magnitude bound computed on the device needs no host round trip), dtype AFCM_F16 or AFCM_BF16, each a
- *   dense tensor of x's shape, part_stride ELEMENTS apart (>= planes * hw, a multiple of 4).
- * afcm_conv2d_split: y[n][cout][P][Q] fp32 = oscale[n,o] * sum_t conv(W_t, part_{x(t)}) + obias[o], 3x3, stride 1, 0 <= pad <= 2, w even.
- *   x_parts as written by afcm_split16 on the [n][cin][h][w] tensor (it must hold every part a term names); term t (t < terms <= 8) reads
- *   part (term_parts >> 4 t) & 15 and the channel block [t * cin16, (t + 1) * cin16) of the packed weights, cin16 = cin rounded up
- *   to 16 -- i.e. wpacked is afcm_conv2d_pack_weights(dtype, mode 0) of the [cout][terms * cin16][3][3] tensor that stacks the weight
- *   part of every term (values exactly representable in dtype, zero rows for the padding channels).
+ * afcm_amax_bits: out[0] = max(out[0], bit pattern of max |scale[plane] * x[plane, :]|) (scale NULL: 1) -- the caller zeroes the word
+ *   (or passes one that already holds another tensor's bound to get a joint one).  Non-negative floats order like their bit patterns; a NaN
+ *   ranks above inf.  The consumers below turn the word into the power of two g with g * bound in [2^14, 2^15) (g = 1 for a non-finite
+ *   bound), on the device: no host round trip between the magnitude pass and the split.
+ * afcm_split16: parts[k] (k < nparts in {2, 3}) = part k of g * scale[plane] * x[plane, :] (scale NULL: 1; bound NULL: g = 1, the
+ *   bfloat16 case), dtype AFCM_F16 or AFCM_BF16, each a dense tensor of x's shape, part_stride ELEMENTS apart (>= planes * hw, a
+ *   multiple of 4).
+ * afcm_conv2d_pack_split: the weight image of a split conv -- channel block t of [terms * cin16] holds part (term_wparts >> 4 t) & 15 of
+ *   g * w ([cout][cin][3][3] fp32; g from `bound`, the weights' afcm_amax_bits word, or 1), in the layout of afcm_conv2d_pack_weights
+ *   (mode 0: forward, rows = cout; mode 1: data gradient, transposed and flipped, rows = cin and cin16 is cout rounded up to 16):
+ *   dst [terms * cin16 / 16][9][rows_pad][16].
+ * afcm_conv2d_split: y[n][cout][P][Q] fp32 = oscale[n,o] / (g_a g_b) * sum_t conv(W_t, part_{x(t)}) + obias[o], 3x3, stride 1,
+ *   0 <= pad <= 2, w even.  x_parts as written by afcm_split16 on the [n][cin][h][w] tensor (it must hold every part a term names); term
+ *   t (t < terms <= 8) reads part (term_parts >> 4 t) & 15 and the channel block t of wpacked (afcm_conv2d_pack_split).  bound_a /
+ *   bound_b: the two operands' bound words or NULL (g = 1).
+ * afcm_unscale: t[i] /= g_a g_b in place (the weight gradient summed from split parts of dy and x: afcm_conv2d_wgrad_ld per term).
  * ---------------------------------------------------------------------------------------- */
-int afcm_split16(void* parts, const float* x, const float* scale, const float* gscale, int32_t dtype, int64_t planes, int32_t hw,
+int afcm_amax_bits(uint32_t* out, const float* x, int64_t planes, int32_t hw, const float* scale, void* stream);
+int afcm_split16(void* parts, const float* x, const float* scale, const uint32_t* bound, int32_t dtype, int64_t planes, int32_t hw,
                  int32_t nparts, int64_t part_stride, void* stream);
+int afcm_unscale(float* t, int64_t numel, const uint32_t* bound_a, const uint32_t* bound_b, void* stream);
+int afcm_conv2d_pack_split(void* dst, const float* w, const uint32_t* bound, int32_t dtype, int32_t cout, int32_t cin, int32_t mode,
+                           int32_t rows_pad, int32_t terms, uint32_t term_wparts, void* stream);
 int afcm_conv2d_split(float* y, const void* x_parts, const void* wpacked, const float* oscale, const float* obias, int32_t dtype, int32_t n,
                       int32_t cin, int32_t cout, int32_t h, int32_t w, int32_t pad, int32_t rows_pad, int32_t terms, uint32_t term_parts,
-                      int64_t part_stride, void* stream);
+                      int64_t part_stride, const uint32_t* bound_a, const uint32_t* bound_b, void* stream);
 
 /* ----------------------------------------------------------------------------------------
  * 3x3 convolution at stride 2 (the discriminator's down-sampling convs, CoModGAN/generator.py:613-692, after the blur): 16-bit x

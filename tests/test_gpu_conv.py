@@ -431,14 +431,39 @@ def test_split16_parts_sum_back_to_the_fp32_value():
     y = (torch.randn([2, 5, 6, 10], generator=g) * torch.logspace(-12, 3, 600).view(2, 5, 6, 10)).cuda()
     for scale in (None, sc):
         v = (y if scale is None else y * scale[:, :, None, None]).double()
-        gs = C._pow2_scale(C._magnitude(y) * (1.0 if scale is None else scale.abs().max()))
-        top = float((v.abs().max() * gs.double()).item())
-        assert 2.0 ** 13 <= top < 2.0 ** 15 and float(torch.frexp(gs)[0]) == 0.5          # a power of two; the bound may be loose by the scale's spread
-        parts = C.split16(y, scale, 2, torch.float16, gs)
+        word = C.amax_bits(y, scale)
+        gs = C.pow2_factor(word)
+        bound = float((y if scale is None else y * scale[:, :, None, None]).abs().max())
+        assert word.view(torch.float32).item() == bound and 2.0 ** 14 <= bound * gs < 2.0 ** 15 and float(np.frexp(gs)[0]) == 0.5      # a power of two
+        parts = C.split16(y, scale, 2, torch.float16, word)
         assert parts.dtype == torch.float16 and bool(torch.isfinite(parts.float()).all())
-        err = (parts.double().sum(0) - v * gs.double()).abs()
-        big = (v * gs.double()).abs() >= 2.0 ** -3
-        assert float((err[big] / (v * gs.double()).abs()[big]).max()) <= 2.0 ** -22 and float(err[~big].max()) <= 2.0 ** -25
+        err = (parts.double().sum(0) - v * gs).abs()
+        big = (v * gs).abs() >= 2.0 ** -3
+        assert float((err[big] / (v * gs).abs()[big]).max()) <= 2.0 ** -22 and float(err[~big].max()) <= 2.0 ** -25
+
+
+def test_amax_bits_edge_cases():
+    from afcm_amd.torch_utils.ops import conv2d as C
+    z = torch.zeros([1, 2, 4, 6]).cuda()
+    assert C.amax_bits(z).item() == 0 and np.isfinite(C.pow2_factor(C.amax_bits(z)))      # all zeros: some finite power of two
+    for bad in (float('inf'), float('nan')):
+        t = torch.randn([1, 2, 4, 6]).cuda()
+        t[0, 1, 2, 3] = bad
+        assert C.pow2_factor(C.amax_bits(t)) == 1.0                                          # non-finite magnitudes: the tensor passes as it is
+        parts = C.split16(t, None, 2, torch.float16, C.amax_bits(t))
+        assert torch.equal(parts[0].float().isnan(), t.isnan()) and torch.equal(parts[0].float().isinf(), t.isinf())
+    t = torch.randn([3, 7, 5, 9]).cuda()                                                     # 945 elements: the scalar path and an unaligned view
+    for v in (t, t.flatten()[1:].view(1, 1, 8, 118)):
+        v = v.contiguous()
+        assert C.amax_bits(v).view(torch.float32).item() == float(v.abs().max())
+    big = torch.randn([4, 8, 64, 66]).cuda()                                                 # vector path, per-plane factors, a word raised twice
+    sc = (torch.rand([4, 8]).cuda() - 0.5) * 8
+    w1 = C.amax_bits(big, sc)
+    assert w1.view(torch.float32).item() == float((big * sc[:, :, None, None]).abs().max())
+    w2 = C.amax_bits(big * 3, None, out=C.amax_bits(big))
+    assert w2.view(torch.float32).item() == float((big * 3).abs().max())
+    tiny = torch.full([1, 1, 2, 2], 1e-38).cuda()
+    assert np.isfinite(C.pow2_factor(C.amax_bits(tiny)))
 
 
 _SPLIT_MODES = [((torch.float16, 3, 3, 3), 1.5e-6), ((torch.bfloat16, 6, 6, 6), 1.5e-6), ((torch.bfloat16, 3, 3, 3), 2e-5)]
