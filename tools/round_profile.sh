@@ -25,7 +25,12 @@ python tools/bench_flrelu.py --dtype fp32 > gpurun_out/${tag}_flrelu_layers_fp32
 # load-only replica of the wave kernels' access pattern: built here from its source (binaries are not tracked)
 if [ -x /opt/rocm/bin/hipcc ]; then
   /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -Wno-unused-value tools/ubench/strip_read.hip -o /tmp/strip_read.bin > /dev/null 2>&1 && timeout -k 5 120 /tmp/strip_read.bin > gpurun_out/${tag}_strip_read.txt 2>&1 || echo "strip_read: not built / failed (skipped)"
+  /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -Wno-unused-result tools/ubench/buffer_range_probe.hip -o /tmp/buffer_range_probe.bin > /dev/null 2>&1 && timeout -k 5 60 /tmp/buffer_range_probe.bin > gpurun_out/${tag}_buffer_range_probe.txt 2>&1 || echo "buffer_range_probe: not built / failed (skipped)"
 else
-  echo "strip_read: no hipcc on this box (skipped)"
+  echo "strip_read / buffer_range_probe: no hipcc on this box (skipped)"
 fi
+# fp32 step: kernel table, the split-operand modes against the native fp32 MFMA kernels, the fp32 -> 16-bit passes
+bash tools/fp32_prof.sh ${tag} > gpurun_out/${tag}_fp32_step_kernels.txt 2>&1 < /dev/null || true
+bash tools/fp32_split_probe.sh > gpurun_out/${tag}_fp32_split_modes.txt 2>&1 < /dev/null || true
+PYTHONPATH=. python tools/bench_split16.py > gpurun_out/${tag}_split16_passes.txt 2>&1 < /dev/null || true
 echo ALLDONE
