@@ -304,7 +304,7 @@ def _wgrad_split(dy_parts, x_parts, cout, cin, pad, terms, bounds=(None, None)):
     """fp32 weight gradient of a 3x3 conv from the 16-bit parts of dy and x: one 16-bit weight-gradient launch per term, summed."""
     dw = None
     for a, b in _SPLIT_TERMS[terms]:
-        d = _wgrad_raw(dy_parts[b], x_parts[a], cout, cin, 3, pad)
+        d = _wgrad_raw(dy_parts[b], x_parts[a], cout, cin, 3, pad, work_share=1.0 / terms)
         dw = d if dw is None else dw.add_(d)
     if bounds[0] is not None or bounds[1] is not None:
         _lib.check(_lib.load().afcm_unscale(dw.data_ptr(), dw.numel(), _lib.ptr(bounds[0]), _lib.ptr(bounds[1]), _lib.stream_ptr(dw)), 'unscale')
@@ -350,10 +350,11 @@ def _conv_raw(x, wp, rows_pad, oscale, cout, ks, pad, obias=None, pitched_out=Fa
 _FRAME_WGRAD_MAX = 1 << 24        # elements of dy up to which a pad-1 weight gradient is computed as pad-2 on a zero-framed dy
 
 
-def _wgrad_raw(dy, x, cout, cin, ks, pad):
+def _wgrad_raw(dy, x, cout, cin, ks, pad, work_share=1.0):
+    """``work_share``: the fraction of the algorithmic flops this launch stands for in the kernel timing (a split-operand term: 1 / terms)."""
     lib = _lib.load()
     n, _, h, w = x.shape
-    work = 2.0 * n * cout * cin * ks * ks * (h + 2 * pad - ks + 1) * (w + 2 * pad - ks + 1)      # algorithmic flops (before any framing)
+    work = work_share * 2.0 * n * cout * cin * ks * ks * (h + 2 * pad - ks + 1) * (w + 2 * pad - ks + 1)      # algorithmic flops (before any framing)
     if ks == 3 and pad == 1 and x.dtype in (torch.bfloat16, torch.float16) and dy.numel() <= _FRAME_WGRAD_MAX:
         # pad-1 weight gradients only have the dword LDS-DMA kernel (0.41 PF/s on the generator's 512 -> 512 bottleneck conv at
         # 36^2: 236 us); with dy framed by one ring of zeros the same sums are a pad-2 weight gradient, which the 16-byte granule

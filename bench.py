@@ -285,16 +285,23 @@ def main():
                                     ms_per_step=d['total_ms'] / max(1, timed_with_events))
             else:
                 ach = d['work'] / (d['total_ms'] * 1e-3) / 1e12
-                peak = PEAK_MFMA_TFLOPS[args.dtype]
+                peak, pipe = PEAK_MFMA_TFLOPS[args.dtype], None
+                if args.dtype == 'fp32' and conv_ops.FP32_SPLIT is not None:
+                    # fp32 products from split 16-bit operands: `achieved` stays the ALGORITHMIC (fp32) flop rate; the pipe that
+                    # executes them is the 16-bit one, and an fp32 product costs `terms` of its multiplications
+                    terms = conv_ops.FP32_SPLIT[3] if fam == 'conv2d_wgrad' else max(conv_ops.FP32_SPLIT[1:3])
+                    peak = PEAK_MFMA_TFLOPS['fp16'] / terms
+                    pipe = f'{args.fp32_conv}: 16-bit MFMA pipe (2500 TFLOP/s dense), {terms} product terms per fp32 product'
                 kernels[fam] = dict(bound='mfma', achieved=ach, peak=peak, unit='TFLOP/s', frac=ach / peak, traffic=None,
                                     launches=d['launches'], avg_launch_ms=avg_ms, total_ms=d['total_ms'], steps_timed=timed_with_events,
-                                    ms_per_step=d['total_ms'] / max(1, timed_with_events))
+                                    ms_per_step=d['total_ms'] / max(1, timed_with_events), **({'pipe': pipe} if pipe else {}))
         dominant = max(kernels, key=lambda k: kernels[k]['total_ms']) if kernels else None
         roofline = dict(kernels[dominant], kernel=dominant) if dominant else None
         # HBM traffic: NOT measured in this run -- bytes per launch from the committed rocprofv3 PMC passes of this same command
         # (tools/pmc_traffic.sh -> profiles/pmc_traffic.json, which names the build it was taken on); said so in `traffic_source`
         tpath = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
-        if os.path.exists(tpath):
+        default_workload = args.dtype == 'bf16' and args.batch == 16 and args.res == 256 and not args.with_discriminator
+        if os.path.exists(tpath) and default_workload:        # the PMC passes were taken on the default command only
             try:
                 t = json.load(open(tpath))
                 src = f'profiles/pmc_traffic.json ({t.get("_source", "rocprofv3 --pmc passes of bench.py")}), not measured in this run'
