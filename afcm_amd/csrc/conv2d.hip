@@ -2192,6 +2192,9 @@ __global__ __launch_bounds__(512, 1) void conv2d_wgrad16_kernel(WgradParams p) {
 // rebuilds a 128-bit descriptor per piece -- 64-bit base, exact record count, validity select, three v_readfirstlane --
 // ~45 scalar instructions per piece, 310 per K step of 36 MFMAs: the wave's own instruction stream, not the matrix pipe, set
 // the step time (PMC r01e: MFMA pipe 49 % busy, 8.7 SALU per MFMA).
+#ifndef AFCM_WGRAD_NBUF
+#define AFCM_WGRAD_NBUF 3          // LDS ring depth of conv2d_wgrad16g_kernel (2: measured in profiles/r04_wgrad_ring.txt)
+#endif
 template <typename T, int KS, int NBUF, bool SMALL>
 __global__ __launch_bounds__(512, 1) void conv2d_wgrad16g_kernel(WgradParams p) {
     static_assert(sizeof(T) == 2, "16-bit types only");
@@ -2960,7 +2963,7 @@ extern "C" int afcm_conv2d_wgrad_ld(float* dw, float* workspace, const void* dy,
                            if (ks == 3 && (pad & 1) == 0) hipLaunchKernelGGL((conv2d_wgrad16_kernel<T, 3, 0, NB>), grid, block, 0, st, p); \
                            else if (ks == 3) hipLaunchKernelGGL((conv2d_wgrad16_kernel<T, 3, 1, NB>), grid, block, 0, st, p); \
                            else hipLaunchKernelGGL((conv2d_wgrad16_kernel<T, 1, 0, NB>), grid, block, 0, st, p); } while (0)
-#define AFCM_WG16G(T) do { constexpr int NB = 3; \
+#define AFCM_WG16G(T) do { constexpr int NB = AFCM_WGRAD_NBUF; \
                             if (small && ks == 3) hipLaunchKernelGGL((conv2d_wgrad16g_kernel<T, 3, NB, true>), grid, block, 0, st, p); \
                             else if (small) hipLaunchKernelGGL((conv2d_wgrad16g_kernel<T, 1, NB, true>), grid, block, 0, st, p); \
                             else if (ks == 3) hipLaunchKernelGGL((conv2d_wgrad16g_kernel<T, 3, NB, false>), grid, block, 0, st, p); \
