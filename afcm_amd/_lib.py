@@ -98,6 +98,7 @@ SIGNATURES = {
     'afcm_conv2d_split': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, C.c_uint32, _i64, _vp, _vp, _vp]),
     'afcm_amax_bits': (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp]),
     'afcm_unscale': (C.c_int, [_vp, _i64, _vp, _vp, _vp]),
+    'afcm_plane_dot_parts': (C.c_int, [_vp, _vp, _i64, _i32, _vp, _i32, _i64, _i32, _vp, _vp]),
     'afcm_conv2d_pack_split': (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, C.c_uint32, _vp]),
     'afcm_plane_dot_gated_ld': (C.c_int, [_vp, _vp, _vp, _i32, _i64, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
     'afcm_weight_norm_fwd': (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),

@@ -1308,6 +1308,46 @@ __global__ __launch_bounds__(256) void amax_bits_kernel(unsigned* __restrict__ o
     }
 }
 
+// out[plane] = <sum_k parts[k][plane, :], b[plane, :]> / g: the style gradient's dot product <x, dx> of an fp32 conv whose backward kept the
+// 16-bit parts of x (split16_kernel) instead of x.  One workgroup per plane; 4 elements per lane and iteration where the plane allows.
+template <typename TP>
+__global__ __launch_bounds__(256) void plane_dot_parts_kernel(float* __restrict__ out, const TP* __restrict__ parts, long long part_stride, int nparts,
+                                                              const float* __restrict__ b, long long planes, int hw, const unsigned* __restrict__ bound) {
+    __shared__ float red[4];
+    const long long plane = blockIdx.x;
+    if (plane >= planes) return;
+    const TP* ap = parts + plane * hw;
+    const float* bp = b + plane * hw;
+    float acc = 0.f;
+    if ((hw & 3) == 0 && (part_stride & 3) == 0) {          // 8-byte part loads, 16-byte b loads (the generator's planes: hw % 4 == 0)
+        union V8 { uint2 u; TP v[4]; };
+        for (int i = threadIdx.x * 4; i < hw; i += blockDim.x * 4) {
+            const float4 b0 = *(const float4*)(bp + i);
+            const float bv[4] = {b0.x, b0.y, b0.z, b0.w};
+            for (int k = 0; k < nparts; k++) {
+                V8 a; a.u = *(const uint2*)(ap + k * part_stride + i);
+#pragma unroll
+                for (int e = 0; e < 4; e++) acc += (float)a.v[e] * bv[e];
+            }
+        }
+    } else {
+        for (int i = threadIdx.x; i < hw; i += blockDim.x) {
+            float a = 0.f;
+            for (int k = 0; k < nparts; k++) a += (float)ap[k * part_stride + i];
+            acc += a * bp[i];
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float inv = 1.f;
+        if (bound) pow2_factor(bound[0], &inv);
+        out[plane] = (red[0] + red[1] + red[2] + red[3]) * inv;
+    }
+}
+
 // t *= 1 / (g_a g_b): the power-of-two factors of two split operands undone (weight gradient of split parts).
 __global__ __launch_bounds__(256) void unscale_kernel(float* __restrict__ t, long long numel, const unsigned* __restrict__ bound_a, const unsigned* __restrict__ bound_b) {
     float ia = 1.f, ib = 1.f;
@@ -2831,6 +2871,19 @@ extern "C" int afcm_amax_bits(uint32_t* out, const float* x, int64_t planes, int
     long long blocks = (planes * hw / 16 + 255) / 256;          // >= 4 16-byte groups per lane
     blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
     hipLaunchKernelGGL(amax_bits_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (unsigned*)out, x, (long long)planes, hw, scale);
+    return hip_status(hipGetLastError());
+}
+
+extern "C" int afcm_plane_dot_parts(float* out, const void* parts, int64_t part_stride, int32_t nparts, const float* b, int32_t dtype, int64_t planes,
+                                    int32_t hw, const uint32_t* bound, void* stream) {
+    AFCM_REQUIRE(out != nullptr && parts != nullptr && b != nullptr && planes > 0 && hw > 0, "plane_dot_parts: empty input");
+    AFCM_REQUIRE(dtype == AFCM_BF16 || dtype == AFCM_F16, "plane_dot_parts: parts are bfloat16 or float16");
+    AFCM_REQUIRE(nparts >= 1 && nparts <= 3 && part_stride >= planes * (long long)hw, "plane_dot_parts: 1..3 parts, a stride covering the tensor");
+    AFCM_REQUIRE(planes < (1ll << 31), "plane_dot_parts: too many planes");
+    AFCM_REQUIRE(((uintptr_t)parts & 7) == 0 && ((uintptr_t)b & 15) == 0, "plane_dot_parts: parts must be 8-byte, b 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == AFCM_BF16) hipLaunchKernelGGL((plane_dot_parts_kernel<bf16_t>), dim3((unsigned)planes), dim3(256), 0, st, out, (const bf16_t*)parts, (long long)part_stride, nparts, b, (long long)planes, hw, (const unsigned*)bound);
+    else hipLaunchKernelGGL((plane_dot_parts_kernel<f16_t>), dim3((unsigned)planes), dim3(256), 0, st, out, (const f16_t*)parts, (long long)part_stride, nparts, b, (long long)planes, hw, (const unsigned*)bound);
     return hip_status(hipGetLastError());
 }
 

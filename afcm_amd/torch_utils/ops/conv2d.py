@@ -242,6 +242,19 @@ def split16(x, scale=None, nparts=2, dtype=torch.float16, bound=None):
     return buf[:, :total].view(nparts, n, c, h, w)
 
 
+def plane_dot_parts(parts, b, bound=None):
+    """[N, C] fp32: sum over H, W of (sum of the 16-bit parts) * b / g (C ABI afcm_plane_dot_parts) -- plane_dot(x, b) for an x that was kept as
+    its split16 parts (factor g from ``bound``)."""
+    lib = _lib.load()
+    nparts, n, c, h, w = parts.shape
+    b = b.contiguous()
+    assert b.dtype == torch.float32 and tuple(b.shape) == (n, c, h, w) and parts.stride(1) == c * h * w
+    out = torch.empty([n, c], dtype=torch.float32, device=b.device)
+    _lib.check(lib.afcm_plane_dot_parts(out.data_ptr(), parts.data_ptr(), parts.stride(0), nparts, b.data_ptr(), _lib._DTYPES[parts.dtype], n * c, h * w,
+                                        _lib.ptr(bound), _lib.stream_ptr(b)), 'plane_dot_parts')
+    return out
+
+
 def _split_operand(x, scale, terms, dtype, bound=None):
     """(parts, bound): the parts of scale * x for a `terms`-term product; float16 parts carry the power of two of the magnitude word
     ``bound`` (given: the same tensor and scale were measured before)."""
@@ -400,11 +413,16 @@ class _ScaledConv2d(torch.autograd.Function):
             parts, gsx = _split_operand(x, eff_in, tf, dt)
             wp, rows_pad, gsw = pack_weights_split(w, tf, dt)
             y = _conv_split(parts, wp, rows_pad, tf, out_scale, cout, padding, bounds=(gsx, gsw))
-            ctx.save_for_backward(x, w, in_scale, out_scale, y if (out_scale is not None and ctx.needs_input_grad[3]) else None)
+            # A modulated conv (scales present: never differentiated twice) keeps the PARTS of s * x for its backward -- the weight
+            # gradient's operand as it is, the style gradient through plane_dot_parts, same bytes as x -- and not x; a plain conv
+            # (the discriminator's: R1 differentiates its backward) keeps x and splits it again.
+            keep_parts = (in_scale is not None or out_scale is not None) and _nparts(plan[3]) <= parts.shape[0]
+            ctx.save_for_backward(parts if keep_parts else x, w, in_scale, out_scale, y if (out_scale is not None and ctx.needs_input_grad[3]) else None)
             ctx.padding = padding
             ctx.prescaled = bool(prescaled)
             ctx.split = plan
-            ctx.x_bound = gsx                 # the same x and style factor are split again for the weight gradient
+            ctx.kept_parts = keep_parts
+            ctx.x_bound = gsx                 # the magnitude word of s * x
             return y
         ctx.split = None
         xs = scale_planes(x, in_scale) if (in_scale is not None and not prescaled) else x
@@ -452,11 +470,19 @@ class _ScaledConv2d(torch.autograd.Function):
                 wpt, rows_pad, gsw = pack_weights_split(w, td, dt, transposed=True)
                 dx = _conv_split(dparts, wpt, rows_pad, td, in_scale, cin, ks - 1 - pad, bounds=(gsd, gsw))
                 if ctx.needs_input_grad[2] and in_scale is not None:
-                    # d in_scale[n,i] = <x, g> with dx = s * g  =>  <x, dx> / s
                     s1 = in_scale.to(torch.float32)
-                    d_in = torch.where(s1 != 0, plane_dot(xs, dx) / torch.where(s1 != 0, s1, torch.ones_like(s1)), torch.zeros_like(s1)).to(in_scale.dtype)
+                    if ctx.kept_parts:
+                        # d in_scale[n,i] = sum_pix x * g with the parts holding s * x and dx = s * g  =>  <s x, dx> / s^2
+                        s2 = s1.square()
+                        d_in = torch.where(s2 > 0, plane_dot_parts(xs, dx, ctx.x_bound) / s2.clamp_min(1e-30), torch.zeros_like(s2)).to(in_scale.dtype)
+                    else:
+                        # ... = <x, dx> / s
+                        d_in = torch.where(s1 != 0, plane_dot(xs, dx) / torch.where(s1 != 0, s1, torch.ones_like(s1)), torch.zeros_like(s1)).to(in_scale.dtype)
             if ctx.needs_input_grad[1]:
-                xparts, gsx = _split_operand(xs, in_scale, tw, dt, bound=ctx.x_bound)
+                if ctx.kept_parts:
+                    xparts, gsx = xs, ctx.x_bound
+                else:
+                    xparts, gsx = _split_operand(xs, in_scale, tw, dt, bound=ctx.x_bound)
                 dw = _wgrad_split(dparts, xparts, cout, cin, pad, tw, bounds=(gsd, gsx)).to(w.dtype)
             if ctx.needs_input_grad[3]:
                 d_out = (plane_dot(dy, y) / out_scale.to(torch.float32)).to(out_scale.dtype)

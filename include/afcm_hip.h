@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define AFCM_ABI_VERSION 11  /* 11 (r04): + afcm_amax_bits, afcm_split16, afcm_conv2d_pack_split, afcm_conv2d_split, afcm_unscale (additions only).  10 (r04): + afcm_filtered_lrelu_args.clamp_flags (appended), afcm_plane_dot_gated_ld; the runtime getenv switches are gone.  9 (r03): + afcm_affine_bank_*, afcm_modulation_bank_*, afcm_conv2d_pack_bank, afcm_conv2d_stride2 (additions only; every v8 entry point and struct is unchanged) */
+#define AFCM_ABI_VERSION 11  /* 11 (r04): + afcm_amax_bits, afcm_split16, afcm_conv2d_pack_split, afcm_conv2d_split, afcm_unscale, afcm_plane_dot_parts (additions only).  10 (r04): + afcm_filtered_lrelu_args.clamp_flags (appended), afcm_plane_dot_gated_ld; the runtime getenv switches are gone.  9 (r03): + afcm_affine_bank_*, afcm_modulation_bank_*, afcm_conv2d_pack_bank, afcm_conv2d_stride2 (additions only; every v8 entry point and struct is unchanged) */
 
 enum { AFCM_F32 = 0, AFCM_F16 = 1, AFCM_BF16 = 2 };
 enum { AFCM_OK = 0, AFCM_E_NOKERNEL = -1, AFCM_E_INVALID = -2 };
@@ -385,11 +385,15 @@ int afcm_conv2d_pack_bank(const afcm_pack_entry* entries, int32_t count, int32_t
  *   t (t < terms <= 8) reads part (term_parts >> 4 t) & 15 and the channel block t of wpacked (afcm_conv2d_pack_split).  bound_a /
  *   bound_b: the two operands' bound words or NULL (g = 1).
  * afcm_unscale: t[i] /= g_a g_b in place (the weight gradient summed from split parts of dy and x: afcm_conv2d_wgrad_ld per term).
+ * afcm_plane_dot_parts: out[plane] = <sum_k parts[k][plane, :], b[plane, :]> / g, b fp32 -- afcm_plane_dot for a tensor that only exists as
+ *   its split parts (the style gradient <x, dx> when the backward keeps x's parts instead of x).
  * ---------------------------------------------------------------------------------------- */
 int afcm_amax_bits(uint32_t* out, const float* x, int64_t planes, int32_t hw, const float* scale, void* stream);
 int afcm_split16(void* parts, const float* x, const float* scale, const uint32_t* bound, int32_t dtype, int64_t planes, int32_t hw,
                  int32_t nparts, int64_t part_stride, void* stream);
 int afcm_unscale(float* t, int64_t numel, const uint32_t* bound_a, const uint32_t* bound_b, void* stream);
+int afcm_plane_dot_parts(float* out, const void* parts, int64_t part_stride, int32_t nparts, const float* b, int32_t dtype, int64_t planes,
+                         int32_t hw, const uint32_t* bound, void* stream);
 int afcm_conv2d_pack_split(void* dst, const float* w, const uint32_t* bound, int32_t dtype, int32_t cout, int32_t cin, int32_t mode,
                            int32_t rows_pad, int32_t terms, uint32_t term_wparts, void* stream);
 int afcm_conv2d_split(float* y, const void* x_parts, const void* wpacked, const float* oscale, const float* obias, int32_t dtype, int32_t n,
