@@ -527,3 +527,21 @@ def test_fp32_split_route_is_the_default_and_native_kernels_remain():
     xn[0, 3, 9, 10] = float('nan')
     yn = C._ScaledConv2d.apply(xn, wt, None, None, 2, False)
     assert bool(yn[0, :, 9:12, 10:13].isnan().all())
+
+
+@pytest.mark.parametrize('dtype,k', [(torch.float16, 2), (torch.bfloat16, 3)])
+@pytest.mark.parametrize('shape', [(2, 5, 6, 10), (1, 3, 7, 9), (2, 4, 38, 38)], ids=str)
+def test_plane_dot_of_split_parts(dtype, k, shape):
+    """afcm_plane_dot_parts: <x, b> per plane from the 16-bit parts of scale * x, factor undone (vector and scalar paths)."""
+    from afcm_amd.torch_utils.ops import conv2d as C
+    g = torch.Generator().manual_seed(13)
+    x, b = torch.randn(shape, generator=g).cuda() * 37.0, torch.randn(shape, generator=g).cuda()
+    sc = (torch.rand(shape[:2], generator=g) + 0.5).cuda()
+    if shape[3] % 2:                                     # split16 itself takes any width; the conv route needs even ones
+        pass
+    bound = C.amax_bits(x, sc) if dtype == torch.float16 else None
+    parts = C.split16(x, sc, k, dtype, bound)
+    got = C.plane_dot_parts(parts, b, bound)
+    want = ((x.double() * sc.double()[:, :, None, None]) * b.double()).sum([2, 3])
+    size = ((x.double() * sc.double()[:, :, None, None]).abs() * b.double().abs()).sum([2, 3])
+    assert float(((got.double() - want).abs() / size).max()) <= (2e-6 if dtype == torch.float16 or k == 3 else 2e-4)
