@@ -2347,7 +2347,8 @@ __global__ __launch_bounds__(512, 1) void conv2d_wgrad16g_kernel(WgradParams p) 
                 constexpr int xr = I - R;
                 const int row = c_prow0 - p.pad + xr;
                 const unsigned soff = c_x32 + (unsigned)(row * Ws + c_q0 - XLEAD) * 2u;
-#ifdef AFCM_WGRAD_EXPERIMENT_HALFX      // timing experiment only (wrong results): the two x rows shared with the previous row pair are not requested
+#ifdef AFCM_WGRAD_EXPERIMENT_HALFX      // timing experiment only (wrong results): the two x rows shared with the previous row pair are not requested.
+                                        // CAUTION: its -8 % is the clock, not the bytes -- the rows then multiply zeros (profiles/r04_wgrad_ring.txt)
                 const unsigned sinv = ((unsigned)row < (unsigned)p.H && c_live && xr >= 2) ? 0u : kOob;
 #else
                 const unsigned sinv = ((unsigned)row < (unsigned)p.H && c_live) ? 0u : kOob;
