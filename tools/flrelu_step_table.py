@@ -9,7 +9,8 @@ generator's layers in a fixed order (forward: enc0..13, L0..L14; backward: rever
  and GB/s.  With --fetch / --write (separate --pmc passes of the same command) also the HBM bytes of each
 launch (FETCH_SIZE doubled per the gfx950 correction, 1024-byte units) and their ratio to the algorithmic bytes.
 VERDICT r02 'next' 1c: explains the gap between the isolated per-layer table (tools/bench_flrelu.py) and the in-step time."""
-import argparse, csv, glob, os, re, sys
+import argparse
+import re, csv, glob, os, re, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
@@ -101,13 +102,17 @@ def main():
         L = order[i] if len(fl) == len(order) else None
         us = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
         ab = alg_bytes(L) if L else None
+        # a forward launch of a decoder layer with an encoder skip (EPI bit 2, the kernel's last template argument) also reads the skip
+        # tensor -- bytes the fused op needs, though SURVEY 8(d)'s per-op figure (x + y + signs) does not count them: ratio2 includes them
+        m = re.search(r'Li(\d+)EEEv', r['Kernel_Name'])
+        skip_b = a.batch * L['cout'] * L['out_size'] ** 2 * 2 if (L and m and int(m.group(1)) & 2) else 0
         line = f'{i:3d} {(L["name"] if L else "?"):14s} {("fwd" if i < len(res_layers) else "bwd"):3s} {short(r["Kernel_Name"]):30s} {int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"]):7d} {r["VGPR_Count"]:>4s} {r["Scratch_Size"]:>4s} {us:8.1f}'
         if ab:
             line += f' {ab / 1e6:8.1f} {ab / us / 1e3:7.0f}'
             tot_b += ab
         if pmc and all(len(v) == len(fl) for v in pmc.values()):
             rd, wr = pmc.get('rd', [0] * len(fl))[i], pmc.get('wr', [0] * len(fl))[i]
-            line += f'  {rd / 1e6:9.1f} {wr / 1e6:6.1f}' + (f'  {(rd + wr) / ab:5.2f}' if ab else '')
+            line += f'  {rd / 1e6:9.1f} {wr / 1e6:6.1f}' + (f'  {(rd + wr) / ab:5.2f}' if ab else '') + (f'  ({(rd + wr) / (ab + skip_b):4.2f} with the skip operand)' if (ab and skip_b) else '')
             k = ('fwd' if i < len(res_layers) else 'bwd')
             f = fam.setdefault(k, [0.0, 0.0, 0.0])
             f[0] += rd; f[1] += wr; f[2] += ab or 0
