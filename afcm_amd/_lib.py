@@ -84,6 +84,8 @@ SIGNATURES = {
                                  _i32, _i32, _i32, _f32, _vp]),
     'afcm_bias_act': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i64, _i32, _i32, _i32, _f32, _f32, _f32, _vp]),
     'afcm_conv2d_block_k': (C.c_int, [_i32]),
+    'afcm_conv2d_block_k_ks': (C.c_int, [_i32, _i32]),
+    'afcm_conv2d_pack_weights_bk': (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     'afcm_conv2d_pack_weights': (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     'afcm_conv2d_pack_weights2': (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     'afcm_conv2d': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
@@ -132,8 +134,8 @@ def load():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
-        if lib.afcm_abi_version() != 11:
-            raise RuntimeError(f'libafcm_hip.so ABI version {lib.afcm_abi_version()} does not match this package (11); rebuild it')
+        if lib.afcm_abi_version() != 12:
+            raise RuntimeError(f'libafcm_hip.so ABI version {lib.afcm_abi_version()} does not match this package (12); rebuild it')
         _lib = lib
     return _lib
 

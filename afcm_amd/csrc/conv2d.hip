@@ -45,7 +45,22 @@ template <> struct ConvCfg<bf16_t> { static constexpr int BK = 16, PITCH = 24; }
 template <> struct ConvCfg<f16_t>  { static constexpr int BK = 16, PITCH = 24; };
 template <> struct ConvCfg<float>  { static constexpr int BK = 8,  PITCH = 9;  };   // 36-byte rows: conflict-free b32
 
+// MFMA shape of the 16-bit 3x3 stride-1 kernel: 1 = v_mfma_f32_16x16x32 (conv2d_fwd16x_kernel, K-chunks of 32 channels), 0 = 32x32x16
+// (conv2d_fwd16_kernel, chunks of 16).  -DAFCM_CONV_AB builds both and a debug switch (tools/ab_conv_shape.py): the A/B of r05.
+#ifndef AFCM_CONV_X16
+#define AFCM_CONV_X16 1
+#endif
+#ifdef AFCM_CONV_AB
+static int g_conv_x16 = AFCM_CONV_X16;
+#define AFCM_X16_ON (g_conv_x16 != 0)
+#else
+#define AFCM_X16_ON (AFCM_CONV_X16 != 0)
+#endif
+// K-chunk (channels) of the packed weight image for (dtype, kernel size)
+static inline int conv_bk(int dtype, int ks);
+
 constexpr int kPatchMax = 416;   // LDS patch capacity in pixels
+constexpr int kPatchMaxX16 = 412; // ... of conv2d_fwd16x_kernel (planes of kPatchMax pixels, the last four a sink)
 constexpr int kPatchMaxS2 = 704; // ... of the stride-2 kernel (two staging items per thread: <= 1024)
 constexpr int kSlots = 256;      // output pixels per workgroup
 
@@ -357,7 +372,9 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? 1 : 2)) void conv2d_fwd_kern
 #ifdef AFCM_CONV_STAMPS        // diagnostic build only: shader-clock stamps per workgroup (entry, K loop start, K loop end, exit)
 __device__ unsigned long long afcm_conv_stamps_buf[4 * 65536];
 __device__ unsigned long long afcm_conv_bar_buf[4 * 65536];    // per wave: cycles spent at the K loop's barriers
-#define AFCM_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 65536) afcm_conv_stamps_buf[4 * blockIdx.x + (k)] = __builtin_readcyclecounter(); } while (0)
+__device__ unsigned long long afcm_conv_rt_buf[4 * 65536];     // the 100 MHz constant clock at the same four points: shader clock = d cycles / d ticks x 100 MHz
+#define AFCM_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 65536) { afcm_conv_stamps_buf[4 * blockIdx.x + (k)] = __builtin_readcyclecounter(); \
+                                                                          afcm_conv_rt_buf[4 * blockIdx.x + (k)] = __builtin_amdgcn_s_memrealtime(); } } while (0)
 #else
 #define AFCM_STAMP(k) do { } while (0)
 #endif
@@ -778,6 +795,365 @@ __global__ __launch_bounds__(256, 2) void conv2d_fwd16_kernel(ConvParams p) {
             }
         }
     }
+    AFCM_STAMP(3);
+}
+
+// ---- r05: the same tile on v_mfma_f32_16x16x32 -------------------------------------------------------------------------------------
+// conv2d_fwd16_kernel's >= 256-channel layers hold ~1.5 GHz under their MFMA load (all-zero operands: +23 %, profiles/r04_power_probe.txt),
+// and on a clock-limited loop the chip holds a higher clock on the 16x16x32 shape than on 32x32x16 at equal cycles per flop
+// (MI355X_MICROARCH.md, DVFS give-back item 7).  Same workgroup tile (BM_O channels x 256 pixels), same wave tile ((BM_O / 2) x 128:
+// MO x 8 accumulator tiles of 16 x 16 = the same accumulator registers), same operand bytes per MFMA cycle; what changes:
+//   * a K step is 32 channels of one tap: K-chunks of 32 channels (packed weights [kc][tap][Opad][32], a lane's fragment = 16 bytes at
+//     row (lane & 15), channel group (lane >> 4); a wave still reads one contiguous 1 KB per fragment), half as many barriers;
+//   * the LDS patch is PLANAR: four planes [channel group of 8][pixel][8 channels], a pixel = 16 bytes, planes a multiple of 256 bytes
+//     apart.  A B fragment is 16 consecutive pixels x 4 channel groups; ds_read_b128 serves lanes in four groups of 16 that each hold all
+//     16 pixel columns with two of the channel groups, so every group reads 16 consecutive 16-byte slots = all 64 banks once, at any
+//     pixel offset (taps shift by 1 and 2 pixels) -- no padding (the [pixel][32 channels] row form conflicts for every odd pitch);
+//     a plane holds 512 pixels = one 4-pixel group per staging thread, so lanes outside the patch need no sink and no predicate;
+//   * B fragments live in a ring of four, read four 16-pixel blocks ahead of their MFMAs (one fragment feeds MO MFMAs = 64 cycles);
+//     the tap's column offset is the read's immediate, the row offset is added to the block's base register in place: 32 vector adds
+//     per chunk of 72 reads;
+//   * weight fragments: buffer loads (lane offset + scalar tap offset: no vector address arithmetic), ring of three taps refilled in
+//     place after the tap's last MFMA;
+//   * staging: a thread owns 4 pixels x 2 items of 8 channels; one register set, item 0 requested at the top of the chunk and written
+//     under tap 4, item 1 requested under tap 5 and written under tap 8.  Lanes 2, 3 (mod 4) of a group write their pixel pairs in
+//     swapped order (the permute's selector is a register): 2-way instead of 4-way conflicts on the transposing 16-byte writes;
+//   * the issue order is the source order: the loop is written as 72 steps (MO MFMAs, the read four steps ahead, a slice of the
+//     staging work) with a scheduling barrier after each.  Left to the scheduler (sched_group_barrier pipelines as in
+//     conv2d_fwd16_kernel) the MFMAs of different taps were reordered around the reads and every read was waited for at once.
+template <typename T, int BM_O, bool SPLIT = false>
+__global__ __launch_bounds__(256, 2) void conv2d_fwd16x_kernel(ConvParams p) {
+    static_assert(sizeof(T) == 2, "16-bit types only");
+    typedef typename std::conditional<SPLIT, float, T>::type TO;      // output element
+    constexpr int KS = 3, KK = 9, BK = 32, MO = BM_O / 32, NT = 8, BRING = 4;
+    // weight-fragment ring, in fragments: a chunk's KK * MO fragments (tap-major) cycle through ARING slots.  MO = 4: 9 slots = 2.25 taps
+    // (3 taps = 48 registers do not fit beside 128 accumulator registers at two waves per SIMD); MO = 2: 6 slots = 3 taps
+    constexpr int ARING = MO == 4 ? 9 : 6;
+    static_assert((KK * MO) % ARING == 0 && ARING >= 2 * MO, "static slots; a tap's fragments and the next tap's are live together");
+    // bytes of one channel-group plane: kPatchMax = 416 pixels.  2 buffers x 4 planes = 53,248 bytes per workgroup: THREE workgroups per
+    // CU for the 64-row blocks (<= 168 registers), as conv2d_fwd16_kernel runs them (40 KB) -- with 512-pixel planes (64 KB, two per CU)
+    // the 64-row layers lost 10 % to it.  The patch itself may use kPatchMaxX16 = 412 pixels: the last four are the sink of the 24
+    // staging threads whose pixel group lies past the plane (branch-free staging writes every thread's four pixels).
+    constexpr int PLANE_B = kPatchMax * 16;
+    constexpr int BUF_B = 4 * PLANE_B;
+    static_assert(PLANE_B % 256 == 0 && kPatchMaxX16 + 4 <= kPatchMax && kPatchMaxX16 % 4 == 0, "planes: a multiple of 256 bytes apart, patch + sink inside");
+    typedef typename std::conditional<std::is_same<T, bf16_t>::value, bf16x8, f16x8>::type frag_t;
+    typedef __attribute__((ext_vector_type(4))) float f32x4;
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+    typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+    __shared__ __attribute__((aligned(256))) unsigned char lds[2 * BUF_B];
+
+    AFCM_STAMP(0);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wo = wave & 1, wpx = wave >> 1;
+    const int c16 = lane & 15, g = lane >> 4;
+
+    int bid = blockIdx.x;
+    {
+        const int total = gridDim.x;
+        bid = xcd_order(bid, total);
+    }
+    unsigned q0 = udiv_magic((unsigned)bid, p.magicTX);
+    const int tx = __builtin_amdgcn_readfirstlane(bid - (int)q0 * p.tilesX);
+    unsigned q1 = udiv_magic(q0, p.magicTY);
+    const int ty = __builtin_amdgcn_readfirstlane((int)q0 - (int)q1 * p.tilesY);
+    unsigned q2 = udiv_magic(q1, p.magicN);
+    const int n = __builtin_amdgcn_readfirstlane((int)q1 - (int)q2 * p.N);
+    const int ob = __builtin_amdgcn_readfirstlane((int)q2);
+    const int y0 = ty * p.TH, x0 = tx * p.TW;
+    const int o0 = ob * BM_O;
+    const int PH = p.TH + KS - 1, PWL = p.PWL;
+    const int xorg = (x0 - p.pad) & ~1;
+    const int xoff = (x0 - p.pad) - xorg;
+
+    f32x4 acc[MO][NT];
+#pragma unroll
+    for (int mo = 0; mo < MO; mo++)
+#pragma unroll
+        for (int ti = 0; ti < NT; ti++) acc[mo][ti] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // ---- A fragments: straight from the packed weights (one buffer: the whole image, < 2^31 bytes -- host)
+    const int wtap_b = p.Opad * BK * 2;                                    // bytes per tap
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, p.nkc * KK * wtap_b, 0x00020000);
+    const unsigned wvoff = (unsigned)(((o0 + wo * (BM_O / 2) + c16) * BK + g * 8) * 2);
+    auto load_a = [&](int kc, int tap, int mo) __attribute__((always_inline)) {
+        return __builtin_bit_cast(frag_t, __builtin_amdgcn_raw_buffer_load_b128(wrs, wvoff + mo * (16 * BK * 2), (kc * KK + tap) * wtap_b, 0));
+    };
+
+    // ---- patch staging: thread = (channel-group parity cg, 4-pixel group pg); item it covers channel group 2 it + cg
+    const int cg = (tid >> 5) & 1, pg = (tid & 31) + 32 * (tid >> 6);
+    const int pcols = PWL >> 2;
+    const int prow = (int)udiv_magic((unsigned)pg, p.magicPC), pcol4 = pg - prow * pcols;
+    const bool pvalid = prow < PH;
+    const int iy = y0 - p.pad + prow, ix = xorg + 4 * pcol4;
+    const bool rowok = pvalid && (unsigned)iy < (unsigned)p.H;
+    const T* xn = (const T*)p.x + (size_t)n * p.Cin * p.H * p.ldx;
+    const long long pix_off = (long long)(rowok ? iy : 0) * p.ldx + ix;
+    constexpr unsigned kOob = 0x80000000u;
+    const bool d0ok = rowok && (unsigned)ix < (unsigned)p.W, d1ok = rowok && (unsigned)(ix + 2) < (unsigned)p.W;
+    const bool lshift = !d0ok && d1ok;                                                // never touch bytes before a row 0
+    const unsigned pm_lo = (d0ok && !lshift) ? ~0u : 0u, pm_hi = d1ok ? ~0u : 0u;
+    const unsigned pvoff = (d0ok || d1ok) ? (unsigned)(((long long)cg * 8 * p.H * p.ldx + pix_off + (lshift ? 2 : 0)) * 2ll) : kOob;
+    // (the descriptor ends with the image -- split form: with the highest part read -- so channels past Cin read zeros in the plain form)
+    const long long img_bytes = (long long)p.Cin * p.H * p.ldx * 2ll + (SPLIT ? (long long)p.last_part_bytes : 0ll);
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)xn, 0, (int)(img_bytes > 0x7fffffffll ? 0x7fffffffll : img_bytes), 0x00020000);
+    const int hw2 = p.H * p.ldx * 2;
+    // the patch is dense in pixels (PWL = 4 pcols): this thread's pixels are 4 pg .. 4 pg + 3 -- inside the plane whether or not the
+    // patch has that row, except for the groups past the plane's end: those write the sink pixels.  Pixel written at step e: e ^ rot
+    const int rot = (pg >> 1) & 1;
+    const int pgd = 4 * pg < kPatchMaxX16 ? 4 * pg : kPatchMaxX16;
+    const unsigned pdst_a = (unsigned)(pgd * 16 + cg * PLANE_B + rot * 16);          // steps 0, 2 (+ 32 bytes at step 2)
+    const unsigned pdst_b = (unsigned)(pgd * 16 + cg * PLANE_B + (1 - rot) * 16);    // steps 1, 3
+    const unsigned sel_a = rot ? 0x07060302u : 0x05040100u, sel_b = rot ? 0x05040100u : 0x07060302u;
+
+    // (branch-free, issued on every chunk -- past the last one with the out-of-range offset: see conv2d_fwd16_kernel)
+    auto issue_patch = [&](unsigned (&pr)[8][2], int kc, bool live, int item) __attribute__((always_inline)) {
+        int kcr = kc, sbase = 0;                           // chunk inside its term, byte offset of the term's part (scalar unit)
+        if constexpr (SPLIT) {
+            const int term = (int)udiv_magic((unsigned)kc, p.magicNK);
+            kcr = kc - term * p.nkc_real;
+            sbase = (int)((p.term_parts >> (4 * term)) & 15u) * p.part_bytes;
+        }
+        const int cbase = kcr * BK + item * 16 + cg * 8;
+        const int climit = live ? p.Cin : 0;
+        const unsigned voff = live ? pvoff : kOob;
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            unsigned off = voff;
+            if constexpr (SPLIT) off = (cbase + c < climit) ? pvoff : kOob;     // the descriptor runs on into the next part
+            const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(xrs, off, sbase + (kcr * BK + item * 16 + c) * hw2, 0);
+            pr[c][0] = v.x; pr[c][1] = v.y;
+        }
+    };
+    // edge masks of one channel's two dwords (pixels 0, 1 | 2, 3): unconditional, as in conv2d_fwd16_kernel
+    auto mask_ch = [&](unsigned (&pr)[8][2], int c) __attribute__((always_inline)) {
+        const unsigned lo = pr[c][0] & pm_lo;
+        const unsigned hi = (lshift ? pr[c][0] : pr[c][1]) & pm_hi;
+        pr[c][0] = lo; pr[c][1] = hi;
+    };
+    // step e of the transposing write: 8 channels of one pixel = 16 bytes; sbyte: buffer + item planes (scalar)
+    auto write_px = [&](unsigned (&pr)[8][2], int e, int sbyte) __attribute__((always_inline)) {
+        const unsigned sel = (e & 1) ? sel_b : sel_a;
+        u32x4 v;
+        v.x = __builtin_amdgcn_perm(pr[1][e >> 1], pr[0][e >> 1], sel);
+        v.y = __builtin_amdgcn_perm(pr[3][e >> 1], pr[2][e >> 1], sel);
+        v.z = __builtin_amdgcn_perm(pr[5][e >> 1], pr[4][e >> 1], sel);
+        v.w = __builtin_amdgcn_perm(pr[7][e >> 1], pr[6][e >> 1], sel);
+        *(u32x4*)(lds + ((e & 1) ? pdst_b : pdst_a) + (unsigned)sbyte + (e >> 1) * 32) = v;
+    };
+
+    frag_t ar[ARING];
+    unsigned preg[8][2];
+    {
+        unsigned preg1[8][2];                                // the prologue requests both items at once (the accumulators are not live yet)
+        issue_patch(preg, 0, true, 0);
+        issue_patch(preg1, 0, true, 1);
+#pragma unroll
+        for (int q = 0; q < ARING; q++) ar[q] = load_a(0, q / MO, q % MO);
+#pragma unroll
+        for (int c = 0; c < 8; c++) { mask_ch(preg, c); mask_ch(preg1, c); }
+#pragma unroll
+        for (int e = 0; e < 4; e++) { write_px(preg, e, 0); write_px(preg1, e, 2 * PLANE_B); }
+    }
+    // this lane's eight B fragments: bbyte[ti] = byte address of the fragment of the tap ROW under way in the buffer under way (tile-local
+    // pixel 128 wpx + 16 ti + lane & 15, channel group lane >> 4) -- walks down the patch rows and over to the other buffer in place
+    unsigned bbyte[NT];
+#pragma unroll
+    for (int ti = 0; ti < NT; ti++) {
+        const int j = wpx * 128 + ti * 16 + c16;
+        int py = (int)__umulhi((unsigned)j, p.magicTW), px = j - py * p.TW;
+        if (j >= p.TH * p.TW) { py = 0; px = 0; }
+        bbyte[ti] = (unsigned)((py * PWL + px + xoff) * 16 + g * PLANE_B);
+    }
+    __syncthreads();
+    AFCM_STAMP(1);
+
+    const int last = p.nkc - 1;
+    const unsigned rowstep = (unsigned)(PWL * 16);
+    for (int kc = 0; kc < p.nkc; kc++) {
+        const int nxt_b = ((kc + 1) & 1) * BUF_B;
+        const bool more = kc < last;
+        const int knext = kc + (int)more;
+        const unsigned bufstep = (unsigned)(((kc & 1) ? -BUF_B : BUF_B) - 2 * (int)rowstep);     // to tap row 0 of the other buffer
+        frag_t b[BRING];
+#pragma unroll
+        for (int s = 0; s < BRING; s++) b[s] = *(const frag_t*)(lds + bbyte[s]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int tap = 0; tap < KK; tap++) {
+#pragma unroll
+            for (int ti = 0; ti < NT; ti++) {
+                const int s = tap * NT + ti;
+#pragma unroll
+                for (int mo = 0; mo < MO; mo++) {
+                    if constexpr (std::is_same<T, bf16_t>::value)
+                        acc[mo][ti] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ar[(tap * MO + mo) % ARING], b[s % BRING], acc[mo][ti], 0, 0, 0);
+                    else
+                        acc[mo][ti] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ar[(tap * MO + mo) % ARING], b[s % BRING], acc[mo][ti], 0, 0, 0);
+                }
+                const int s2 = s + BRING;
+                if (s2 < KK * NT) {
+                    const int t2 = s2 / NT, ti2 = s2 % NT;
+                    if (t2 > 0 && t2 % KS == 0) bbyte[ti2] += rowstep;                 // first tap of the next patch row
+                    b[s % BRING] = *(const frag_t*)(lds + bbyte[ti2] + (t2 % KS) * 16);
+                }
+                // ---- this step's slice of the staging work
+                if (tap == 0 && ti == 0) issue_patch(preg, knext, more, 0);
+                if (tap == 5 && ti == 0) issue_patch(preg, knext, more, 1);
+                if (tap == 4 || tap == 8) {
+                    // item 0 (tap 4) / item 1 (tap 8) of the next chunk into the other buffer: masks under blocks 0-3, a pixel under each of 4-7
+                    if (ti < 4) { mask_ch(preg, 2 * ti); mask_ch(preg, 2 * ti + 1); }
+                    else write_px(preg, ti - 4, nxt_b + (tap == 8 ? 2 * PLANE_B : 0));
+                }
+                if (tap == 8 && ti >= 4) { bbyte[2 * (ti - 4)] += bufstep; bbyte[2 * (ti - 4) + 1] += bufstep; }   // (the chunk's reads are done)
+                if (ti == NT - 1) {
+                    // the tap's ring slots take the fragments ARING ahead now that its MFMAs have read them (clamped at the end: no branch around a load)
+#pragma unroll
+                    for (int mo = 0; mo < MO; mo++) {
+                        const int q = tap * MO + mo, q2 = q + ARING;
+                        ar[q % ARING] = load_a(q2 < KK * MO ? kc : knext, (q2 % (KK * MO)) / MO, q2 % MO);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __syncthreads();
+    }
+
+    AFCM_STAMP(2);
+    // ---- epilogue: a 16 x 16 tile has its pixel on the lane (col = lane & 15) and channels 4 g .. 4 g + 3 in the 4 registers
+    // (the lane id goes through an empty asm: otherwise the pixel coordinates computed before the loop are kept -- spilled -- for the
+    // stores below instead of being recomputed)
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
+    const int c16e = lane_e & 15, ge = lane_e >> 4;
+    if (!SPLIT) {
+        // as conv2d_fwd16_kernel: per 32-channel pass stage [pixel][32 channels] rows (64 bytes, 8-byte chunk c of pixel p at
+        // c ^ ((p >> 1) & 7)) and read them back transposed; here a lane stages ONE 8-byte chunk per tile (channels 16 (mo & 1) + 4 g ..).
+        // For EVERY tile width (even): a granule of 8 tile-local pixels that stays inside one tile row and the image goes out as 16
+        // bytes, one that runs over a row end (tile widths that are not multiples of 8: the 5 x 50 tiles of the 150-wide planes, 28, 42)
+        // as four pixel pairs with their own coordinates.  (r05: the per-element path below took 86k cycles per workgroup on those
+        // tiles -- 16 lanes x 2 bytes per run -- against 10k for this one; it remains for fp32 output.)
+        typedef __attribute__((ext_vector_type(4))) short s16x4;
+        typedef __attribute__((ext_vector_type(4))) unsigned eu32x4;
+        constexpr int EROW = 64;
+        unsigned char* const ebuf = (unsigned char*)lds + wave * (128 * EROW);
+        const int pq = p.P * p.ldy;
+        const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void*)((T*)p.y + (size_t)n * p.Cout * pq), 0, p.Cout * pq * 2, 0x00020000);
+        const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.oscale ? p.oscale + (size_t)n * p.Cout : (const float*)p.y), 0, p.oscale ? p.Cout * 4 : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.obias ? p.obias : (const float*)p.y), 0, p.obias ? p.Cout * 4 : 0, 0x00020000);
+        constexpr unsigned kGOut = 0x80000000u, kOOut = 0xc0000000u;
+        const bool has_sc = p.oscale != nullptr, has_ob = p.obias != nullptr;
+        f32x4 sc[MO], ob[MO];
+#pragma unroll
+        for (int mo = 0; mo < MO; mo++) {
+            const unsigned sboff = (unsigned)((o0 + wo * (BM_O / 2) + mo * 16 + 4 * ge) * 4);
+            sc[mo] = (f32x4){1.f, 1.f, 1.f, 1.f};
+            ob[mo] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (has_sc) sc[mo] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srs, sboff, 0, 0));
+            if (has_ob) ob[mo] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(brs, sboff, 0, 0));
+        }
+        // read side: lane = (half hh: granule parity, chalf: channel half, i16: channel / address role inside the 16-lane group)
+        const int i16 = lane_e & 15, chalf = (lane_e >> 4) & 1, hh = lane_e >> 5;
+        const int q4 = i16 >> 2, p4 = i16 & 3;
+        unsigned rd_off[2];
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            const int prw = 8 * hh + 4 * r + q4;                 // + 16 pixels per iteration: (prw >> 1) & 7 does not change
+            rd_off[r] = prw * EROW + (((chalf * 4 + p4) ^ ((prw >> 1) & 7)) << 3);
+        }
+        // write side: pixel 16 ti + c16 (its swizzle (pix >> 1) & 7 does not depend on ti), chunk 4 (mo & 1) + g
+        unsigned wr_off[2];
+#pragma unroll
+        for (int k = 0; k < 2; k++) wr_off[k] = (unsigned)(c16e * EROW + (((4 * k + ge) ^ ((c16e >> 1) & 7)) << 3));
+        unsigned gbyte[8], gfullm = 0;
+#pragma unroll
+        for (int it = 0; it < 8; it++) {
+            const int j0 = wpx * 128 + (2 * it + hh) * 8;
+            const int gpy = (int)__umulhi((unsigned)j0, p.magicTW), gpx = j0 - gpy * p.TW;
+            const int gy = y0 + gpy, gx = x0 + gpx;
+            gbyte[it] = (j0 < p.TH * p.TW && gy < p.P && gx < p.Q) ? (unsigned)((gy * p.ldy + gx) * 2) : kGOut;
+            if (gpx + 8 <= p.TW && gx + 8 <= p.ldy) gfullm |= 1u << it;        // one tile row, inside the (pitched) image row
+        }
+#pragma unroll
+        for (int mi = 0; mi < MO / 2; mi++) {
+            const int rowbase = o0 + wo * (BM_O / 2) + mi * 32;
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const int mo = 2 * mi + k;
+#pragma unroll
+                for (int ti = 0; ti < NT; ti++) {
+                    uint2 w;
+                    w.x = pack2<T>(acc[mo][ti][0] * sc[mo][0] + ob[mo][0], acc[mo][ti][1] * sc[mo][1] + ob[mo][1]);
+                    w.y = pack2<T>(acc[mo][ti][2] * sc[mo][2] + ob[mo][2], acc[mo][ti][3] * sc[mo][3] + ob[mo][3]);
+                    *(uint2*)(ebuf + wr_off[k] + ti * (16 * EROW)) = w;
+                }
+            }
+            // same wave wrote and reads: LDS operations of a wave complete in order, no barrier needed
+            const int o = rowbase + chalf * 16 + i16;
+            const unsigned obyte = o < p.Cout ? (unsigned)(o * pq * 2) : kOOut;
+#pragma unroll
+            for (int it = 0; it < 8; it++) {
+                union { s16x4 v[2]; eu32x4 q; } u;
+#pragma unroll
+                for (int r = 0; r < 2; r++)
+                    u.v[r] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ebuf + it * (16 * EROW) + rd_off[r]));
+                const unsigned off = obyte + gbyte[it];
+                if ((gfullm >> it) & 1) {
+                    __builtin_amdgcn_raw_buffer_store_b128(u.q, yrs, off, 0, 0);
+                } else {                                          // the granule runs over the tile row's or the image's right end (even widths: whole pairs)
+#pragma unroll
+                    for (int w2 = 0; w2 < 4; w2++) {
+                        const int j = wpx * 128 + (2 * it + hh) * 8 + 2 * w2;
+                        const int py = (int)__umulhi((unsigned)j, p.magicTW), px = j - py * p.TW;
+                        const bool ok = j < p.TH * p.TW && y0 + py < p.P && x0 + px < p.Q;
+                        __builtin_amdgcn_raw_buffer_store_b32(u.q[w2], yrs, ok ? obyte + (unsigned)(((y0 + py) * p.ldy + x0 + px) * 2) : kGOut, 0, 0);
+                    }
+                }
+            }
+        }
+        AFCM_STAMP(3);
+        return;
+    }
+    TO* yn = (TO*)p.y + (size_t)n * p.Cout * p.P * p.ldy;
+    int poff[NT];                                    // pixel offset inside a plane, -1: not stored
+#pragma unroll
+    for (int ti = 0; ti < NT; ti++) {
+        const int j = wpx * 128 + ti * 16 + c16e;
+        const int py = (int)__umulhi((unsigned)j, p.magicTW), px = j - py * p.TW;
+        poff[ti] = (j < p.TH * p.TW && y0 + py < p.P && x0 + px < p.Q) ? (y0 + py) * p.ldy + x0 + px : -1;
+    }
+    const float* osn = p.oscale ? p.oscale + (size_t)n * p.Cout : nullptr;
+    const int pq = p.P * p.ldy;
+    float inv = 1.f;
+    if constexpr (SPLIT) {
+        float ia = 1.f, ib = 1.f;
+        if (p.bound_a) pow2_factor(p.bound_a[0], &ia);
+        if (p.bound_b) pow2_factor(p.bound_b[0], &ib);
+        inv = ia * ib;
+    }
+#pragma unroll
+    for (int mo = 0; mo < MO; mo++) {
+        float sc[4], ob[4];
+        const int obase = o0 + wo * (BM_O / 2) + mo * 16 + 4 * ge;
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) {
+            sc[reg] = (osn != nullptr ? osn[min(obase + reg, p.Cout - 1)] : 1.f) * inv;
+            ob[reg] = p.obias != nullptr ? p.obias[min(obase + reg, p.Cout - 1)] : 0.f;
+        }
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) {
+            const int o = obase + reg;
+            if (o < p.Cout) {
+                TO* yo = yn + (size_t)o * pq;
+#pragma unroll
+                for (int ti = 0; ti < NT; ti++)
+                    if (poff[ti] >= 0) yo[poff[ti]] = from_f32<TO>(acc[mo][ti][reg] * sc[reg] + ob[reg]);
+            }
+        }
+    }
+    AFCM_STAMP(3);
 }
 
 // Stride-2 form of conv2d_fwd16_kernel for the discriminator's down-sampling convs (CoModGAN/generator.py:613-692: blur, then a 3x3
@@ -1144,10 +1520,12 @@ __global__ __launch_bounds__(256) void conv2d_pack_kernel(T* __restrict__ dst, c
 // -- so the weights are read once for the two images, the index arithmetic is per 8 elements, and the forward and the backward
 // image of a layer come out of ONE launch (a null destination skips that image).  The per-element gather kernel above is kept
 // as the definition the layout test checks against.
+// tile of the pack: TO output x TI input channels, both at least one K-chunk (the data-gradient image chunks the OUTPUT channels)
+template <int BK> struct PackTile { static constexpr int TO = BK > 16 ? 32 : 16, TI = BK > 16 ? 32 : 64; };
 template <typename T, int KK, int BK>
 __device__ __forceinline__ void pack_tile_body(float* tile, int bx, int by, T* __restrict__ dst0, T* __restrict__ dst1, const float* __restrict__ w,
                                                int O, int I, int rows_pad0, int rows_pad1) {
-    constexpr int TO = 16, TI = 64, ROW = TI * KK + 1;             // + 1: the 8 channel runs of a store start 9 floats apart
+    constexpr int TO = PackTile<BK>::TO, TI = PackTile<BK>::TI, ROW = TI * KK + 1;             // + 1: the 8 channel runs of a store start 9 floats apart
     struct alignas(8 * sizeof(T)) Out { T v[8]; };
     const int i0 = bx * TI, o0 = by * TO;
     {
@@ -1216,7 +1594,7 @@ __device__ __forceinline__ void pack_tile_body(float* tile, int bx, int by, T* _
 template <typename T, int KK, int BK>
 __global__ __launch_bounds__(256) void conv2d_pack_tile_kernel(T* __restrict__ dst0, T* __restrict__ dst1, const float* __restrict__ w, int O,
                                                                int I, int rows_pad0, int rows_pad1) {
-    __shared__ float tile[16 * (64 * KK + 1)];
+    __shared__ float tile[PackTile<BK>::TO * (PackTile<BK>::TI * KK + 1)];
     pack_tile_body<T, KK, BK>(tile, blockIdx.x, blockIdx.y, dst0, dst1, w, O, I, rows_pad0, rows_pad1);
 }
 
@@ -1230,7 +1608,7 @@ struct PackBank {
 };
 template <typename T, int KK, int BK>
 __global__ __launch_bounds__(256) void conv2d_pack_bank_kernel(const PackBank b) {
-    __shared__ float tile[16 * (64 * KK + 1)];
+    __shared__ float tile[PackTile<BK>::TO * (PackTile<BK>::TI * KK + 1)];
     int l = 0;
     while (l + 1 < b.count && (int)blockIdx.x >= b.blk[l + 1]) l++;
     const int loc = blockIdx.x - b.blk[l];
@@ -1363,8 +1741,8 @@ __global__ __launch_bounds__(256) void unscale_kernel(float* __restrict__ t, lon
 template <typename T>
 __global__ __launch_bounds__(256) void conv2d_pack_split_kernel(T* __restrict__ dst, const float* __restrict__ w, const unsigned* __restrict__ bound,
                                                                 int O, int I, int rows, int cols, int rows_pad, int nkc_real, int terms,
-                                                                unsigned term_wparts, int mode) {
-    constexpr int KS = 3, KK = 9, BK = 16;
+                                                                unsigned term_wparts, int mode, int BK) {
+    constexpr int KS = 3, KK = 9;
     const float gs = bound ? pow2_factor(bound[0]) : 1.f;
     const long long total = (long long)terms * nkc_real * KK * rows_pad * BK;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
@@ -2620,7 +2998,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce4_kernel(float* __restrict__ 
     }
 }
 
-static void choose_tile(int P, int Q, int KS, int* TH, int* TW, int* PWL) {
+static void choose_tile(int P, int Q, int KS, int* TH, int* TW, int* PWL, int patch_max = kPatchMax) {
     // Tile of TH x TW output pixels with TH*TW <= 256 slots and an LDS patch (TH+KS-1) x round4(TW+KS) <= kPatchMax,
     // chosen to maximise the fraction of useful slots.
     double best = -1;
@@ -2630,7 +3008,7 @@ static void choose_tile(int P, int Q, int KS, int* TH, int* TW, int* PWL) {
         if (th > P) th = P;
         for (; th >= 1; th--) {
             const int pwl = round_up(tw + KS, 4);
-            if ((th + KS - 1) * pwl > kPatchMax) continue;
+            if ((th + KS - 1) * pwl > patch_max) continue;
             const double tiles = (double)cdiv(P, th) * cdiv(Q, tw);
             const double util = (double)P * Q / (tiles * kSlots);
             // small preference for wide tiles (longer contiguous runs for loads/stores); rows of whole 8-pixel granules
@@ -2667,7 +3045,15 @@ static int launch_conv(ConvParams p, int ks, hipStream_t st) {
     dim3 grid((unsigned)blocks), block(256);
     if constexpr (sizeof(T) == 2) {
         if (ks == 3) {
+#if defined(AFCM_CONV_AB) || AFCM_CONV_X16
+            if (AFCM_X16_ON) {
+                hipLaunchKernelGGL((conv2d_fwd16x_kernel<T, BM_O>), grid, block, 0, st, p);
+                return hip_status(hipGetLastError());
+            }
+#endif
+#if defined(AFCM_CONV_AB) || !AFCM_CONV_X16
             hipLaunchKernelGGL((conv2d_fwd16_kernel<T, BM_O>), grid, block, 0, st, p);
+#endif
             return hip_status(hipGetLastError());
         }
     }
@@ -2684,6 +3070,9 @@ using namespace afcm;
 extern "C" int afcm_debug_conv_stamps(void* dst, int n_blocks) {
     return hip_status(hipMemcpyFromSymbol(dst, HIP_SYMBOL(afcm_conv_stamps_buf), (size_t)n_blocks * 32, 0, hipMemcpyDeviceToHost));
 }
+extern "C" int afcm_debug_conv_realtime(void* dst, int n_blocks) {
+    return hip_status(hipMemcpyFromSymbol(dst, HIP_SYMBOL(afcm_conv_rt_buf), (size_t)n_blocks * 32, 0, hipMemcpyDeviceToHost));
+}
 extern "C" int afcm_debug_conv_barrier_cycles(void* dst, int n_blocks) {
     return hip_status(hipMemcpyFromSymbol(dst, HIP_SYMBOL(afcm_conv_bar_buf), (size_t)n_blocks * 32, 0, hipMemcpyDeviceToHost));
 }
@@ -2695,20 +3084,46 @@ extern "C" int afcm_debug_conv_stamps_clear() {
 }
 #endif
 extern "C" int afcm_conv2d_block_k(int32_t dtype) { return dtype == AFCM_F32 ? ConvCfg<float>::BK : ConvCfg<bf16_t>::BK; }
+static inline int afcm::conv_bk(int dtype, int ks) { return (dtype != AFCM_F32 && ks == 3 && AFCM_X16_ON) ? 32 : afcm_conv2d_block_k(dtype); }
+extern "C" int afcm_conv2d_block_k_ks(int32_t dtype, int32_t ks) { return conv_bk(dtype, ks); }
+#ifdef AFCM_CONV_AB
+extern "C" int afcm_debug_conv_variant(int x16) { g_conv_x16 = x16; return AFCM_OK; }
+#endif
 
 template <typename T>
 static void launch_pack8(void* dst0, void* dst1, const float* w, int cout, int cin, int ks, int rows_pad0, int rows_pad1, int BK, hipStream_t st) {
     // tiles cover the padded row ranges of both images: o up to rows_pad0 (forward rows) and the last started K-chunk of the
     // data-gradient image, i up to rows_pad1 and the forward image's last K-chunk (rows_pad are multiples of 64 >= the extents)
     const int omax = dst0 ? rows_pad0 : round_up(cout, BK), imax = dst1 ? rows_pad1 : round_up(cin, BK);
-    dim3 grid((unsigned)cdiv(imax > cin ? imax : cin, 64), (unsigned)cdiv(omax > cout ? omax : cout, 16)), block(256);
     constexpr int BKT = ConvCfg<T>::BK;
+    const int ti = BK > 16 ? PackTile<32>::TI : PackTile<BKT>::TI, to = BK > 16 ? PackTile<32>::TO : PackTile<BKT>::TO;
+    dim3 grid((unsigned)cdiv(imax > cin ? imax : cin, ti), (unsigned)cdiv(omax > cout ? omax : cout, to)), block(256);
+    if constexpr (sizeof(T) == 2) {
+        if (BK == 32) {           // the 16x16x32 kernel's image (3x3 only)
+            hipLaunchKernelGGL((conv2d_pack_tile_kernel<T, 9, 32>), grid, block, 0, st, (T*)dst0, (T*)dst1, w, cout, cin, rows_pad0, rows_pad1);
+            return;
+        }
+    }
     if (ks == 3) hipLaunchKernelGGL((conv2d_pack_tile_kernel<T, 9, BKT>), grid, block, 0, st, (T*)dst0, (T*)dst1, w, cout, cin, rows_pad0, rows_pad1);
     else hipLaunchKernelGGL((conv2d_pack_tile_kernel<T, 1, BKT>), grid, block, 0, st, (T*)dst0, (T*)dst1, w, cout, cin, rows_pad0, rows_pad1);
 }
 
+static int pack_weights2_bk(void* dst_fwd, void* dst_dgrad, const float* w, int32_t dtype, int32_t cout, int32_t cin, int32_t ks,
+                            int32_t rows_pad_fwd, int32_t rows_pad_dgrad, int BK, void* stream);
 extern "C" int afcm_conv2d_pack_weights2(void* dst_fwd, void* dst_dgrad, const float* w, int32_t dtype, int32_t cout, int32_t cin, int32_t ks,
                                          int32_t rows_pad_fwd, int32_t rows_pad_dgrad, void* stream) {
+    return pack_weights2_bk(dst_fwd, dst_dgrad, w, dtype, cout, cin, ks, rows_pad_fwd, rows_pad_dgrad, conv_bk(dtype, ks), stream);
+}
+extern "C" int afcm_conv2d_pack_weights_bk(void* dst, const float* w, int32_t dtype, int32_t cout, int32_t cin, int32_t ks, int32_t mode,
+                                           int32_t rows_pad, int32_t block_k, void* stream) {
+    AFCM_REQUIRE(dst != nullptr && w != nullptr, "conv2d_pack_weights: null pointer");
+    AFCM_REQUIRE(mode == 0 || mode == 1, "mode must be 0 (forward) or 1 (data gradient)");
+    AFCM_REQUIRE(block_k == afcm_conv2d_block_k(dtype) || block_k == conv_bk(dtype, ks), "conv2d_pack_weights_bk: K-chunk %d is not one of this dtype's", block_k);
+    return mode == 0 ? pack_weights2_bk(dst, nullptr, w, dtype, cout, cin, ks, rows_pad, 0, block_k, stream)
+                     : pack_weights2_bk(nullptr, dst, w, dtype, cout, cin, ks, 0, rows_pad, block_k, stream);
+}
+static int pack_weights2_bk(void* dst_fwd, void* dst_dgrad, const float* w, int32_t dtype, int32_t cout, int32_t cin, int32_t ks,
+                            int32_t rows_pad_fwd, int32_t rows_pad_dgrad, int BK, void* stream) {
     AFCM_REQUIRE(w != nullptr && (dst_fwd != nullptr || dst_dgrad != nullptr), "conv2d_pack_weights: null pointer");
     AFCM_REQUIRE(dtype == AFCM_F32 || dtype == AFCM_F16 || dtype == AFCM_BF16, "dtype must be float32, float16 or bfloat16");
     AFCM_REQUIRE(ks == 1 || ks == 3, "only 1x1 and 3x3 kernels are supported");
@@ -2716,7 +3131,6 @@ extern "C" int afcm_conv2d_pack_weights2(void* dst_fwd, void* dst_dgrad, const f
     AFCM_REQUIRE(dst_fwd == nullptr || (rows_pad_fwd >= cout && rows_pad_fwd % 64 == 0), "rows_pad must be a multiple of 64 covering the rows");
     AFCM_REQUIRE(dst_dgrad == nullptr || (rows_pad_dgrad >= cin && rows_pad_dgrad % 64 == 0), "rows_pad must be a multiple of 64 covering the rows");
     AFCM_REQUIRE((((uintptr_t)dst_fwd | (uintptr_t)dst_dgrad) & 31) == 0, "conv2d_pack_weights: destinations must be 32-byte aligned");
-    const int BK = afcm_conv2d_block_k(dtype);
     hipStream_t st = (hipStream_t)stream;
     switch (dtype) {
         case AFCM_F32: launch_pack8<float>(dst_fwd, dst_dgrad, w, cout, cin, ks, rows_pad_fwd, rows_pad_dgrad, BK, st); break;
@@ -2735,8 +3149,14 @@ extern "C" int afcm_conv2d_pack_weights(void* dst, const float* w, int32_t dtype
 }
 
 template <typename T>
-static void launch_pack_bank(const PackBank& b, int blocks, int ks, hipStream_t st) {
+static void launch_pack_bank(const PackBank& b, int blocks, int ks, int BK, hipStream_t st) {
     constexpr int BKT = ConvCfg<T>::BK;
+    if constexpr (sizeof(T) == 2) {
+        if (BK == 32) {
+            hipLaunchKernelGGL((conv2d_pack_bank_kernel<T, 9, 32>), dim3(blocks), dim3(256), 0, st, b);
+            return;
+        }
+    }
     if (ks == 3) hipLaunchKernelGGL((conv2d_pack_bank_kernel<T, 9, BKT>), dim3(blocks), dim3(256), 0, st, b);
     else hipLaunchKernelGGL((conv2d_pack_bank_kernel<T, 1, BKT>), dim3(blocks), dim3(256), 0, st, b);
 }
@@ -2745,7 +3165,8 @@ extern "C" int afcm_conv2d_pack_bank(const afcm_pack_entry* entries, int32_t cou
     AFCM_REQUIRE(entries != nullptr && count > 0 && count <= AFCM_PACK_MAX, "conv2d_pack_bank: 1..%d entries", AFCM_PACK_MAX);
     AFCM_REQUIRE(dtype == AFCM_F32 || dtype == AFCM_F16 || dtype == AFCM_BF16, "dtype must be float32, float16 or bfloat16");
     AFCM_REQUIRE(ks == 1 || ks == 3, "only 1x1 and 3x3 kernels are supported");
-    const int BK = afcm_conv2d_block_k(dtype);
+    const int BK = conv_bk(dtype, ks);
+    const int ti = BK > 16 ? PackTile<32>::TI : 64, to = BK > 16 ? PackTile<32>::TO : 16;
     PackBank b;
     b.count = count;
     int tot = 0;
@@ -2757,7 +3178,7 @@ extern "C" int afcm_conv2d_pack_bank(const afcm_pack_entry* entries, int32_t cou
         AFCM_REQUIRE((((uintptr_t)e.dst_fwd | (uintptr_t)e.dst_dgrad) & 31) == 0, "conv2d_pack_bank: entry %d: destinations must be 32-byte aligned", l);
         // as launch_pack8: tiles cover the padded row ranges of both images
         const int omax = e.dst_fwd ? e.rows_pad_fwd : round_up(e.cout, BK), imax = e.dst_dgrad ? e.rows_pad_dgrad : round_up(e.cin, BK);
-        const int gx = cdiv(imax > e.cin ? imax : e.cin, 64), gy = cdiv(omax > e.cout ? omax : e.cout, 16);
+        const int gx = cdiv(imax > e.cin ? imax : e.cin, ti), gy = cdiv(omax > e.cout ? omax : e.cout, to);
         b.e[l] = e;
         b.gx[l] = gx;
         b.blk[l] = tot;
@@ -2766,9 +3187,9 @@ extern "C" int afcm_conv2d_pack_bank(const afcm_pack_entry* entries, int32_t cou
     b.blk[count] = tot;
     hipStream_t st = (hipStream_t)stream;
     switch (dtype) {
-        case AFCM_F32: launch_pack_bank<float>(b, tot, ks, st); break;
-        case AFCM_F16: launch_pack_bank<f16_t>(b, tot, ks, st); break;
-        default: launch_pack_bank<bf16_t>(b, tot, ks, st); break;
+        case AFCM_F32: launch_pack_bank<float>(b, tot, ks, BK, st); break;
+        case AFCM_F16: launch_pack_bank<f16_t>(b, tot, ks, BK, st); break;
+        default: launch_pack_bank<bf16_t>(b, tot, ks, BK, st); break;
     }
     return hip_status(hipGetLastError());
 }
@@ -2830,12 +3251,12 @@ extern "C" int afcm_conv2d_ld(void* y, const void* x, const void* wpacked, const
         AFCM_REQUIRE((long long)cout * p.P * p.ldy < (1ll << 30), "conv2d: pitched output image is out of range");
     }
     AFCM_REQUIRE(dtype == AFCM_F32 || ks != 3 || (long long)cout * p.P * p.ldy * 2 < (1ll << 30), "conv2d: 16-bit output image of %lld bytes is out of range (< 2^30)", (long long)cout * p.P * p.ldy * 2);
-    choose_tile(p.P, p.Q, ks, &p.TH, &p.TW, &p.PWL);
+    choose_tile(p.P, p.Q, ks, &p.TH, &p.TW, &p.PWL, (dtype != AFCM_F32 && ks == 3 && AFCM_X16_ON) ? kPatchMaxX16 : kPatchMax);
     p.tilesX = cdiv(p.Q, p.TW); p.tilesY = cdiv(p.P, p.TH);
     p.magicTW = (unsigned)((0x100000000ull + (unsigned)p.TW - 1) / (unsigned)p.TW);
     p.magicTX = magic_u32((unsigned)p.tilesX); p.magicTY = magic_u32((unsigned)p.tilesY); p.magicN = magic_u32((unsigned)p.N); p.magicPC = magic_u32((unsigned)(p.PWL >> 2));
     p.Opad = rows_pad;
-    p.nkc = cdiv(cin, afcm_conv2d_block_k(dtype));
+    p.nkc = cdiv(cin, conv_bk(dtype, ks));
     p.nkc_real = p.nkc; p.magicNK = 0; p.term_parts = 0; p.part_bytes = 0; p.last_part_bytes = 0; p.bound_a = p.bound_b = nullptr;
     hipStream_t st = (hipStream_t)stream;
     // 64-row blocks when they waste fewer padded rows than 128-row blocks
@@ -2905,13 +3326,14 @@ extern "C" int afcm_conv2d_pack_split(void* dst, const float* w, const uint32_t*
     const int rows = mode == 0 ? cout : cin, cols = mode == 0 ? cin : cout;
     AFCM_REQUIRE(rows_pad >= rows && rows_pad % 64 == 0, "rows_pad must be a multiple of 64 covering the rows");
     for (int t = 0; t < terms; t++) AFCM_REQUIRE(((term_wparts >> (4 * t)) & 15u) <= 2, "conv2d_pack_split: parts 0..2");
-    const int nkc_real = cdiv(cols, 16);
-    const long long total = (long long)terms * nkc_real * 9 * rows_pad * 16;
+    const int BK = conv_bk(dtype, 3);
+    const int nkc_real = cdiv(cols, BK);
+    const long long total = (long long)terms * nkc_real * 9 * rows_pad * BK;
     long long blocks = (total + 255) / 256;
     if (blocks > 8192) blocks = 8192;
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == AFCM_BF16) hipLaunchKernelGGL((conv2d_pack_split_kernel<bf16_t>), dim3((unsigned)blocks), dim3(256), 0, st, (bf16_t*)dst, w, (const unsigned*)bound, cout, cin, rows, cols, rows_pad, nkc_real, terms, term_wparts, mode);
-    else hipLaunchKernelGGL((conv2d_pack_split_kernel<f16_t>), dim3((unsigned)blocks), dim3(256), 0, st, (f16_t*)dst, w, (const unsigned*)bound, cout, cin, rows, cols, rows_pad, nkc_real, terms, term_wparts, mode);
+    if (dtype == AFCM_BF16) hipLaunchKernelGGL((conv2d_pack_split_kernel<bf16_t>), dim3((unsigned)blocks), dim3(256), 0, st, (bf16_t*)dst, w, (const unsigned*)bound, cout, cin, rows, cols, rows_pad, nkc_real, terms, term_wparts, mode, BK);
+    else hipLaunchKernelGGL((conv2d_pack_split_kernel<f16_t>), dim3((unsigned)blocks), dim3(256), 0, st, (f16_t*)dst, w, (const unsigned*)bound, cout, cin, rows, cols, rows_pad, nkc_real, terms, term_wparts, mode, BK);
     return hip_status(hipGetLastError());
 }
 
@@ -2938,12 +3360,12 @@ extern "C" int afcm_conv2d_split(float* y, const void* x_parts, const void* wpac
     AFCM_REQUIRE(p.P >= 1 && p.Q >= 1, "output must be at least 1x1");
     p.pad = pad;
     p.ldx = w; p.ldy = p.Q;
-    choose_tile(p.P, p.Q, ks, &p.TH, &p.TW, &p.PWL);
+    choose_tile(p.P, p.Q, ks, &p.TH, &p.TW, &p.PWL, AFCM_X16_ON ? kPatchMaxX16 : kPatchMax);
     p.tilesX = cdiv(p.Q, p.TW); p.tilesY = cdiv(p.P, p.TH);
     p.magicTW = (unsigned)((0x100000000ull + (unsigned)p.TW - 1) / (unsigned)p.TW);
     p.magicTX = magic_u32((unsigned)p.tilesX); p.magicTY = magic_u32((unsigned)p.tilesY); p.magicN = magic_u32((unsigned)p.N); p.magicPC = magic_u32((unsigned)(p.PWL >> 2));
     p.Opad = rows_pad;
-    p.nkc_real = cdiv(cin, ConvCfg<bf16_t>::BK);
+    p.nkc_real = cdiv(cin, conv_bk(dtype, 3));
     p.nkc = terms * p.nkc_real;
     p.magicNK = magic_u32((unsigned)p.nkc_real);
     p.term_parts = term_parts;
@@ -2955,6 +3377,19 @@ extern "C" int afcm_conv2d_split(float* y, const void* x_parts, const void* wpac
     AFCM_REQUIRE(blocks > 0 && blocks < (1ll << 31), "conv2d_split: grid of %lld blocks is out of range", blocks);
     dim3 grid((unsigned)blocks), block(256);
     hipStream_t st = (hipStream_t)stream;
+#if defined(AFCM_CONV_AB) || AFCM_CONV_X16
+    if (AFCM_X16_ON) {
+        if (dtype == AFCM_BF16) {
+            if (small) hipLaunchKernelGGL((conv2d_fwd16x_kernel<bf16_t, 64, true>), grid, block, 0, st, p);
+            else hipLaunchKernelGGL((conv2d_fwd16x_kernel<bf16_t, 128, true>), grid, block, 0, st, p);
+        } else {
+            if (small) hipLaunchKernelGGL((conv2d_fwd16x_kernel<f16_t, 64, true>), grid, block, 0, st, p);
+            else hipLaunchKernelGGL((conv2d_fwd16x_kernel<f16_t, 128, true>), grid, block, 0, st, p);
+        }
+        return hip_status(hipGetLastError());
+    }
+#endif
+#if defined(AFCM_CONV_AB) || !AFCM_CONV_X16
     if (dtype == AFCM_BF16) {
         if (small) hipLaunchKernelGGL((conv2d_fwd16_kernel<bf16_t, 64, true>), grid, block, 0, st, p);
         else hipLaunchKernelGGL((conv2d_fwd16_kernel<bf16_t, 128, true>), grid, block, 0, st, p);
@@ -2962,6 +3397,7 @@ extern "C" int afcm_conv2d_split(float* y, const void* x_parts, const void* wpac
         if (small) hipLaunchKernelGGL((conv2d_fwd16_kernel<f16_t, 64, true>), grid, block, 0, st, p);
         else hipLaunchKernelGGL((conv2d_fwd16_kernel<f16_t, 128, true>), grid, block, 0, st, p);
     }
+#endif
     return hip_status(hipGetLastError());
 }
 

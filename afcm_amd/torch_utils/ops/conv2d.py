@@ -27,7 +27,7 @@ def pack_weights(w, dtype, mode):
     assert kh == kw and kh in (1, 3), 'only 1x1 and 3x3 kernels are supported'
     w = w.detach().to(torch.float32).contiguous()
     code = _lib._DTYPES[dtype]
-    bk = lib.afcm_conv2d_block_k(code)
+    bk = lib.afcm_conv2d_block_k_ks(code, kh)
     rows, cols = (o, i) if mode == 0 else (i, o)
     rows_pad = _pad64(rows)
     nkc = (cols + bk - 1) // bk
@@ -45,7 +45,7 @@ def pack_weights_both(w, dtype):
     assert kh == kw and kh in (1, 3), 'only 1x1 and 3x3 kernels are supported'
     w = w.detach().to(torch.float32).contiguous()
     code = _lib._DTYPES[dtype]
-    bk = lib.afcm_conv2d_block_k(code)
+    bk = lib.afcm_conv2d_block_k_ks(code, kh)
     rp0, rp1 = _pad64(o), _pad64(i)
     d0 = torch.empty([(i + bk - 1) // bk, kh * kw, rp0, bk], dtype=dtype, device=w.device)
     d1 = torch.empty([(o + bk - 1) // bk, kh * kw, rp1, bk], dtype=dtype, device=w.device)
@@ -66,7 +66,7 @@ def pack_weights_bank(ws, dtype, need_dgrad=True):
     ks = int(ws[0].shape[2])
     assert ks in (1, 3) and all(tuple(w.shape[2:]) == (ks, ks) for w in ws), 'one kernel size (1x1 or 3x3) per bank'
     code = _lib._DTYPES[dtype]
-    bk = lib.afcm_conv2d_block_k(code)
+    bk = lib.afcm_conv2d_block_k_ks(code, ks)
     table = (_lib.PackEntry * len(ws))()
     out, keep = [], []
     for e, w in zip(table, ws):
@@ -280,7 +280,8 @@ def pack_weights_split(w, terms, dtype, transposed=False):
     rows_pad = _pad64(rows)
     bound = amax_bits(w) if dtype == torch.float16 else None
     table = _SPLIT_TERMS[terms]
-    dst = torch.empty([terms * ((cols + 15) // 16), 9, rows_pad, 16], dtype=dtype, device=w.device)
+    bk = lib.afcm_conv2d_block_k_ks(_lib._DTYPES[dtype], 3)
+    dst = torch.empty([terms * ((cols + bk - 1) // bk), 9, rows_pad, bk], dtype=dtype, device=w.device)
     code = sum(b << (4 * t) for t, (_, b) in enumerate(table))
     _lib.check(lib.afcm_conv2d_pack_split(dst.data_ptr(), w.data_ptr(), _lib.ptr(bound), _lib._DTYPES[dtype], o, i, 1 if transposed else 0, rows_pad,
                                           terms, code, _lib.stream_ptr(w)), 'conv2d_pack_split')
@@ -294,7 +295,8 @@ def _conv_split(parts, wp, rows_pad, terms, oscale, cout, pad, obias=None, bound
     nparts, n, cin, h, w = parts.shape
     table = _SPLIT_TERMS[terms]
     assert nparts > max(a for a, _ in table) and parts.dtype == wp.dtype and parts.stride(1) == cin * h * w
-    assert tuple(wp.shape) == (terms * ((cin + 15) // 16), 9, rows_pad, 16), 'the weight image does not belong to this split'
+    bk = lib.afcm_conv2d_block_k_ks(_lib._DTYPES[parts.dtype], 3)
+    assert tuple(wp.shape) == (terms * ((cin + bk - 1) // bk), 9, rows_pad, bk), 'the weight image does not belong to this split'
     p, q = h + 2 * pad - 2, w + 2 * pad - 2
     y = torch.empty([n, cout, p, q], dtype=torch.float32, device=parts.device)
     if oscale is not None:
@@ -533,7 +535,32 @@ class _ConvWgrad(torch.autograd.Function):
         return g_dy, g_x, None, None
 
 
-_S2_PACKS = {}          # (weight storage, version, shape, dtype, device) -> packed image of the stride-2 kernel
+# id(weight tensor) -> (weak reference to it, its version counter, activation dtype, packed image of the stride-2 kernel).  The entry
+# is only valid for the very tensor OBJECT it was made from, at the version it had (a key on data_ptr matched the temporaries
+# `weight * gain` of later iterations and of other same-shape layers whenever the allocator handed their address out again -- a stale
+# image of other weights).  A tensor that died takes its entry along (weak-reference callback), so a recycled id() cannot match either.
+_S2_PACKS = {}
+
+
+def _s2_pack_lookup(w, dtype):
+    e = _S2_PACKS.get(id(w))
+    if e is not None and e[0]() is w and e[1] == w._version and e[2] == dtype:
+        return e[3]
+    return None
+
+
+def _s2_pack_store(w, dtype, wp):
+    import weakref
+    key = id(w)
+
+    def _gone(ref, key=key):
+        e = _S2_PACKS.get(key)
+        if e is not None and e[0] is ref:
+            del _S2_PACKS[key]
+
+    if len(_S2_PACKS) >= 64:
+        _S2_PACKS.clear()
+    _S2_PACKS[key] = (weakref.ref(w, _gone), w._version, dtype, wp)
 
 
 class _StridedConv2d(torch.autograd.Function):
@@ -552,17 +579,14 @@ class _StridedConv2d(torch.autograd.Function):
         code = _lib._DTYPES[x.dtype]
         bk = lib.afcm_conv2d_block_k(code)
         rows_pad = (cout + 127) // 128 * 128                       # the stride-2 kernel runs 128-row blocks only
-        # the packed image is reused while the weight tensor is unchanged (a D iteration runs every down-conv three times --
-        # fake, real, R1 -- on the same weights: ADVICE r03); keyed on storage, version counter and dtype
-        key = (w.data_ptr(), w._version, tuple(w.shape), x.dtype, x.device)
-        wp = _S2_PACKS.get(key)
+        # the packed image is reused while the SAME weight tensor object is unchanged (a caller that passes its Parameter runs a
+        # down-conv three times per D iteration -- fake, real, R1 -- on one image); a temporary (`weight * gain`) is packed per call
+        wp = _s2_pack_lookup(w, x.dtype)
         if wp is None:
             w32 = w.detach().to(torch.float32).contiguous()
             wp = torch.empty([(cin + bk - 1) // bk, 9, rows_pad, bk], dtype=x.dtype, device=x.device)
-            _lib.check(lib.afcm_conv2d_pack_weights(wp.data_ptr(), w32.data_ptr(), code, cout, cin, 3, 0, rows_pad, _lib.stream_ptr(x)), 'conv2d_pack_weights')
-            if len(_S2_PACKS) >= 64:
-                _S2_PACKS.clear()
-            _S2_PACKS[key] = wp
+            _lib.check(lib.afcm_conv2d_pack_weights_bk(wp.data_ptr(), w32.data_ptr(), code, cout, cin, 3, 0, rows_pad, bk, _lib.stream_ptr(x)), 'conv2d_pack_weights')
+            _s2_pack_store(w, x.dtype, wp)
         p, q = (h + 2 * padding - 3) // 2 + 1, (wd + 2 * padding - 3) // 2 + 1
         y = torch.empty([n, cout, p, q], dtype=x.dtype, device=x.device)
         span = profiling.span('conv2d', 2.0 * n * cout * cin * 9 * p * q)

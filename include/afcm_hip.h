@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define AFCM_ABI_VERSION 11  /* 11 (r04): + afcm_amax_bits, afcm_split16, afcm_conv2d_pack_split, afcm_conv2d_split, afcm_unscale, afcm_plane_dot_parts (additions only).  10 (r04): + afcm_filtered_lrelu_args.clamp_flags (appended), afcm_plane_dot_gated_ld; the runtime getenv switches are gone.  9 (r03): + afcm_affine_bank_*, afcm_modulation_bank_*, afcm_conv2d_pack_bank, afcm_conv2d_stride2 (additions only; every v8 entry point and struct is unchanged) */
+#define AFCM_ABI_VERSION 12  /* 12 (r05): + afcm_conv2d_block_k_ks, afcm_conv2d_pack_weights_bk; the packed layout's K-chunk depends on (dtype, kernel size): 16-bit 3x3 images are [nkc][9][rows_pad][32] for the v_mfma 16x16x32 kernel (the pack / conv entry points keep their signatures).  11 (r04): + afcm_amax_bits, afcm_split16, afcm_conv2d_pack_split, afcm_conv2d_split, afcm_unscale, afcm_plane_dot_parts (additions only).  10 (r04): + afcm_filtered_lrelu_args.clamp_flags (appended), afcm_plane_dot_gated_ld; the runtime getenv switches are gone.  9 (r03): + afcm_affine_bank_*, afcm_modulation_bank_*, afcm_conv2d_pack_bank, afcm_conv2d_stride2 (additions only; every v8 entry point and struct is unchanged) */
 
 enum { AFCM_F32 = 0, AFCM_F16 = 1, AFCM_BF16 = 2 };
 enum { AFCM_OK = 0, AFCM_E_NOKERNEL = -1, AFCM_E_INVALID = -2 };
@@ -167,11 +167,15 @@ int afcm_bias_act(void* y, const void* x, const void* b, const void* xref, const
  * All of them are cross-correlations (F.conv2d semantics) with stride 1, k in {1,3}, 0 <= pad <= k-1.
  * ---------------------------------------------------------------------------------------- */
 
-/* K-chunk of the packed weight layout for a dtype (16 for 16-bit, 8 for fp32). */
+/* K-chunk (channels) of the packed weight layout.
+ * afcm_conv2d_block_k(dtype): the fp32, 1x1 and stride-2 (afcm_conv2d_stride2) kernels -- 16 for 16-bit, 8 for fp32;
+ * afcm_conv2d_block_k_ks(dtype, ks): the stride-1 kernel for this kernel size -- 32 for 16-bit 3x3 (one v_mfma_f32_16x16x32 K step),
+ * else as above.  afcm_conv2d[_ld], afcm_conv2d_split and the pack entry points below use this one. */
 int afcm_conv2d_block_k(int32_t dtype);
+int afcm_conv2d_block_k_ks(int32_t dtype, int32_t ks);
 
 /* Pack fp32 weights w[cout][cin][k][k] into the kernel layout [ceil(cols/BK)][k*k][rows_pad][BK] of
- * `dtype`, zero padded.  mode 0: forward (rows = cout, cols = cin).  mode 1: data gradient
+ * `dtype` (BK = afcm_conv2d_block_k_ks(dtype, ks)), zero padded.  mode 0: forward (rows = cout, cols = cin).  mode 1: data gradient
  * (rows = cin, cols = cout, taps flipped).  rows_pad: multiple of 64, >= rows. */
 int afcm_conv2d_pack_weights(void* dst, const float* w, int32_t dtype, int32_t cout, int32_t cin, int32_t ks,
                              int32_t mode, int32_t rows_pad, void* stream);
@@ -180,6 +184,10 @@ int afcm_conv2d_pack_weights(void* dst, const float* w, int32_t dtype, int32_t c
  * dst_dgrad as mode 1 of afcm_conv2d_pack_weights; either may be NULL.  Destinations 32-byte aligned. */
 int afcm_conv2d_pack_weights2(void* dst_fwd, void* dst_dgrad, const float* w, int32_t dtype, int32_t cout, int32_t cin, int32_t ks,
                               int32_t rows_pad_fwd, int32_t rows_pad_dgrad, void* stream);
+/* afcm_conv2d_pack_weights with an explicit K-chunk: block_k = afcm_conv2d_block_k(dtype) (the image afcm_conv2d_stride2 reads) or
+ * afcm_conv2d_block_k_ks(dtype, ks). */
+int afcm_conv2d_pack_weights_bk(void* dst, const float* w, int32_t dtype, int32_t cout, int32_t cin, int32_t ks, int32_t mode,
+                                int32_t rows_pad, int32_t block_k, void* stream);
 
 /* y[n, cout, h+2*pad-k+1, w+2*pad-k+1] = oscale[n*cout+o] * sum W * x + obias[o].   oscale / obias (fp32) may be NULL.
  * obias is the layer bias the reference adds at the head of filtered_lrelu (x + b before the padding, NET:371 ->
@@ -402,7 +410,7 @@ int afcm_conv2d_split(float* y, const void* x_parts, const void* wpacked, const 
 
 /* ----------------------------------------------------------------------------------------
  * 3x3 convolution at stride 2 (the discriminator's down-sampling convs, CoModGAN/generator.py:613-692, after the blur): 16-bit x
- * [n][cin][h][w] (dense, w even), weights packed by afcm_conv2d_pack_weights(mode 0) with rows_pad a multiple of 128, y
+ * [n][cin][h][w] (dense, w even), weights packed by afcm_conv2d_pack_weights_bk(mode 0, block_k = afcm_conv2d_block_k(dtype)) with rows_pad a multiple of 128, y
  * [n][cout][(h + 2 pad - 3) / 2 + 1][(w + 2 pad - 3) / 2 + 1] = the even rows / columns of afcm_conv2d's result, bit for bit, at a
  * quarter of its MFMAs and without the full-resolution intermediate.  Forward only (the gradients are stride-1 convolutions with the
  * zero-stuffed dy: afcm_conv2d / afcm_conv2d_wgrad).
