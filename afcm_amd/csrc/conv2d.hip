@@ -2613,10 +2613,17 @@ __global__ __launch_bounds__(512, 1) void conv2d_wgrad16_kernel(WgradParams p) {
 #ifndef AFCM_WGRAD_NBUF
 #define AFCM_WGRAD_NBUF 3          // LDS ring depth of conv2d_wgrad16g_kernel (2: measured in profiles/r04_wgrad_ring.txt)
 #endif
-template <typename T, int KS, int NBUF, bool SMALL>
+// X16 (r05): the same tile on v_mfma_f32_16x16x32 -- a wave's 32 (o) x 32 (i) tile is 2 x 2 tiles of 16 x 16 per tap (the same 144
+// accumulator registers), a K step is 32 pixels = FOUR granules, one per 16-lane group: wave th takes pixels 32 th .. 32 th + 31 of the
+// chunk.  ds_read_b128 serves the lanes in groups that hold all 16 rows with TWO neighbouring granules (G, G + 1), so the swizzle is
+// slot = granule ^ (((row >> 1) & 3) << 1): both row sets of a group take the even XOR values once, G and G + 1 differ in bit 0 (G even)
+// or flip bits that keep the even set (G odd: the hi half of the x windows): 16 distinct slots for every read (the (row >> 1) & 7 form
+// of the 32x32x16 kernel is conflict-free only when all lanes of a group read the SAME granule).  A/B of the shapes: profiles/r05_*.
+template <typename T, int KS, int NBUF, bool SMALL, bool X16 = false>
 __global__ __launch_bounds__(512, 1) void conv2d_wgrad16g_kernel(WgradParams p) {
     static_assert(sizeof(T) == 2, "16-bit types only");
     constexpr int R = 2, KK = KS * KS, XR = R + KS - 1;
+    auto swz = [](int row) __attribute__((always_inline)) { return X16 ? (((row >> 1) & 3) << 1) : ((row >> 1) & 7); };
     constexpr int ROWB = 128;                       // bytes of one staged row (64 pixels)
     constexpr int DY_BYTES = R * 64 * ROWB;
     constexpr int XMAIN = XR * 64 * ROWB;
@@ -2648,6 +2655,8 @@ __global__ __launch_bounds__(512, 1) void conv2d_wgrad16g_kernel(WgradParams p) 
     const int ib = tile - obk * tiles_i;
     const int o0 = obk * 64, i0 = ib * 64;
 
+    // 32x32x16: one 32 x 32 tile per tap, element e = MFMA register e; 16x16x32: element 4 (2 ob2 + ib2) + reg of the (ob2, ib2) 16 x 16 tile
+    typedef __attribute__((ext_vector_type(4))) float wf32x4;
     f32x16 acc[KK];
 #pragma unroll
     for (int t = 0; t < KK; t++)
@@ -2656,7 +2665,7 @@ __global__ __launch_bounds__(512, 1) void conv2d_wgrad16g_kernel(WgradParams p) 
 
     // ---- load maps.  Wave w stages rows (channels) 8w..8w+7 of both operands: lane = (row, slot) of an 8-row piece.
     const int prow = 8 * wave + (lane >> 3), pslot = lane & 7;
-    const int pg = pslot ^ ((prow >> 1) & 7);                                    // logical granule that lives in this slot
+    const int pg = pslot ^ swz(prow);                                            // logical granule that lives in this slot
     const int pq = p.P * p.lddy, hw = p.H * p.ldx;                                // plane strides (rows by pitch)
     // p.W also feeds per-lane offsets, so the compiler keeps it in a VGPR and then evaluates the (uniform) row addresses of the
     // x pieces on the vector pipe; an explicit scalar copy keeps them on the SALU
@@ -2770,7 +2779,7 @@ __global__ __launch_bounds__(512, 1) void conv2d_wgrad16g_kernel(WgradParams p) 
         if (f_live && vw != 0 && gw >= 0 && gw <= (TAIL ? 8 : 7) && lane < 8 * XR) {
             const int xr = lane >> 3, row = 8 * wave + (lane & 7);
             char* g = lds + f_bufa + DY_BYTES +
-                      (gw < 8 ? xr * (64 * ROWB) + row * ROWB + ((gw ^ ((row >> 1) & 7)) << 4) : XMAIN + wave * (XR * 128) + lane * 16);
+                      (gw < 8 ? xr * (64 * ROWB) + row * ROWB + ((gw ^ swz(row)) << 4) : XMAIN + wave * (XR * 128) + lane * 16);
 #pragma unroll
             for (int d = 1; d < 4; d++)
                 if (2 * d >= vw) *(unsigned*)(g + 4 * d) = 0u;
@@ -2778,18 +2787,23 @@ __global__ __launch_bounds__(512, 1) void conv2d_wgrad16g_kernel(WgradParams p) 
     };
 
     // ---- fragment read offsets inside a buffer (swizzled)
-    const int rowA = wo * 32 + r32, rowB = wi * 32 + r32;
-    const int fA = (rowA >> 1) & 7, fB = (rowB >> 1) & 7;
+    // X16: index 0 / 1 = the 16-row block (ob2 for dy, ib2 for x); lane = (row c16, granule G = 4 th + (lane >> 4)) -- rows 16 apart share
+    // the swizzle, so block 1 is block 0 + 16 rows (the tail granule of x: + 2 channel octets)
+    const int c16 = lane & 15, g4 = lane >> 4;
+    const int rowA = wo * 32 + (X16 ? c16 : r32), rowB = wi * 32 + (X16 ? c16 : r32);
+    const int fA = swz(rowA), fB = swz(rowB);
     unsigned a_off[2], x0_off[2], x1_off[2][XR];
 #pragma unroll
     for (int kq = 0; kq < 2; kq++) {
-        const int g = kq * 4 + th * 2 + h;             // 16-pixel groups interleaved over the sibling waves: th 0: 0, 2; th 1: 1, 3
-        a_off[kq] = rowA * ROWB + ((g ^ fA) << 4);
-        x0_off[kq] = DY_BYTES + rowB * ROWB + ((g ^ fB) << 4);
+        // 32x32x16: 16-pixel groups interleaved over the sibling waves: th 0: 0, 2; th 1: 1, 3
+        const int g = X16 ? 4 * th + g4 : kq * 4 + th * 2 + h;
+        const int ra = X16 ? rowA + 16 * kq : rowA, rb = X16 ? rowB + 16 * kq : rowB;
+        a_off[kq] = ra * ROWB + ((g ^ fA) << 4);
+        x0_off[kq] = DY_BYTES + rb * ROWB + ((g ^ fB) << 4);
 #pragma unroll
         for (int xr = 0; xr < XR; xr++)
-            x1_off[kq][xr] = (g + 1 < 8) ? DY_BYTES + xr * (64 * ROWB) + rowB * ROWB + (((g + 1) ^ fB) << 4)
-                                         : DY_BYTES + XMAIN + (rowB >> 3) * (XR * 128) + xr * 128 + (rowB & 7) * 16;
+            x1_off[kq][xr] = (g + 1 < 8) ? DY_BYTES + xr * (64 * ROWB) + rb * ROWB + (((g + 1) ^ fB) << 4)
+                                         : DY_BYTES + XMAIN + (rb >> 3) * (XR * 128) + xr * 128 + (rb & 7) * 16;
     }
 
     // ---- pipeline: NBUF-1 steps of loads in flight; a step's loads are waited for (counted vmcnt) before the barrier that
@@ -2844,7 +2858,70 @@ __global__ __launch_bounds__(512, 1) void conv2d_wgrad16g_kernel(WgradParams p) 
                 }
             }
         };
-        if constexpr (!TAIL) {
+        if constexpr (X16) {
+            // one K step of 32 pixels per wave: 8 iterations (x row, 16-channel block of x), each the next loads' share, one window
+            // (read one iteration ahead), its KS shifted B fragments and their MFMAs into the (o block, i block) tiles of the taps
+            typedef __attribute__((ext_vector_type(4))) float cf32x4;
+            auto mma = [&](const frag_t& av, const frag_t& bv, int t, int blk) __attribute__((always_inline)) {
+                cf32x4 c = {acc[t][4 * blk + 0], acc[t][4 * blk + 1], acc[t][4 * blk + 2], acc[t][4 * blk + 3]};
+                if constexpr (std::is_same<T, bf16_t>::value) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, c, 0, 0, 0);
+                else c = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bv, c, 0, 0, 0);
+                acc[t][4 * blk + 0] = c[0]; acc[t][4 * blk + 1] = c[1]; acc[t][4 * blk + 2] = c[2]; acc[t][4 * blk + 3] = c[3];
+            };
+            if (th * 32 >= vq) {                       // this wave's 32 pixels lie beyond the row's end: only its share of the next loads
+                issue_range(std::integral_constant<int, 0>{}, std::integral_constant<int, NPIECE>{});
+            } else if constexpr (!TAIL) {
+                frag_t a[2][R];
+#pragma unroll
+                for (int ob2 = 0; ob2 < 2; ob2++)
+#pragma unroll
+                    for (int rr = 0; rr < R; rr++) a[ob2][rr] = *(const frag_t*)(buf + a_off[ob2] + rr * (64 * ROWB));
+                static_for<0, 2 * XR>([&](auto itc) __attribute__((always_inline)) {
+                    constexpr int it = decltype(itc)::value, xr = it >> 1, ib2 = it & 1, NIT = 2 * XR;
+                    issue_range(std::integral_constant<int, (it * NPIECE) / NIT>{}, std::integral_constant<int, ((it + 1) * NPIECE) / NIT>{});
+                    const frag_t bv = *(const frag_t*)(buf + x0_off[ib2] + xr * (64 * ROWB));
+#pragma unroll
+                    for (int ob2 = 0; ob2 < 2; ob2++) mma(a[ob2][xr], bv, 0, 2 * ob2 + ib2);
+                });
+            } else {
+                frag_t a[2][R];
+#pragma unroll
+                for (int ob2 = 0; ob2 < 2; ob2++)
+#pragma unroll
+                    for (int rr = 0; rr < R; rr++) a[ob2][rr] = *(const frag_t*)(buf + a_off[ob2] + rr * (64 * ROWB));
+                uint4 lo_n = *(const uint4*)(buf + x0_off[0]);
+                uint4 hi_n = *(const uint4*)(buf + x1_off[0][0]);
+                static_for<0, 2 * XR>([&](auto itc) __attribute__((always_inline)) {
+                    constexpr int it = decltype(itc)::value, xr = it >> 1, ib2 = it & 1, NIT = 2 * XR;
+                    const uint4 lo = lo_n, hi = hi_n;
+                    if constexpr (it + 1 < NIT) {
+                        constexpr int xr1 = (it + 1) >> 1, ib1 = (it + 1) & 1;
+                        lo_n = *(const uint4*)(buf + x0_off[ib1] + xr1 * (64 * ROWB));
+                        hi_n = *(const uint4*)(buf + x1_off[ib1][xr1]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    issue_range(std::integral_constant<int, (it * NPIECE) / NIT>{}, std::integral_constant<int, ((it + 1) * NPIECE) / NIT>{});
+                    asm volatile("" : : "v"(lo.x), "v"(lo.y), "v"(lo.z));               // keep the read a full (conflict-free) b128
+                    const unsigned d[5] = {lo.w, hi.x, hi.y, hi.z, hi.w};               // pixels 8G+6 .. 8G+15 of the staged row
+#pragma unroll
+                    for (int sft = 0; sft < KS; sft++) {
+                        union { unsigned u[4]; frag_t f; } bw;
+#pragma unroll
+                        for (int w = 0; w < 4; w++)
+                            bw.u[w] = (sft == 0) ? d[w] : (sft == 1) ? __builtin_amdgcn_alignbyte(d[w + 1], d[w], 2) : d[w + 1];
+#pragma unroll
+                        for (int rr = 0; rr < R; rr++) {
+                            const int r = xr - rr;
+                            if (r >= 0 && r < KS) {
+#pragma unroll
+                                for (int ob2 = 0; ob2 < 2; ob2++) mma(a[ob2][rr], bw.f, r * KS + sft, 2 * ob2 + ib2);
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            }
+        } else if constexpr (!TAIL) {
             static_for<0, 2>([&](auto kqc) __attribute__((always_inline)) {
                 constexpr int kq = decltype(kqc)::value;
                 if ((kq * 2 + th) * 16 >= vq) {
@@ -2944,8 +3021,9 @@ __global__ __launch_bounds__(512, 1) void conv2d_wgrad16g_kernel(WgradParams p) 
         float* out = p.part + (size_t)split * p.O * p.I * KK;
 #pragma unroll
         for (int reg = 0; reg < 16; reg++) {
-            const int o = o0 + wo * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-            const int i = i0 + wi * 32 + r32;
+            // 16x16x32: element 4 (2 ob2 + ib2) + r of the (ob2, ib2) tile = row 16 ob2 + 4 (lane >> 4) + r, column 16 ib2 + (lane & 15)
+            const int o = o0 + wo * 32 + (X16 ? 16 * (reg >> 3) + 4 * g4 + (reg & 3) : (reg & 3) + 8 * (reg >> 2) + 4 * h);
+            const int i = i0 + wi * 32 + (X16 ? 16 * ((reg >> 2) & 1) + c16 : r32);
             if (o < p.O && i < p.I) {
                 float* dst = out + ((size_t)o * p.I + i) * KK;
 #pragma unroll
@@ -3453,11 +3531,17 @@ extern "C" int afcm_conv2d_wgrad_ld(float* dw, float* workspace, const void* dy,
                            if (ks == 3 && (pad & 1) == 0) hipLaunchKernelGGL((conv2d_wgrad16_kernel<T, 3, 0, NB>), grid, block, 0, st, p); \
                            else if (ks == 3) hipLaunchKernelGGL((conv2d_wgrad16_kernel<T, 3, 1, NB>), grid, block, 0, st, p); \
                            else hipLaunchKernelGGL((conv2d_wgrad16_kernel<T, 1, 0, NB>), grid, block, 0, st, p); } while (0)
-#define AFCM_WG16G(T) do { constexpr int NB = AFCM_WGRAD_NBUF; \
-                            if (small && ks == 3) hipLaunchKernelGGL((conv2d_wgrad16g_kernel<T, 3, NB, true>), grid, block, 0, st, p); \
-                            else if (small) hipLaunchKernelGGL((conv2d_wgrad16g_kernel<T, 1, NB, true>), grid, block, 0, st, p); \
-                            else if (ks == 3) hipLaunchKernelGGL((conv2d_wgrad16g_kernel<T, 3, NB, false>), grid, block, 0, st, p); \
-                            else hipLaunchKernelGGL((conv2d_wgrad16g_kernel<T, 1, NB, false>), grid, block, 0, st, p); } while (0)
+#define AFCM_WG16G_(T, X) do { constexpr int NB = AFCM_WGRAD_NBUF; \
+                            if (small && ks == 3) hipLaunchKernelGGL((conv2d_wgrad16g_kernel<T, 3, NB, true, X>), grid, block, 0, st, p); \
+                            else if (small) hipLaunchKernelGGL((conv2d_wgrad16g_kernel<T, 1, NB, true, X>), grid, block, 0, st, p); \
+                            else if (ks == 3) hipLaunchKernelGGL((conv2d_wgrad16g_kernel<T, 3, NB, false, X>), grid, block, 0, st, p); \
+                            else hipLaunchKernelGGL((conv2d_wgrad16g_kernel<T, 1, NB, false, X>), grid, block, 0, st, p); } while (0)
+    // MFMA shape (template flag X16; profiles/r05_conv_shape_ab.txt): 16x16x32 holds a higher clock on the large layers (+3 .. 6 %), but its K
+    // step is 32 pixels where the 32x32x16 form skips dead 16-pixel groups: rows whose last 64-pixel chunk holds 33 .. 48 pixels (the 38-wide
+    // planes of the 36^2 layers) cost it a whole extra step (-12 % there) -- those keep the 32x32x16 form.
+    const int q_last = p.Q % 64;
+    const bool wg_x16 = AFCM_X16_ON && !(q_last > 32 && q_last <= 48);
+#define AFCM_WG16G(T) do { if (wg_x16) AFCM_WG16G_(T, true); else AFCM_WG16G_(T, false); } while (0)
     // tensors below 2 GB: one descriptor per tensor; larger ones: a descriptor per LDS-DMA piece (the general form)
     const bool small = (long long)n * cout * p.P * p.lddy * 2 < (1ll << 31) - 65536 &&
                        (long long)n * cin * h * p.ldx * 2 < (1ll << 31) - 65536;
@@ -3470,6 +3554,7 @@ extern "C" int afcm_conv2d_wgrad_ld(float* dw, float* workspace, const void* dy,
         default: if (granule) AFCM_WG16G(bf16_t); else AFCM_WG16(bf16_t); break;
     }
 #undef AFCM_WG16G
+#undef AFCM_WG16G_
 #undef AFCM_WG16
 #undef AFCM_WG
     int rc = hip_status(hipGetLastError());

@@ -39,6 +39,10 @@ def parse():
     ap.add_argument('--cpu-baseline-worker', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--cpu-threads', type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument('--cpu-timed', type=int, default=2, help=argparse.SUPPRESS)
+    ap.add_argument('--host-threads', type=int, default=0,
+                    help='intra-op threads of this rank (torch.set_num_threads); 0 = cpu_count // (8 * ranks): the host side of a step is a '
+                         'stream of launches from ONE Python thread, and a pool of 128 OpenMP workers per rank (torch\'s default on a 256-thread '
+                         'host) only adds wake-ups -- eight ranks share that host')
     ap.add_argument('--no-kernel-timing', action='store_true', help='skip the HIP-event spans around the hot kernels')
     ap.add_argument('--kernel-timing-every', type=int, default=4,
                     help='bracket the hot launches with HIP events in every n-th timed step only (every event fences its launch: all steps '
@@ -98,17 +102,17 @@ def cpu_baseline_worker(res, batch=2, timed=2, threads=0):
 def run_cpu_baseline(res, budget=230.0):
     """Bounded CPU samples, each in a child process under its own time limit so the GPU number is never blocked: the bench resolution
     on 32 threads (1 warm-up + 2 timed iterations; the oracle's small aten ops stop scaling beyond a few dozen threads), config-1's
-    shape (128^2, BASELINE.json configs[0]: the reference's own CPU-runnable case; 1 + 1), then the bench resolution on EVERY host core
-    ("all cores"; 1 + 1) with what the budget leaves.  `value` is the FASTER point at the bench resolution; every point
-    is listed with its thread count, every sample that did not finish is named."""
+    shape (128^2, BASELINE.json configs[0]: the reference's own CPU-runnable case; 1 + 1).  `value` is the point at the bench resolution;
+    every point is listed with its thread count, every sample that did not finish or was not taken is named."""
     points, notes = [], []
     t_start = time.time()
     ncores = os.cpu_count() or 1
 
     def sample(r, threads, timed, limit):
         try:
+            env = dict(os.environ, OMP_NUM_THREADS=str(threads))          # (this process capped its own pool: the sample sets its own)
             out = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-baseline-worker', '--res', str(r), '--cpu-threads', str(threads),
-                                  '--cpu-timed', str(timed)], capture_output=True, text=True, timeout=limit, cwd=ROOT)
+                                  '--cpu-timed', str(timed)], capture_output=True, text=True, timeout=limit, cwd=ROOT, env=env)
             d = json.loads([l for l in out.stdout.splitlines() if l.startswith('{"seconds"')][-1])
             points.append(dict(resolution=r, batch=d['batch'], images_per_sec=d['images'] / d['seconds'], s_per_iteration=d['seconds'],
                                warmup_s=d['warmup_seconds'], timed_iterations=d['timed'], cores=d['cores'], cpu=d['cpu']))
@@ -120,14 +124,11 @@ def run_cpu_baseline(res, budget=230.0):
     at_res = [p for p in points if p['resolution'] == res]
     if res != 128 and budget - (time.time() - t_start) > 50.0:
         sample(128, few, 1, min(70.0, budget - (time.time() - t_start)))
-    left = budget - (time.time() - t_start)
     if ncores > few:
-        # every core: on the GPU boxes' 256-thread hosts the oracle's small aten ops run SLOWER than on 32 threads
-        # (r04: not finished in 90 s against 32 s per iteration) -- tried with what the budget leaves, reported either way
-        if left > 40.0:
-            sample(res, ncores, 1, left)
-        else:
-            notes.append(f'{res}x{res} on {ncores} threads: not tried ({left:.0f} s of the budget left)')
+        # (r03 / r04 also tried every core -- SURVEY.md 8(d) "all cores": on the GPU boxes' 256-thread hosts the oracle's small aten ops run
+        # slower than on 32 threads and the sample never finished inside 80-90 s against 31-33 s per iteration on 32; it cost every bench
+        # run ~87 s for no number, so r05 dropped it and says so here)
+        notes.append(f'{res}x{res} on all {ncores} threads: not sampled (r03/r04: did not finish in 80-90 s; 32 threads is the stated value)')
     at_res = [p for p in points if p['resolution'] == res]
     if not points:
         return dict(value=None, unit='images/sec', cores=ncores, kind='port', sample='not measured: ' + '; '.join(notes))
@@ -137,7 +138,7 @@ def run_cpu_baseline(res, budget=230.0):
                        f'batch {h["batch"]}, fwd + L1 + bwd on the GPU run\'s synthetic tensors, 1 warm-up ({h["warmup_s"]:.1f} s) + '
                        f'{h["timed_iterations"]} timed iteration(s) ({h["s_per_iteration"]:.1f} s each) on {h["cores"]} threads of {h["cpu"]} '
                        f'({ncores} cores; the faster of the thread counts in `points`)'
-                       + ('' if not notes else '; not finished: ' + '; '.join(notes)),
+                       + ('' if not notes else '; ' + '; '.join(notes)),
                 points=points)
 
 
@@ -163,8 +164,12 @@ def main():
         return
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(self_launch(args.gpus))
+    world_env = int(os.environ.get('WORLD_SIZE', 1))
+    host_threads = args.host_threads or max(1, (os.cpu_count() or 8) // (8 * world_env))
+    os.environ.setdefault('OMP_NUM_THREADS', str(host_threads))      # before torch creates its pools
     import torch
     import torch.distributed as dist
+    torch.set_num_threads(host_threads)
     from afcm_amd import layer_schedule as sched
     from afcm_amd import profiling, synthetic
     from afcm_amd.networks_stylegan3 import Stylegan3Generator
@@ -328,7 +333,7 @@ def main():
             'host_ms_per_step': host_wall / args.steps * 1e3,
             'host_cpu_ms_per_step': host_cpu / args.steps * 1e3,
             'host_threads': dict(omp_num_threads=os.environ.get('OMP_NUM_THREADS'), torch_num_threads=torch.get_num_threads(),
-                                 cpu_count=os.cpu_count(), ranks_on_host=world),
+                                 cpu_count=os.cpu_count(), ranks_on_host=world, rule='--host-threads, default cpu_count // (8 * ranks)'),
             # every AFCM_* variable set in this process's environment (they select libraries / layouts: a stray one changes what is measured)
             'env': {k: v for k, v in sorted(os.environ.items()) if k.startswith('AFCM_')},
             'higher_is_better': True,

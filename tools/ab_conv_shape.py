@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """A/B of the MFMA shape of the 16-bit 3x3 conv kernel: conv2d_fwd16_kernel (v_mfma_f32_32x32x16, K-chunks of 16
-channels) against conv2d_fwd16x_kernel (v_mfma_f32_16x16x32, chunks of 32) at the same workgroup and wave tile, per generator layer, forward
-and data gradient, on RANDOM data, both kernels in ONE library and ONE process, rounds interleaved (cdna_hip_programming.md rule 24).
+channels) against conv2d_fwd16x_kernel (v_mfma_f32_16x16x32, chunks of 32) at the same workgroup and wave tile, and conv2d_wgrad16g_kernel in
+its two shapes (X16 template flag), per generator layer: forward, data gradient and weight gradient, on RANDOM data, both kernels in ONE library and ONE process, rounds interleaved (cdna_hip_programming.md rule 24).
 Needs a library built with -DAFCM_CONV_AB (both kernels + afcm_debug_conv_variant):
     tools/build_variant.sh conv_ab conv2d.hip "-DAFCM_CONV_AB"
     AFCM_HIP_LIB=$PWD/afcm_amd/csrc/variants/conv_ab.so python tools/ab_conv_shape.py [--rounds 7]
@@ -55,7 +55,8 @@ def stamps(fn):
 
 pl = sched.plan(256, 4, 1, {})
 seen = set()
-tot = {(v, k): 0.0 for v in (0, 1) for k in ('fwd', 'dgrad')}
+KINDS = ('fwd', 'dgrad', 'wgrad')
+tot = {(v, k): 0.0 for v in (0, 1) for k in KINDS}
 flops_tot = 0.0
 print(f'# batch {a.batch}, bf16, {"zeros" if a.zeros else "random"} operands; ' + ('median shader cycles per workgroup: prologue + K loop + epilogue, clock held inside the K loop'
       if a.stamps else f'ms per launch: median of {a.rounds} interleaved rounds x {a.iters} launches; TF/s = algorithmic flops / that'))
@@ -82,6 +83,8 @@ for L in pl['enc'] + pl['dec']:
         (wp, rp), (wpt, rpt) = packs[v]
         if kind == 'fwd':
             return lambda: C._conv_raw(x, wp, rp, None, co, k, pad)
+        if kind == 'wgrad':
+            return lambda: C._wgrad_raw(y, x, co, ci, k, pad)
         return lambda: C._conv_raw(y, wpt, rpt, None, ci, k, k - 1 - pad)
 
     key = (ci, co, h)
@@ -97,8 +100,12 @@ for L in pl['enc'] + pl['dec']:
                 out.append(f'{kind} {NAMES[v]} {pro:6.0f} + {cyc:7.0f} + {epi:6.0f} cyc {ghz:4.2f} GHz')
         print(f'{L["name"]:14s} {ci:3d}->{co:3d} @{h:3d}  ' + ' | '.join(out))
         continue
+    dws = {}
+    for v in (0, 1):
+        dws[v] = run(v, 'wgrad')()
+    werr = (dws[0] - dws[1]).abs().max().item() / max(1e-9, dws[0].abs().max().item())
     res = {}
-    for kind in ('fwd', 'dgrad'):
+    for kind in KINDS:
         for v in (0, 1):
             run(v, kind)(); run(v, kind)()
         samples = {0: [], 1: []}
@@ -114,7 +121,7 @@ for L in pl['enc'] + pl['dec']:
         seen.add(key)
         print(f'{L["name"]:14s} {ci:3d}->{co:3d} @{h:3d}  ' + ' | '.join(
             f'{kind} {NAMES[0]} {res[(0, kind)]:6.3f} ms {fl / res[(0, kind)] / 1e9:6.0f} TF  {NAMES[1]} {res[(1, kind)]:6.3f} ms {fl / res[(1, kind)] / 1e9:6.0f} TF  x{res[(0, kind)] / res[(1, kind)]:.3f}'
-            for kind in ('fwd', 'dgrad')) + f'  (outputs differ by {err:.1e} of scale)')
+            for kind in KINDS) + f'  (outputs differ by {err:.1e}, weight gradients by {werr:.1e} of scale)')
 if not a.stamps:
     print('TOTAL (29 layers) ' + ' | '.join(f'{kind} {NAMES[0]} {tot[(0, kind)]:.2f} ms {flops_tot / tot[(0, kind)] / 1e9:.0f} TF  {NAMES[1]} {tot[(1, kind)]:.2f} ms '
-                                           f'{flops_tot / tot[(1, kind)] / 1e9:.0f} TF  x{tot[(0, kind)] / tot[(1, kind)]:.3f}' for kind in ('fwd', 'dgrad')))
+                                           f'{flops_tot / tot[(1, kind)] / 1e9:.0f} TF  x{tot[(0, kind)] / tot[(1, kind)]:.3f}' for kind in KINDS))
