@@ -375,8 +375,13 @@ __device__ unsigned long long afcm_conv_bar_buf[4 * 65536];    // per wave: cycl
 __device__ unsigned long long afcm_conv_rt_buf[4 * 65536];     // the 100 MHz constant clock at the same four points: shader clock = d cycles / d ticks x 100 MHz
 #define AFCM_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 65536) { afcm_conv_stamps_buf[4 * blockIdx.x + (k)] = __builtin_readcyclecounter(); \
                                                                           afcm_conv_rt_buf[4 * blockIdx.x + (k)] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+// inside the prologue of conv2d_fwd16x_kernel (wave 0): 0 = requests issued, 1 = all of them returned (an explicit vmcnt(0)), 2 = patch written
+__device__ unsigned long long afcm_conv_pro_buf[4 * 65536];
+#define AFCM_STAMP_P(k) do { if ((k) == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); \
+                             if (threadIdx.x == 0 && blockIdx.x < 65536) afcm_conv_pro_buf[4 * blockIdx.x + (k)] = __builtin_readcyclecounter(); } while (0)
 #else
 #define AFCM_STAMP(k) do { } while (0)
+#define AFCM_STAMP_P(k) do { } while (0)
 #endif
 template <typename T, int BM_O, bool SPLIT = false>
 __global__ __launch_bounds__(256, 2) void conv2d_fwd16_kernel(ConvParams p) {
@@ -951,10 +956,13 @@ __global__ __launch_bounds__(256, 2) void conv2d_fwd16x_kernel(ConvParams p) {
         issue_patch(preg1, 0, true, 1);
 #pragma unroll
         for (int q = 0; q < ARING; q++) ar[q] = load_a(0, q / MO, q % MO);
+        AFCM_STAMP_P(0);
+        AFCM_STAMP_P(1);
 #pragma unroll
         for (int c = 0; c < 8; c++) { mask_ch(preg, c); mask_ch(preg1, c); }
 #pragma unroll
         for (int e = 0; e < 4; e++) { write_px(preg, e, 0); write_px(preg1, e, 2 * PLANE_B); }
+        AFCM_STAMP_P(2);
     }
     // this lane's eight B fragments: bbyte[ti] = byte address of the fragment of the tap ROW under way in the buffer under way (tile-local
     // pixel 128 wpx + 16 ti + lane & 15, channel group lane >> 4) -- walks down the patch rows and over to the other buffer in place
@@ -3151,6 +3159,9 @@ extern "C" int afcm_debug_conv_stamps(void* dst, int n_blocks) {
 extern "C" int afcm_debug_conv_realtime(void* dst, int n_blocks) {
     return hip_status(hipMemcpyFromSymbol(dst, HIP_SYMBOL(afcm_conv_rt_buf), (size_t)n_blocks * 32, 0, hipMemcpyDeviceToHost));
 }
+extern "C" int afcm_debug_conv_prologue(void* dst, int n_blocks) {
+    return hip_status(hipMemcpyFromSymbol(dst, HIP_SYMBOL(afcm_conv_pro_buf), (size_t)n_blocks * 32, 0, hipMemcpyDeviceToHost));
+}
 extern "C" int afcm_debug_conv_barrier_cycles(void* dst, int n_blocks) {
     return hip_status(hipMemcpyFromSymbol(dst, HIP_SYMBOL(afcm_conv_bar_buf), (size_t)n_blocks * 32, 0, hipMemcpyDeviceToHost));
 }
@@ -3158,6 +3169,8 @@ extern "C" int afcm_debug_conv_stamps_clear() {
     void* a; void* b;
     if (hipGetSymbolAddress(&a, HIP_SYMBOL(afcm_conv_stamps_buf)) != hipSuccess || hipGetSymbolAddress(&b, HIP_SYMBOL(afcm_conv_bar_buf)) != hipSuccess) return AFCM_E_INVALID;
     (void)hipMemset(a, 0, sizeof(afcm_conv_stamps_buf));
+    void* c;
+    if (hipGetSymbolAddress(&c, HIP_SYMBOL(afcm_conv_pro_buf)) == hipSuccess) (void)hipMemset(c, 0, sizeof(afcm_conv_pro_buf));
     return hip_status(hipMemset(b, 0, sizeof(afcm_conv_bar_buf)));
 }
 #endif

@@ -19,12 +19,15 @@ from afcm_amd.torch_utils.ops import conv2d as C
 ap = argparse.ArgumentParser()
 ap.add_argument('--batch', type=int, default=16); ap.add_argument('--rounds', type=int, default=7); ap.add_argument('--iters', type=int, default=4)
 ap.add_argument('--stamps', action='store_true'); ap.add_argument('--zeros', action='store_true')
+ap.add_argument('--variants', default='0,1', help='two values of afcm_debug_conv_variant to compare (bit 0: 16x16x32, bit 1: row blocks fastest)')
 a = ap.parse_args()
 lib = _lib.load()
 dbg = ctypes.CDLL(_lib.LIB_PATH)
 assert hasattr(dbg, 'afcm_debug_conv_variant'), 'build conv2d.hip with -DAFCM_CONV_AB (see the docstring)'
 dt = torch.bfloat16
-NAMES = {0: '32x32x16', 1: '16x16x32'}
+VA, VB = [int(v) for v in a.variants.split(',')]
+NAMES = {0: '32x32x16', 1: '16x16x32', 3: '16x16x32/ob'}
+VMAP = {0: VA, 1: VB}
 
 
 def timed(fn, iters):
@@ -50,7 +53,14 @@ def stamps(fn):
     c, r = cyc[ok].astype(np.int64), rt[ok].astype(np.int64)
     kl, kr = c[:, 2] - c[:, 1], r[:, 2] - r[:, 1]
     good = kr > 0
-    return float(np.median(kl)), float(np.median(kl[good] / kr[good]) * 0.1), float(np.median(c[:, 1] - c[:, 0])), float(np.median(c[:, 3] - c[:, 2]))    # K loop cycles, GHz, prologue, epilogue
+    extra = ''
+    if hasattr(dbg, 'afcm_debug_conv_prologue'):
+        pro = np.zeros([nb, 4], dtype=np.uint64)
+        assert dbg.afcm_debug_conv_prologue(pro.ctypes.data_as(ctypes.c_void_p), nb) == 0
+        pr = pro[ok].astype(np.int64)
+        if (pr[:, 0] > 0).any():          # (the 16x16x32 kernel stamps its prologue: entry -> requests issued -> all returned -> patch written -> barrier)
+            extra = ' [prologue: ' + ' / '.join(f'{np.median(v):.0f}' for v in (pr[:, 0] - c[:, 0], pr[:, 1] - pr[:, 0], pr[:, 2] - pr[:, 1], c[:, 1] - pr[:, 2])) + ']'
+    return float(np.median(kl)), float(np.median(kl[good] / kr[good]) * 0.1), float(np.median(c[:, 1] - c[:, 0])), float(np.median(c[:, 3] - c[:, 2])), extra    # K loop cycles, GHz, prologue, epilogue
 
 
 pl = sched.plan(256, 4, 1, {})
@@ -71,7 +81,7 @@ for L in pl['enc'] + pl['dec']:
         x.zero_(); w.zero_()
     packs, ys = {}, {}
     for v in (0, 1):
-        assert dbg.afcm_debug_conv_variant(v) == 0
+        assert dbg.afcm_debug_conv_variant(VMAP[v]) == 0
         packs[v] = (C.pack_weights(w, dt, 0), C.pack_weights(w, dt, 1))
         ys[v] = C._conv_raw(x, packs[v][0][0], packs[v][0][1], None, co, k, pad)
     err = (ys[0].float() - ys[1].float()).abs().max().item() / max(1e-9, ys[0].float().abs().max().item())
@@ -79,7 +89,7 @@ for L in pl['enc'] + pl['dec']:
     fl = 2.0 * n * co * ci * k * k * y.shape[2] * y.shape[3]
 
     def run(v, kind):
-        dbg.afcm_debug_conv_variant(v)
+        dbg.afcm_debug_conv_variant(VMAP[v])
         (wp, rp), (wpt, rpt) = packs[v]
         if kind == 'fwd':
             return lambda: C._conv_raw(x, wp, rp, None, co, k, pad)
@@ -95,9 +105,9 @@ for L in pl['enc'] + pl['dec']:
         out = []
         for kind in ('fwd', 'dgrad'):
             for v in (0, 1):
-                dbg.afcm_debug_conv_variant(v)
-                cyc, ghz, pro, epi = stamps(run(v, kind))
-                out.append(f'{kind} {NAMES[v]} {pro:6.0f} + {cyc:7.0f} + {epi:6.0f} cyc {ghz:4.2f} GHz')
+                dbg.afcm_debug_conv_variant(VMAP[v])
+                cyc, ghz, pro, epi, extra = stamps(run(v, kind))
+                out.append(f'{kind} {NAMES[VMAP[v]]} {pro:6.0f} + {cyc:7.0f} + {epi:6.0f} cyc {ghz:4.2f} GHz{extra}')
         print(f'{L["name"]:14s} {ci:3d}->{co:3d} @{h:3d}  ' + ' | '.join(out))
         continue
     dws = {}
@@ -111,7 +121,7 @@ for L in pl['enc'] + pl['dec']:
         samples = {0: [], 1: []}
         for r in range(a.rounds):
             for v in ((0, 1) if r % 2 == 0 else (1, 0)):
-                dbg.afcm_debug_conv_variant(v)
+                dbg.afcm_debug_conv_variant(VMAP[v])
                 samples[v].append(timed(run(v, kind), a.iters))
         for v in (0, 1):
             res[(v, kind)] = float(np.median(samples[v]))
@@ -120,8 +130,8 @@ for L in pl['enc'] + pl['dec']:
     if key not in seen:
         seen.add(key)
         print(f'{L["name"]:14s} {ci:3d}->{co:3d} @{h:3d}  ' + ' | '.join(
-            f'{kind} {NAMES[0]} {res[(0, kind)]:6.3f} ms {fl / res[(0, kind)] / 1e9:6.0f} TF  {NAMES[1]} {res[(1, kind)]:6.3f} ms {fl / res[(1, kind)] / 1e9:6.0f} TF  x{res[(0, kind)] / res[(1, kind)]:.3f}'
+            f'{kind} {NAMES[VA]} {res[(0, kind)]:6.3f} ms {fl / res[(0, kind)] / 1e9:6.0f} TF  {NAMES[VB]} {res[(1, kind)]:6.3f} ms {fl / res[(1, kind)] / 1e9:6.0f} TF  x{res[(0, kind)] / res[(1, kind)]:.3f}'
             for kind in KINDS) + f'  (outputs differ by {err:.1e}, weight gradients by {werr:.1e} of scale)')
 if not a.stamps:
-    print('TOTAL (29 layers) ' + ' | '.join(f'{kind} {NAMES[0]} {tot[(0, kind)]:.2f} ms {flops_tot / tot[(0, kind)] / 1e9:.0f} TF  {NAMES[1]} {tot[(1, kind)]:.2f} ms '
+    print('TOTAL (29 layers) ' + ' | '.join(f'{kind} {NAMES[VA]} {tot[(0, kind)]:.2f} ms {flops_tot / tot[(0, kind)] / 1e9:.0f} TF  {NAMES[VB]} {tot[(1, kind)]:.2f} ms '
                                            f'{flops_tot / tot[(1, kind)] / 1e9:.0f} TF  x{tot[(0, kind)] / tot[(1, kind)]:.3f}' for kind in KINDS))
