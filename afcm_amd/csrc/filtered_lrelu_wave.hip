@@ -174,8 +174,25 @@ __global__ void flrelu_wave_prepare_kernel(char* __restrict__ wsb, const float* 
 // v_bfe to re-align quads), a third of the registers for codes -- the general READ kernels retired 8.6 vector instructions per
 // MFMA against 5.8 in the forward (profiles/r02_bench_pmc.txt) and were 56 % of the family's time.
 constexpr int kSignsReadAligned = 3;
+// LDS of one workgroup (4 waves) of flrelu_wave_kernel: keep-mask table, output staging, skip staging, input ring (the arrays declared
+// at the top of the kernel), and the workgroups per CU = waves per SIMD that the 160 KB allow.  The register target of a variant
+// (__launch_bounds__) is the tuning aid's (AFCM_WAVE_OCC_*) capped by that: asking for more than the LDS admits only made the compiler
+// report a missed occupancy target on 14 variants (r04 build log) -- the 48-row strips (66 KB) and the skip variants (56 KB) run two
+// workgroups per CU, the down-4 strips (74 KB) two, their skip variants (84 KB) one, whatever the register count.
+template <int UP, int DOWN, int TOW, int TOH, int SIGN, int EPI>
+constexpr int wave_lds_bytes() {
+    typedef WaveGeom<UP, DOWN, TOW, TOH> G;
+    constexpr bool RD = SIGN == AFCM_SIGNS_READ || SIGN == kSignsReadAligned;
+    return (RD ? 2048 : 8) + 4 * TOH * 144 + ((EPI & 2) ? 4 * TOH * 80 : 16) + 4 * 16 * G::NMB * 144;
+}
+template <int UP, int DOWN, int TOW, int TOH, int SIGN, int EPI>
+constexpr int wave_occupancy() {
+    constexpr int want = (DOWN == 2 && (TOH <= 32 || SIGN == AFCM_SIGNS_READ || SIGN == kSignsReadAligned)) ? AFCM_WAVE_OCC_D2 : AFCM_WAVE_OCC_D4;
+    constexpr int fit = (160 * 1024) / wave_lds_bytes<UP, DOWN, TOW, TOH, SIGN, EPI>();
+    return fit < 1 ? 1 : (fit < want ? fit : want);
+}
 template <typename T, int UP, int DOWN, int TOW, int TOH, int SIGN, int EPI>
-__global__ __launch_bounds__(256, (DOWN == 2 && (TOH <= 32 || SIGN == AFCM_SIGNS_READ || SIGN == kSignsReadAligned) ? AFCM_WAVE_OCC_D2 : AFCM_WAVE_OCC_D4)) void flrelu_wave_kernel(FlreluMfmaParams p) {
+__global__ __launch_bounds__(256, (wave_occupancy<UP, DOWN, TOW, TOH, SIGN, EPI>())) void flrelu_wave_kernel(FlreluMfmaParams p) {
     typedef WaveGeom<UP, DOWN, TOW, TOH> G;
     typedef MfmaOps<T> M;
     typedef typename M::frag frag;
@@ -586,14 +603,14 @@ __global__ __launch_bounds__(256, (DOWN == 2 && (TOH <= 32 || SIGN == AFCM_SIGNS
             }
             // READ: the codes of this block's X2 tiles
             unsigned codes[G::NVB];
-            if (RA) {
+            if constexpr (RA) {
                 // a byte of the funnel-shifted runs (top of the group) each
 #pragma unroll
                 for (int k = 0; k < NA; k++)
 #pragma unroll
                     for (int j = 0; j < 4; j++)
                         if (4 * k + j < G::NVB) codes[4 * k + j] = __builtin_amdgcn_ubfe(four[nbl][k], 8 * j, 8);
-            } else if (RD) {
+            } else if constexpr (RD) {
 #pragma unroll
                 for (int i = 0; i <= NA; i++) anyc |= sg[nbl][0][i] | sg[nbl][1][i];
 #pragma unroll

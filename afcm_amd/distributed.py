@@ -54,7 +54,7 @@ import torch.distributed as dist
 
 class GradientBuckets:
     def __init__(self, params, bucket_bytes=25 * 1024 * 1024, process_group=None, comm_dtype=None, force=False, passes=1,
-                 static_graph=True, rebucket=True):
+                 static_graph=True, rebucket=True, tail_bytes=None, tail_bucket_bytes=None):
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.active = self.world > 1 or (force and dist.is_initialized())   # force: exercise the hooks/collectives on one rank
@@ -65,6 +65,12 @@ class GradientBuckets:
             raise ValueError('passes must be >= 1')
         self.static_graph = bool(static_graph)
         self.bucket_bytes = bucket_bytes
+        # The gradients that become final LAST are reduced with nothing left to hide behind: the last `tail_bytes` of the bucket order
+        # go into buckets of at most `tail_bucket_bytes` (defaults: 1.25 buckets' worth in eighths of a bucket), so that what is issued
+        # in the final milliseconds of backward -- and at its end -- is small (r04's rehearsal timeline: a 25.9 MB bucket 3.5 ms before
+        # the end of backward and a 9 MB one at the end; VERDICT r04 #7: nothing above 8 MB in the last 5 ms)
+        self.tail_bytes = int(bucket_bytes * 1.25) if tail_bytes is None else int(tail_bytes)
+        self.tail_bucket_bytes = max(1, bucket_bytes // 8) if tail_bucket_bytes is None else int(tail_bucket_bytes)
         self._rebucket = bool(rebucket)
         self._arrival = []          # first iteration: parameters in the order their gradients became final
         self._build(list(reversed(self.params)))
@@ -91,14 +97,21 @@ class GradientBuckets:
     def _build(self, ordered):
         self._buckets = []          # dicts: params, flat, comm, offs, count, pending, launched, handle, redo
         self._where = {}            # parameter -> (bucket index, position inside the bucket)
-        cur, cur_bytes = [], 0
-        for p in ordered:
-            nbytes = p.numel() * p.element_size()
-            if cur and cur_bytes + nbytes > self.bucket_bytes:
+        cur, cur_bytes, cur_in_tail = [], 0, False
+        sizes = [p.numel() * p.element_size() for p in ordered]
+        left = sum(sizes)                              # bytes from this parameter to the end of the order
+        for p, nbytes in zip(ordered, sizes):
+            in_tail = left <= self.tail_bytes
+            limit = self.tail_bucket_bytes if in_tail else self.bucket_bytes
+            # (the first tail parameter also closes the big bucket under way: a tail bucket never starts inside one)
+            if cur and (cur_bytes + nbytes > limit or (in_tail and not cur_in_tail)):
                 self._add_bucket(cur)
                 cur, cur_bytes = [], 0
+            if not cur:
+                cur_in_tail = in_tail
             cur.append(p)
             cur_bytes += nbytes
+            left -= nbytes
         if cur:
             self._add_bucket(cur)
         self._order = [p for b in self._buckets for p in b['params']]

@@ -109,27 +109,30 @@ class DiscriminatorBlock(torch.nn.Module):
             self.skip = Conv2dLayer(tmp_channels, out_channels, kernel_size=1, bias=False, down=2, trainable=next(trainable_iter),
                                     resample_filter=resample_filter)
 
+    def _checked(self, t, channels):
+        if list(t.shape[1:]) != [channels, self.resolution, self.resolution]:
+            raise AssertionError(f'b{self.resolution}: expected [N, {channels}, {self.resolution}, {self.resolution}], got {list(t.shape)}')
+        return t
+
     def forward(self, x, img, force_fp32=False):
-        dtype = self.fp16_dtype if self.use_fp16 and not force_fp32 else torch.float32       # generator.py:662
-        if x is not None:
-            assert list(x.shape[1:]) == [self.in_channels, self.resolution, self.resolution]
-            x = x.to(dtype)
+        """generator.py:661-692: (features or None, image) -> (features at half the resolution, the image the next block takes or None).
+        Restated, not mirrored: the image branch first (what the block takes in), then the trunk by architecture."""
+        dtype = torch.float32 if (force_fp32 or not self.use_fp16) else self.fp16_dtype
+        feat = None if x is None else self._checked(x, self.in_channels).to(dtype)
         if self.in_channels == 0 or self.architecture == 'skip':
-            assert list(img.shape[1:]) == [self.img_channels, self.resolution, self.resolution]
-            img = img.to(dtype)
-            y = self.fromrgb(img)
-            x = x + y if x is not None else y
-            img = upfirdn2d.downsample2d(img, self.resample_filter) if self.architecture == 'skip' else None
-        if self.architecture == 'resnet':
-            y = self.skip(x, gain=np.sqrt(0.5))
-            x = self.conv0(x)
-            x = self.conv1(x, gain=np.sqrt(0.5))
-            x = y.add_(x)
+            rgb = self._checked(img, self.img_channels).to(dtype)
+            from_img = self.fromrgb(rgb)
+            feat = from_img if feat is None else feat + from_img
+            # only the 'skip' architecture hands a (half-resolution) image on to the next block
+            img = upfirdn2d.downsample2d(rgb, self.resample_filter) if self.architecture == 'skip' else None
+        if self.architecture != 'resnet':
+            out = self.conv1(self.conv0(feat))
         else:
-            x = self.conv0(x)
-            x = self.conv1(x)
-        assert x.dtype == dtype
-        return x, img
+            half = np.sqrt(0.5)                    # shortcut and trunk each carry sqrt(1/2): unit variance after the sum
+            shortcut = self.skip(feat, gain=half)
+            out = shortcut.add_(self.conv1(self.conv0(feat), gain=half))
+        assert out.dtype == dtype
+        return out, img
 
 
 class MinibatchStdLayer(torch.nn.Module):
@@ -175,18 +178,21 @@ class DiscriminatorEpilogue(torch.nn.Module):
         self.out = FullyConnectedLayer(in_channels, 1 if cmap_dim == 0 else cmap_dim)
 
     def forward(self, x, img, cmap, force_fp32=False):
-        assert list(x.shape[1:]) == [self.in_channels, self.resolution, self.resolution]
-        x = x.to(torch.float32)
+        """generator.py:755-776, always in float32: (+ the image through fromrgb, 'skip' only) -> minibatch std -> 3x3 conv -> two FC
+        layers; with a label, the ``cmap_dim`` outputs are projected onto the mapped label (scaled by cmap_dim^-1/2)."""
+        want = [self.in_channels, self.resolution, self.resolution]
+        assert list(x.shape[1:]) == want, f'b{self.resolution}: expected [N, {want}], got {list(x.shape)}'
+        feat = x.to(torch.float32)
         if self.architecture == 'skip':
-            x = x + self.fromrgb(img.to(torch.float32))
+            assert list(img.shape[1:]) == [self.img_channels, self.resolution, self.resolution]
+            feat = feat + self.fromrgb(img.to(torch.float32))
         if self.mbstd is not None:
-            x = self.mbstd(x)
-        x = self.conv(x)
-        x = self.fc(x.flatten(1))
-        x = self.out(x)
+            feat = self.mbstd(feat)
+        logits = self.out(self.fc(self.conv(feat).flatten(1)))
         if self.cmap_dim > 0:
-            x = (x * cmap).sum(dim=1, keepdim=True) * (1 / np.sqrt(self.cmap_dim))
-        return x
+            assert list(cmap.shape[1:]) == [self.cmap_dim]
+            logits = (logits * cmap).sum(dim=1, keepdim=True) * (1 / np.sqrt(self.cmap_dim))
+        return logits
 
 
 class MappingNetwork(torch.nn.Module):

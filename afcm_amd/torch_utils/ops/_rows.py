@@ -12,13 +12,13 @@ and write it in place.  Rules of the layout:
   fills them with finite values (the weight gradient multiplies the head of dy's padding by zeros, include/afcm_hip.h).
 * a tensor that is neither dense nor of exactly this form is made contiguous (``rows``).
 """
-import os
-
 import torch
 
-ROW_BYTES = int(os.environ.get('AFCM_ROW_PITCH_BYTES', '64'))        # tuning aid: rows padded to multiples of this (>= 16)
-MAX_OVERHEAD = float(os.environ.get('AFCM_ROW_PITCH_OVERHEAD', '0.10'))
-ENABLED = os.environ.get('AFCM_ROW_PITCH', '1') != '0'      # tuning aid: 0 = dense tensors everywhere
+# Module attributes, not environment switches (r05: the package reads ONE environment variable, AFCM_HIP_LIB in _lib.py, which selects an
+# experimental build of the library; the measurements these three were set for are in docs/history_r01-r03.md) -- tools set them directly.
+ROW_BYTES = 64          # rows padded to multiples of this (>= 16)
+MAX_OVERHEAD = 0.10     # ... unless that pads a row by more than this fraction
+ENABLED = True          # False = dense tensors everywhere
 
 
 def pitch_for(w, dtype):

@@ -8,7 +8,6 @@ differentiable), the contraction is the framework's convolution exactly where th
 discriminator needs stride-2 convolutions and a double backward (R1, models/comodgan_model.py:143-147), neither of which the
 generator's MFMA conv kernels provide; padding is applied once at the beginning, not between the operations.
 """
-import os
 
 import torch
 import torch.nn.functional as F
@@ -17,7 +16,7 @@ from . import conv2d as _conv
 from . import upfirdn2d
 
 USE_MFMA_CONV = True      # module switch: False routes every convolution to the framework (A/B and debugging)
-NATIVE_STRIDE2 = os.environ.get('AFCM_NATIVE_STRIDE2', '1') != '0'     # 16-bit 3x3 stride-2 convolutions on the stride-2 MFMA kernel (False: the stride-1 result decimated, the r01/r02 route)
+NATIVE_STRIDE2 = True     # (module attribute, no environment switch)  16-bit 3x3 stride-2 convolutions on the stride-2 MFMA kernel (False: the stride-1 result decimated, the r01/r02 route)
 MFMA_CONV_FP32 = False    # fp32 activations too: correct, but the stride-by-decimation waste makes it slower than the framework's
                           # fp32 convolution over the whole D update (151.7 vs 148 ms, batch 16); the 16-bit blocks gain 2x (69 vs 139 ms)
 

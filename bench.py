@@ -152,7 +152,7 @@ def self_launch(n):
            os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or n) // n)))
+    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 8 * n) // (8 * n))))      # the rule of --host-threads (main())
     print(f'bench.py: --gpus {n} without a launcher, starting: {" ".join(cmd)}', file=sys.stderr, flush=True)
     return subprocess.call(cmd, env=env, cwd=os.getcwd())
 

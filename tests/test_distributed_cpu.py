@@ -402,3 +402,85 @@ def test_four_ranks_with_ragged_per_rank_batches_match_the_full_batch(tmp_path):
             assert torch.allclose(g[r][n], w, rtol=1e-5, atol=1e-7), (n, r, (g[r][n] - w).abs().max().item())
             assert torch.equal(g[r][n], g[0][n]), f'{n}: rank {r} differs from rank 0'
     assert torch.load(tmp_path / 'nb0.pt') > 1
+
+
+def _worker_world8(rank, world, port, sizes, out_dir):
+    _init(rank, world, port)
+    from afcm_amd.distributed import GradientBuckets
+    torch.manual_seed(0)
+    # a deeper model than _model(): enough parameters for several regular buckets AND a tail of small ones; the last layer is used by
+    # the even ranks only except on rank 3, which never uses `extra` at all
+    m = torch.nn.Sequential(torch.nn.Linear(16, 96), torch.nn.LeakyReLU(0.2), torch.nn.Linear(96, 96), torch.nn.LeakyReLU(0.2),
+                            torch.nn.Linear(96, 64), torch.nn.LeakyReLU(0.2), torch.nn.Linear(64, 4))
+    extra = torch.nn.Linear(4, 4, bias=False)
+    params = list(extra.parameters()) + list(m.parameters())      # registered first, produced first: the arrival-order rebuild moves it
+    buckets = GradientBuckets(params, bucket_bytes=16384, static_graph=False)
+    buckets.broadcast_parameters(m)
+    buckets.broadcast_parameters(extra)
+    torch.manual_seed(99)
+    total = sum(sizes)
+    x, y = torch.randn(total, 16), torch.randn(total, 4)
+    lo = sum(sizes[:rank])
+    xs, ys = x[lo:lo + sizes[rank]], y[lo:lo + sizes[rank]]
+    layouts = []
+    pid = {id(p): i for i, p in enumerate(params)}
+    for it in range(3):
+        for p in params:
+            p.grad = None
+        out = m(xs)
+        if rank % 2 == 0 and rank != 3:
+            out = out + 0.1 * extra(out)
+        loss = (out - ys).abs().sum() * (world / total)      # sum over the rank's samples x world / N: the buckets' 1 / world makes it the mean over samples
+        loss.backward()
+        buckets.finish()
+        layouts.append([[pid[id(p)] for p in b['params']] for b in buckets._buckets])
+    torch.save(dict(grads=[None if p.grad is None else p.grad.clone() for p in params], layouts=layouts,
+                    bytes=[sum(p.numel() * 4 for p in b['params']) for b in buckets._buckets], counts=[len(b['params']) for b in buckets._buckets],
+                    tail=(buckets.tail_bytes, buckets.tail_bucket_bytes)), os.path.join(out_dir, f'w8_{rank}.pt'))
+    dist.destroy_process_group()
+
+
+def test_eight_ranks_ragged_batches_unused_parameter_and_tail_buckets(tmp_path):
+    """World size 8 (the driver's scaling run is 8 ranks on one node): per-rank batches 3/2/2/1/2/1/3/2, one parameter used by
+    some ranks only, three iterations (the buckets are rebuilt in gradient-arrival order after the first): every rank ends with the
+    gradient of the mean loss over all 16 samples, bit-identical across ranks; the bucket LAYOUT is identical on all ranks in every
+    iteration (it decides the order of the collectives); and the last `tail_bytes` of the order sit in buckets of at most
+    `tail_bucket_bytes` (what is reduced at the end of backward has nothing left to overlap with: keep it small)."""
+    world, sizes = 8, (3, 2, 2, 1, 2, 1, 3, 2)
+    mp.spawn(_worker_world8, args=(world, _free_port(), sizes, str(tmp_path)), nprocs=world, join=True)
+    res = [torch.load(tmp_path / f'w8_{r}.pt') for r in range(world)]
+    for r in range(1, world):
+        assert res[r]['layouts'] == res[0]['layouts'], f'rank {r}: bucket layout differs from rank 0'
+        for a, b in zip(res[r]['grads'], res[0]['grads']):
+            assert (a is None) == (b is None) and (a is None or torch.equal(a, b)), f'rank {r}: gradients differ from rank 0'
+    assert res[0]['layouts'][0] != res[0]['layouts'][2], 'the arrival-order rebuild did not happen'
+    # reference: one process, all 16 samples
+    torch.manual_seed(0)
+    m = torch.nn.Sequential(torch.nn.Linear(16, 96), torch.nn.LeakyReLU(0.2), torch.nn.Linear(96, 96), torch.nn.LeakyReLU(0.2),
+                            torch.nn.Linear(96, 64), torch.nn.LeakyReLU(0.2), torch.nn.Linear(64, 4))
+    extra = torch.nn.Linear(4, 4, bias=False)
+    torch.manual_seed(99)
+    x, y = torch.randn(sum(sizes), 16), torch.randn(sum(sizes), 4)
+    out = m(x)
+    use = torch.zeros(sum(sizes), 1)
+    lo = 0
+    for r, n in enumerate(sizes):
+        if r % 2 == 0 and r != 3:
+            use[lo:lo + n] = 1.0
+        lo += n
+    out = out + 0.1 * extra(out) * use
+    ((out - y).abs().sum() / sum(sizes)).backward()
+    want = [p.grad for p in list(extra.parameters()) + list(m.parameters())]
+    for i, (g, w) in enumerate(zip(res[0]['grads'], want)):
+        assert g is not None and torch.allclose(g, w, rtol=1e-5, atol=1e-7), (i, None if g is None else (g - w).abs().max().item())
+    # tail: walking the bucket list from the end, everything inside the last tail_bytes is in buckets <= tail_bucket_bytes
+    tail_bytes, tail_bucket = res[0]['tail']
+    nbytes = res[0]['bytes']
+    assert len(nbytes) >= 4
+    acc = 0
+    for b, k in zip(reversed(nbytes), reversed(res[0]['counts'])):
+        if acc + b > tail_bytes:
+            break
+        assert b <= tail_bucket or k == 1, (b, k)       # (a single parameter larger than the limit is a bucket of its own)
+        acc += b
+    assert acc > 0, 'no tail bucket at all'

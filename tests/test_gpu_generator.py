@@ -299,7 +299,7 @@ def test_full_width_generator_fp32_matches_oracle():
         y16 = G16.cuda()(z.cuda(), c.cuda(), real_A.cuda()).float().cpu()
     ps = synthetic.psnr(y16, ref)
     print(f'full-width bf16: max-abs {(y16 - ref).abs().max().item():.3e}, PSNR vs fp32 oracle {ps:.1f} dB')
-    assert ps >= 30.0
+    assert ps >= 44.5, ps          # measured 46.5 dB (r03-r05); the bound is the measurement - 2 dB (30 dB let a 16 dB regression pass)
 
 
 def test_full_width_16bit_accuracy_budget():
@@ -308,7 +308,7 @@ def test_full_width_16bit_accuracy_budget():
     P_t <= 32.6 dB needs P_e >= 52 dB.  Measured on the full-width 256^2 generator (the fp32 GPU forward is itself within 2e-6
     of the CPU oracle, test_full_width_generator_fp32_matches_oracle): fp16 must meet the budget -- it is what `test()` /
     `forward_ema()` use when training runs in bf16 (StyleGAN3GeneratorStep(eval_dtype='auto')); bf16 is reported, bounded below
-    at 40 dB, and is a training-throughput dtype only."""
+    at its measurement - 2 dB, and is a training-throughput dtype only."""
     import copy
     import math
     from afcm_amd import synthetic
@@ -328,11 +328,12 @@ def test_full_width_16bit_accuracy_budget():
     ps16, psb = synthetic.psnr(out[torch.float16], out[torch.float32]), synthetic.psnr(out[torch.bfloat16], out[torch.float32])
     cost = lambda pe, pt: 10 * math.log10(1 + 10 ** ((pt - pe) / 10))
     print(f'full-width vs fp32: fp16 {ps16:.1f} dB (costs {cost(ps16, 32.6):.3f} dB at a 32.6 dB task), bf16 {psb:.1f} dB ({cost(psb, 32.6):.3f} dB)')
-    assert ps16 >= 52.0, ps16
-    assert psb >= 40.0, psb
+    # the budget needs 52 dB; the bounds are the measurements (fp16 69 dB, bf16 46.5 dB) - 2 dB, so that a regression shows long before the budget
+    assert ps16 >= 67.0, ps16
+    assert psb >= 44.5, psb
     step = StyleGAN3GeneratorStep(G, ema=True)                               # training dtype bf16 -> evaluation copy in fp16
     assert step.netG_ema.synthesis.compute_dtype == torch.float16 and G.synthesis.compute_dtype == torch.bfloat16
     step.set_input(a, torch.zeros(4, 1, 256, 256), z, c)
     step.test()
-    assert synthetic.psnr(step.fake_B.float().cpu(), out[torch.float32]) >= 52.0
+    assert synthetic.psnr(step.fake_B.float().cpu(), out[torch.float32]) >= 67.0
     assert StyleGAN3GeneratorStep(G, ema=True, eval_dtype=torch.float32).netG_ema.synthesis.compute_dtype == torch.float32
