@@ -172,13 +172,27 @@ _SPLIT_TERMS = {           # (part of the activations, part of the weights) per 
 }
 
 
-def _split_plan(x, ks):
+def _parts_fit(shape):
+    """The parts of a [N, C, H, W] tensor (up to three, each the tensor's size rounded up to 4 elements, 2 bytes per element) lie inside
+    the split kernel's 2^31-byte scalar offsets (afcm_conv2d_split: (parts - 1) * part stride + one image < 2^31 bytes)."""
+    n, c, h, w = [int(v) for v in shape]
+    numel = n * c * h * w
+    return (numel + 3) // 4 * 4 * 2 * 2 + c * h * w * 2 < (1 << 31)
+
+
+def _split_plan(x, ks, cout=None, padding=None):
     """The split-operand route takes fp32 tensors on the GPU, 3x3 kernels, even widths and parts inside the kernel's 2^31-byte
-    scalar offsets."""
+    scalar offsets -- of the input AND, when ``cout`` / ``padding`` say what the output is, of the gradient the backward will split
+    (ADVICE r04: a conv whose forward fitted but whose dy [N, cout, P, Q] did not failed in backward with "part stride out of range";
+    decided here it takes the native fp32 kernels in both directions instead)."""
     if FP32_SPLIT is None or x.dtype != torch.float32 or ks != 3 or x.device.type != 'cuda' or x.ndim != 4 or x.shape[3] % 2:
         return None
-    if (x.numel() + 3) // 4 * 4 * 2 * 2 + x[0].numel() * 2 >= (1 << 31):
+    if not _parts_fit(x.shape):
         return None
+    if cout is not None and padding is not None:
+        p, q = x.shape[2] + 2 * padding - 2, x.shape[3] + 2 * padding - 2
+        if q % 2 or not _parts_fit((x.shape[0], cout, p, q)):
+            return None
     return FP32_SPLIT
 
 
@@ -407,7 +421,7 @@ class _ScaledConv2d(torch.autograd.Function):
         # prescaled: the producer of x already applied in_scale (fused into its epilogue) and owns the gradient of in_scale
         # a backward that will need the data gradient gets its (transposed, flipped) weight image from the same launch
         ctx.wpt = None
-        plan = _split_plan(x, ks)
+        plan = _split_plan(x, ks, cout, padding)
         if plan is not None:
             # fp32 on the 16-bit matrix pipe.  The style factor is applied while splitting; the unscaled x is what the backward keeps
             dt, tf = plan[0], plan[1]

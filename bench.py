@@ -267,6 +267,24 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
 
+    # launches per step (rank 0, one extra untimed step under the framework's kernel tracer): total, the three hot families, the rest
+    launches = None
+    if rank != 0:
+        one_step()                      # (every rank runs the step: it carries the collectives)
+        torch.cuda.synchronize()
+    else:
+        try:
+            import collections
+            from torch.profiler import profile, ProfilerActivity
+            with profile(activities=[ProfilerActivity.CUDA]) as prof:
+                one_step()
+                torch.cuda.synchronize()
+            names = [e.name for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA and 'Memcpy' not in e.name and 'Memset' not in e.name]
+            fam = collections.Counter('conv2d' if ('conv2d_fwd' in n) else 'conv2d_wgrad' if 'conv2d_wgrad' in n else 'filtered_lrelu' if ('flrelu_wave' in n or 'flrelu_mfma_kernel' in n or 'flrelu_strip' in n or 'flrelu_sep' in n) else
+                                      'other_afcm' if 'afcm' in n else 'framework' for n in names)
+            launches = dict(total=len(names), **fam, outside_the_three_families=fam['other_afcm'] + fam['framework'])
+        except Exception as e:          # the tracer is an aid: never lose the bench line to it
+            launches = dict(error=f'{type(e).__name__}: {e}')
     bucket_timeline = None
     if use_dist and step.buckets is not None and getattr(step, 'phase_events', None):
         # where in the backward pass of the last TIMED step each gradient bucket's all-reduce was issued (GPU timeline of this rank;
@@ -332,6 +350,7 @@ def main():
             # both well below ms_per_step = the GPU is the limiter and the host runs ahead
             'host_ms_per_step': host_wall / args.steps * 1e3,
             'host_cpu_ms_per_step': host_cpu / args.steps * 1e3,
+            'launches_per_step': launches,
             'host_threads': dict(omp_num_threads=os.environ.get('OMP_NUM_THREADS'), torch_num_threads=torch.get_num_threads(),
                                  cpu_count=os.cpu_count(), ranks_on_host=world, rule='--host-threads, default cpu_count // (8 * ranks)'),
             # every AFCM_* variable set in this process's environment (they select libraries / layouts: a stray one changes what is measured)
