@@ -15,7 +15,7 @@ and write it in place.  Rules of the layout:
 import torch
 
 # Module attributes, not environment switches (r05: the package reads ONE environment variable, AFCM_HIP_LIB in _lib.py, which selects an
-# experimental build of the library; the measurements these three were set for are in docs/history_r01-r03.md) -- tools set them directly.
+# experimental build of the library; the measurements these three were set for are in docs/history_r01-r04.md) -- tools set them directly.
 ROW_BYTES = 64          # rows padded to multiples of this (>= 16)
 MAX_OVERHEAD = 0.10     # ... unless that pads a row by more than this fraction
 ENABLED = True          # False = dense tensors everywhere

@@ -267,6 +267,17 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
 
+    bucket_timeline = None
+    if use_dist and step.buckets is not None and getattr(step, 'phase_events', None):
+        # where in the backward pass of the last TIMED step each gradient bucket's all-reduce was issued (GPU timeline of this rank;
+        # a one-rank run has no peer to exchange with, the N-rank runs overlap from these points on)
+        pe = step.phase_events
+        bwd_ms = pe['backward'].elapsed_time(pe['finish'])
+        bucket_timeline = dict(step='last timed step', forward_ms=pe['forward'].elapsed_time(pe['backward']), backward_ms=bwd_ms,
+                               finish_and_optimizer_ms=pe['finish'].elapsed_time(pe['end']),
+                               buckets=[dict(bucket=i, mbytes=round(nb / 1e6, 1), issued_at_ms=round(pe['backward'].elapsed_time(e), 2),
+                                             backward_left_ms=round(bwd_ms - pe['backward'].elapsed_time(e), 2)) for i, nb, e in step.buckets.trace])
+        step.buckets.trace = step.phase_events = None
     # launches per step (rank 0, one extra untimed step under the framework's kernel tracer): total, the three hot families, the rest
     launches = None
     if rank != 0:
@@ -285,17 +296,6 @@ def main():
             launches = dict(total=len(names), **fam, outside_the_three_families=fam['other_afcm'] + fam['framework'])
         except Exception as e:          # the tracer is an aid: never lose the bench line to it
             launches = dict(error=f'{type(e).__name__}: {e}')
-    bucket_timeline = None
-    if use_dist and step.buckets is not None and getattr(step, 'phase_events', None):
-        # where in the backward pass of the last TIMED step each gradient bucket's all-reduce was issued (GPU timeline of this rank;
-        # a one-rank run has no peer to exchange with, the N-rank runs overlap from these points on)
-        pe = step.phase_events
-        bwd_ms = pe['backward'].elapsed_time(pe['finish'])
-        bucket_timeline = dict(step='last timed step', forward_ms=pe['forward'].elapsed_time(pe['backward']), backward_ms=bwd_ms,
-                               finish_and_optimizer_ms=pe['finish'].elapsed_time(pe['end']),
-                               buckets=[dict(bucket=i, mbytes=round(nb / 1e6, 1), issued_at_ms=round(pe['backward'].elapsed_time(e), 2),
-                                             backward_left_ms=round(bwd_ms - pe['backward'].elapsed_time(e), 2)) for i, nb, e in step.buckets.trace])
-        step.buckets.trace = step.phase_events = None
     if rank == 0:
         fams = profiling.summary()
         kernels = {}
