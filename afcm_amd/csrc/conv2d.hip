@@ -60,7 +60,8 @@ static int g_conv_x16 = AFCM_CONV_X16;
 static inline int conv_bk(int dtype, int ks);
 
 constexpr int kPatchMax = 416;   // LDS patch capacity in pixels
-constexpr int kPatchMaxX16 = 412; // ... of conv2d_fwd16x_kernel (planes of kPatchMax pixels, the last four a sink)
+constexpr int kPlaneX16 = 416;    // pixels per channel-group plane of conv2d_fwd16x_kernel (a multiple of 16: planes 256 bytes apart) ...
+constexpr int kPatchMaxX16 = kPlaneX16 - 4; // ... of which the patch may use all but the last four (the sink of the staging threads past the plane)
 constexpr int kPatchMaxS2 = 704; // ... of the stride-2 kernel (two staging items per thread: <= 1024)
 constexpr int kSlots = 256;      // output pixels per workgroup
 
@@ -75,6 +76,7 @@ struct ConvParams {
     int pad;
     int TH, TW, PWL, tilesX, tilesY;
     int Opad, nkc;
+    int total_blocks;     // conv2d_fwd16x_kernel (persistent workgroups): work items = tiles x images x row blocks; the grid may be smaller
     unsigned magicTW;     // ceil(2^32 / TW): j / TW = umulhi(j, magicTW) for the tile-local pixel indices (j < 2^16)
     unsigned magicTX, magicTY, magicN, magicPC;   // ... / tilesX, tilesY, N (block index decode: dividend x divisor < 2^32), / (PWL / 4)
     // split-precision form (conv2d_fwd16_kernel<bf16, BM, true>): x holds `parts` bf16 tensors [N, Cin, H, ldx] part_bytes apart,
@@ -379,9 +381,13 @@ __device__ unsigned long long afcm_conv_rt_buf[4 * 65536];     // the 100 MHz co
 __device__ unsigned long long afcm_conv_pro_buf[4 * 65536];
 #define AFCM_STAMP_P(k) do { if ((k) == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); \
                              if (threadIdx.x == 0 && blockIdx.x < 65536) afcm_conv_pro_buf[4 * blockIdx.x + (k)] = __builtin_readcyclecounter(); } while (0)
+// (the persistent kernel stamps per TILE: slot = the work item; a workgroup's first tile carries the prologue)
+#define AFCM_STAMP_I(k, it) do { if (threadIdx.x == 0 && (it) < 65536) { afcm_conv_stamps_buf[4 * (it) + (k)] = __builtin_readcyclecounter(); \
+                                                                          afcm_conv_rt_buf[4 * (it) + (k)] = __builtin_amdgcn_s_memrealtime(); } } while (0)
 #else
 #define AFCM_STAMP(k) do { } while (0)
 #define AFCM_STAMP_P(k) do { } while (0)
+#define AFCM_STAMP_I(k, it) do { } while (0)
 #endif
 template <typename T, int BM_O, bool SPLIT = false>
 __global__ __launch_bounds__(256, 2) void conv2d_fwd16_kernel(ConvParams p) {
@@ -830,89 +836,117 @@ template <typename T, int BM_O, bool SPLIT = false>
 __global__ __launch_bounds__(256, 2) void conv2d_fwd16x_kernel(ConvParams p) {
     static_assert(sizeof(T) == 2, "16-bit types only");
     typedef typename std::conditional<SPLIT, float, T>::type TO;      // output element
-    constexpr int KS = 3, KK = 9, BK = 32, MO = BM_O / 32, NT = 8, BRING = 4;
+    // B fragments: a ring read BRING 16-pixel blocks ahead of their MFMAs.  MO = 4: four (a block = 64 MFMA cycles); MO = 2: three -- a block
+    // is 32 cycles, but the three waves of a SIMD take turns, and the fourth slot is the register that decides between 168 (three waves
+    // per SIMD) and 169
+    constexpr int KS = 3, KK = 9, BK = 32, MO = BM_O / 32, NT = 8, BRING = MO == 4 ? 4 : 3;
     // weight-fragment ring, in fragments: a chunk's KK * MO fragments (tap-major) cycle through ARING slots.  MO = 4: 9 slots = 2.25 taps
     // (3 taps = 48 registers do not fit beside 128 accumulator registers at two waves per SIMD); MO = 2: 6 slots = 3 taps
     constexpr int ARING = MO == 4 ? 9 : 6;
     static_assert((KK * MO) % ARING == 0 && ARING >= 2 * MO, "static slots; a tap's fragments and the next tap's are live together");
-    // bytes of one channel-group plane: kPatchMax = 416 pixels.  2 buffers x 4 planes = 53,248 bytes per workgroup: THREE workgroups per
-    // CU for the 64-row blocks (<= 168 registers), as conv2d_fwd16_kernel runs them (40 KB) -- with 512-pixel planes (64 KB, two per CU)
-    // the 64-row layers lost 10 % to it.  The patch itself may use kPatchMaxX16 = 412 pixels: the last four are the sink of the 24
-    // staging threads whose pixel group lies past the plane (branch-free staging writes every thread's four pixels).
-    constexpr int PLANE_B = kPatchMax * 16;
+    // bytes of one channel-group plane: kPlaneX16 = 416 pixels.  2 buffers x 4 planes = 53,248 bytes per workgroup.  The patch itself may
+    // use kPatchMaxX16 = 412 pixels: the last four are the sink of the staging threads whose pixel group lies past the plane (branch-free
+    // staging writes every thread's four pixels).  Occupancy: two workgroups per CU for both block heights.  The 64-row kernel fits three
+    // by registers (<= 168) and LDS (159,744 of 163,840 bytes) on paper; the wave counters show ~1.7 alive (SQ_WAVE_CYCLES x 4 = 58 % of
+    // the dispatch), a grid of two per CU runs as fast as one of three (profiles/r05_conv_persistent.txt), and FORCING three
+    // (__launch_bounds__(256, 3), 51 KB planes) cost 17 spilled registers and 15-20 % on those layers: two it is.
+    constexpr int PLANE_B = kPlaneX16 * 16;
     constexpr int BUF_B = 4 * PLANE_B;
-    static_assert(PLANE_B % 256 == 0 && kPatchMaxX16 + 4 <= kPatchMax && kPatchMaxX16 % 4 == 0, "planes: a multiple of 256 bytes apart, patch + sink inside");
+    static_assert(PLANE_B % 256 == 0 && kPatchMaxX16 % 4 == 0, "planes: a multiple of 256 bytes apart, patch + sink inside");
     typedef typename std::conditional<std::is_same<T, bf16_t>::value, bf16x8, f16x8>::type frag_t;
     typedef __attribute__((ext_vector_type(4))) float f32x4;
     typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
     typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
     __shared__ __attribute__((aligned(256))) unsigned char lds[2 * BUF_B];
 
-    AFCM_STAMP(0);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wo = wave & 1, wpx = wave >> 1;
     const int c16 = lane & 15, g = lane >> 4;
-
-    int bid = blockIdx.x;
-    {
-        const int total = gridDim.x;
-        bid = xcd_order(bid, total);
-    }
-    unsigned q0 = udiv_magic((unsigned)bid, p.magicTX);
-    const int tx = __builtin_amdgcn_readfirstlane(bid - (int)q0 * p.tilesX);
-    unsigned q1 = udiv_magic(q0, p.magicTY);
-    const int ty = __builtin_amdgcn_readfirstlane((int)q0 - (int)q1 * p.tilesY);
-    unsigned q2 = udiv_magic(q1, p.magicN);
-    const int n = __builtin_amdgcn_readfirstlane((int)q1 - (int)q2 * p.N);
-    const int ob = __builtin_amdgcn_readfirstlane((int)q2);
-    const int y0 = ty * p.TH, x0 = tx * p.TW;
-    const int o0 = ob * BM_O;
     const int PH = p.TH + KS - 1, PWL = p.PWL;
-    const int xorg = (x0 - p.pad) & ~1;
-    const int xoff = (x0 - p.pad) - xorg;
+
+    // ---- work items.  The workgroup is PERSISTENT (r05): it takes tiles item, item + gridDim.x, ... (the host launches one round of
+    // resident workgroups, a multiple of 8: an item's XCD-aware position, xcd_order(), is then the same function of the item index as it
+    // was of the hardware block index) and requests the first K-chunk of its NEXT tile during the last K-chunk of the one under way --
+    // the staging slots of that chunk used to issue dead loads -- so that a tile starts on a patch that is already in LDS.  What that
+    // hides: a new workgroup needed 7-15k cycles from its first instruction to its first barrier (its address set-up is issued
+    // in the slots two MFMA-dense older waves leave, then a memory round trip: profiles/r05_conv_prologue_stamps.txt), a quarter of a
+    // workgroup's life on the <= 128-channel layers.
+    // Only the 64-row kernel is persistent: carrying a second tile's staging state across the K loop costs the 128-row kernel, which
+    // sits at 250 of its 256 registers, 19-52 spilled registers in every form tried (its workgroups live 150-200k cycles, the prologue
+    // is 3 % of that); the 64-row kernel -- the <= 64-channel and the 181-channel layers, where the prologue is a quarter -- fits in the
+    // 168 registers of three waves per SIMD.  A non-persistent launch has one item per workgroup (the host sizes the grid accordingly).
+    constexpr bool PERSIST = BM_O == 64;
+    struct Tile { int y0, x0, n, o0; };
+    auto decode = [&](int it) __attribute__((always_inline)) -> Tile {
+        const int bid = xcd_order(it, p.total_blocks);
+        // block index -> (tile x, tile y, image, row block): multiplications by host-made reciprocals, results pinned to SGPRs
+        const unsigned q0 = udiv_magic((unsigned)bid, p.magicTX);
+        const int tx = __builtin_amdgcn_readfirstlane(bid - (int)q0 * p.tilesX);
+        const unsigned q1 = udiv_magic(q0, p.magicTY);
+        const int ty = __builtin_amdgcn_readfirstlane((int)q0 - (int)q1 * p.tilesY);
+        const unsigned q2 = udiv_magic(q1, p.magicN);
+        const int n = __builtin_amdgcn_readfirstlane((int)q1 - (int)q2 * p.N);
+        const int ob = __builtin_amdgcn_readfirstlane((int)q2);
+        return Tile{ty * p.TH, tx * p.TW, n, ob * BM_O};
+    };
 
     f32x4 acc[MO][NT];
-#pragma unroll
-    for (int mo = 0; mo < MO; mo++)
-#pragma unroll
-        for (int ti = 0; ti < NT; ti++) acc[mo][ti] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     // ---- A fragments: straight from the packed weights (one buffer: the whole image, < 2^31 bytes -- host)
     const int wtap_b = p.Opad * BK * 2;                                    // bytes per tap
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, p.nkc * KK * wtap_b, 0x00020000);
-    const unsigned wvoff = (unsigned)(((o0 + wo * (BM_O / 2) + c16) * BK + g * 8) * 2);
-    auto load_a = [&](int kc, int tap, int mo) __attribute__((always_inline)) {
-        return __builtin_bit_cast(frag_t, __builtin_amdgcn_raw_buffer_load_b128(wrs, wvoff + mo * (16 * BK * 2), (kc * KK + tap) * wtap_b, 0));
+    // ONE lane offset; the row block (o0), the tap and the fragment ride in the scalar offset (as vector offsets the compiler kept four
+    // registers per row block in flight: lane offset + 1 KB per fragment)
+    const unsigned wlane = (unsigned)(((wo * (BM_O / 2) + c16) * BK + g * 8) * 2);
+    auto load_a = [&](int o0s, int kc, int tap, int mo) __attribute__((always_inline)) {
+        return __builtin_bit_cast(frag_t, __builtin_amdgcn_raw_buffer_load_b128(wrs, wlane, (kc * KK + tap) * wtap_b + (o0s + mo * 16) * (BK * 2), 0));
     };
 
-    // ---- patch staging: thread = (channel-group parity cg, 4-pixel group pg); item it covers channel group 2 it + cg
+    // ---- patch staging: thread = (channel-group parity cg, 4-pixel group pg); item it covers channel group 2 it + cg.
+    // Tile-independent geometry first
     const int cg = (tid >> 5) & 1, pg = (tid & 31) + 32 * (tid >> 6);
     const int pcols = PWL >> 2;
-    const int prow = (int)udiv_magic((unsigned)pg, p.magicPC), pcol4 = pg - prow * pcols;
-    const bool pvalid = prow < PH;
-    const int iy = y0 - p.pad + prow, ix = xorg + 4 * pcol4;
-    const bool rowok = pvalid && (unsigned)iy < (unsigned)p.H;
-    const T* xn = (const T*)p.x + (size_t)n * p.Cin * p.H * p.ldx;
-    const long long pix_off = (long long)(rowok ? iy : 0) * p.ldx + ix;
     constexpr unsigned kOob = 0x80000000u;
-    const bool d0ok = rowok && (unsigned)ix < (unsigned)p.W, d1ok = rowok && (unsigned)(ix + 2) < (unsigned)p.W;
-    const bool lshift = !d0ok && d1ok;                                                // never touch bytes before a row 0
-    const unsigned pm_lo = (d0ok && !lshift) ? ~0u : 0u, pm_hi = d1ok ? ~0u : 0u;
-    const unsigned pvoff = (d0ok || d1ok) ? (unsigned)(((long long)cg * 8 * p.H * p.ldx + pix_off + (lshift ? 2 : 0)) * 2ll) : kOob;
-    // (the descriptor ends with the image -- split form: with the highest part read -- so channels past Cin read zeros in the plain form)
     const long long img_bytes = (long long)p.Cin * p.H * p.ldx * 2ll + (SPLIT ? (long long)p.last_part_bytes : 0ll);
-    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)xn, 0, (int)(img_bytes > 0x7fffffffll ? 0x7fffffffll : img_bytes), 0x00020000);
+    const int img_records = (int)(img_bytes > 0x7fffffffll ? 0x7fffffffll : img_bytes);
     const int hw2 = p.H * p.ldx * 2;
     // the patch is dense in pixels (PWL = 4 pcols): this thread's pixels are 4 pg .. 4 pg + 3 -- inside the plane whether or not the
     // patch has that row, except for the groups past the plane's end: those write the sink pixels.  Pixel written at step e: e ^ rot
     const int rot = (pg >> 1) & 1;
     const int pgd = 4 * pg < kPatchMaxX16 ? 4 * pg : kPatchMaxX16;
-    const unsigned pdst_a = (unsigned)(pgd * 16 + cg * PLANE_B + rot * 16);          // steps 0, 2 (+ 32 bytes at step 2)
-    const unsigned pdst_b = (unsigned)(pgd * 16 + cg * PLANE_B + (1 - rot) * 16);    // steps 1, 3
-    const unsigned sel_a = rot ? 0x07060302u : 0x05040100u, sel_b = rot ? 0x05040100u : 0x07060302u;
+    // steps 0, 2 (+ 32 bytes at step 2): address pdst_a, selector sel_a; steps 1, 3: the other pixel of the pair = pdst_a ^ 16, the other
+    // halves = sel_a ^ 0x02020202 (two registers instead of four across the loop)
+    const unsigned pdst_a = (unsigned)(pgd * 16 + cg * PLANE_B + rot * 16);
+    const unsigned sel_a = rot ? 0x07060302u : 0x05040100u;
+    // ... then the state of the tile whose chunks are being STAGED (the tile under way, or the next one during its last chunk)
+    unsigned pvoff = kOob, pm_lo = 0, pm_hi = 0;
+    bool lshift = false;
+    __amdgpu_buffer_rsrc_t xrs = wrs;
+    auto stage_tile = [&](const Tile& t) __attribute__((always_inline)) {
+        // (the thread's patch coordinates are recomputed from an opaque copy of its index: kept live across the tile loop they -- and
+        // everything else the compiler can hoist out of it -- cost the 128-row kernel 52 spilled registers and the 64-row kernel its
+        // third workgroup per CU)
+        int tid_o = tid;
+        asm volatile("" : "+v"(tid_o));
+        const int pg_o = (tid_o & 31) + 32 * (tid_o >> 6), cg_o = (tid_o >> 5) & 1;
+        const int prow = (int)udiv_magic((unsigned)pg_o, p.magicPC), pcol4 = pg_o - prow * pcols;
+        const bool pvalid = prow < PH;
+        const int cg = cg_o;
+        const int xorg = (t.x0 - p.pad) & ~1;
+        const int iy = t.y0 - p.pad + prow, ix = xorg + 4 * pcol4;
+        const bool rowok = pvalid && (unsigned)iy < (unsigned)p.H;
+        const long long pix_off = (long long)(rowok ? iy : 0) * p.ldx + ix;
+        const bool d0ok = rowok && (unsigned)ix < (unsigned)p.W, d1ok = rowok && (unsigned)(ix + 2) < (unsigned)p.W;
+        lshift = !d0ok && d1ok;                                                       // never touch bytes before a row 0
+        pm_lo = (d0ok && !lshift) ? ~0u : 0u;
+        pm_hi = d1ok ? ~0u : 0u;
+        pvoff = (d0ok || d1ok) ? (unsigned)(((long long)cg * 8 * p.H * p.ldx + pix_off + (lshift ? 2 : 0)) * 2ll) : kOob;
+        // (the descriptor ends with the image -- split form: with the highest part read -- so channels past Cin read zeros in the plain form)
+        xrs = __builtin_amdgcn_make_buffer_rsrc((void*)((const T*)p.x + (size_t)t.n * p.Cin * p.H * p.ldx), 0, img_records, 0x00020000);
+    };
 
-    // (branch-free, issued on every chunk -- past the last one with the out-of-range offset: see conv2d_fwd16_kernel)
+    // (branch-free, issued on every chunk -- past the last one of the last tile with the out-of-range offset: see conv2d_fwd16_kernel)
     auto issue_patch = [&](unsigned (&pr)[8][2], int kc, bool live, int item) __attribute__((always_inline)) {
         int kcr = kc, sbase = 0;                           // chunk inside its term, byte offset of the term's part (scalar unit)
         if constexpr (SPLIT) {
@@ -939,15 +973,37 @@ __global__ __launch_bounds__(256, 2) void conv2d_fwd16x_kernel(ConvParams p) {
     };
     // step e of the transposing write: 8 channels of one pixel = 16 bytes; sbyte: buffer + item planes (scalar)
     auto write_px = [&](unsigned (&pr)[8][2], int e, int sbyte) __attribute__((always_inline)) {
-        const unsigned sel = (e & 1) ? sel_b : sel_a;
+        const unsigned sel = (e & 1) ? (sel_a ^ 0x02020202u) : sel_a;
         u32x4 v;
         v.x = __builtin_amdgcn_perm(pr[1][e >> 1], pr[0][e >> 1], sel);
         v.y = __builtin_amdgcn_perm(pr[3][e >> 1], pr[2][e >> 1], sel);
         v.z = __builtin_amdgcn_perm(pr[5][e >> 1], pr[4][e >> 1], sel);
         v.w = __builtin_amdgcn_perm(pr[7][e >> 1], pr[6][e >> 1], sel);
-        *(u32x4*)(lds + ((e & 1) ? pdst_b : pdst_a) + (unsigned)sbyte + (e >> 1) * 32) = v;
+        *(u32x4*)(lds + ((e & 1) ? (pdst_a ^ 16u) : pdst_a) + (unsigned)sbyte + (e >> 1) * 32) = v;
+    };
+    // this lane's eight B fragments: bbyte[ti] = byte address of the fragment of the tap ROW under way in the buffer under way (tile-local
+    // pixel 128 wpx + 16 ti + lane & 15, channel group lane >> 4) -- walks down the patch rows and over to the other buffer in place;
+    // set at the start of a tile (its xoff, the buffer its first chunk is in)
+    unsigned bbyte[NT];
+    auto set_bbyte = [&](const Tile& t, int buf) __attribute__((always_inline)) {
+        const int xoff = (t.x0 - p.pad) & 1;
+        int lane_o = tid;                                    // (opaque: see stage_tile; from tid: one register less across the loop than tid AND lane)
+        asm volatile("" : "+v"(lane_o));
+        lane_o &= 63;
+#pragma unroll
+        for (int ti = 0; ti < NT; ti++) {
+            const int j = wpx * 128 + ti * 16 + (lane_o & 15);
+            int py = (int)__umulhi((unsigned)j, p.magicTW), px = j - py * p.TW;
+            if (j >= p.TH * p.TW) { py = 0; px = 0; }
+            bbyte[ti] = (unsigned)((py * PWL + px + xoff) * 16 + (lane_o >> 4) * PLANE_B + buf * BUF_B);
+        }
     };
 
+    // ---- the first tile of this workgroup: the one exposed prologue
+    int item = blockIdx.x;
+    Tile S = decode(item);
+    AFCM_STAMP_I(0, item);
+    stage_tile(S);
     frag_t ar[ARING];
     unsigned preg[8][2];
     {
@@ -955,7 +1011,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_fwd16x_kernel(ConvParams p) {
         issue_patch(preg, 0, true, 0);
         issue_patch(preg1, 0, true, 1);
 #pragma unroll
-        for (int q = 0; q < ARING; q++) ar[q] = load_a(0, q / MO, q % MO);
+        for (int q = 0; q < ARING; q++) ar[q] = load_a(S.o0, 0, q / MO, q % MO);
         AFCM_STAMP_P(0);
         AFCM_STAMP_P(1);
 #pragma unroll
@@ -964,204 +1020,237 @@ __global__ __launch_bounds__(256, 2) void conv2d_fwd16x_kernel(ConvParams p) {
         for (int e = 0; e < 4; e++) { write_px(preg, e, 0); write_px(preg1, e, 2 * PLANE_B); }
         AFCM_STAMP_P(2);
     }
-    // this lane's eight B fragments: bbyte[ti] = byte address of the fragment of the tap ROW under way in the buffer under way (tile-local
-    // pixel 128 wpx + 16 ti + lane & 15, channel group lane >> 4) -- walks down the patch rows and over to the other buffer in place
-    unsigned bbyte[NT];
-#pragma unroll
-    for (int ti = 0; ti < NT; ti++) {
-        const int j = wpx * 128 + ti * 16 + c16;
-        int py = (int)__umulhi((unsigned)j, p.magicTW), px = j - py * p.TW;
-        if (j >= p.TH * p.TW) { py = 0; px = 0; }
-        bbyte[ti] = (unsigned)((py * PWL + px + xoff) * 16 + g * PLANE_B);
-    }
+    int cb = 0;                                              // buffer of the chunk under way
+    set_bbyte(S, cb);
     __syncthreads();
-    AFCM_STAMP(1);
+    AFCM_STAMP_I(1, item);
 
     const int last = p.nkc - 1;
     const unsigned rowstep = (unsigned)(PWL * 16);
-    for (int kc = 0; kc < p.nkc; kc++) {
-        const int nxt_b = ((kc + 1) & 1) * BUF_B;
-        const bool more = kc < last;
-        const int knext = kc + (int)more;
-        const unsigned bufstep = (unsigned)(((kc & 1) ? -BUF_B : BUF_B) - 2 * (int)rowstep);     // to tap row 0 of the other buffer
-        frag_t b[BRING];
+    for (;;) {
+        const int item_n = item + (int)gridDim.x;
+        const bool has_next = PERSIST && item_n < p.total_blocks;
 #pragma unroll
-        for (int s = 0; s < BRING; s++) b[s] = *(const frag_t*)(lds + bbyte[s]);
-        __builtin_amdgcn_sched_barrier(0);
+        for (int mo = 0; mo < MO; mo++)
 #pragma unroll
-        for (int tap = 0; tap < KK; tap++) {
-#pragma unroll
-            for (int ti = 0; ti < NT; ti++) {
-                const int s = tap * NT + ti;
-#pragma unroll
-                for (int mo = 0; mo < MO; mo++) {
-                    if constexpr (std::is_same<T, bf16_t>::value)
-                        acc[mo][ti] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ar[(tap * MO + mo) % ARING], b[s % BRING], acc[mo][ti], 0, 0, 0);
-                    else
-                        acc[mo][ti] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ar[(tap * MO + mo) % ARING], b[s % BRING], acc[mo][ti], 0, 0, 0);
-                }
-                const int s2 = s + BRING;
-                if (s2 < KK * NT) {
-                    const int t2 = s2 / NT, ti2 = s2 % NT;
-                    if (t2 > 0 && t2 % KS == 0) bbyte[ti2] += rowstep;                 // first tap of the next patch row
-                    b[s % BRING] = *(const frag_t*)(lds + bbyte[ti2] + (t2 % KS) * 16);
-                }
-                // ---- this step's slice of the staging work
-                if (tap == 0 && ti == 0) issue_patch(preg, knext, more, 0);
-                if (tap == 5 && ti == 0) issue_patch(preg, knext, more, 1);
-                if (tap == 4 || tap == 8) {
-                    // item 0 (tap 4) / item 1 (tap 8) of the next chunk into the other buffer: masks under blocks 0-3, a pixel under each of 4-7
-                    if (ti < 4) { mask_ch(preg, 2 * ti); mask_ch(preg, 2 * ti + 1); }
-                    else write_px(preg, ti - 4, nxt_b + (tap == 8 ? 2 * PLANE_B : 0));
-                }
-                if (tap == 8 && ti >= 4) { bbyte[2 * (ti - 4)] += bufstep; bbyte[2 * (ti - 4) + 1] += bufstep; }   // (the chunk's reads are done)
-                if (ti == NT - 1) {
-                    // the tap's ring slots take the fragments ARING ahead now that its MFMAs have read them (clamped at the end: no branch around a load)
-#pragma unroll
-                    for (int mo = 0; mo < MO; mo++) {
-                        const int q = tap * MO + mo, q2 = q + ARING;
-                        ar[q % ARING] = load_a(q2 < KK * MO ? kc : knext, (q2 % (KK * MO)) / MO, q2 % MO);
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
+            for (int ti = 0; ti < NT; ti++) acc[mo][ti] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int kc = 0; kc < p.nkc; kc++) {
+            const bool fin = kc == last;                    // the tile's last chunk stages chunk 0 of the next tile
+            int o0_n = S.o0;                                // row block of the chunk after this one
+            if (PERSIST && fin) {
+                const Tile N = decode(has_next ? item_n : item);     // (decoded where it is needed: four scalars less across the K loop)
+                stage_tile(N);
+                o0_n = N.o0;
             }
-        }
-        __syncthreads();
-    }
-
-    AFCM_STAMP(2);
-    // ---- epilogue: a 16 x 16 tile has its pixel on the lane (col = lane & 15) and channels 4 g .. 4 g + 3 in the 4 registers
-    // (the lane id goes through an empty asm: otherwise the pixel coordinates computed before the loop are kept -- spilled -- for the
-    // stores below instead of being recomputed)
-    int lane_e = lane;
-    asm volatile("" : "+v"(lane_e));
-    const int c16e = lane_e & 15, ge = lane_e >> 4;
-    if (!SPLIT) {
-        // as conv2d_fwd16_kernel: per 32-channel pass stage [pixel][32 channels] rows (64 bytes, 8-byte chunk c of pixel p at
-        // c ^ ((p >> 1) & 7)) and read them back transposed; here a lane stages ONE 8-byte chunk per tile (channels 16 (mo & 1) + 4 g ..).
-        // For EVERY tile width (even): a granule of 8 tile-local pixels that stays inside one tile row and the image goes out as 16
-        // bytes, one that runs over a row end (tile widths that are not multiples of 8: the 5 x 50 tiles of the 150-wide planes, 28, 42)
-        // as four pixel pairs with their own coordinates.  (r05: the per-element path below took 86k cycles per workgroup on those
-        // tiles -- 16 lanes x 2 bytes per run -- against 10k for this one; it remains for fp32 output.)
-        typedef __attribute__((ext_vector_type(4))) short s16x4;
-        typedef __attribute__((ext_vector_type(4))) unsigned eu32x4;
-        constexpr int EROW = 64;
-        unsigned char* const ebuf = (unsigned char*)lds + wave * (128 * EROW);
-        const int pq = p.P * p.ldy;
-        const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void*)((T*)p.y + (size_t)n * p.Cout * pq), 0, p.Cout * pq * 2, 0x00020000);
-        const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.oscale ? p.oscale + (size_t)n * p.Cout : (const float*)p.y), 0, p.oscale ? p.Cout * 4 : 0, 0x00020000);
-        const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.obias ? p.obias : (const float*)p.y), 0, p.obias ? p.Cout * 4 : 0, 0x00020000);
-        constexpr unsigned kGOut = 0x80000000u, kOOut = 0xc0000000u;
-        const bool has_sc = p.oscale != nullptr, has_ob = p.obias != nullptr;
-        f32x4 sc[MO], ob[MO];
+            const int nxt_b = (cb ^ 1) * BUF_B;
+            const bool more = !fin || has_next;
+            const int knext = fin ? 0 : kc + 1;
+            const unsigned bufstep = (unsigned)((cb ? -BUF_B : BUF_B) - 2 * (int)rowstep);     // to tap row 0 of the other buffer
+            frag_t b[BRING];
 #pragma unroll
-        for (int mo = 0; mo < MO; mo++) {
-            const unsigned sboff = (unsigned)((o0 + wo * (BM_O / 2) + mo * 16 + 4 * ge) * 4);
-            sc[mo] = (f32x4){1.f, 1.f, 1.f, 1.f};
-            ob[mo] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (has_sc) sc[mo] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srs, sboff, 0, 0));
-            if (has_ob) ob[mo] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(brs, sboff, 0, 0));
-        }
-        // read side: lane = (half hh: granule parity, chalf: channel half, i16: channel / address role inside the 16-lane group)
-        const int i16 = lane_e & 15, chalf = (lane_e >> 4) & 1, hh = lane_e >> 5;
-        const int q4 = i16 >> 2, p4 = i16 & 3;
-        unsigned rd_off[2];
+            for (int s = 0; s < BRING; s++) b[s] = *(const frag_t*)(lds + bbyte[s]);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int r = 0; r < 2; r++) {
-            const int prw = 8 * hh + 4 * r + q4;                 // + 16 pixels per iteration: (prw >> 1) & 7 does not change
-            rd_off[r] = prw * EROW + (((chalf * 4 + p4) ^ ((prw >> 1) & 7)) << 3);
-        }
-        // write side: pixel 16 ti + c16 (its swizzle (pix >> 1) & 7 does not depend on ti), chunk 4 (mo & 1) + g
-        unsigned wr_off[2];
-#pragma unroll
-        for (int k = 0; k < 2; k++) wr_off[k] = (unsigned)(c16e * EROW + (((4 * k + ge) ^ ((c16e >> 1) & 7)) << 3));
-        unsigned gbyte[8], gfullm = 0;
-#pragma unroll
-        for (int it = 0; it < 8; it++) {
-            const int j0 = wpx * 128 + (2 * it + hh) * 8;
-            const int gpy = (int)__umulhi((unsigned)j0, p.magicTW), gpx = j0 - gpy * p.TW;
-            const int gy = y0 + gpy, gx = x0 + gpx;
-            gbyte[it] = (j0 < p.TH * p.TW && gy < p.P && gx < p.Q) ? (unsigned)((gy * p.ldy + gx) * 2) : kGOut;
-            if (gpx + 8 <= p.TW && gx + 8 <= p.ldy) gfullm |= 1u << it;        // one tile row, inside the (pitched) image row
-        }
-#pragma unroll
-        for (int mi = 0; mi < MO / 2; mi++) {
-            const int rowbase = o0 + wo * (BM_O / 2) + mi * 32;
-#pragma unroll
-            for (int k = 0; k < 2; k++) {
-                const int mo = 2 * mi + k;
+            for (int tap = 0; tap < KK; tap++) {
 #pragma unroll
                 for (int ti = 0; ti < NT; ti++) {
-                    uint2 w;
-                    w.x = pack2<T>(acc[mo][ti][0] * sc[mo][0] + ob[mo][0], acc[mo][ti][1] * sc[mo][1] + ob[mo][1]);
-                    w.y = pack2<T>(acc[mo][ti][2] * sc[mo][2] + ob[mo][2], acc[mo][ti][3] * sc[mo][3] + ob[mo][3]);
-                    *(uint2*)(ebuf + wr_off[k] + ti * (16 * EROW)) = w;
+                    const int s = tap * NT + ti;
+#pragma unroll
+                    for (int mo = 0; mo < MO; mo++) {
+                        if constexpr (std::is_same<T, bf16_t>::value)
+                            acc[mo][ti] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ar[(tap * MO + mo) % ARING], b[s % BRING], acc[mo][ti], 0, 0, 0);
+                        else
+                            acc[mo][ti] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ar[(tap * MO + mo) % ARING], b[s % BRING], acc[mo][ti], 0, 0, 0);
+                    }
+                    const int s2 = s + BRING;
+                    if (s2 < KK * NT) {
+                        const int t2 = s2 / NT, ti2 = s2 % NT;
+                        if (t2 > 0 && t2 % KS == 0) bbyte[ti2] += rowstep;                 // first tap of the next patch row
+                        b[s % BRING] = *(const frag_t*)(lds + bbyte[ti2] + (t2 % KS) * 16);
+                    }
+                    // ---- this step's slice of the staging work
+                    if (tap == 0 && ti == 0) issue_patch(preg, knext, more, 0);
+                    if (tap == 5 && ti == 0) issue_patch(preg, knext, more, 1);
+                    if (tap == 4 || tap == 8) {
+                        // item 0 (tap 4) / item 1 (tap 8) of the next chunk into the other buffer: masks under blocks 0-3, a pixel under each of 4-7
+                        if (ti < 4) { mask_ch(preg, 2 * ti); mask_ch(preg, 2 * ti + 1); }
+                        else write_px(preg, ti - 4, nxt_b + (tap == 8 ? 2 * PLANE_B : 0));
+                    }
+                    if (tap == 8 && ti >= 4) { bbyte[2 * (ti - 4)] += bufstep; bbyte[2 * (ti - 4) + 1] += bufstep; }   // (the chunk's reads are done)
+                    if (ti == NT - 1) {
+                        // the tap's ring slots take the fragments ARING ahead now that its MFMAs have read them (past the last tile: the same
+                        // fragments again -- no branch around a load)
+#pragma unroll
+                        for (int mo = 0; mo < MO; mo++) {
+                            const int q = tap * MO + mo, q2 = q + ARING;
+                            ar[q % ARING] = (q2 < KK * MO) ? load_a(S.o0, kc, q2 / MO, q2 % MO) : load_a(o0_n, knext, (q2 - KK * MO) / MO, q2 % MO);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            // same wave wrote and reads: LDS operations of a wave complete in order, no barrier needed
-            const int o = rowbase + chalf * 16 + i16;
-            const unsigned obyte = o < p.Cout ? (unsigned)(o * pq * 2) : kOOut;
+            cb ^= 1;
+            __syncthreads();
+        }
+        AFCM_STAMP_I(2, item);
+        // ---- epilogue of tile S: a 16 x 16 tile has its pixel on the lane (col = lane & 15) and channels 4 g .. 4 g + 3 in the 4 registers
+        // (the lane id goes through an empty asm: otherwise pixel coordinates computed for the K loop are kept -- spilled -- for the stores
+        // below instead of being recomputed)
+        int lane_e = tid;
+        asm volatile("" : "+v"(lane_e));
+        lane_e &= 63;
+        const int c16e = lane_e & 15, ge = lane_e >> 4;
+        const int y0 = S.y0, x0 = S.x0, n = S.n, o0 = S.o0;
+        if constexpr (!SPLIT) {
+            // as conv2d_fwd16_kernel: per 32-channel pass stage [pixel][32 channels] rows (64 bytes, 8-byte chunk c of pixel p at
+            // c ^ ((p >> 1) & 7)) and read them back transposed; here a lane stages ONE 8-byte chunk per tile (channels 16 (mo & 1) + 4 g ..),
+            // 64 pixels at a time: the staging area (4 KB per wave) lies in the patch buffer the last chunk read -- the other one already
+            // holds the next tile's first chunk.
+            // For EVERY tile width (even): a granule of 8 tile-local pixels that stays inside one tile row and the image goes out as 16
+            // bytes, one that runs over a row end (tile widths that are not multiples of 8: the 5 x 50 tiles of the 150-wide planes, 28, 42)
+            // as four pixel pairs with their own coordinates.  (r05: the per-element path below took 86k cycles per workgroup on those
+            // tiles -- 16 lanes x 2 bytes per run -- against 10k for this one; it remains for fp32 output.)
+            typedef __attribute__((ext_vector_type(4))) short s16x4;
+            typedef __attribute__((ext_vector_type(4))) unsigned eu32x4;
+            constexpr int EROW = 64;
+            unsigned char* const ebuf = lds + (cb ^ 1) * BUF_B + wave * (64 * EROW);
+            const int pq = p.P * p.ldy;
+            const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void*)((T*)p.y + (size_t)n * p.Cout * pq), 0, p.Cout * pq * 2, 0x00020000);
+            const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.oscale ? p.oscale + (size_t)n * p.Cout : (const float*)p.y), 0, p.oscale ? p.Cout * 4 : 0, 0x00020000);
+            const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.obias ? p.obias : (const float*)p.y), 0, p.obias ? p.Cout * 4 : 0, 0x00020000);
+            constexpr unsigned kGOut = 0x80000000u, kOOut = 0xc0000000u;
+            const bool has_sc = p.oscale != nullptr, has_ob = p.obias != nullptr;
+            f32x4 sc[MO], ob[MO];
+#pragma unroll
+            for (int mo = 0; mo < MO; mo++) {
+                const unsigned sboff = (unsigned)((o0 + wo * (BM_O / 2) + mo * 16 + 4 * ge) * 4);
+                sc[mo] = (f32x4){1.f, 1.f, 1.f, 1.f};
+                ob[mo] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (has_sc) sc[mo] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srs, sboff, 0, 0));
+                if (has_ob) ob[mo] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(brs, sboff, 0, 0));
+            }
+            // read side: lane = (half hh: granule parity, chalf: channel half, i16: channel / address role inside the 16-lane group)
+            const int i16 = lane_e & 15, chalf = (lane_e >> 4) & 1, hh = lane_e >> 5;
+            const int q4 = i16 >> 2, p4 = i16 & 3;
+            unsigned rd_off[2];
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+                const int prw = 8 * hh + 4 * r + q4;                 // + 16 pixels per iteration: (prw >> 1) & 7 does not change
+                rd_off[r] = prw * EROW + (((chalf * 4 + p4) ^ ((prw >> 1) & 7)) << 3);
+            }
+            // write side: pixel 16 ti + c16 (its swizzle (pix >> 1) & 7 does not depend on ti), chunk 4 (mo & 1) + g
+            unsigned wr_off[2];
+#pragma unroll
+            for (int k = 0; k < 2; k++) wr_off[k] = (unsigned)(c16e * EROW + (((4 * k + ge) ^ ((c16e >> 1) & 7)) << 3));
+            // gfullm bit `it`: this lane's granule goes out as 16 bytes (one tile row, inside the (pitched) image row) -- or not at all (a
+            // granule outside the tile or the image: its offset carries the marker); slow_any bit `it` (wave-uniform): SOME lane's granule of
+            // iteration `it` needs the pair-by-pair path.  That path is behind a SCALAR branch: under a per-lane predicate only, its ~40
+            // vector instructions per granule (two quarter-rate multiplies per pixel pair) were issued with an empty EXEC mask on every tile
+            // -- ~3k issue cycles per wave and tile, a third of what a tile of a 64-channel layer has to issue at all.
+            unsigned gbyte[8], gfullm = 0, slow_any = 0;
 #pragma unroll
             for (int it = 0; it < 8; it++) {
-                union { s16x4 v[2]; eu32x4 q; } u;
+                const int j0 = wpx * 128 + (2 * it + hh) * 8;
+                const int gpy = (int)__umulhi((unsigned)j0, p.magicTW), gpx = j0 - gpy * p.TW;
+                const int gy = y0 + gpy, gx = x0 + gpx;
+                const bool in_tile = j0 < p.TH * p.TW && gy < p.P;
+                const bool valid = in_tile && gx < p.Q;
+                const bool straddle = gpx + 8 > p.TW;                    // runs on into the next tile row (whose pixels may be inside the image when these are not)
+                const bool slow = in_tile && (straddle || (valid && gx + 8 > p.ldy));
+                gbyte[it] = valid ? (unsigned)((gy * p.ldy + gx) * 2) : kGOut;
+                if (!slow) gfullm |= 1u << it;
+                if (__builtin_amdgcn_ballot_w64(slow) != 0) slow_any |= 1u << it;
+            }
 #pragma unroll
-                for (int r = 0; r < 2; r++)
-                    u.v[r] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ebuf + it * (16 * EROW) + rd_off[r]));
-                const unsigned off = obyte + gbyte[it];
-                if ((gfullm >> it) & 1) {
-                    __builtin_amdgcn_raw_buffer_store_b128(u.q, yrs, off, 0, 0);
-                } else {                                          // the granule runs over the tile row's or the image's right end (even widths: whole pairs)
+            for (int mi = 0; mi < MO / 2; mi++) {
+                const int rowbase = o0 + wo * (BM_O / 2) + mi * 32;
+                const int o = rowbase + chalf * 16 + i16;
+                const unsigned obyte = o < p.Cout ? (unsigned)(o * pq * 2) : kOOut;
 #pragma unroll
-                    for (int w2 = 0; w2 < 4; w2++) {
-                        const int j = wpx * 128 + (2 * it + hh) * 8 + 2 * w2;
-                        const int py = (int)__umulhi((unsigned)j, p.magicTW), px = j - py * p.TW;
-                        const bool ok = j < p.TH * p.TW && y0 + py < p.P && x0 + px < p.Q;
-                        __builtin_amdgcn_raw_buffer_store_b32(u.q[w2], yrs, ok ? obyte + (unsigned)(((y0 + py) * p.ldy + x0 + px) * 2) : kGOut, 0, 0);
+                for (int half = 0; half < 2; half++) {
+#pragma unroll
+                    for (int k = 0; k < 2; k++) {
+                        const int mo = 2 * mi + k;
+#pragma unroll
+                        for (int t4 = 0; t4 < 4; t4++) {
+                            const int ti = 4 * half + t4;
+                            uint2 w;
+                            w.x = pack2<T>(acc[mo][ti][0] * sc[mo][0] + ob[mo][0], acc[mo][ti][1] * sc[mo][1] + ob[mo][1]);
+                            w.y = pack2<T>(acc[mo][ti][2] * sc[mo][2] + ob[mo][2], acc[mo][ti][3] * sc[mo][3] + ob[mo][3]);
+                            *(uint2*)(ebuf + wr_off[k] + t4 * (16 * EROW)) = w;
+                        }
+                    }
+                    // same wave wrote and reads: LDS operations of a wave complete in order, no barrier needed
+#pragma unroll
+                    for (int i4 = 0; i4 < 4; i4++) {
+                        const int it = 4 * half + i4;
+                        union { s16x4 v[2]; eu32x4 q; } u;
+#pragma unroll
+                        for (int r = 0; r < 2; r++)
+                            u.v[r] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ebuf + i4 * (16 * EROW) + rd_off[r]));
+                        const bool full = (gfullm >> it) & 1;
+                        // (no branch around the common store: a lane on the pair path sends its 16 bytes out of range)
+                        __builtin_amdgcn_raw_buffer_store_b128(u.q, yrs, full ? obyte + gbyte[it] : kGOut, 0, 0);
+                        if ((slow_any >> it) & 1) {                       // wave-uniform
+                            if (!full) {                                  // the granule runs over the tile row's or the image's right end (even widths: whole pairs)
+#pragma unroll
+                                for (int w2 = 0; w2 < 4; w2++) {
+                                    const int j = wpx * 128 + (2 * it + hh) * 8 + 2 * w2;
+                                    const int py = (int)__umulhi((unsigned)j, p.magicTW), px = j - py * p.TW;
+                                    const bool ok = j < p.TH * p.TW && y0 + py < p.P && x0 + px < p.Q;
+                                    __builtin_amdgcn_raw_buffer_store_b32(u.q[w2], yrs, ok ? obyte + (unsigned)(((y0 + py) * p.ldy + x0 + px) * 2) : kGOut, 0, 0);
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        } else {
+            TO* yn = (TO*)p.y + (size_t)n * p.Cout * p.P * p.ldy;
+            int poff[NT];                                    // pixel offset inside a plane, -1: not stored
+#pragma unroll
+            for (int ti = 0; ti < NT; ti++) {
+                const int j = wpx * 128 + ti * 16 + c16e;
+                const int py = (int)__umulhi((unsigned)j, p.magicTW), px = j - py * p.TW;
+                poff[ti] = (j < p.TH * p.TW && y0 + py < p.P && x0 + px < p.Q) ? (y0 + py) * p.ldy + x0 + px : -1;
+            }
+            const float* osn = p.oscale ? p.oscale + (size_t)n * p.Cout : nullptr;
+            const int pq = p.P * p.ldy;
+            float ia = 1.f, ib = 1.f;
+            if (p.bound_a) pow2_factor(p.bound_a[0], &ia);
+            if (p.bound_b) pow2_factor(p.bound_b[0], &ib);
+            const float inv = ia * ib;
+#pragma unroll
+            for (int mo = 0; mo < MO; mo++) {
+                float sc[4], ob[4];
+                const int obase = o0 + wo * (BM_O / 2) + mo * 16 + 4 * ge;
+#pragma unroll
+                for (int reg = 0; reg < 4; reg++) {
+                    sc[reg] = (osn != nullptr ? osn[min(obase + reg, p.Cout - 1)] : 1.f) * inv;
+                    ob[reg] = p.obias != nullptr ? p.obias[min(obase + reg, p.Cout - 1)] : 0.f;
+                }
+#pragma unroll
+                for (int reg = 0; reg < 4; reg++) {
+                    const int o = obase + reg;
+                    if (o < p.Cout) {
+                        TO* yo = yn + (size_t)o * pq;
+#pragma unroll
+                        for (int ti = 0; ti < NT; ti++)
+                            if (poff[ti] >= 0) yo[poff[ti]] = from_f32<TO>(acc[mo][ti][reg] * sc[reg] + ob[reg]);
                     }
                 }
             }
         }
-        AFCM_STAMP(3);
-        return;
+        AFCM_STAMP_I(3, item);
+        if (!has_next) break;
+        // the staging area of the epilogue (the buffer the last chunk read) is the one the next tile's first chunk stages INTO
+        if (!SPLIT) __syncthreads();
+        S = decode(item_n);
+        item = item_n;
+        set_bbyte(S, cb);
+        AFCM_STAMP_I(0, item);
+        AFCM_STAMP_I(1, item);
     }
-    TO* yn = (TO*)p.y + (size_t)n * p.Cout * p.P * p.ldy;
-    int poff[NT];                                    // pixel offset inside a plane, -1: not stored
-#pragma unroll
-    for (int ti = 0; ti < NT; ti++) {
-        const int j = wpx * 128 + ti * 16 + c16e;
-        const int py = (int)__umulhi((unsigned)j, p.magicTW), px = j - py * p.TW;
-        poff[ti] = (j < p.TH * p.TW && y0 + py < p.P && x0 + px < p.Q) ? (y0 + py) * p.ldy + x0 + px : -1;
-    }
-    const float* osn = p.oscale ? p.oscale + (size_t)n * p.Cout : nullptr;
-    const int pq = p.P * p.ldy;
-    float inv = 1.f;
-    if constexpr (SPLIT) {
-        float ia = 1.f, ib = 1.f;
-        if (p.bound_a) pow2_factor(p.bound_a[0], &ia);
-        if (p.bound_b) pow2_factor(p.bound_b[0], &ib);
-        inv = ia * ib;
-    }
-#pragma unroll
-    for (int mo = 0; mo < MO; mo++) {
-        float sc[4], ob[4];
-        const int obase = o0 + wo * (BM_O / 2) + mo * 16 + 4 * ge;
-#pragma unroll
-        for (int reg = 0; reg < 4; reg++) {
-            sc[reg] = (osn != nullptr ? osn[min(obase + reg, p.Cout - 1)] : 1.f) * inv;
-            ob[reg] = p.obias != nullptr ? p.obias[min(obase + reg, p.Cout - 1)] : 0.f;
-        }
-#pragma unroll
-        for (int reg = 0; reg < 4; reg++) {
-            const int o = obase + reg;
-            if (o < p.Cout) {
-                TO* yo = yn + (size_t)o * pq;
-#pragma unroll
-                for (int ti = 0; ti < NT; ti++)
-                    if (poff[ti] >= 0) yo[poff[ti]] = from_f32<TO>(acc[mo][ti][reg] * sc[reg] + ob[reg]);
-            }
-        }
-    }
-    AFCM_STAMP(3);
 }
 
 // Stride-2 form of conv2d_fwd16_kernel for the discriminator's down-sampling convs (CoModGAN/generator.py:613-692: blur, then a 3x3
@@ -3124,16 +3213,37 @@ static void choose_tile_s2(int P, int Q, int* TH, int* TW, int* PWL) {
     }
 }
 
+// Grid of the persistent conv2d_fwd16x_kernel: one round of resident workgroups (compute units x workgroups per CU, a multiple of 8 so that
+// the XCD-aware item order is the same function of the item as of the hardware block index), or every item when there are fewer.
+// The compute-unit count is a property of the device, read once per device (speed only: any grid size computes the same result).
+static int conv_persistent_grid(long long items, int per_cu) {
+    static int cus[16] = {0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    int n = (dev >= 0 && dev < 16) ? cus[dev] : 0;
+    if (n == 0) {
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        if (dev >= 0 && dev < 16) cus[dev] = n;
+    }
+#ifdef AFCM_CONV_AB
+    if (g_conv_x16 >> 4) per_cu = g_conv_x16 >> 4;         // experiment: workgroups per CU of the persistent grid from the debug switch
+#endif
+    const long long slots = (long long)round_up(n * per_cu, 8);
+    return (int)(items < slots ? items : slots);
+}
+
 template <typename T, int BM_O>
 static int launch_conv(ConvParams p, int ks, hipStream_t st) {
     const long long blocks = (long long)p.tilesX * p.tilesY * p.N * cdiv(p.Cout, BM_O);
     AFCM_REQUIRE(blocks > 0 && blocks < (1ll << 31), "conv2d: grid of %lld blocks is out of range", blocks);
     dim3 grid((unsigned)blocks), block(256);
+    p.total_blocks = (int)blocks;
     if constexpr (sizeof(T) == 2) {
         if (ks == 3) {
 #if defined(AFCM_CONV_AB) || AFCM_CONV_X16
             if (AFCM_X16_ON) {
-                hipLaunchKernelGGL((conv2d_fwd16x_kernel<T, BM_O>), grid, block, 0, st, p);
+                // (the 64-row kernel is persistent: one round of three workgroups per CU; the 128-row kernel takes one item per workgroup)
+                hipLaunchKernelGGL((conv2d_fwd16x_kernel<T, BM_O>), BM_O == 64 ? dim3((unsigned)conv_persistent_grid(blocks, 3)) : grid, block, 0, st, p);
                 return hip_status(hipGetLastError());
             }
 #endif
@@ -3305,7 +3415,7 @@ extern "C" int afcm_conv2d_stride2(void* y, const void* x, const void* wpacked, 
     p.magicTX = magic_u32((unsigned)p.tilesX); p.magicTY = magic_u32((unsigned)p.tilesY); p.magicN = magic_u32((unsigned)p.N); p.magicPC = magic_u32((unsigned)(p.PWL >> 2));
     p.Opad = rows_pad;
     p.nkc = cdiv(cin, afcm_conv2d_block_k(dtype));
-    p.nkc_real = p.nkc; p.magicNK = 0; p.term_parts = 0; p.part_bytes = 0; p.last_part_bytes = 0; p.bound_a = p.bound_b = nullptr;
+    p.nkc_real = p.nkc; p.magicNK = 0; p.term_parts = 0; p.part_bytes = 0; p.last_part_bytes = 0; p.bound_a = p.bound_b = nullptr; p.total_blocks = 0;
     const long long blocks = (long long)p.tilesX * p.tilesY * n * cdiv(cout, 128);
     AFCM_REQUIRE(blocks > 0 && blocks < (1ll << 31), "conv2d_stride2: grid of %lld blocks is out of range", blocks);
     AFCM_REQUIRE((long long)cin * h * w * 2ll < (1ll << 31), "conv2d_stride2: image out of range");
@@ -3348,7 +3458,7 @@ extern "C" int afcm_conv2d_ld(void* y, const void* x, const void* wpacked, const
     p.magicTX = magic_u32((unsigned)p.tilesX); p.magicTY = magic_u32((unsigned)p.tilesY); p.magicN = magic_u32((unsigned)p.N); p.magicPC = magic_u32((unsigned)(p.PWL >> 2));
     p.Opad = rows_pad;
     p.nkc = cdiv(cin, conv_bk(dtype, ks));
-    p.nkc_real = p.nkc; p.magicNK = 0; p.term_parts = 0; p.part_bytes = 0; p.last_part_bytes = 0; p.bound_a = p.bound_b = nullptr;
+    p.nkc_real = p.nkc; p.magicNK = 0; p.term_parts = 0; p.part_bytes = 0; p.last_part_bytes = 0; p.bound_a = p.bound_b = nullptr; p.total_blocks = 0;
     hipStream_t st = (hipStream_t)stream;
     // 64-row blocks when they waste fewer padded rows than 128-row blocks
     const bool small = (rows_pad % 128 != 0) || cout <= 64;
@@ -3470,12 +3580,14 @@ extern "C" int afcm_conv2d_split(float* y, const void* x_parts, const void* wpac
     hipStream_t st = (hipStream_t)stream;
 #if defined(AFCM_CONV_AB) || AFCM_CONV_X16
     if (AFCM_X16_ON) {
+        p.total_blocks = (int)blocks;
+        const dim3 pgrid(small ? (unsigned)conv_persistent_grid(blocks, 3) : (unsigned)blocks);
         if (dtype == AFCM_BF16) {
-            if (small) hipLaunchKernelGGL((conv2d_fwd16x_kernel<bf16_t, 64, true>), grid, block, 0, st, p);
-            else hipLaunchKernelGGL((conv2d_fwd16x_kernel<bf16_t, 128, true>), grid, block, 0, st, p);
+            if (small) hipLaunchKernelGGL((conv2d_fwd16x_kernel<bf16_t, 64, true>), pgrid, block, 0, st, p);
+            else hipLaunchKernelGGL((conv2d_fwd16x_kernel<bf16_t, 128, true>), pgrid, block, 0, st, p);
         } else {
-            if (small) hipLaunchKernelGGL((conv2d_fwd16x_kernel<f16_t, 64, true>), grid, block, 0, st, p);
-            else hipLaunchKernelGGL((conv2d_fwd16x_kernel<f16_t, 128, true>), grid, block, 0, st, p);
+            if (small) hipLaunchKernelGGL((conv2d_fwd16x_kernel<f16_t, 64, true>), pgrid, block, 0, st, p);
+            else hipLaunchKernelGGL((conv2d_fwd16x_kernel<f16_t, 128, true>), pgrid, block, 0, st, p);
         }
         return hip_status(hipGetLastError());
     }

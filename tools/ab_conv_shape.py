@@ -26,7 +26,7 @@ dbg = ctypes.CDLL(_lib.LIB_PATH)
 assert hasattr(dbg, 'afcm_debug_conv_variant'), 'build conv2d.hip with -DAFCM_CONV_AB (see the docstring)'
 dt = torch.bfloat16
 VA, VB = [int(v) for v in a.variants.split(',')]
-NAMES = {0: '32x32x16', 1: '16x16x32', 3: '16x16x32/ob'}
+NAMES = {0: '32x32x16', 1: '16x16x32', 3: '16x16x32/ob', 33: '16x16x32/2wg', 49: '16x16x32/3wg', 65: '16x16x32/4wg', 97: '16x16x32/6wg'}
 VMAP = {0: VA, 1: VB}
 
 
@@ -54,12 +54,16 @@ def stamps(fn):
     kl, kr = c[:, 2] - c[:, 1], r[:, 2] - r[:, 1]
     good = kr > 0
     extra = ''
+    # realtime (100 MHz) view of the launch: its span, and how many stamped units (workgroups; tiles of the persistent kernel) were alive on average
+    span_rt = int(r[:, 3].max() - r[:, 0].min())
+    alive = float((r[:, 3] - r[:, 0]).sum()) / max(1, span_rt)
+    extra = f' [{ok.sum()} units, span {span_rt / 100.0:.1f} us, {alive:.0f} alive on average]'
     if hasattr(dbg, 'afcm_debug_conv_prologue'):
         pro = np.zeros([nb, 4], dtype=np.uint64)
         assert dbg.afcm_debug_conv_prologue(pro.ctypes.data_as(ctypes.c_void_p), nb) == 0
         pr = pro[ok].astype(np.int64)
         if (pr[:, 0] > 0).any():          # (the 16x16x32 kernel stamps its prologue: entry -> requests issued -> all returned -> patch written -> barrier)
-            extra = ' [prologue: ' + ' / '.join(f'{np.median(v):.0f}' for v in (pr[:, 0] - c[:, 0], pr[:, 1] - pr[:, 0], pr[:, 2] - pr[:, 1], c[:, 1] - pr[:, 2])) + ']'
+            extra += ' [prologue: ' + ' / '.join(f'{np.median(v):.0f}' for v in (pr[:, 0] - c[:, 0], pr[:, 1] - pr[:, 0], pr[:, 2] - pr[:, 1], c[:, 1] - pr[:, 2])) + ']'
     return float(np.median(kl)), float(np.median(kl[good] / kr[good]) * 0.1), float(np.median(c[:, 1] - c[:, 0])), float(np.median(c[:, 3] - c[:, 2])), extra    # K loop cycles, GHz, prologue, epilogue
 
 
