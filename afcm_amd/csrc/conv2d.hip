@@ -2065,7 +2065,8 @@ constexpr int kWgKQ = 64;        // pixels of one output row per K macro-step
 // planes per workgroup (small planes, as plane_dot_wave_kernel).  Needs w >= 16 / sizeof(T).
 // Gate of the "dot product by homogeneity" (afcm_plane_dot_gated_ld): a plane none of whose strips could reach the clamp takes
 //     out = osc (gz - nsc gsk)                     (nsc, gsk may be NULL: 1, 0)
-// and its wave / workgroup leaves without touching a or b; a flagged plane gets the real dot product.
+// and its wave / workgroup leaves without touching a or b; a flagged plane gets the real dot product, and so does a plane whose two
+// sums cancel to less than 1/8 of their size (|skip| >> |F(y)| amplifies the rounding of z by that ratio).
 struct PlaneGate {
     const int* flags;     // [planes][slots], NULL: no gate
     int slots;
@@ -2085,8 +2086,15 @@ __global__ __launch_bounds__(256) void plane_dot_rows_kernel(float* __restrict__
         int any = 0;                                           // (wave- / workgroup-uniform: every thread reads the same words)
         for (int i = 0; i < gate.slots; i++) any |= gate.flags[plane * gate.slots + i];
         if (!any) {
-            if (t == 0) out[plane] = gate.osc[plane] * (gate.gz[plane] - (gate.nsc ? gate.nsc[plane] : 1.f) * (gate.gsk ? gate.gsk[plane] : 0.f));
-            return;
+            // ... unless the two sums cancel: each carries the 16-bit rounding of z / skip (2^-9 relative in bf16), so their difference is
+            // trusted down to 1/8 of their size (a skip branch that dwarfs this layer's own output); beyond that the plane takes the real
+            // dot product like a flagged one
+            const float zz = gate.gz[plane], kk = gate.gsk ? (gate.nsc ? gate.nsc[plane] : 1.f) * gate.gsk[plane] : 0.f;
+            const float diff = zz - kk;
+            if (!(gate.gsk != nullptr && fabsf(diff) * 8.f < fabsf(zz) + fabsf(kk))) {
+                if (t == 0) out[plane] = gate.osc[plane] * diff;
+                return;
+            }
         }
     }
     const int nvec = (w + E - 1) / E, total = h * nvec;

@@ -138,8 +138,8 @@ def plane_dot(a, b=None):
 
 def plane_dot_gated(a, b, flags, out_scale, gz, next_scale=None, gskip=None):
     """[N, C] fp32: out_scale * (gz - next_scale * gskip) for the planes whose ``flags`` ([N, C, slots] int32, afcm_filtered_lrelu_args.
-    clamp_flags) are all zero, the real sum over H, W of a * b for the others (C ABI afcm_plane_dot_gated_ld).  Operands outside the
-    row kernel's preconditions: the plain dot product."""
+    clamp_flags) are all zero, the real sum over H, W of a * b for the others and for planes whose two sums cancel below 1/8 of their
+    size (C ABI afcm_plane_dot_gated_ld).  Operands outside the row kernel's preconditions: the plain dot product."""
     lib = _lib.load()
     assert b.shape == a.shape and b.dtype == a.dtype
     lda, ldb = _rows.pitch_of(a), _rows.pitch_of(b)
@@ -165,6 +165,14 @@ def plane_dot_gated(a, b, flags, out_scale, gz, next_scale=None, gskip=None):
 #   float16, 3 terms of a two-way split, operands scaled by a power of two to just below 2^15: 22 significand bits -- measured equal to
 #     an fp32 dot product of the same length (3e-7 of the output scale at K = 4608).  The default.
 #   bfloat16 (no scaling, any range): 3 terms keep ~16 bits (4e-6), the 6 terms of order <= 2 of a three-way split all 24 (2e-7).
+# Dynamic range of the float16 route -- ONE power-of-two bound per tensor (amax_bits over all N * C planes; a bound per
+# sample would not factor out of the weight gradient's sum over samples):
+#   * an element more than ~2^18 below the tensor's largest keeps only its first part (11 bits): a sample or plane that small next to
+#     the rest of the batch is computed to float16, not fp32, precision;
+#   * an inf / NaN anywhere sets the scale to 1; finite |v| > 65504 in that tensor then become inf in float16 -- more non-finites than
+#     the native kernels would produce, for a tensor that already held one.
+# Activations of a normalised generator sit within a few powers of two of each other, which is why this is the default; a caller with
+# wider tensors sets FP32_SPLIT = (torch.bfloat16, 6, 6, 6) (any range, 24 bits) or None (the native fp32 kernels).
 FP32_SPLIT = (torch.float16, 3, 3, 3)
 _SPLIT_TERMS = {           # (part of the activations, part of the weights) per term, smallest products first
     3: ((1, 0), (0, 1), (0, 0)),
@@ -332,8 +340,12 @@ def _conv_split(parts, wp, rows_pad, terms, oscale, cout, pad, obias=None, bound
 def _wgrad_split(dy_parts, x_parts, cout, cin, pad, terms, bounds=(None, None)):
     """fp32 weight gradient of a 3x3 conv from the 16-bit parts of dy and x: one 16-bit weight-gradient launch per term, summed."""
     dw = None
+    framed = {}            # a dy part is framed for the pad-1 route once, not once per term that uses it (ADVICE r04)
     for a, b in _SPLIT_TERMS[terms]:
-        d = _wgrad_raw(dy_parts[b], x_parts[a], cout, cin, 3, pad, work_share=1.0 / terms)
+        if b not in framed:
+            framed[b] = _frame_dy(dy_parts[b], 3, pad)
+        dyb, padb = framed[b]
+        d = _wgrad_raw(dyb, x_parts[a], cout, cin, 3, padb, work_share=1.0 / terms)
         dw = d if dw is None else dw.add_(d)
     if bounds[0] is not None or bounds[1] is not None:
         _lib.check(_lib.load().afcm_unscale(dw.data_ptr(), dw.numel(), _lib.ptr(bounds[0]), _lib.ptr(bounds[1]), _lib.stream_ptr(dw)), 'unscale')
@@ -379,16 +391,21 @@ def _conv_raw(x, wp, rows_pad, oscale, cout, ks, pad, obias=None, pitched_out=Fa
 _FRAME_WGRAD_MAX = 1 << 24        # elements of dy up to which a pad-1 weight gradient is computed as pad-2 on a zero-framed dy
 
 
+def _frame_dy(dy, ks, pad):
+    """(dy, pad) for the weight-gradient kernels: pad-1 weight gradients only have the dword LDS-DMA kernel (0.41 PF/s on the generator's
+    512 -> 512 bottleneck conv at 36^2: 236 us); with dy framed by one ring of zeros the same sums are a pad-2 weight gradient, which the
+    16-byte granule kernel takes.  Worth it while the framing copy is small (the discriminator's large planes: measured, no gain)."""
+    if ks == 3 and pad == 1 and dy.dtype in (torch.bfloat16, torch.float16) and dy.numel() <= _FRAME_WGRAD_MAX:
+        return torch.nn.functional.pad(dy, [1, 1, 1, 1]), 2
+    return dy, pad
+
+
 def _wgrad_raw(dy, x, cout, cin, ks, pad, work_share=1.0):
     """``work_share``: the fraction of the algorithmic flops this launch stands for in the kernel timing (a split-operand term: 1 / terms)."""
     lib = _lib.load()
     n, _, h, w = x.shape
     work = work_share * 2.0 * n * cout * cin * ks * ks * (h + 2 * pad - ks + 1) * (w + 2 * pad - ks + 1)      # algorithmic flops (before any framing)
-    if ks == 3 and pad == 1 and x.dtype in (torch.bfloat16, torch.float16) and dy.numel() <= _FRAME_WGRAD_MAX:
-        # pad-1 weight gradients only have the dword LDS-DMA kernel (0.41 PF/s on the generator's 512 -> 512 bottleneck conv at
-        # 36^2: 236 us); with dy framed by one ring of zeros the same sums are a pad-2 weight gradient, which the 16-byte granule
-        # kernel takes.  Worth it while the framing copy is small (the discriminator's large planes: measured, no gain).
-        dy, pad = torch.nn.functional.pad(dy, [1, 1, 1, 1]), 2
+    dy, pad = _frame_dy(dy, ks, pad)
     p = h + 2 * pad - ks + 1
     if _pitch_wgrad(x.dtype, ks, pad):
         (dy, lddy), (x, ldx) = _rows.rows(dy), _rows.rows(x)

@@ -230,7 +230,9 @@ int afcm_plane_dot_ld(float* out, const void* a, const void* b, int32_t dtype, i
 /* The demodulation gradient's dot product by homogeneity (fused layer node, NET:41-57 backward): for a plane whose clamp_flags
  * (afcm_filtered_lrelu_args, [planes][slots]) are all 0,  out = out_scale * (gz - next_scale * gskip)  -- <dys, y> = d <dL/dy, y> =
  * d (<g, z> - s_next <g, skip>) by Euler's identity for the degree-1 homogeneous filtered_lrelu -- and neither a nor b is read;
- * a flagged plane gets the real dot product sum a * b.  next_scale / gskip may be NULL (1 / 0). */
+ * a flagged plane gets the real dot product sum a * b, and so does a plane whose two sums cancel below 1/8 of their size
+ * (|gz - next_scale gskip| * 8 < |gz| + |next_scale gskip|: a skip branch far larger than the layer's own output would amplify the
+ * 16-bit rounding of z by that ratio).  next_scale / gskip may be NULL (1 / 0). */
 int afcm_plane_dot_gated_ld(float* out, const void* a, const void* b, int32_t dtype, int64_t planes, int32_t h, int32_t w,
                             int32_t a_pitch, int32_t b_pitch, const int32_t* flags, int32_t slots, const float* out_scale,
                             const float* gz, const float* next_scale, const float* gskip, void* stream);

@@ -605,3 +605,50 @@ def test_plane_dot_of_split_parts(dtype, k, shape):
     want = ((x.double() * sc.double()[:, :, None, None]) * b.double()).sum([2, 3])
     size = ((x.double() * sc.double()[:, :, None, None]).abs() * b.double().abs()).sum([2, 3])
     assert float(((got.double() - want).abs() / size).max()) <= (2e-6 if dtype == torch.float16 or k == 3 else 2e-4)
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+def test_demodulation_gradient_takes_the_real_dot_product_when_the_skip_branch_dwarfs_the_layer(dtype):
+    """<dys, y> = d (<g, z> - s_next <g, skip>) is a difference of two nearly equal plane sums when |skip| >> |F(y)|, each with
+    the 16-bit rounding of z, so the error of d_out grows by |skip| / |F|.  The gate (afcm_plane_dot_gated_ld) sends a plane whose sums
+    cancel below 1/8 of their size to the real dot product: with a skip 200 x the layer's output every plane must come out bit-identical
+    to the all-real-dot-products path (and no plane is flagged by the clamp); with a skip of the layer's own size the homogeneous route is
+    still taken (results differ in rounding only)."""
+    from afcm_amd.torch_utils.ops import fused_layer
+    from oracle import generator as ogen
+    pl = ogen.plan(256, 4, 1, {})
+    L = [l for l in pl['dec'] if l['name'] == 'L9_148_181'][0]
+    torch.manual_seed(13)
+    n, cin, cout, h = 2, 16, 8, L['in_size']
+    x = torch.randn(n, cin, h, h).to(dtype)
+    w = torch.randn(cout, cin, 3, 3) / np.sqrt(cin * 9)
+    s = torch.rand(n, cin) + 0.5
+    d = (torch.rand(n, cout) + 0.5) * 0.05                      # far below the clamp: no plane is flagged
+    b = torch.randn(cout) * 0.01
+    oh = L['out_size']
+    ns = torch.rand(n, cout) + 0.5
+    act = dict(up=L['up'], down=L['down'], padding=L['padding'], gain=float(np.sqrt(2)), slope=0.2, clamp=4.0)
+    r = torch.randn(n, cout, oh, oh).to(dtype).float().cuda()
+
+    def run(homog, skip):
+        fused_layer.HOMOGENEOUS_DOT = homog
+        try:
+            dev = [t.detach().cuda().requires_grad_(True) for t in (x, w, s, d, b, skip.to(dtype), ns)]
+            got = fused_layer.conv_filtered_lrelu(dev[0], dev[1], dev[2], dev[3], dev[4], L['fu'].cuda(), L['fd'].cuda(), conv_pad=2,
+                                                  skip=dev[5], next_scale=dev[6], **act)
+            flags = got.grad_fn.saved_tensors[11]
+            (gd,) = torch.autograd.grad((got.float() * r).sum(), [dev[3]])
+            return flags, gd.cpu()
+        finally:
+            fused_layer.HOMOGENEOUS_DOT = True
+    base = torch.randn(n, cout, oh, oh)
+    big = base * 10.0                                          # |F| ~ 0.05: a ratio of ~200
+    flags, gd_h = run(True, big)
+    _, gd_r = run(False, big)
+    assert flags is not None and int(flags.sum()) == 0
+    assert torch.equal(gd_h, gd_r), 'cancelling planes must take the real dot product'
+    small = base * 0.05
+    _, gd_h2 = run(True, small)
+    _, gd_r2 = run(False, small)
+    assert not torch.equal(gd_h2, gd_r2), 'comparable magnitudes stay on the homogeneous route'
+    _close_rel(gd_h2, gd_r2, 4e-2 if dtype == torch.bfloat16 else 8e-3, 'homogeneity vs real dot products')
