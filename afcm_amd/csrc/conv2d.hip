@@ -77,6 +77,7 @@ struct ConvParams {
     int TH, TW, PWL, tilesX, tilesY;
     int Opad, nkc;
     int total_blocks;     // conv2d_fwd16x_kernel (persistent workgroups): work items = tiles x images x row blocks; the grid may be smaller
+    int o_base;           // conv2d_fwd16x_kernel: first output row of this launch (a layer may be split between the 128- and the 64-row kernel)
     unsigned magicTW;     // ceil(2^32 / TW): j / TW = umulhi(j, magicTW) for the tile-local pixel indices (j < 2^16)
     unsigned magicTX, magicTY, magicN, magicPC;   // ... / tilesX, tilesY, N (block index decode: dividend x divisor < 2^32), / (PWL / 4)
     // split-precision form (conv2d_fwd16_kernel<bf16, BM, true>): x holds `parts` bf16 tensors [N, Cin, H, ldx] part_bytes apart,
@@ -888,7 +889,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_fwd16x_kernel(ConvParams p) {
         const unsigned q2 = udiv_magic(q1, p.magicN);
         const int n = __builtin_amdgcn_readfirstlane((int)q1 - (int)q2 * p.N);
         const int ob = __builtin_amdgcn_readfirstlane((int)q2);
-        return Tile{ty * p.TH, tx * p.TW, n, ob * BM_O};
+        return Tile{ty * p.TH, tx * p.TW, n, p.o_base + ob * BM_O};
     };
 
     f32x4 acc[MO][NT];
@@ -2715,6 +2716,9 @@ __global__ __launch_bounds__(512, 1) void conv2d_wgrad16_kernel(WgradParams p) {
 // rebuilds a 128-bit descriptor per piece -- 64-bit base, exact record count, validity select, three v_readfirstlane --
 // ~45 scalar instructions per piece, 310 per K step of 36 MFMAs: the wave's own instruction stream, not the matrix pipe, set
 // the step time (PMC r01e: MFMA pipe 49 % busy, 8.7 SALU per MFMA).
+#ifndef AFCM_CONV_MIXED
+#define AFCM_CONV_MIXED 1          // 128 k + (1 .. 64) output rows: 128-row kernel + one 64-row block (0: 64-row blocks only; A/B builds)
+#endif
 #ifndef AFCM_WGRAD_NBUF
 #define AFCM_WGRAD_NBUF 3          // LDS ring depth of conv2d_wgrad16g_kernel (2: measured in profiles/r04_wgrad_ring.txt)
 #endif
@@ -3240,9 +3244,11 @@ static int conv_persistent_grid(long long items, int per_cu) {
     return (int)(items < slots ? items : slots);
 }
 
+// o_base / row_blocks: the launch covers output rows [o_base, o_base + row_blocks * BM_O) (16-bit 3x3 16x16x32 kernel only; 0: all rows)
 template <typename T, int BM_O>
-static int launch_conv(ConvParams p, int ks, hipStream_t st) {
-    const long long blocks = (long long)p.tilesX * p.tilesY * p.N * cdiv(p.Cout, BM_O);
+static int launch_conv(ConvParams p, int ks, hipStream_t st, int o_base = 0, int row_blocks = 0) {
+    const long long blocks = (long long)p.tilesX * p.tilesY * p.N * (row_blocks ? row_blocks : cdiv(p.Cout, BM_O));
+    p.o_base = o_base;
     AFCM_REQUIRE(blocks > 0 && blocks < (1ll << 31), "conv2d: grid of %lld blocks is out of range", blocks);
     dim3 grid((unsigned)blocks), block(256);
     p.total_blocks = (int)blocks;
@@ -3423,7 +3429,7 @@ extern "C" int afcm_conv2d_stride2(void* y, const void* x, const void* wpacked, 
     p.magicTX = magic_u32((unsigned)p.tilesX); p.magicTY = magic_u32((unsigned)p.tilesY); p.magicN = magic_u32((unsigned)p.N); p.magicPC = magic_u32((unsigned)(p.PWL >> 2));
     p.Opad = rows_pad;
     p.nkc = cdiv(cin, afcm_conv2d_block_k(dtype));
-    p.nkc_real = p.nkc; p.magicNK = 0; p.term_parts = 0; p.part_bytes = 0; p.last_part_bytes = 0; p.bound_a = p.bound_b = nullptr; p.total_blocks = 0;
+    p.nkc_real = p.nkc; p.magicNK = 0; p.term_parts = 0; p.part_bytes = 0; p.last_part_bytes = 0; p.bound_a = p.bound_b = nullptr; p.total_blocks = 0; p.o_base = 0;
     const long long blocks = (long long)p.tilesX * p.tilesY * n * cdiv(cout, 128);
     AFCM_REQUIRE(blocks > 0 && blocks < (1ll << 31), "conv2d_stride2: grid of %lld blocks is out of range", blocks);
     AFCM_REQUIRE((long long)cin * h * w * 2ll < (1ll << 31), "conv2d_stride2: image out of range");
@@ -3466,10 +3472,19 @@ extern "C" int afcm_conv2d_ld(void* y, const void* x, const void* wpacked, const
     p.magicTX = magic_u32((unsigned)p.tilesX); p.magicTY = magic_u32((unsigned)p.tilesY); p.magicN = magic_u32((unsigned)p.N); p.magicPC = magic_u32((unsigned)(p.PWL >> 2));
     p.Opad = rows_pad;
     p.nkc = cdiv(cin, conv_bk(dtype, ks));
-    p.nkc_real = p.nkc; p.magicNK = 0; p.term_parts = 0; p.part_bytes = 0; p.last_part_bytes = 0; p.bound_a = p.bound_b = nullptr; p.total_blocks = 0;
+    p.nkc_real = p.nkc; p.magicNK = 0; p.term_parts = 0; p.part_bytes = 0; p.last_part_bytes = 0; p.bound_a = p.bound_b = nullptr; p.total_blocks = 0; p.o_base = 0;
     hipStream_t st = (hipStream_t)stream;
     // 64-row blocks when they waste fewer padded rows than 128-row blocks
     const bool small = (rows_pad % 128 != 0) || cout <= 64;
+    // ... and both when the rows are 128 k + (1 .. 64) (the 181-channel layers: 192 padded rows): the 128-row kernel moves half the
+    // pixel-fragment bytes per flop of the 64-row one, so rows [0, 128 k) go to it and only the last 64 to the 64-row kernel -- two
+    // launches, disjoint output rows, the same number of passes over x as three 64-row blocks had
+    if (AFCM_CONV_MIXED && AFCM_X16_ON && dtype != AFCM_F32 && ks == 3 && rows_pad % 128 == 64 && rows_pad > 128) {
+        const int big = rows_pad / 128;
+        const int rc = dtype == AFCM_F16 ? launch_conv<f16_t, 128>(p, ks, st, 0, big) : launch_conv<bf16_t, 128>(p, ks, st, 0, big);
+        if (rc != AFCM_OK) return rc;
+        return dtype == AFCM_F16 ? launch_conv<f16_t, 64>(p, ks, st, big * 128, 1) : launch_conv<bf16_t, 64>(p, ks, st, big * 128, 1);
+    }
     switch (dtype) {
         case AFCM_F32: return small ? launch_conv<float, 64>(p, ks, st) : launch_conv<float, 128>(p, ks, st);
         case AFCM_F16: return small ? launch_conv<f16_t, 64>(p, ks, st) : launch_conv<f16_t, 128>(p, ks, st);
@@ -3588,7 +3603,7 @@ extern "C" int afcm_conv2d_split(float* y, const void* x_parts, const void* wpac
     hipStream_t st = (hipStream_t)stream;
 #if defined(AFCM_CONV_AB) || AFCM_CONV_X16
     if (AFCM_X16_ON) {
-        p.total_blocks = (int)blocks;
+        p.total_blocks = (int)blocks; p.o_base = 0;
         const dim3 pgrid(small ? (unsigned)conv_persistent_grid(blocks, 3) : (unsigned)blocks);
         if (dtype == AFCM_BF16) {
             if (small) hipLaunchKernelGGL((conv2d_fwd16x_kernel<bf16_t, 64, true>), pgrid, block, 0, st, p);

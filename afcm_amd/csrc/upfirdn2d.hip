@@ -21,6 +21,9 @@ struct UpfirdnParams {
 };
 
 constexpr int kMaxTaps = 4096;
+#ifndef AFCM_UPFIRDN_ROWS
+#define AFCM_UPFIRDN_ROWS 1        // 16-bit small filters on upfirdn2d_rows_kernel (0: the LDS tile kernel; A/B builds)
+#endif
 
 template <typename T>
 __global__ __launch_bounds__(256) void upfirdn2d_kernel(UpfirdnParams p, const float* __restrict__ f) {
@@ -173,6 +176,167 @@ __global__ __launch_bounds__(256) void upfirdn2d_tile_kernel(UpfirdnParams p, co
     }
 }
 
+// 16-bit small-filter kernel, no LDS: filters of at most 4 x 4 taps, (up, down) in {(1, 1), (1, 2), (2, 1)}, EVEN widths (rows then start on
+// 4-byte boundaries, which is all a 16-byte global access needs).  A thread owns 8 consecutive output columns x RPT output rows: every
+// input row it needs arrives as one, two or three 16-byte loads, all in flight before the first product (the tile kernel above moves 2 bytes
+// per lane and instruction through LDS: 1.3 TB/s on the discriminator's 256^2 blur); the rows above / below are the neighbouring thread's
+// in L1 / L2.  Outputs leave as one 16-byte store per row.  The taps meet every output in the tile kernel's order (ky, then kx), so both
+// kernels produce the same bits.  Column groups whose loads would cross the plane's left / right edge take guarded 2-byte loads.
+//   XODD: the first input column of a group is odd (UP 1: padx0 odd; UP 2: the zero-inserted origin x0 - padx0 is odd);  YODD (UP 2): the
+//   zero-inserted origin row is odd.  Both are uniform over the launch (x0 is a multiple of 8, the first row of a strip a multiple of RPT).
+template <int UP, int DOWN> struct UpfRows {
+    static constexpr int RPT = (UP == 1 && DOWN == 2) ? 4 : 8;                          // output rows per thread
+    static constexpr int NIN = UP == 1 ? (RPT - 1) * DOWN + 4 : 6;                      // input rows a thread reads
+    static constexpr int NEED = UP == 1 ? 7 * DOWN + 4 : 6;                             // input columns per row (from the group's first)
+    static constexpr int NL = (NEED + 1 + 7) / 8;                                       // 16-byte loads per row (+ 1: the odd start)
+};
+
+template <typename T, int UP, int DOWN, bool XODD, bool YODD>
+__global__ __launch_bounds__(256) void upfirdn2d_rows_kernel(UpfirdnParams p, const float* __restrict__ f, int ncg, int nstrips, long long total) {
+    typedef UpfRows<UP, DOWN> G;
+    constexpr int RPT = G::RPT, NIN = G::NIN, NL = G::NL;
+    static_assert(sizeof(T) == 2, "16-bit types");
+    float t[4][4];
+    const int nt = p.fw * p.fh;
+#pragma unroll
+    for (int ky = 0; ky < 4; ky++)
+#pragma unroll
+        for (int kx = 0; kx < 4; kx++) {
+            const int i = ky * p.fw + kx;
+            t[ky][kx] = (ky < p.fh && kx < p.fw) ? (p.flip ? f[i] : f[nt - 1 - i]) * p.gain : 0.f;
+        }
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= total) return;
+    const int cg = (int)(gid % ncg);
+    const long long rest = gid / ncg;
+    const int strip = (int)(rest % nstrips);
+    const long long plane = rest / nstrips;
+    const int x0 = cg * 8, oy0 = strip * RPT;
+    const T* xp = (const T*)p.x + plane * p.xh * p.xw;
+
+    // first input column / row of the group, and the even column the loads start from
+    int c0, iy0;
+    if constexpr (UP == 1) {
+        c0 = x0 * DOWN - p.padx0; iy0 = oy0 * DOWN - p.pady0;
+    } else {
+        const int Ux0 = x0 - p.padx0, Uy0 = oy0 - p.pady0;
+        c0 = (Ux0 + (XODD ? 1 : 0)) / 2; iy0 = (Uy0 + (YODD ? 1 : 0)) / 2;              // exact: the numerators are even
+    }
+    const int e = UP == 1 ? (XODD ? 1 : 0) : (c0 & 1);                                  // (UP 2: uniform over the launch as well)
+    const int a0 = c0 - e;
+    union Row { uint4 q[NL]; T v[NL * 8]; unsigned short h[NL * 8]; };
+    Row raw[NIN];
+    if (a0 >= 0 && a0 + NL * 8 <= p.xw) {
+#pragma unroll
+        for (int r = 0; r < NIN; r++) {
+            const int iy = iy0 + r;
+#pragma unroll
+            for (int l = 0; l < NL; l++) raw[r].q[l] = make_uint4(0u, 0u, 0u, 0u);
+            if ((unsigned)iy < (unsigned)p.xh) {
+                const T* src = xp + (size_t)iy * p.xw + a0;
+#pragma unroll
+                for (int l = 0; l < NL; l++) __builtin_memcpy(&raw[r].q[l], __builtin_assume_aligned(src + 8 * l, 4), 16);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < NIN; r++) {
+            const int iy = iy0 + r;
+            const bool rowok = (unsigned)iy < (unsigned)p.xh;
+#pragma unroll
+            for (int i = 0; i < NL * 8; i++) {
+                const int c = a0 + i;
+                raw[r].h[i] = (rowok && (unsigned)c < (unsigned)p.xw) ? ((const unsigned short*)xp)[(size_t)iy * p.xw + c] : (unsigned short)0;
+            }
+        }
+    }
+    float acc[RPT][8];
+#pragma unroll
+    for (int o = 0; o < RPT; o++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) acc[o][j] = 0.f;
+#pragma unroll
+    for (int r = 0; r < NIN; r++) {
+        float v[NL * 8 - 1];
+#pragma unroll
+        for (int i = 0; i < NL * 8 - 1; i++) v[i] = e ? to_f32(raw[r].v[i + 1]) : to_f32(raw[r].v[i]);
+        if constexpr (UP == 1) {
+#pragma unroll
+            for (int o = 0; o < RPT; o++) {
+                constexpr int dummy = 0; (void)dummy;
+                const int ky = r - o * DOWN;                                               // compile-time after unrolling
+                if (ky >= 0 && ky < 4) {
+#pragma unroll
+                    for (int j = 0; j < 8; j++)
+#pragma unroll
+                        for (int kx = 0; kx < 4; kx++) acc[o][j] = fmaf(t[ky][kx], v[j * DOWN + kx], acc[o][j]);
+                }
+            }
+        } else {
+            // zero insertion: output row o (zero-inserted row Uy0 + o) meets the taps ky = par + 2 a at input row (o + par - qy) / 2 + a
+#pragma unroll
+            for (int o = 0; o < RPT; o++) {
+                const int qy = YODD ? 1 : 0, par = (qy + o) & 1;
+#pragma unroll
+                for (int a = 0; a < 2; a++) {
+                    if ((o + par - qy) / 2 + a != r) continue;
+                    const int ky = par + 2 * a;
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        const int qx = XODD ? 1 : 0, parx = (qx + j) & 1;
+#pragma unroll
+                        for (int b = 0; b < 2; b++) {
+                            const int kx = parx + 2 * b;
+                            acc[o][j] = fmaf(t[ky][kx], v[(j + parx - qx) / 2 + b], acc[o][j]);
+                        }
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < RPT; o++) {
+        const int oy = oy0 + o;
+        if (oy >= p.yh) break;
+        T* yp = (T*)p.y + plane * p.yh * p.yw + (size_t)oy * p.yw + x0;
+        if (x0 + 8 <= p.yw) {
+            union { uint4 q; T v[8]; } out;
+#pragma unroll
+            for (int j = 0; j < 8; j++) out.v[j] = from_f32<T>(acc[o][j]);
+            __builtin_memcpy(__builtin_assume_aligned(yp, 4), &out.q, 16);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+                if (x0 + j < p.yw) yp[j] = from_f32<T>(acc[o][j]);
+        }
+    }
+}
+
+template <typename T>
+static bool launch_rows(const UpfirdnParams& p, const float* f, hipStream_t st) {
+    if constexpr (sizeof(T) != 2) return false;
+    else {
+        const bool sq = p.upx == p.upy && p.downx == p.downy && p.fw <= 4 && p.fh <= 4;
+        if (!sq || ((p.xw | p.yw) & 1) || (((uintptr_t)p.x | (uintptr_t)p.y) & 3)) return false;
+        const int up = p.upx, down = p.downx;
+        if (!((up == 1 && (down == 1 || down == 2)) || (up == 2 && down == 1))) return false;
+        const int rpt = (up == 1 && down == 2) ? 4 : 8;
+        const int ncg = (p.yw + 7) / 8, nstrips = (p.yh + rpt - 1) / rpt;
+        const long long total = (long long)ncg * nstrips * p.planes;
+        const long long nblk = (total + 255) / 256;
+        if (nblk <= 0 || nblk >= (1ll << 31)) return false;
+        dim3 grid((unsigned)nblk), block(256);
+        const bool xo = (p.padx0 & 1) != 0, yo = (p.pady0 & 1) != 0;      // x0 is a multiple of 8, a strip's first row a multiple of 4
+#define AFCM_UPF_ROWS(U, D, XO, YO) hipLaunchKernelGGL((upfirdn2d_rows_kernel<T, U, D, XO, YO>), grid, block, 0, st, p, f, ncg, nstrips, total)
+        if (up == 1 && down == 1) { if (xo) AFCM_UPF_ROWS(1, 1, true, false); else AFCM_UPF_ROWS(1, 1, false, false); }
+        else if (up == 1) { if (xo) AFCM_UPF_ROWS(1, 2, true, false); else AFCM_UPF_ROWS(1, 2, false, false); }
+        else if (xo) { if (yo) AFCM_UPF_ROWS(2, 1, true, true); else AFCM_UPF_ROWS(2, 1, true, false); }
+        else { if (yo) AFCM_UPF_ROWS(2, 1, false, true); else AFCM_UPF_ROWS(2, 1, false, false); }
+#undef AFCM_UPF_ROWS
+        return true;
+    }
+}
+
 template <typename T>
 static bool launch_tile(const UpfirdnParams& p, const float* f, hipStream_t st) {
     const bool sq = p.upx == p.upy && p.downx == p.downy && p.fw <= 4 && p.fh <= 4;
@@ -210,6 +374,10 @@ extern "C" int afcm_upfirdn2d(void* y, const void* x, const float* f, int32_t dt
     if (nblk > 256 * 64) nblk = 256 * 64;
     dim3 grid((unsigned)nblk), block(256);
     hipStream_t st = (hipStream_t)stream;
+    if (AFCM_UPFIRDN_ROWS && dtype != AFCM_F32) {
+        const bool done = dtype == AFCM_F16 ? launch_rows<f16_t>(p, f, st) : launch_rows<bf16_t>(p, f, st);
+        if (done) return hip_status(hipGetLastError());
+    }
     {
         const bool done = dtype == AFCM_F32 ? launch_tile<float>(p, f, st) : dtype == AFCM_F16 ? launch_tile<f16_t>(p, f, st) : launch_tile<bf16_t>(p, f, st);
         if (done) return hip_status(hipGetLastError());

@@ -383,6 +383,38 @@ def test_upfirdn2d_small_filter_tile_kernel_vs_oracle(fshape, up, down, pad, dty
         assert (ggot.float().cpu() - gref).abs().max().item() <= tol * gscale, (fshape, up, down, pad, flip, 'grad')
 
 
+@pytest.mark.parametrize('dtype,tol', [(torch.bfloat16, 8e-3), (torch.float16, 1e-3)])
+@pytest.mark.parametrize('up,down,pad', [(1, 1, [2, 2, 2, 2]), (1, 1, [1, 3, 2, 1]), (1, 1, [2, 3, 2, 3]), (1, 2, [1, 1, 1, 1]), (1, 2, [2, 2, 0, 3]), (2, 1, [2, 1, 2, 1]),
+                                         (2, 1, [1, 2, 3, 0]), (2, 1, [2, 2, 2, 2]), (1, 1, [-1, 3, 0, -2]), (2, 1, [-1, 4, 0, 2]), (1, 2, [-2, 4, 1, 0])])
+@pytest.mark.parametrize('fshape', [(4, 4), (3, 2), (1, 4)])
+@pytest.mark.parametrize('hw', [(37, 72), (9, 18), (64, 258)])
+def test_upfirdn2d_small_filter_row_kernel_vs_oracle(hw, fshape, up, down, pad, dtype, tol):
+    """The 16-bit row-vector kernel (csrc/upfirdn2d.hip, upfirdn2d_rows_kernel: even widths, filters of at most 4 x 4 taps, the
+    discriminator's blur / decimation / their transposes) against the CPU oracle, forward and input gradient: widths of one, a few and
+    many 8-column groups with a ragged last group (18, 72, 258 and whatever the padding makes of them), odd and even paddings (the odd
+    ones start every 16-byte load one element early), negative paddings, row counts that leave the last strip ragged, asymmetric filters
+    with and without flip.  Shapes whose output width comes out odd take the LDS tile kernel -- the same expectations hold."""
+    from afcm_amd.torch_utils.ops import upfirdn2d as ufd
+    from oracle import aten_ops as ops
+    torch.manual_seed(hw[1] + 7 * up + down)
+    x = torch.randn(2, 3, *hw).to(dtype).float()
+    f = torch.randn(*fshape)
+    for flip in (False, True):
+        xr = x.clone().requires_grad_(True)
+        ref = ops.upfirdn2d(xr, f, up=up, down=down, padding=pad, flip_filter=flip, gain=up ** 2)
+        r = torch.randn_like(ref)
+        gref, = torch.autograd.grad((ref * r).sum(), xr)
+        xg = x.cuda().to(dtype).requires_grad_(True)
+        got = ufd.upfirdn2d(xg, f.cuda(), up=up, down=down, padding=pad, flip_filter=flip, gain=up ** 2)
+        assert got.shape == ref.shape and got.dtype == dtype
+        ref = ref.detach()
+        scale = max(1.0, float(ref.abs().max()))
+        assert (got.detach().float().cpu() - ref).abs().max().item() <= tol * scale, (fshape, up, down, pad, flip)
+        ggot, = torch.autograd.grad((got.float() * r.cuda()).sum(), xg)
+        gscale = max(1.0, float(gref.abs().max()))
+        assert (ggot.float().cpu() - gref).abs().max().item() <= tol * gscale, (fshape, up, down, pad, flip, 'grad')
+
+
 @pytest.mark.parametrize('name', ['F1_up2_down2', 'F2_up2_down4', 'F3_up4_down2', 'F4_crop', 'F6_clamp', 'F7_flip_asym'])
 def test_plugin_surface_runs_the_reference_wrapper_call_sequence(name):
     """custom_ops.get_plugin (the reference's loader signature) returns the pybind-level functions on the C ABI: the forward and
