@@ -21,6 +21,9 @@ struct UpfirdnParams {
 };
 
 constexpr int kMaxTaps = 4096;
+#ifndef AFCM_UPF_RPT11
+#define AFCM_UPF_RPT11 8           // output rows per thread of the (up 1, down 1) row kernel (tuning aid)
+#endif
 #ifndef AFCM_UPFIRDN_ROWS
 #define AFCM_UPFIRDN_ROWS 1        // 16-bit small filters on upfirdn2d_rows_kernel (0: the LDS tile kernel; A/B builds)
 #endif
@@ -181,11 +184,11 @@ __global__ __launch_bounds__(256) void upfirdn2d_tile_kernel(UpfirdnParams p, co
 // input row it needs arrives as one, two or three 16-byte loads, all in flight before the first product (the tile kernel above moves 2 bytes
 // per lane and instruction through LDS: 1.3 TB/s on the discriminator's 256^2 blur); the rows above / below are the neighbouring thread's
 // in L1 / L2.  Outputs leave as one 16-byte store per row.  The taps meet every output in the tile kernel's order (ky, then kx), so both
-// kernels produce the same bits.  Column groups whose loads would cross the plane's left / right edge take guarded 2-byte loads.
+// kernels produce the same bits.
 //   XODD: the first input column of a group is odd (UP 1: padx0 odd; UP 2: the zero-inserted origin x0 - padx0 is odd);  YODD (UP 2): the
 //   zero-inserted origin row is odd.  Both are uniform over the launch (x0 is a multiple of 8, the first row of a strip a multiple of RPT).
 template <int UP, int DOWN> struct UpfRows {
-    static constexpr int RPT = (UP == 1 && DOWN == 2) ? 4 : 8;                          // output rows per thread
+    static constexpr int RPT = (UP == 1 && DOWN == 2) ? 4 : (UP == 1 ? AFCM_UPF_RPT11 : 8);   // output rows per thread
     static constexpr int NIN = UP == 1 ? (RPT - 1) * DOWN + 4 : 6;                      // input rows a thread reads
     static constexpr int NEED = UP == 1 ? 7 * DOWN + 4 : 6;                             // input columns per row (from the group's first)
     static constexpr int NL = (NEED + 1 + 7) / 8;                                       // 16-byte loads per row (+ 1: the odd start)
@@ -203,7 +206,8 @@ __global__ __launch_bounds__(256) void upfirdn2d_rows_kernel(UpfirdnParams p, co
 #pragma unroll
         for (int kx = 0; kx < 4; kx++) {
             const int i = ky * p.fw + kx;
-            t[ky][kx] = (ky < p.fh && kx < p.fw) ? (p.flip ? f[i] : f[nt - 1 - i]) * p.gain : 0.f;
+            const float tv = (ky < p.fh && kx < p.fw) ? (p.flip ? f[i] : f[nt - 1 - i]) * p.gain : 0.f;
+            t[ky][kx] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, tv)));   // the product runs on the vector pipe: pin the tap to an SGPR
         }
     const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
     if (gid >= total) return;
@@ -224,31 +228,54 @@ __global__ __launch_bounds__(256) void upfirdn2d_rows_kernel(UpfirdnParams p, co
     }
     const int e = UP == 1 ? (XODD ? 1 : 0) : (c0 & 1);                                  // (UP 2: uniform over the launch as well)
     const int a0 = c0 - e;
-    union Row { uint4 q[NL]; T v[NL * 8]; unsigned short h[NL * 8]; };
+    union Row { uint4 q[NL]; T v[NL * 8]; unsigned d[NL * 4]; };
     Row raw[NIN];
-    if (a0 >= 0 && a0 + NL * 8 <= p.xw) {
+    // One code path for every group (a wave of 64 consecutive groups always holds some that touch the plane's left or right edge: as a
+    // separate guarded path every wave ran both, and the guarded one set the time).  Buffer loads over the whole tensor: a dword before
+    // its first or after its last element reads as zero instead of faulting; columns outside [0, xw) -- which lie in the neighbouring
+    // rows -- are masked per 16-bit half with masks made once per thread; a row outside the plane reads the nearest valid one and is
+    // masked whole.  Every load is in flight before the first use.
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)(p.planes * p.xh * p.xw * 2), 0x00020000);
+    const int plane_el = (int)plane * p.xh * p.xw;
+#pragma unroll
+    for (int r = 0; r < NIN; r++) {
+        const int iyc = min(max(iy0 + r, 0), p.xh - 1);
+        const unsigned off = (unsigned)((plane_el + iyc * p.xw + a0) * 2);
+#pragma unroll
+        for (int l = 0; l < NL; l++) raw[r].q[l] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(xrs, off + 16u * l, 0, 0));
+    }
+    if (plane_el + a0 < 0) {
+        // the tensor's very first group: row 0 would start at a negative offset, which the range check answers with zeros for the whole
+        // vector, not only for the dwords before the buffer -- read it from offset 0 and move the dwords up (a0 = -2 or -4: 1 or 2 dwords)
+        const int sh = (-a0) >> 1;
 #pragma unroll
         for (int r = 0; r < NIN; r++) {
-            const int iy = iy0 + r;
+            if (iy0 + r > 0) continue;                                                   // rows <= 0 all read row 0
+            unsigned ld[NL * 4];
 #pragma unroll
-            for (int l = 0; l < NL; l++) raw[r].q[l] = make_uint4(0u, 0u, 0u, 0u);
-            if ((unsigned)iy < (unsigned)p.xh) {
-                const T* src = xp + (size_t)iy * p.xw + a0;
-#pragma unroll
-                for (int l = 0; l < NL; l++) __builtin_memcpy(&raw[r].q[l], __builtin_assume_aligned(src + 8 * l, 4), 16);
+            for (int l = 0; l < NL; l++) {
+                const uint4 q = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(xrs, 16u * l, 0, 0));
+                ld[4 * l] = q.x; ld[4 * l + 1] = q.y; ld[4 * l + 2] = q.z; ld[4 * l + 3] = q.w;
             }
-        }
-    } else {
 #pragma unroll
-        for (int r = 0; r < NIN; r++) {
-            const int iy = iy0 + r;
-            const bool rowok = (unsigned)iy < (unsigned)p.xh;
-#pragma unroll
-            for (int i = 0; i < NL * 8; i++) {
-                const int c = a0 + i;
-                raw[r].h[i] = (rowok && (unsigned)c < (unsigned)p.xw) ? ((const unsigned short*)xp)[(size_t)iy * p.xw + c] : (unsigned short)0;
-            }
+            for (int k = 0; k < NL * 4; k++) raw[r].d[k] = sh == 1 ? (k >= 1 ? ld[k >= 1 ? k - 1 : 0] : 0u) : (k >= 2 ? ld[k >= 2 ? k - 2 : 0] : 0u);
         }
+    }
+    if (a0 < 0 || a0 + NL * 8 > p.xw) {                                                  // an edge group: columns outside the row
+        unsigned cm[NL * 4];
+#pragma unroll
+        for (int k = 0; k < NL * 4; k++)
+            cm[k] = ((unsigned)(a0 + 2 * k) < (unsigned)p.xw ? 0xffffu : 0u) | ((unsigned)(a0 + 2 * k + 1) < (unsigned)p.xw ? 0xffff0000u : 0u);
+#pragma unroll
+        for (int r = 0; r < NIN; r++)
+#pragma unroll
+            for (int k = 0; k < NL * 4; k++) raw[r].d[k] &= cm[k];
+    }
+#pragma unroll
+    for (int r = 0; r < NIN; r++) {
+        const unsigned keep = (unsigned)(iy0 + r) < (unsigned)p.xh ? 0xffffffffu : 0u;
+#pragma unroll
+        for (int k = 0; k < NL * 4; k++) raw[r].d[k] &= keep;
     }
     float acc[RPT][8];
 #pragma unroll
@@ -318,9 +345,11 @@ static bool launch_rows(const UpfirdnParams& p, const float* f, hipStream_t st) 
     else {
         const bool sq = p.upx == p.upy && p.downx == p.downy && p.fw <= 4 && p.fh <= 4;
         if (!sq || ((p.xw | p.yw) & 1) || (((uintptr_t)p.x | (uintptr_t)p.y) & 3)) return false;
+        if (p.planes * p.xh * p.xw * 2 >= (1ll << 31) || p.planes * p.yh * p.yw >= (1ll << 31)) return false;   // 32-bit buffer offsets / element indices
         const int up = p.upx, down = p.downx;
         if (!((up == 1 && (down == 1 || down == 2)) || (up == 2 && down == 1))) return false;
-        const int rpt = (up == 1 && down == 2) ? 4 : 8;
+        if (p.padx0 > (up == 1 ? 3 : 6)) return false;                      // the first group starts at most 4 columns left of the plane (kernel: sh <= 2)
+        const int rpt = up == 2 ? UpfRows<2, 1>::RPT : down == 2 ? UpfRows<1, 2>::RPT : UpfRows<1, 1>::RPT;
         const int ncg = (p.yw + 7) / 8, nstrips = (p.yh + rpt - 1) / rpt;
         const long long total = (long long)ncg * nstrips * p.planes;
         const long long nblk = (total + 255) / 256;

@@ -385,7 +385,7 @@ def test_upfirdn2d_small_filter_tile_kernel_vs_oracle(fshape, up, down, pad, dty
 
 @pytest.mark.parametrize('dtype,tol', [(torch.bfloat16, 8e-3), (torch.float16, 1e-3)])
 @pytest.mark.parametrize('up,down,pad', [(1, 1, [2, 2, 2, 2]), (1, 1, [1, 3, 2, 1]), (1, 1, [2, 3, 2, 3]), (1, 2, [1, 1, 1, 1]), (1, 2, [2, 2, 0, 3]), (2, 1, [2, 1, 2, 1]),
-                                         (2, 1, [1, 2, 3, 0]), (2, 1, [2, 2, 2, 2]), (1, 1, [-1, 3, 0, -2]), (2, 1, [-1, 4, 0, 2]), (1, 2, [-2, 4, 1, 0])])
+                                         (2, 1, [1, 2, 3, 0]), (2, 1, [2, 2, 2, 2]), (1, 1, [-1, 3, 0, -2]), (2, 1, [-1, 4, 0, 2]), (1, 2, [-2, 4, 1, 0]), (1, 1, [5, 1, 4, 0]), (2, 1, [6, 2, 7, 1]), (2, 1, [8, 2, 1, 1])])
 @pytest.mark.parametrize('fshape', [(4, 4), (3, 2), (1, 4)])
 @pytest.mark.parametrize('hw', [(37, 72), (9, 18), (64, 258)])
 def test_upfirdn2d_small_filter_row_kernel_vs_oracle(hw, fshape, up, down, pad, dtype, tol):
@@ -393,7 +393,8 @@ def test_upfirdn2d_small_filter_row_kernel_vs_oracle(hw, fshape, up, down, pad, 
     discriminator's blur / decimation / their transposes) against the CPU oracle, forward and input gradient: widths of one, a few and
     many 8-column groups with a ragged last group (18, 72, 258 and whatever the padding makes of them), odd and even paddings (the odd
     ones start every 16-byte load one element early), negative paddings, row counts that leave the last strip ragged, asymmetric filters
-    with and without flip.  Shapes whose output width comes out odd take the LDS tile kernel -- the same expectations hold."""
+    with and without flip.  Shapes whose output width comes out odd, and left paddings beyond what the kernel's first column group covers
+    (> 3 at up 1, > 6 at up 2), take the LDS tile kernel -- the same expectations hold."""
     from afcm_amd.torch_utils.ops import upfirdn2d as ufd
     from oracle import aten_ops as ops
     torch.manual_seed(hw[1] + 7 * up + down)
