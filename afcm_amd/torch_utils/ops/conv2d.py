@@ -388,7 +388,9 @@ def _conv_raw(x, wp, rows_pad, oscale, cout, ks, pad, obias=None, pitched_out=Fa
     return y
 
 
-_FRAME_WGRAD_MAX = 1 << 24        # elements of dy up to which a pad-1 weight gradient is computed as pad-2 on a zero-framed dy
+# elements of dy up to which a pad-1 weight gradient is computed as pad-2 on a zero-framed dy (profiles/r05_wgrad_pad1.txt, batch 16:
+# 32^2 x 512 = 8.4 M: 139 us framed against 207 on the dword kernel; 64^2 x 256 = 16.8 M: 150 against 123; larger planes: the dword kernel)
+_FRAME_WGRAD_MAX = 12 << 20
 
 
 def _frame_dy(dy, ks, pad):
