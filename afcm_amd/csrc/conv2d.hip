@@ -843,7 +843,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_fwd16x_kernel(ConvParams p) {
     constexpr int KS = 3, KK = 9, BK = 32, MO = BM_O / 32, NT = 8, BRING = MO == 4 ? 4 : 3;
     // weight-fragment ring, in fragments: a chunk's KK * MO fragments (tap-major) cycle through ARING slots.  MO = 4: 9 slots = 2.25 taps
     // (3 taps = 48 registers do not fit beside 128 accumulator registers at two waves per SIMD); MO = 2: 6 slots = 3 taps
-    constexpr int ARING = MO == 4 ? 9 : 6;
+    constexpr int ARING = MO == 2 ? 6 : 9;
     static_assert((KK * MO) % ARING == 0 && ARING >= 2 * MO, "static slots; a tap's fragments and the next tap's are live together");
     // bytes of one channel-group plane: kPlaneX16 = 416 pixels.  2 buffers x 4 planes = 53,248 bytes per workgroup.  The patch itself may
     // use kPatchMaxX16 = 412 pixels: the last four are the sink of the staging threads whose pixel group lies past the plane (branch-free
@@ -1163,15 +1163,17 @@ __global__ __launch_bounds__(256, 2) void conv2d_fwd16x_kernel(ConvParams p) {
                 if (__builtin_amdgcn_ballot_w64(slow) != 0) slow_any |= 1u << it;
             }
 #pragma unroll
-            for (int mi = 0; mi < MO / 2; mi++) {
+            for (int mi = 0; mi < (MO + 1) / 2; mi++) {
                 const int rowbase = o0 + wo * (BM_O / 2) + mi * 32;
                 const int o = rowbase + chalf * 16 + i16;
-                const unsigned obyte = o < p.Cout ? (unsigned)(o * pq * 2) : kOOut;
+                // (MO odd -- the 96-row block: the last pass carries 16 channels, its upper half belongs to the other wave's rows)
+                const unsigned obyte = (o < p.Cout && mi * 32 + chalf * 16 < BM_O / 2) ? (unsigned)(o * pq * 2) : kOOut;
 #pragma unroll
                 for (int half = 0; half < 2; half++) {
 #pragma unroll
                     for (int k = 0; k < 2; k++) {
                         const int mo = 2 * mi + k;
+                        if (mo >= MO) continue;
 #pragma unroll
                         for (int t4 = 0; t4 < 4; t4++) {
                             const int ti = 4 * half + t4;
@@ -2716,6 +2718,12 @@ __global__ __launch_bounds__(512, 1) void conv2d_wgrad16_kernel(WgradParams p) {
 // rebuilds a 128-bit descriptor per piece -- 64-bit base, exact record count, validity select, three v_readfirstlane --
 // ~45 scalar instructions per piece, 310 per K step of 36 MFMAs: the wave's own instruction stream, not the matrix pipe, set
 // the step time (PMC r01e: MFMA pipe 49 % busy, 8.7 SALU per MFMA).
+#ifndef AFCM_CONV_BM96
+#define AFCM_CONV_BM96 1           // 65 .. 96 output rows on one 96-row block of conv2d_fwd16x_kernel (0: a 128-row block; A/B builds)
+#endif
+#ifndef AFCM_CONV_BM96_192
+#define AFCM_CONV_BM96_192 0       // experiment: 129 .. 192 rows as two 96-row blocks instead of 128 + 64 (measured: the same, profiles/r05_conv_bm96_ab.txt)
+#endif
 #ifndef AFCM_CONV_MIXED
 #define AFCM_CONV_MIXED 1          // 128 k + (1 .. 64) output rows: 128-row kernel + one 64-row block (0: 64-row blocks only; A/B builds)
 #endif
@@ -3479,6 +3487,15 @@ extern "C" int afcm_conv2d_ld(void* y, const void* x, const void* wpacked, const
     // ... and both when the rows are 128 k + (1 .. 64) (the 181-channel layers: 192 padded rows): the 128-row kernel moves half the
     // pixel-fragment bytes per flop of the 64-row one, so rows [0, 128 k) go to it and only the last 64 to the 64-row kernel -- two
     // launches, disjoint output rows, the same number of passes over x as three 64-row blocks had
+    if (AFCM_CONV_BM96 && AFCM_X16_ON && dtype != AFCM_F32 && ks == 3 && ((cout > 64 && cout <= 96) || (AFCM_CONV_BM96_192 && cout > 128 && cout <= 192 && rows_pad >= 192))) {
+        // 65 .. 96 output rows (the 91-channel layers): one 96-row block instead of 128 rows of MFMAs for them
+        const long long blocks = (long long)p.tilesX * p.tilesY * p.N * cdiv(cout, 96);
+        AFCM_REQUIRE(blocks > 0 && blocks < (1ll << 31), "conv2d: grid of %lld blocks is out of range", blocks);
+        p.total_blocks = (int)blocks; p.o_base = 0;
+        if (dtype == AFCM_F16) hipLaunchKernelGGL((conv2d_fwd16x_kernel<f16_t, 96>), dim3((unsigned)blocks), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((conv2d_fwd16x_kernel<bf16_t, 96>), dim3((unsigned)blocks), dim3(256), 0, st, p);
+        return hip_status(hipGetLastError());
+    }
     if (AFCM_CONV_MIXED && AFCM_X16_ON && dtype != AFCM_F32 && ks == 3 && rows_pad % 128 == 64 && rows_pad > 128) {
         const int big = rows_pad / 128;
         const int rc = dtype == AFCM_F16 ? launch_conv<f16_t, 128>(p, ks, st, 0, big) : launch_conv<bf16_t, 128>(p, ks, st, 0, big);

@@ -63,6 +63,10 @@ CASES = [
     (1, 64, 64, 3, 6, 62, 2),        # Q = 64: exactly one chunk
     (1, 64, 64, 3, 6, 64, 2),        # Q = 66: second chunk with 2 live pixels
     (2, 64, 128, 3, 6, 98, 2),       # Q = 100: 36 live pixels in the second chunk, two o-tiles
+    # 65 .. 96 output rows take the 96-row block of the 16x16x32 kernel (forward: Cout, data gradient: Cin)
+    (2, 91, 64, 3, 22, 26, 2),       # data gradient with 91 rows
+    (1, 64, 80, 3, 40, 54, 2),       # 80 rows: the last 16-row fragment of each wave half empty
+    (2, 96, 65, 3, 12, 150, 2),      # 65 rows forward, 96 rows in the data gradient, 50-wide tiles
 ]
 
 
