@@ -2148,6 +2148,11 @@ struct WgradParams {
     int N, O, I, H, W, P, Q, pad;
     int lddy, ldx;                // row pitch (elements) of dy / x; = Q / W for dense tensors.  conv2d_wgrad16g_kernel only.
     int splits, steps_per_split;  // K macro-steps = N * rowgroups * qchunks
+    // conv2d_wgrad16g_kernel: two classes of 64 x 64 tiles.  The tiles (obk < fo, ib < fi) are FULL: `splits` workgroups of
+    // `steps_per_split` steps each; the others have at most 32 live rows or columns -- two of their four wave quadrants multiply nothing and
+    // are skipped -- and get `splits_p` workgroups of `steps_per_split_p` steps (fewer, longer shares: a step costs them ~0.6 of a full
+    // tile's).  No partial class: fo / fi = the tile counts, splits_p = splits.
+    int fo, fi, splits_p, steps_per_split_p;
     int qchunks;                  // ceil(Q / kWgKQ)
     int rowgroups;                // ceil(P / R)
 };
@@ -2756,20 +2761,35 @@ __global__ __launch_bounds__(512, 1) void conv2d_wgrad16g_kernel(WgradParams p) 
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wo = wave & 1, wi = (wave >> 1) & 1, th = wave >> 2;     // th: which half of the chunk's pixels this wave accumulates
+    // th: which half of the chunk's pixels this wave accumulates; (wo, wi): its 32 x 32 quadrant of the tile.  The two waves of a SIMD
+    // (wave, wave + 4) take DIAGONALLY OPPOSITE quadrants: when a tile's rows 32.. or columns 32.. lie outside the matrix (the last tile of a
+    // 91-channel operand: 27 live rows), every SIMD then holds one live and one idle wave instead of two SIMDs holding both
+    const int th = wave >> 2, wo = (wave & 1) ^ th, wi = ((wave >> 1) & 1) ^ th;
     const int r32 = lane & 31, h = lane >> 5;
 
-    const int tiles_i = cdiv(p.I, 64), tiles = tiles_i * cdiv(p.O, 64);
+    const int tiles_i = cdiv(p.I, 64), tiles_o = cdiv(p.O, 64);
     int bid = blockIdx.x;
-    const int total = tiles * p.splits;
-    bid = xcd_order(bid, total);          // XCD x: contiguous logical ids (split-major)
+    const int n_full = p.fo * p.fi, total = n_full * p.splits + (tiles_i * tiles_o - n_full) * p.splits_p;
+    bid = xcd_order(bid, total);          // XCD x: contiguous logical ids (split-major within a class)
     // integer division runs on the vector pipe even for uniform operands: pin the results to SGPRs, or every per-step address
     // and descriptor computation derived from them runs as 64-bit VALU code + v_readfirstlane (measured: ~130 vector
     // instructions per step beside the 36 MFMAs)
-    const int split = __builtin_amdgcn_readfirstlane(bid / tiles);
-    const int tile = bid - split * tiles;
-    const int obk = __builtin_amdgcn_readfirstlane(tile / tiles_i);
-    const int ib = tile - obk * tiles_i;
+    int split, obk, ib, my_steps;
+    if (bid < n_full * p.splits) {
+        split = __builtin_amdgcn_readfirstlane(bid / n_full);
+        const int tile = bid - split * n_full;                                       // index in the fo x fi grid of full tiles
+        obk = __builtin_amdgcn_readfirstlane(tile / p.fi);
+        ib = tile - obk * p.fi;
+        my_steps = p.steps_per_split;
+    } else {
+        // partial tiles: the column ib = fi (when fi < tiles_i), all tiles_o rows of it, then the row obk = fo (fo < tiles_o), ib < fi
+        const int rel = bid - n_full * p.splits, n_part = tiles_i * tiles_o - n_full;
+        split = __builtin_amdgcn_readfirstlane(rel / n_part);
+        const int j = rel - split * n_part;
+        const int ncol = p.fi < tiles_i ? tiles_o : 0;
+        if (j < ncol) { obk = j; ib = p.fi; } else { obk = p.fo; ib = j - ncol; }
+        my_steps = p.steps_per_split_p;
+    }
     const int o0 = obk * 64, i0 = ib * 64;
 
     // 32x32x16: one 32 x 32 tile per tap, element e = MFMA register e; 16x16x32: element 4 (2 ob2 + ib2) + reg of the (ob2, ib2) 16 x 16 tile
@@ -2797,8 +2817,10 @@ __global__ __launch_bounds__(512, 1) void conv2d_wgrad16g_kernel(WgradParams p) 
     unsigned c_dy32 = 0, c_x32 = 0;                                              // byte offsets of (image n, channel o0 / i0)
 
     const int steps_per_img = p.rowgroups * p.qchunks;
-    const int s0 = split * p.steps_per_split;
-    const int s1 = min(s0 + p.steps_per_split, p.N * steps_per_img);
+    const int s0 = split * my_steps;
+    const int s1 = min(s0 + my_steps, p.N * steps_per_img);
+    // a quadrant wholly outside the matrix: its waves only issue their share of the loads
+    const bool quad_dead = o0 + wo * 32 >= p.O || i0 + wi * 32 >= p.I;
     int ld_n = __builtin_amdgcn_readfirstlane(s0 / steps_per_img);
     int ld_rg = __builtin_amdgcn_readfirstlane((s0 - ld_n * steps_per_img) / p.qchunks);
     int ld_qc = s0 - ld_n * steps_per_img - ld_rg * p.qchunks;
@@ -2947,7 +2969,7 @@ __global__ __launch_bounds__(512, 1) void conv2d_wgrad16g_kernel(WgradParams p) 
         // 16-pixel groups of the chunk that lie beyond the row's end would multiply zeros (rows of 86, 150, 278 pixels end
         // with 22 pixels of a 64-pixel chunk): a wave skips its dead groups and only issues its share of the next loads.  The
         // groups alternate between the two waves that share a SIMD (th 0 / th 1), so a 22-pixel chunk costs both one group.
-        const int vq = p.Q - u_qc * kWgKQ;
+        const int vq = quad_dead ? 0 : p.Q - u_qc * kWgKQ;
         if (++u_qc == p.qchunks) u_qc = 0;
         // one x row of one 16-pixel group: the next loads' share, the three shifted B fragments, 3 or 6 MFMAs
         auto row_mfmas = [&](auto kqc, auto xrc, const uint4 lo, const uint4 hi, const frag_t* a) __attribute__((always_inline)) {
@@ -3115,7 +3137,7 @@ __global__ __launch_bounds__(512, 1) void conv2d_wgrad16g_kernel(WgradParams p) 
         constexpr int TPR_CAP = (NBUF * BUF) / (4 * 16 * 64 * (int)sizeof(float));     // taps per round
         constexpr int TPR = TPR_CAP < KK ? TPR_CAP : KK;
         static_assert(TPR >= 1, "LDS too small for the half-sum");
-        const int wv4 = wave & 3;
+        const int wv4 = wo + 2 * wi;                                     // the quadrant: both pixel halves of it meet in the same slot
 #pragma unroll
         for (int t0 = 0; t0 < KK; t0 += TPR) {
             if (t0 > 0) __syncthreads();
@@ -3150,9 +3172,17 @@ __global__ __launch_bounds__(512, 1) void conv2d_wgrad16g_kernel(WgradParams p) 
     }
 }
 
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(float* __restrict__ dw, const float* __restrict__ part, long long numel, int splits) {
+// Slabs an element's tile wrote (WgradParams: full tiles `splits`, partial ones `splits_p`; the slabs beyond were never written)
+struct WgradSlabs { int I, KK, fo, fi, splits, splits_p; };
+__device__ __forceinline__ int slabs_of(const WgradSlabs& w, long long idx) {
+    if (w.splits_p == w.splits) return w.splits;
+    const int oi = (int)(idx / w.KK), o = oi / w.I, i = oi - o * w.I;
+    return ((o >> 6) < w.fo && (i >> 6) < w.fi) ? w.splits : w.splits_p;
+}
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(float* __restrict__ dw, const float* __restrict__ part, long long numel, WgradSlabs w) {
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < numel; idx += (long long)gridDim.x * blockDim.x) {
         float s = 0.f;
+        const int splits = slabs_of(w, idx);
         for (int k = 0; k < splits; k++) s += part[(size_t)k * numel + idx];
         dw[idx] = s;
     }
@@ -3162,7 +3192,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(float* __restrict__ d
 // COLS float4 columns x (256 / COLS) split groups, group partials summed through LDS.  A 64 -> 64 layer has 36,864 outputs and 256
 // splits (151 MB of partials): one thread per output is 144 workgroups of serial 4-byte loads on a 256-CU chip.
 template <int COLS>
-__global__ __launch_bounds__(256) void wgrad_reduce4_kernel(float* __restrict__ dw, const float* __restrict__ part, long long numel4, int splits) {
+__global__ __launch_bounds__(256) void wgrad_reduce4_kernel(float* __restrict__ dw, const float* __restrict__ part, long long numel4, WgradSlabs w) {
     constexpr int GROUPS = 256 / COLS;
     typedef __attribute__((ext_vector_type(4))) float f32x4v;
     __shared__ f32x4v red[GROUPS][COLS];
@@ -3171,6 +3201,18 @@ __global__ __launch_bounds__(256) void wgrad_reduce4_kernel(float* __restrict__ 
     f32x4v s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
     if (c4 < numel4) {
         const f32x4v* src = (const f32x4v*)part + c4;
+        // the four elements of a column may belong to tiles of different classes (9 taps per (o, i): columns straddle i and tile borders):
+        // common slabs as whole vectors, the rest element by element
+        int ne[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) ne[e] = slabs_of(w, 4 * c4 + e);
+        const int splits = min(min(ne[0], ne[1]), min(ne[2], ne[3]));
+        const int most = max(max(ne[0], ne[1]), max(ne[2], ne[3]));
+        for (int k2 = splits + grp; k2 < most; k2 += GROUPS) {
+            const f32x4v v = src[(size_t)k2 * numel4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) s1[e] += k2 < ne[e] ? v[e] : 0.f;
+        }
         int k = grp;
         for (; k + 3 * GROUPS < splits; k += 4 * GROUPS) {
             const f32x4v v0 = src[(size_t)k * numel4], v1 = src[(size_t)(k + GROUPS) * numel4];
@@ -3647,16 +3689,41 @@ extern "C" int afcm_conv2d_split(float* y, const void* x_parts, const void* wpac
 // Split count for the weight gradient: enough workgroups to fill the chip, bounded by the K macro-steps.
 static int wgrad_rows_per_step(int dtype) { return dtype == AFCM_F32 ? 1 : 2; }
 
-extern "C" int afcm_conv2d_wgrad_splits(int32_t n, int32_t cout, int32_t cin, int32_t p_rows) {
-    const int tiles = cdiv(cout, 64) * cdiv(cin, 64);
-    // One workgroup per CU is resident (LDS ring), so aim for ONE full round of the 256 CUs and never one workgroup more:
-    // rounding up (258 workgroups = two rounds) halves the throughput, and every extra split costs a 36 x 64 x 64 x 4 B
-    // partial tile written and read back (at 768 workgroups the partials of a 64 -> 64 layer were 2/3 of its time).
-    int splits = 256 / tiles;
+// Workgroups per 64 x 64 tile.  One workgroup per CU is resident (LDS ring), so aim for ONE full round of the 256 CUs and never one
+// workgroup more: rounding up (258 workgroups = two rounds) halves the throughput, and every extra split costs a 36 x 64 x 64 x 4 B
+// partial tile written and read back (at 768 workgroups the partials of a 64 -> 64 layer were 2/3 of its time).
+// two_class (conv2d_wgrad16g_kernel): tiles whose last 32 rows or columns lie outside the matrix (WgradParams::fo / fi) run their steps
+// at ~0.6 of a full tile's cost (one live wave per SIMD: 1152 MFMA cycles + the ~600 of barrier and bookkeeping, against 2304 + 600),
+// so they get 0.6 of a full tile's workgroups -- the round stays one round and every workgroup ends at about the same time.
+// MEASURED (profiles/r05_wgrad_partial_tiles.txt): the skipped quadrants alone are worth 3-6 % on the 91-channel layers (L11 0.33 -> 0.31 ms)
+// with the same number of workgroups per tile; the two-class plan on top made them SLOWER (L11 0.31 -> 0.36): a lone wave per SIMD cannot
+// hide its own LDS latency, a step costs a partial tile nearer 0.8 than 0.6 of a full one.  Off; the plan and the reduce kernels keep the
+// machinery (tests/test_gpu_conv.py ran green with it on).
+#ifndef AFCM_WGRAD_TWO_CLASS
+#define AFCM_WGRAD_TWO_CLASS 0
+#endif
+static void wgrad_plan(int n, int cout, int cin, int p_rows, bool two_class, int* fo, int* fi, int* splits, int* splits_p) {
+    const int to = cdiv(cout, 64), ti = cdiv(cin, 64), tiles = to * ti;
     const long long ksteps = (long long)n * p_rows;   // upper bound on the macro-steps of any dtype
-    if (splits > ksteps) splits = (int)ksteps;
-    if (splits < 1) splits = 1;
-    return splits;
+    auto clampk = [&](int v) { if (v > ksteps) v = (int)ksteps; return v < 1 ? 1 : v; };
+    *fo = to; *fi = ti;
+    *splits = *splits_p = clampk(256 / tiles);
+    if (!two_class || !AFCM_WGRAD_TWO_CLASS) return;
+    const int f_o = cout - (to - 1) * 64 <= 32 ? to - 1 : to, f_i = cin - (ti - 1) * 64 <= 32 ? ti - 1 : ti;
+    const int nf = f_o * f_i, np = tiles - nf;
+    if (nf == 0 || np == 0) return;                   // one class only
+    int sf = (int)(256 / (nf + 0.6 * np)), sp = (256 - nf * sf) / np;
+    if (sp < 1) { sp = 1; sf = (256 - np) / nf; }
+    if (sf < 1) return;
+    *fo = f_o; *fi = f_i; *splits = clampk(sf); *splits_p = clampk(sp);
+}
+
+extern "C" int afcm_conv2d_wgrad_splits(int32_t n, int32_t cout, int32_t cin, int32_t p_rows) {
+    // slabs of the workspace: the most any tile of any kernel writes
+    int fo, fi, s0, s0p, s1, s1p;
+    wgrad_plan(n, cout, cin, p_rows, false, &fo, &fi, &s0, &s0p);
+    wgrad_plan(n, cout, cin, p_rows, true, &fo, &fi, &s1, &s1p);
+    return s0 > s1 ? s0 : s1;
 }
 
 extern "C" int afcm_conv2d_wgrad(float* dw, float* workspace, const void* dy, const void* x, int32_t dtype, int32_t n, int32_t cin,
@@ -3683,10 +3750,14 @@ extern "C" int afcm_conv2d_wgrad_ld(float* dw, float* workspace, const void* dy,
     p.qchunks = cdiv(p.Q, kWgKQ);
     p.rowgroups = cdiv(p.P, R);
     const long long ksteps = (long long)n * p.rowgroups * p.qchunks;
-    p.splits = afcm_conv2d_wgrad_splits(n, cout, cin, p.P);
+    const bool granule = (ks == 3 && pad == 2) || (ks == 1 && pad == 0);     // 16-byte LDS-DMA pieces; other paddings: 4-byte pieces
+    wgrad_plan(n, cout, cin, p.P, dtype != AFCM_F32 && granule, &p.fo, &p.fi, &p.splits, &p.splits_p);
     if (p.splits > ksteps) p.splits = (int)ksteps;
+    if (p.splits_p > ksteps) p.splits_p = (int)ksteps;
     p.steps_per_split = (int)((ksteps + p.splits - 1) / p.splits);
-    const long long blocks = (long long)cdiv(cout, 64) * cdiv(cin, 64) * p.splits;
+    p.steps_per_split_p = (int)((ksteps + p.splits_p - 1) / p.splits_p);
+    const long long n_full = (long long)p.fo * p.fi;
+    const long long blocks = n_full * p.splits + ((long long)cdiv(cout, 64) * cdiv(cin, 64) - n_full) * p.splits_p;
     dim3 grid((unsigned)blocks), block(512);
     hipStream_t st = (hipStream_t)stream;
 #define AFCM_WG(T, R) do { if (ks == 3 && (pad & 1) == 0) hipLaunchKernelGGL((conv2d_wgrad_kernel<T, 3, R, 0>), grid, block, 0, st, p); \
@@ -3710,7 +3781,6 @@ extern "C" int afcm_conv2d_wgrad_ld(float* dw, float* workspace, const void* dy,
     // tensors below 2 GB: one descriptor per tensor; larger ones: a descriptor per LDS-DMA piece (the general form)
     const bool small = (long long)n * cout * p.P * p.lddy * 2 < (1ll << 31) - 65536 &&
                        (long long)n * cin * h * p.ldx * 2 < (1ll << 31) - 65536;
-    const bool granule = (ks == 3 && pad == 2) || (ks == 1 && pad == 0);     // 16-byte LDS-DMA pieces; other paddings: 4-byte pieces
     // rows by pitch: the 16-byte LDS-DMA kernel only (a granule straddling x's right edge is zeroed in LDS whatever follows it)
     AFCM_REQUIRE(!pitched || (dtype != AFCM_F32 && granule), "conv2d_wgrad: row pitches need the 16-bit granule kernel (3x3 pad 2 or 1x1 pad 0)");
     switch (dtype) {
@@ -3725,16 +3795,17 @@ extern "C" int afcm_conv2d_wgrad_ld(float* dw, float* workspace, const void* dy,
     int rc = hip_status(hipGetLastError());
     if (rc != AFCM_OK) return rc;
     const long long numel = (long long)cout * cin * ks * ks;
+    const WgradSlabs slabs{cin, ks * ks, p.fo, p.fi, p.splits, p.splits_p};
     long long rb = (numel + 255) / 256;
     if (rb > 2048) rb = 2048;
     // splits beyond the last populated one were never launched with work: they still wrote zeros (acc = 0)
     if ((numel & 3) == 0 && (((uintptr_t)dw | (uintptr_t)workspace) & 15) == 0) {
         const long long n4 = numel / 4;
-        if (p.splits >= 64) hipLaunchKernelGGL(wgrad_reduce4_kernel<16>, dim3((unsigned)cdiv(n4, 16)), dim3(256), 0, st, dw, (const float*)workspace, n4, p.splits);
-        else if (p.splits >= 8) hipLaunchKernelGGL(wgrad_reduce4_kernel<64>, dim3((unsigned)cdiv(n4, 64)), dim3(256), 0, st, dw, (const float*)workspace, n4, p.splits);
-        else hipLaunchKernelGGL(wgrad_reduce4_kernel<256>, dim3((unsigned)cdiv(n4, 256)), dim3(256), 0, st, dw, (const float*)workspace, n4, p.splits);
+        if (p.splits >= 64) hipLaunchKernelGGL(wgrad_reduce4_kernel<16>, dim3((unsigned)cdiv(n4, 16)), dim3(256), 0, st, dw, (const float*)workspace, n4, slabs);
+        else if (p.splits >= 8) hipLaunchKernelGGL(wgrad_reduce4_kernel<64>, dim3((unsigned)cdiv(n4, 64)), dim3(256), 0, st, dw, (const float*)workspace, n4, slabs);
+        else hipLaunchKernelGGL(wgrad_reduce4_kernel<256>, dim3((unsigned)cdiv(n4, 256)), dim3(256), 0, st, dw, (const float*)workspace, n4, slabs);
     } else {
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)rb), dim3(256), 0, st, dw, (const float*)workspace, numel, p.splits);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)rb), dim3(256), 0, st, dw, (const float*)workspace, numel, slabs);
     }
     return hip_status(hipGetLastError());
 }

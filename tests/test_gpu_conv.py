@@ -67,6 +67,11 @@ CASES = [
     (2, 91, 64, 3, 22, 26, 2),       # data gradient with 91 rows
     (1, 64, 80, 3, 40, 54, 2),       # 80 rows: the last 16-row fragment of each wave half empty
     (2, 96, 65, 3, 12, 150, 2),      # 65 rows forward, 96 rows in the data gradient, 50-wide tiles
+    # weight gradient: tiles whose last 32 rows / columns lie outside the matrix form a class of their own (fewer, longer K shares;
+    # their idle wave quadrants are skipped) -- a partial row of tiles, a partial column, both with the corner tile, one live quadrant only
+    (2, 91, 91, 3, 20, 22, 2),       # 2 x 2 tiles: one full, a partial column, a partial row, the corner
+    (1, 130, 100, 3, 14, 30, 2),     # I = 130: third tile column with 2 live columns; O = 100: 36 live rows (full class)
+    (2, 160, 20, 3, 10, 70, 2),      # O = 20: every tile partial (one class again), I = 160: 32 live columns in the last
 ]
 
 
