@@ -17,6 +17,10 @@
 
 #include "common.h"
 
+#ifndef AFCM_CONV_BM96_PERSIST
+#define AFCM_CONV_BM96_PERSIST 1   // the 96-row block as persistent workgroups (two per CU) like the 64-row one: 228 registers, no spills; 3-7 % on the 91-row launches (profiles/r05_conv_bm96_ab.txt)
+#endif
+
 namespace afcm {
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -877,7 +881,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_fwd16x_kernel(ConvParams p) {
     // sits at 250 of its 256 registers, 19-52 spilled registers in every form tried (its workgroups live 150-200k cycles, the prologue
     // is 3 % of that); the 64-row kernel -- the <= 64-channel and the 181-channel layers, where the prologue is a quarter -- fits in the
     // 168 registers of three waves per SIMD.  A non-persistent launch has one item per workgroup (the host sizes the grid accordingly).
-    constexpr bool PERSIST = BM_O == 64;
+    constexpr bool PERSIST = BM_O == 64 || (BM_O == 96 && AFCM_CONV_BM96_PERSIST);
     struct Tile { int y0, x0, n, o0; };
     auto decode = [&](int it) __attribute__((always_inline)) -> Tile {
         const int bid = xcd_order(it, p.total_blocks);
@@ -3534,8 +3538,9 @@ extern "C" int afcm_conv2d_ld(void* y, const void* x, const void* wpacked, const
         const long long blocks = (long long)p.tilesX * p.tilesY * p.N * cdiv(cout, 96);
         AFCM_REQUIRE(blocks > 0 && blocks < (1ll << 31), "conv2d: grid of %lld blocks is out of range", blocks);
         p.total_blocks = (int)blocks; p.o_base = 0;
-        if (dtype == AFCM_F16) hipLaunchKernelGGL((conv2d_fwd16x_kernel<f16_t, 96>), dim3((unsigned)blocks), dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((conv2d_fwd16x_kernel<bf16_t, 96>), dim3((unsigned)blocks), dim3(256), 0, st, p);
+        const dim3 g96((unsigned)(AFCM_CONV_BM96_PERSIST ? conv_persistent_grid(blocks, 2) : blocks));
+        if (dtype == AFCM_F16) hipLaunchKernelGGL((conv2d_fwd16x_kernel<f16_t, 96>), g96, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((conv2d_fwd16x_kernel<bf16_t, 96>), g96, dim3(256), 0, st, p);
         return hip_status(hipGetLastError());
     }
     if (AFCM_CONV_MIXED && AFCM_X16_ON && dtype != AFCM_F32 && ks == 3 && rows_pad % 128 == 64 && rows_pad > 128) {
