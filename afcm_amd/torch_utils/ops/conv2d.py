@@ -596,6 +596,17 @@ def _s2_pack_store(w, dtype, wp):
     _S2_PACKS[key] = (weakref.ref(w, _gone), w._version, dtype, wp)
 
 
+ZERO_STUFF_UPFIRDN = True      # module switch (A/B): the stride-2 backward's zero-stuffed dy through upfirdn2d(up=2, one tap)
+_ONE_TAP = {}
+
+
+def _one_tap(device):
+    f = _ONE_TAP.get(device)
+    if f is None:
+        f = _ONE_TAP[device] = torch.ones([1, 1], dtype=torch.float32, device=device)
+    return f
+
+
 class _StridedConv2d(torch.autograd.Function):
     """y = conv(x, w, pad) at stride 2, 16-bit 3x3 (C ABI afcm_conv2d_stride2): the even rows / columns of the stride-1 result, bit for
     bit, at a quarter of its MFMAs.  The gradients of a strided correlation are stride-1 convolutions with the zero-stuffed dy: the
@@ -636,8 +647,15 @@ class _StridedConv2d(torch.autograd.Function):
         x, w = ctx.saved_tensors
         pad = ctx.padding
         n, _, h, wd = x.shape
-        full = dy.new_zeros([n, dy.shape[1], h + 2 * pad - 2, wd + 2 * pad - 2])
-        full[:, :, ::2, ::2] = dy                                    # zero-stuffed: the gradient of the stride-1 result
+        fh, fw = h + 2 * pad - 2, wd + 2 * pad - 2
+        if ZERO_STUFF_UPFIRDN and fw % 2 == 0 and dy.shape[3] % 2 == 0:
+            # zero-stuffed dy = the gradient of the stride-1 result: upfirdn2d with up 2 and a one-tap filter writes it in ONE pass (row
+            # kernel: 16-byte stores), differentiable like the slice assignment it replaces (a fill + a strided copy: two passes)
+            from . import upfirdn2d as _upf
+            full = _upf.upfirdn2d(dy, _one_tap(dy.device), up=2, padding=[0, fw - 2 * dy.shape[3], 0, fh - 2 * dy.shape[2]])
+        else:
+            full = dy.new_zeros([n, dy.shape[1], fh, fw])
+            full[:, :, ::2, ::2] = dy                                # zero-stuffed: the gradient of the stride-1 result
         dx = dw = None
         if ctx.needs_input_grad[0]:
             dx = _ScaledConv2d.apply(full, w.to(torch.float32).transpose(0, 1).flip([2, 3]).contiguous(), None, None, 2 - pad, False)
