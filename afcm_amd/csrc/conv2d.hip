@@ -2736,6 +2736,9 @@ __global__ __launch_bounds__(512, 1) void conv2d_wgrad16_kernel(WgradParams p) {
 #ifndef AFCM_CONV_MIXED
 #define AFCM_CONV_MIXED 1          // 128 k + (1 .. 64) output rows: 128-row kernel + one 64-row block (0: 64-row blocks only; A/B builds)
 #endif
+#ifndef AFCM_WGRAD_LATE
+#define AFCM_WGRAD_LATE 1          // begin_loads behind the first iteration's MFMAs: 8.55 -> 8.28 ms in the step (profiles/r05_wgrad_late_ab.txt); 0: at the step's top
+#endif
 #ifndef AFCM_WGRAD_NBUF
 #define AFCM_WGRAD_NBUF 3          // LDS ring depth of conv2d_wgrad16g_kernel (2: measured in profiles/r04_wgrad_ring.txt)
 #endif
@@ -2967,7 +2970,10 @@ __global__ __launch_bounds__(512, 1) void conv2d_wgrad16g_kernel(WgradParams p) 
     __syncthreads();
     int cbuf = 0;
     for (int step = s0; step < s1; step++) {
-        begin_loads(step + NBUF - 1 < s1);                 // into the buffer everyone left at the last barrier
+        // LATE (16x16x32, 3x3): the live waves run begin_loads' ~50 scalar / vector instructions after their first iteration's MFMAs
+        // instead of between the barrier and the first MFMA of all eight waves at once (their pieces then go out in iterations 1 .. 7)
+        constexpr bool LATE = X16 && TAIL && AFCM_WGRAD_LATE;
+        if constexpr (!LATE) begin_loads(step + NBUF - 1 < s1);                 // into the buffer everyone left at the last barrier
         const char* buf = lds + cbuf * BUF;
         typedef typename std::conditional<std::is_same<T, bf16_t>::value, bf16x8, f16x8>::type frag_t;
         // 16-pixel groups of the chunk that lie beyond the row's end would multiply zeros (rows of 86, 150, 278 pixels end
@@ -3012,6 +3018,7 @@ __global__ __launch_bounds__(512, 1) void conv2d_wgrad16g_kernel(WgradParams p) 
                 acc[t][4 * blk + 0] = c[0]; acc[t][4 * blk + 1] = c[1]; acc[t][4 * blk + 2] = c[2]; acc[t][4 * blk + 3] = c[3];
             };
             if (th * 32 >= vq) {                       // this wave's 32 pixels lie beyond the row's end: only its share of the next loads
+                if constexpr (LATE) begin_loads(step + NBUF - 1 < s1);
                 issue_range(std::integral_constant<int, 0>{}, std::integral_constant<int, NPIECE>{});
             } else if constexpr (!TAIL) {
                 frag_t a[2][R];
@@ -3043,7 +3050,11 @@ __global__ __launch_bounds__(512, 1) void conv2d_wgrad16g_kernel(WgradParams p) 
                         hi_n = *(const uint4*)(buf + x1_off[ib1][xr1]);
                     }
                     __builtin_amdgcn_sched_barrier(0);
-                    issue_range(std::integral_constant<int, (it * NPIECE) / NIT>{}, std::integral_constant<int, ((it + 1) * NPIECE) / NIT>{});
+                    if constexpr (LATE) {
+                        static_assert(!LATE || NPIECE == NIT - 1, "one piece per iteration after the first");
+                        if constexpr (it > 0) issue_piece(std::integral_constant<int, it - 1>{});
+                    } else
+                        issue_range(std::integral_constant<int, (it * NPIECE) / NIT>{}, std::integral_constant<int, ((it + 1) * NPIECE) / NIT>{});
                     asm volatile("" : : "v"(lo.x), "v"(lo.y), "v"(lo.z));               // keep the read a full (conflict-free) b128
                     const unsigned d[5] = {lo.w, hi.x, hi.y, hi.z, hi.w};               // pixels 8G+6 .. 8G+15 of the staged row
 #pragma unroll
@@ -3061,6 +3072,7 @@ __global__ __launch_bounds__(512, 1) void conv2d_wgrad16g_kernel(WgradParams p) 
                             }
                         }
                     }
+                    if constexpr (LATE && it == 0) begin_loads(step + NBUF - 1 < s1);
                     __builtin_amdgcn_sched_barrier(0);
                 });
             }
