@@ -68,6 +68,7 @@ class PackEntry(C.Structure):
 
 
 _lib = None
+ABI_VERSION = 13
 
 # name -> (restype, argtypes); every symbol include/afcm_hip.h declares must be listed here
 # (tests/test_abi.py cross-checks this table against the header).
@@ -75,6 +76,7 @@ _i32, _i64, _f32, _vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 SIGNATURES = {
     'afcm_abi_version': (C.c_int, []),
     'afcm_last_error': (C.c_char_p, []),
+    'afcm_noop': (C.c_int, [_vp]),
     'afcm_filtered_lrelu_shapes': (C.c_int, [C.POINTER(FilteredLReluArgs)]),
     'afcm_filtered_lrelu': (C.c_int, [C.POINTER(FilteredLReluArgs), _vp]),
     'afcm_filtered_lrelu_workspace_bytes': (C.c_int64, []),
@@ -134,8 +136,8 @@ def load():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
-        if lib.afcm_abi_version() != 12:
-            raise RuntimeError(f'libafcm_hip.so ABI version {lib.afcm_abi_version()} does not match this package (12); rebuild it')
+        if lib.afcm_abi_version() != ABI_VERSION:
+            raise RuntimeError(f'libafcm_hip.so ABI version {lib.afcm_abi_version()} does not match this package ({ABI_VERSION}); rebuild it')
         _lib = lib
     return _lib
 

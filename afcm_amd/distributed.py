@@ -54,7 +54,8 @@ import torch.distributed as dist
 
 class GradientBuckets:
     def __init__(self, params, bucket_bytes=25 * 1024 * 1024, process_group=None, comm_dtype=None, force=False, passes=1,
-                 static_graph=True, rebucket=True, tail_bytes=None, tail_bucket_bytes=None):
+                 static_graph=True, rebucket=True, tail_bytes=None, tail_bucket_bytes=None,
+                 min_bucket_bytes=None):
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.active = self.world > 1 or (force and dist.is_initialized())   # force: exercise the hooks/collectives on one rank
@@ -66,11 +67,13 @@ class GradientBuckets:
         self.static_graph = bool(static_graph)
         self.bucket_bytes = bucket_bytes
         # The gradients that become final LAST are reduced with nothing left to hide behind: the last `tail_bytes` of the bucket order
-        # go into buckets of at most `tail_bucket_bytes` (defaults: 1.25 buckets' worth in eighths of a bucket), so that what is issued
+        # go into buckets of at most `tail_bucket_bytes` (defaults: 0.75 buckets' worth in eighths of a bucket; r05 used 1.25: 17-20 collectives per step, r06 asks <= 14), so that what is issued
         # in the final milliseconds of backward -- and at its end -- is small (r04's rehearsal timeline: a 25.9 MB bucket 3.5 ms before
         # the end of backward and a 9 MB one at the end; VERDICT r04 #7: nothing above 8 MB in the last 5 ms)
-        self.tail_bytes = int(bucket_bytes * 1.25) if tail_bytes is None else int(tail_bytes)
+        self.tail_bytes = int(bucket_bytes * 0.75) if tail_bytes is None else int(tail_bytes)
         self.tail_bucket_bytes = max(1, bucket_bytes // 8) if tail_bucket_bytes is None else int(tail_bucket_bytes)
+        # (256 KB for the default 25 MB buckets; tests with toy buckets scale it down with them)
+        self.min_bucket_bytes = min(256 * 1024, bucket_bytes // 16) if min_bucket_bytes is None else int(min_bucket_bytes)
         self._rebucket = bool(rebucket)
         self._arrival = []          # first iteration: parameters in the order their gradients became final
         self._build(list(reversed(self.params)))
@@ -97,15 +100,19 @@ class GradientBuckets:
     def _build(self, ordered):
         self._buckets = []          # dicts: params, flat, comm, offs, count, pending, launched, handle, redo
         self._where = {}            # parameter -> (bucket index, position inside the bucket)
-        cur, cur_bytes, cur_in_tail = [], 0, False
+        groups, cur, cur_bytes, cur_in_tail = [], [], 0, False
         sizes = [p.numel() * p.element_size() for p in ordered]
         left = sum(sizes)                              # bytes from this parameter to the end of the order
+        # the tail is a FRACTION of the gradient bytes at most: a parameter set of <= 1.25 buckets would otherwise be all
+        # tail -- 1-2 collectives cut into ~10 latency-bound ones
+        tail_bytes = self.effective_tail_bytes = min(self.tail_bytes, left // 4)
         for p, nbytes in zip(ordered, sizes):
-            in_tail = left <= self.tail_bytes
+            in_tail = left <= tail_bytes
             limit = self.tail_bucket_bytes if in_tail else self.bucket_bytes
             # (the first tail parameter also closes the big bucket under way: a tail bucket never starts inside one)
-            if cur and (cur_bytes + nbytes > limit or (in_tail and not cur_in_tail)):
-                self._add_bucket(cur)
+            # (a bucket closes where its size is NEAREST the limit: the 9.4 MB conv weights pack three to a 25 MB bucket, not two)
+            if cur and (cur_bytes + nbytes // 2 > limit or (in_tail and not cur_in_tail)):
+                groups.append((cur, cur_bytes))
                 cur, cur_bytes = [], 0
             if not cur:
                 cur_in_tail = in_tail
@@ -113,7 +120,18 @@ class GradientBuckets:
             cur_bytes += nbytes
             left -= nbytes
         if cur:
-            self._add_bucket(cur)
+            groups.append((cur, cur_bytes))
+        # never a collective for a few KB (three of the rehearsal's 20 buckets carried 0.0 MB -- a run of biases caught
+        # between two parameters that each fill a tail bucket): a group below `min_bucket_bytes` joins its predecessor (the first one its
+        # successor); a launch + a ring latency on xGMI costs the same for 2 KB as for 2 MB
+        merged = []
+        for plist, nbytes in groups:
+            if merged and (nbytes < self.min_bucket_bytes or merged[-1][1] < self.min_bucket_bytes):
+                merged[-1] = (merged[-1][0] + plist, merged[-1][1] + nbytes)
+            else:
+                merged.append((plist, nbytes))
+        for plist, _ in merged:
+            self._add_bucket(plist)
         self._order = [p for b in self._buckets for p in b['params']]
 
     def _add_bucket(self, plist):

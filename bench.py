@@ -16,6 +16,7 @@ import json
 import os
 import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -55,10 +56,25 @@ def parse():
                     help='--dtype fp32 only: the 3x3 convs on the 16-bit matrix pipe from split operands (f16x3: scaled float16 parts, 3 terms, '
                          'fp32-grade; bf16x6: 6 terms, fp32-grade; bf16x663 / 633: 3 terms in the weight / both gradients; bf16x3: ~16 bits) '
                          'or on the native fp32 MFMA kernels')
+    ap.add_argument('--also', default='auto', choices=['auto', 'off'],
+                    help='auto: on the default one-GPU workload, append `also: {fp32, d_plus_g}` -- the same step in the reference\'s own precision '
+                         '(fp32) and the full D + G iteration, --also-steps timed steps each, measured in this process after the headline')
+    ap.add_argument('--also-steps', type=int, default=10)
+    ap.add_argument('--host-calibration', default='auto', choices=['auto', 'off'], help='200 empty launches: host and device microseconds per launch')
+    ap.add_argument('--no-launch-census', action='store_true',
+                    help='skip the extra untimed step under the framework\'s kernel tracer (tools/pmc*.sh pass it: no second tracer beside rocprofv3, '
+                         'no extra step in the kernel statistics)')
     ap.add_argument('--with-discriminator', action='store_true',
                     help='time the FULL iteration (D update with R1, then G update with the GAN term; SURVEY.md row f1) instead of the '
                          'generator step that BASELINE.json\'s metric names')
-    return ap.parse_args()
+    ap.add_argument('--lean', action='store_true',
+                    help='the timed steps and nothing else: --cpu-baseline off --also off --host-calibration off --no-launch-census (A/B tools and '
+                         'every rocprofv3 script: one tracer, no extra steps in the kernel statistics)')
+    a = ap.parse_args()
+    if a.lean:
+        a.cpu_baseline = a.also = a.host_calibration = 'off'
+        a.no_launch_census = True
+    return a
 
 
 def _cpu_model():
@@ -157,6 +173,234 @@ def self_launch(n):
     return subprocess.call(cmd, env=env, cwd=os.getcwd())
 
 
+def _thread_cpu_ns():
+    """{tid: (comm, on-CPU nanoseconds)} of this process's threads (/proc/self/task/*/schedstat; utime + stime ticks where that file is absent)."""
+    out = {}
+    base = '/proc/self/task'
+    try:
+        tids = os.listdir(base)
+    except OSError:
+        return out
+    tick_ns = 1e9 / os.sysconf('SC_CLK_TCK')
+    for tid in tids:
+        try:
+            comm = open(f'{base}/{tid}/comm').read().strip()
+            try:
+                ns = int(open(f'{base}/{tid}/schedstat').read().split()[0])
+            except (OSError, ValueError, IndexError):
+                f = open(f'{base}/{tid}/stat').read().rsplit(')', 1)[1].split()
+                ns = (int(f[11]) + int(f[12])) * tick_ns
+            out[int(tid)] = (comm, ns)
+        except OSError:
+            pass
+    return out
+
+
+def host_calibration(dev, launches=200):
+    """What ONE launch costs the host here, with no work behind it: `launches` empty kernels through the C ABI (ctypes ->
+    hipLaunchKernel) and the same number of one-element framework ops (the Python -> ATen -> hipLaunchKernel path), wall time per call
+    on an idle stream, and the device-side span of the empty launches (HIP events).  A box whose host is slow shows it here."""
+    import torch
+    from afcm_amd import _lib
+    lib = _lib.load()
+    st = torch.cuda.current_stream(dev).cuda_stream
+    t = torch.zeros(1, device=dev)
+    out = {}
+    for name, fn in (('c_abi_noop', lambda: lib.afcm_noop(st)), ('torch_add_', lambda: t.add_(1.0))):
+        for _ in range(20):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        t0 = time.perf_counter()
+        for _ in range(launches):
+            fn()
+        host = time.perf_counter() - t0
+        e1.record()
+        torch.cuda.synchronize()
+        out[name] = dict(host_us_per_launch=host / launches * 1e6, device_us_per_launch=e0.elapsed_time(e1) * 1e3 / launches)
+    out['launches'] = launches
+    return out
+
+
+def build_step(args, dev, dtype_name, with_discriminator, use_dist, fp32_conv):
+    """The module(s), the step object and the synthetic batch of one workload; sets the fp32 conv route for it."""
+    import torch
+    from afcm_amd import layer_schedule as sched
+    from afcm_amd import synthetic
+    from afcm_amd.networks_stylegan3 import Stylegan3Generator
+    from afcm_amd.stylegan3_model import StyleGAN3GeneratorStep
+    from afcm_amd.torch_utils.ops import conv2d as conv_ops
+    bf = torch.bfloat16
+    conv_ops.FP32_SPLIT = {'f16x3': (torch.float16, 3, 3, 3), 'bf16x6': (bf, 6, 6, 6), 'bf16x663': (bf, 6, 6, 3), 'bf16x633': (bf, 6, 3, 3),
+                           'bf16x3': (bf, 3, 3, 3), 'native': None}[fp32_conv]
+    dtype = {'bf16': torch.bfloat16, 'fp16': torch.float16, 'fp32': torch.float32}[dtype_name]
+    comm_dtype = torch.bfloat16 if args.comm_dtype == 'bf16' else None
+    rank = int(os.environ.get('RANK', 0))
+    torch.manual_seed(0)      # identical init on every rank (the step also broadcasts from rank 0)
+    kw = dict(sched.DEFAULT_SYNTHESIS_KWARGS)
+    G = Stylegan3Generator(z_dim=512, c_dim=1, w_dim=512, img_resolution=args.res, img_channels_in=4, img_channels_out=1,
+                           mapping_kwargs=dict(num_layers=8), synthesis_kwargs=dict(kw, compute_dtype=dtype)).to(dev).train()
+    if with_discriminator:
+        from afcm_amd.networks_discriminator import CoModDiscriminator
+        from afcm_amd.stylegan3_model import StyleGAN3Step
+        # the four highest-resolution blocks in the compute dtype (the reference's num_fp16_res switch, generator.py:808; conv_clamp
+        # 256 as its 16-bit configurations use), the rest fp32
+        n16 = 0 if dtype == torch.float32 else 4
+        D = CoModDiscriminator(c_dim=0, img_resolution=args.res, img_channels=5, channel_base=int(0.5 * 32768), channel_max=512,
+                               num_fp16_res=n16, conv_clamp=(256 if n16 else None), block_kwargs=dict(fp16_dtype=dtype if n16 else torch.float16),
+                               epilogue_kwargs=dict(mbstd_group_size=16)).to(dev)
+        step = StyleGAN3Step(G, D, lr_G=0.0025, lr_D=0.0025, lambda_L1=100.0, lambda_r1=10.0, distributed=use_dist,
+                             force_collectives=args.force_dist, comm_dtype=comm_dtype)
+    else:
+        step = StyleGAN3GeneratorStep(G, lr_G=0.0025, lambda_L1=100.0, distributed=use_dist, force_collectives=args.force_dist,
+                                      comm_dtype=comm_dtype)
+    inputs = synthetic.generator_inputs(args.batch, size=args.res, seed=rank, device=dev)
+    return step, inputs
+
+
+def kernel_table(fams, dtype_name, fp32_conv, timed_with_events):
+    """Per hot family: algorithmic work / HIP-event launch durations of this run against the guide's peaks."""
+    from afcm_amd.torch_utils.ops import conv2d as conv_ops
+    kernels = {}
+    for fam, d in fams.items():
+        avg_ms = d['total_ms'] / d['launches']
+        if fam == 'filtered_lrelu':
+            ach = d['work'] / (d['total_ms'] * 1e-3) / 1e9
+            kernels[fam] = dict(bound='hbm', achieved=ach, peak=PEAK_HBM_GBS, unit='GB/s', frac=ach / PEAK_HBM_GBS, traffic=None,
+                                launches=d['launches'], avg_launch_ms=avg_ms, total_ms=d['total_ms'], steps_timed=timed_with_events,
+                                ms_per_step=d['total_ms'] / max(1, timed_with_events))
+        else:
+            ach = d['work'] / (d['total_ms'] * 1e-3) / 1e12
+            peak, pipe = PEAK_MFMA_TFLOPS[dtype_name], None
+            if dtype_name == 'fp32' and conv_ops.FP32_SPLIT is not None:
+                # fp32 products from split 16-bit operands: `achieved` stays the ALGORITHMIC (fp32) flop rate; the pipe that
+                # executes them is the 16-bit one, and an fp32 product costs `terms` of its multiplications
+                terms = conv_ops.FP32_SPLIT[3] if fam == 'conv2d_wgrad' else max(conv_ops.FP32_SPLIT[1:3])
+                peak = PEAK_MFMA_TFLOPS['fp16'] / terms
+                pipe = f'{fp32_conv}: 16-bit MFMA pipe (2500 TFLOP/s dense), {terms} product terms per fp32 product'
+            kernels[fam] = dict(bound='mfma', achieved=ach, peak=peak, unit='TFLOP/s', frac=ach / peak, traffic=None,
+                                launches=d['launches'], avg_launch_ms=avg_ms, total_ms=d['total_ms'], steps_timed=timed_with_events,
+                                ms_per_step=d['total_ms'] / max(1, timed_with_events), **({'pipe': pipe} if pipe else {}))
+    return kernels
+
+
+def timed_steps(step, inputs, steps, warmup, world, use_dist, kernel_timing, every, dev):
+    """`warmup` untimed steps, then EXACTLY `steps` timed ones between barrier + synchronize on both sides (max over ranks).
+    Returns dict(elapsed, host_wall, host_cpu, timed_with_events, families, threads, one_step)."""
+    import torch
+    import torch.distributed as dist
+    from afcm_amd import profiling
+    real_A, real_B, z, c = inputs
+
+    def one_step():
+        step.set_input(real_A, real_B, z, c)
+        step.optimize_parameters()
+
+    for _ in range(warmup):
+        one_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    timed_with_events = 0
+    if kernel_timing:
+        profiling.start()
+    host_wall = host_cpu = 0.0
+    th0 = _thread_cpu_ns()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        if kernel_timing:
+            profiling.enabled = (i % max(1, every) == 0)
+            timed_with_events += int(profiling.enabled)
+        if use_dist and step.buckets is not None and i == steps - 1:
+            # the LAST timed step carries the bucket timeline: CUDA events at the phase boundaries and at every bucket's launch
+            # (records only, nothing waits on them)
+            step.buckets.trace, step.phase_events = [], {}
+        h0, c0 = time.perf_counter(), time.process_time()
+        one_step()
+        host_wall += time.perf_counter() - h0      # wall time of the Python call: the host's own work while it does not run ahead into a full queue
+        host_cpu += time.process_time() - c0       # CPU time of this process (all its threads) inside the call
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    th1 = _thread_cpu_ns()
+    profiling.stop()
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    # which threads of this process were on a CPU during the timed region (VERDICT r05 #4: 45 ms of CPU time inside a 23.6 ms call)
+    busy = sorted(((th1[t][1] - th0.get(t, (None, 0))[1], th1[t][0], t) for t in th1), reverse=True)
+    main_tid = threading.get_native_id()
+    threads = dict(python_threads=threading.active_count(), os_threads=len(th1),
+                   cpu_ms_per_step_by_thread=[dict(thread=('main (Python)' if t == main_tid else name), cpu_ms_per_step=round(ns / 1e6 / steps, 3))
+                                              for ns, name, t in busy[:6] if ns > 0])
+    return dict(elapsed=elapsed, host_wall=host_wall, host_cpu=host_cpu, timed_with_events=timed_with_events,
+                families=profiling.summary() if kernel_timing else {}, threads=threads, one_step=one_step)
+
+
+def launch_census(one_step, rank, world, skip):
+    """Launches per step (rank 0, one extra untimed step under the framework's kernel tracer): total, the three hot families, the rest.
+    EVERY rank runs the step whatever the tracer does on rank 0 (it carries the collectives: ADVICE r05) -- the tracer is set up first,
+    and a failure to set it up falls back to the bare step."""
+    import torch
+    if skip:
+        return dict(skipped='--no-launch-census')
+    if rank != 0:
+        one_step()
+        torch.cuda.synchronize()
+        return None
+    import collections
+    prof = None
+    try:
+        from torch.profiler import profile, ProfilerActivity
+        prof = profile(activities=[ProfilerActivity.CUDA])
+        prof.__enter__()
+    except Exception as e:
+        prof, err = None, f'{type(e).__name__}: {e}'
+    one_step()                          # outside any try: an error in the step itself is the bench's error, on every rank alike
+    torch.cuda.synchronize()
+    if prof is None:
+        return dict(error=err)
+    try:
+        prof.__exit__(None, None, None)
+        names = [e.name for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA and 'Memcpy' not in e.name and 'Memset' not in e.name]
+        fam = collections.Counter('conv2d' if ('conv2d_fwd' in n or 'conv2d_direct' in n) else 'conv2d_wgrad' if 'conv2d_wgrad' in n else
+                                  'filtered_lrelu' if ('flrelu_wave' in n or 'flrelu_mfma_kernel' in n or 'flrelu_strip' in n or 'flrelu_sep' in n) else
+                                  'other_afcm' if 'afcm' in n else 'framework' for n in names)
+        return dict(total=len(names), **fam, outside_the_three_families=fam['other_afcm'] + fam['framework'])
+    except Exception as e:              # the tracer is an aid: never lose the bench line to it
+        return dict(error=f'{type(e).__name__}: {e}')
+
+
+def also_record(args, dev, name, dtype_name, with_discriminator, steps, warmup):
+    """One sub-record of the driver-run line: the same step in the reference's own precision (fp32: NET:619,653) or the
+    full D + G iteration, measured in this process after the headline; the headline fields do not depend on it."""
+    import gc
+    import torch
+    try:
+        step, inputs = build_step(args, dev, dtype_name, with_discriminator, False, args.fp32_conv)
+        r = timed_steps(step, inputs, steps, warmup, 1, False, not args.no_kernel_timing, 2, dev)
+        kernels = kernel_table(r['families'], dtype_name, args.fp32_conv, r['timed_with_events'])
+        ms = r['elapsed'] / steps * 1e3
+        out = dict(metric=('full GAN iteration (D update with R1 + G update) images/sec' if with_discriminator else 'generator fwd+bwd images/sec')
+                   + f' @{args.res}^2', images_per_sec=args.batch * steps / r['elapsed'], ms_per_step=ms, steps=steps, warmup=warmup, dtype=dtype_name,
+                   per_gpu_batch=args.batch, host_ms_per_step=r['host_wall'] / steps * 1e3,
+                   kernels={k: {f: v[f] for f in ('bound', 'achieved', 'peak', 'unit', 'frac', 'ms_per_step', 'launches', 'pipe') if f in v}
+                            for k, v in kernels.items()},
+                   outside_the_three_families_ms=ms - sum(v['ms_per_step'] for v in kernels.values()) if kernels else None,
+                   **({'fp32_conv': args.fp32_conv} if dtype_name == 'fp32' else {}))
+        del step, inputs, r
+    except Exception as e:              # a sub-record never takes the headline down with it
+        out = dict(error=f'{type(e).__name__}: {e}')
+    gc.collect()
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     args = parse()
     if args.cpu_baseline_worker:
@@ -170,10 +414,6 @@ def main():
     import torch
     import torch.distributed as dist
     torch.set_num_threads(host_threads)
-    from afcm_amd import layer_schedule as sched
-    from afcm_amd import profiling, synthetic
-    from afcm_amd.networks_stylegan3 import Stylegan3Generator
-    from afcm_amd.stylegan3_model import StyleGAN3GeneratorStep
 
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
@@ -203,69 +443,10 @@ def main():
     if args.no_homogeneous_dot:
         from afcm_amd.torch_utils.ops import fused_layer
         fused_layer.HOMOGENEOUS_DOT = False
-    from afcm_amd.torch_utils.ops import conv2d as conv_ops
-    bf = torch.bfloat16
-    conv_ops.FP32_SPLIT = {'f16x3': (torch.float16, 3, 3, 3), 'bf16x6': (bf, 6, 6, 6), 'bf16x663': (bf, 6, 6, 3), 'bf16x633': (bf, 6, 3, 3),
-                           'bf16x3': (bf, 3, 3, 3), 'native': None}[args.fp32_conv]
-    dtype = {'bf16': torch.bfloat16, 'fp16': torch.float16, 'fp32': torch.float32}[args.dtype]
-    comm_dtype = torch.bfloat16 if args.comm_dtype == 'bf16' else None
-    torch.manual_seed(0)      # identical init on every rank (the step also broadcasts from rank 0)
-    kw = dict(sched.DEFAULT_SYNTHESIS_KWARGS)
-    G = Stylegan3Generator(z_dim=512, c_dim=1, w_dim=512, img_resolution=args.res, img_channels_in=4, img_channels_out=1,
-                           mapping_kwargs=dict(num_layers=8), synthesis_kwargs=dict(kw, compute_dtype=dtype)).to(dev).train()
-    if args.with_discriminator:
-        from afcm_amd.networks_discriminator import CoModDiscriminator
-        from afcm_amd.stylegan3_model import StyleGAN3Step
-        # the four highest-resolution blocks in the compute dtype (the reference's num_fp16_res switch, generator.py:808; conv_clamp
-        # 256 as its 16-bit configurations use), the rest fp32
-        n16 = 0 if dtype == torch.float32 else 4
-        D = CoModDiscriminator(c_dim=0, img_resolution=args.res, img_channels=5, channel_base=int(0.5 * 32768), channel_max=512,
-                               num_fp16_res=n16, conv_clamp=(256 if n16 else None), block_kwargs=dict(fp16_dtype=dtype if n16 else torch.float16),
-                               epilogue_kwargs=dict(mbstd_group_size=16)).to(dev)
-        step = StyleGAN3Step(G, D, lr_G=0.0025, lr_D=0.0025, lambda_L1=100.0, lambda_r1=10.0, distributed=use_dist,
-                             force_collectives=args.force_dist, comm_dtype=comm_dtype)
-    else:
-        step = StyleGAN3GeneratorStep(G, lr_G=0.0025, lambda_L1=100.0, distributed=use_dist, force_collectives=args.force_dist,
-                                      comm_dtype=comm_dtype)
-    real_A, real_B, z, c = synthetic.generator_inputs(args.batch, size=args.res, seed=rank, device=dev)
-
-    def one_step():
-        step.set_input(real_A, real_B, z, c)
-        step.optimize_parameters()
-
-    for _ in range(args.warmup):
-        one_step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    timed_with_events = 0
-    if not args.no_kernel_timing:
-        profiling.start()
-    host_wall = host_cpu = 0.0
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        if not args.no_kernel_timing:
-            profiling.enabled = (i % max(1, args.kernel_timing_every) == 0)
-            timed_with_events += int(profiling.enabled)
-        if use_dist and step.buckets is not None and i == args.steps - 1:
-            # the LAST timed step carries the bucket timeline: CUDA events at the phase boundaries and at every bucket's launch
-            # (records only, nothing waits on them)
-            step.buckets.trace, step.phase_events = [], {}
-        h0, c0 = time.perf_counter(), time.process_time()
-        one_step()
-        host_wall += time.perf_counter() - h0      # wall time of the Python call: the host's own work while it does not run ahead into a full queue
-        host_cpu += time.process_time() - c0       # CPU time of this process (all its threads) inside the call
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    profiling.stop()
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
+    step, inputs = build_step(args, dev, args.dtype, args.with_discriminator, use_dist, args.fp32_conv)
+    r = timed_steps(step, inputs, args.steps, args.warmup, world, use_dist, not args.no_kernel_timing, args.kernel_timing_every, dev)
+    elapsed, host_wall, host_cpu, timed_with_events = r['elapsed'], r['host_wall'], r['host_cpu'], r['timed_with_events']
+    r_threads, families = r['threads'], r['families']
 
     bucket_timeline = None
     if use_dist and step.buckets is not None and getattr(step, 'phase_events', None):
@@ -278,46 +459,9 @@ def main():
                                buckets=[dict(bucket=i, mbytes=round(nb / 1e6, 1), issued_at_ms=round(pe['backward'].elapsed_time(e), 2),
                                              backward_left_ms=round(bwd_ms - pe['backward'].elapsed_time(e), 2)) for i, nb, e in step.buckets.trace])
         step.buckets.trace = step.phase_events = None
-    # launches per step (rank 0, one extra untimed step under the framework's kernel tracer): total, the three hot families, the rest
-    launches = None
-    if rank != 0:
-        one_step()                      # (every rank runs the step: it carries the collectives)
-        torch.cuda.synchronize()
-    else:
-        try:
-            import collections
-            from torch.profiler import profile, ProfilerActivity
-            with profile(activities=[ProfilerActivity.CUDA]) as prof:
-                one_step()
-                torch.cuda.synchronize()
-            names = [e.name for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA and 'Memcpy' not in e.name and 'Memset' not in e.name]
-            fam = collections.Counter('conv2d' if ('conv2d_fwd' in n) else 'conv2d_wgrad' if 'conv2d_wgrad' in n else 'filtered_lrelu' if ('flrelu_wave' in n or 'flrelu_mfma_kernel' in n or 'flrelu_strip' in n or 'flrelu_sep' in n) else
-                                      'other_afcm' if 'afcm' in n else 'framework' for n in names)
-            launches = dict(total=len(names), **fam, outside_the_three_families=fam['other_afcm'] + fam['framework'])
-        except Exception as e:          # the tracer is an aid: never lose the bench line to it
-            launches = dict(error=f'{type(e).__name__}: {e}')
+    launches = launch_census(r['one_step'], rank, world, args.no_launch_census)
     if rank == 0:
-        fams = profiling.summary()
-        kernels = {}
-        for fam, d in fams.items():
-            avg_ms = d['total_ms'] / d['launches']
-            if fam == 'filtered_lrelu':
-                ach = d['work'] / (d['total_ms'] * 1e-3) / 1e9
-                kernels[fam] = dict(bound='hbm', achieved=ach, peak=PEAK_HBM_GBS, unit='GB/s', frac=ach / PEAK_HBM_GBS, traffic=None,
-                                    launches=d['launches'], avg_launch_ms=avg_ms, total_ms=d['total_ms'], steps_timed=timed_with_events,
-                                    ms_per_step=d['total_ms'] / max(1, timed_with_events))
-            else:
-                ach = d['work'] / (d['total_ms'] * 1e-3) / 1e12
-                peak, pipe = PEAK_MFMA_TFLOPS[args.dtype], None
-                if args.dtype == 'fp32' and conv_ops.FP32_SPLIT is not None:
-                    # fp32 products from split 16-bit operands: `achieved` stays the ALGORITHMIC (fp32) flop rate; the pipe that
-                    # executes them is the 16-bit one, and an fp32 product costs `terms` of its multiplications
-                    terms = conv_ops.FP32_SPLIT[3] if fam == 'conv2d_wgrad' else max(conv_ops.FP32_SPLIT[1:3])
-                    peak = PEAK_MFMA_TFLOPS['fp16'] / terms
-                    pipe = f'{args.fp32_conv}: 16-bit MFMA pipe (2500 TFLOP/s dense), {terms} product terms per fp32 product'
-                kernels[fam] = dict(bound='mfma', achieved=ach, peak=peak, unit='TFLOP/s', frac=ach / peak, traffic=None,
-                                    launches=d['launches'], avg_launch_ms=avg_ms, total_ms=d['total_ms'], steps_timed=timed_with_events,
-                                    ms_per_step=d['total_ms'] / max(1, timed_with_events), **({'pipe': pipe} if pipe else {}))
+        kernels = kernel_table(families, args.dtype, args.fp32_conv, timed_with_events)
         dominant = max(kernels, key=lambda k: kernels[k]['total_ms']) if kernels else None
         roofline = dict(kernels[dominant], kernel=dominant) if dominant else None
         # HBM traffic: NOT measured in this run -- bytes per launch from the committed rocprofv3 PMC passes of this same command
@@ -336,6 +480,23 @@ def main():
                     roofline['traffic_source'] = src if t.get(dominant) is not None else None
             except Exception:
                 pass
+        calibration = None
+        if world == 1 and args.host_calibration == 'auto':
+            try:
+                calibration = host_calibration(dev)
+            except Exception as e:
+                calibration = dict(error=f'{type(e).__name__}: {e}')
+        gradient_buckets = step.buckets.num_buckets if step.buckets is not None else 0
+        bucket_mbytes = [round(b['flat'].numel() * b['flat'].element_size() / 1e6, 2) for b in step.buckets._buckets] if step.buckets is not None else []
+        # the sub-records: same process, after the headline (whose model is released first)
+        also = None
+        if world == 1 and default_workload and args.also == 'auto' and not args.force_dist:
+            del step, inputs, r
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()
+            also = dict(fp32=also_record(args, dev, 'fp32', 'fp32', False, args.also_steps, 2),
+                        d_plus_g=also_record(args, dev, 'd_plus_g', 'bf16', True, args.also_steps, 2))
         cpu = run_cpu_baseline(args.res) if (world == 1 and args.cpu_baseline == 'auto') else None
         images = world * args.batch * args.steps
         out = {
@@ -350,6 +511,8 @@ def main():
             # both well below ms_per_step = the GPU is the limiter and the host runs ahead
             'host_ms_per_step': host_wall / args.steps * 1e3,
             'host_cpu_ms_per_step': host_cpu / args.steps * 1e3,
+            'host_threads_busy': r_threads,
+            'host_calibration': calibration,
             'launches_per_step': launches,
             'host_threads': dict(omp_num_threads=os.environ.get('OMP_NUM_THREADS'), torch_num_threads=torch.get_num_threads(),
                                  cpu_count=os.cpu_count(), ranks_on_host=world, rule='--host-threads, default cpu_count // (8 * ranks)'),
@@ -368,13 +531,17 @@ def main():
                        # what the process group itself reports (a SCALE record can check that RCCL saw N ranks)
                        'world_size': dist.get_world_size() if use_dist else 1,
                        'backend': dist.get_backend() if use_dist else None,
-                       'gradient_buckets': step.buckets.num_buckets if step.buckets is not None else 0,
+                       'gradient_buckets': gradient_buckets, 'gradient_bucket_mbytes': bucket_mbytes,
                        'comm_dtype': args.comm_dtype, 'homogeneous_dot': not args.no_homogeneous_dot,
                        **({'fp32_conv': args.fp32_conv} if args.dtype == 'fp32' else {})},
             'roofline': roofline,
             'kernels': kernels,
+            # milliseconds of the step outside the three hot families
+            'outside_the_three_families_ms': (elapsed / args.steps * 1e3 - sum(k['ms_per_step'] for k in kernels.values())) if kernels else None,
             'cpu_baseline': cpu,
         }
+        if also is not None:
+            out['also'] = also
         if bucket_timeline is not None:
             out['bucket_timeline'] = bucket_timeline
         print(json.dumps(out))

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define AFCM_ABI_VERSION 12  /* 12 (r05): + afcm_conv2d_block_k_ks, afcm_conv2d_pack_weights_bk; the packed layout's K-chunk depends on (dtype, kernel size): 16-bit 3x3 images are [nkc][9][rows_pad][32] for the v_mfma 16x16x32 kernel (the pack / conv entry points keep their signatures).  11 (r04): + afcm_amax_bits, afcm_split16, afcm_conv2d_pack_split, afcm_conv2d_split, afcm_unscale, afcm_plane_dot_parts (additions only).  10 (r04): + afcm_filtered_lrelu_args.clamp_flags (appended), afcm_plane_dot_gated_ld; the runtime getenv switches are gone.  9 (r03): + afcm_affine_bank_*, afcm_modulation_bank_*, afcm_conv2d_pack_bank, afcm_conv2d_stride2 (additions only; every v8 entry point and struct is unchanged) */
+#define AFCM_ABI_VERSION 13  /* 13 (r06): + afcm_noop (additions only; see the end of this header for the r06 entry points).  12 (r05): + afcm_conv2d_block_k_ks, afcm_conv2d_pack_weights_bk; the packed layout's K-chunk depends on (dtype, kernel size): 16-bit 3x3 images are [nkc][9][rows_pad][32] for the v_mfma 16x16x32 kernel (the pack / conv entry points keep their signatures).  11 (r04): + afcm_amax_bits, afcm_split16, afcm_conv2d_pack_split, afcm_conv2d_split, afcm_unscale, afcm_plane_dot_parts (additions only).  10 (r04): + afcm_filtered_lrelu_args.clamp_flags (appended), afcm_plane_dot_gated_ld; the runtime getenv switches are gone.  9 (r03): + afcm_affine_bank_*, afcm_modulation_bank_*, afcm_conv2d_pack_bank, afcm_conv2d_stride2 (additions only; every v8 entry point and struct is unchanged) */
 
 enum { AFCM_F32 = 0, AFCM_F16 = 1, AFCM_BF16 = 2 };
 enum { AFCM_OK = 0, AFCM_E_NOKERNEL = -1, AFCM_E_INVALID = -2 };
@@ -42,6 +42,9 @@ enum { AFCM_SIGNS_NONE = 0, AFCM_SIGNS_WRITE = 1, AFCM_SIGNS_READ = 2 };
 int afcm_abi_version(void);
 /* Human-readable description of the last AFCM_E_INVALID on this thread. */
 const char* afcm_last_error(void);
+/* An empty one-wave launch on `stream`: what a launch costs the host and the device's front end with no work behind it
+ * (bench.py's `host_calibration`).  No counterpart in the reference (its launches go through ATen). */
+int afcm_noop(void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * filtered_lrelu -- fused bias -> zero-insert upsample -> pad/crop -> FIR(fu) * up^2 ->

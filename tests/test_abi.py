@@ -39,7 +39,7 @@ def test_binding_table_matches_header(lib):
 
 
 def test_abi_version(lib):
-    assert lib.afcm_abi_version() == 12
+    assert lib.afcm_abi_version() == 13
 
 
 def test_shapes_helper_is_pure_host(lib):

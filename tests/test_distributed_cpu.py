@@ -414,7 +414,7 @@ def _worker_world8(rank, world, port, sizes, out_dir):
                             torch.nn.Linear(96, 64), torch.nn.LeakyReLU(0.2), torch.nn.Linear(64, 4))
     extra = torch.nn.Linear(4, 4, bias=False)
     params = list(extra.parameters()) + list(m.parameters())      # registered first, produced first: the arrival-order rebuild moves it
-    buckets = GradientBuckets(params, bucket_bytes=16384, static_graph=False)
+    buckets = GradientBuckets(params, bucket_bytes=8192, static_graph=False, min_bucket_bytes=256)
     buckets.broadcast_parameters(m)
     buckets.broadcast_parameters(extra)
     torch.manual_seed(99)
@@ -436,7 +436,7 @@ def _worker_world8(rank, world, port, sizes, out_dir):
         layouts.append([[pid[id(p)] for p in b['params']] for b in buckets._buckets])
     torch.save(dict(grads=[None if p.grad is None else p.grad.clone() for p in params], layouts=layouts,
                     bytes=[sum(p.numel() * 4 for p in b['params']) for b in buckets._buckets], counts=[len(b['params']) for b in buckets._buckets],
-                    tail=(buckets.tail_bytes, buckets.tail_bucket_bytes)), os.path.join(out_dir, f'w8_{rank}.pt'))
+                    tail=(buckets.effective_tail_bytes, buckets.tail_bucket_bytes, buckets.min_bucket_bytes)), os.path.join(out_dir, f'w8_{rank}.pt'))
     dist.destroy_process_group()
 
 
@@ -474,13 +474,53 @@ def test_eight_ranks_ragged_batches_unused_parameter_and_tail_buckets(tmp_path):
     for i, (g, w) in enumerate(zip(res[0]['grads'], want)):
         assert g is not None and torch.allclose(g, w, rtol=1e-5, atol=1e-7), (i, None if g is None else (g - w).abs().max().item())
     # tail: walking the bucket list from the end, everything inside the last tail_bytes is in buckets <= tail_bucket_bytes
-    tail_bytes, tail_bucket = res[0]['tail']
+    tail_bytes, tail_bucket, min_bucket = res[0]['tail']
     nbytes = res[0]['bytes']
     assert len(nbytes) >= 4
+    assert min(nbytes) >= min_bucket, nbytes           # no collective for a handful of biases
     acc = 0
     for b, k in zip(reversed(nbytes), reversed(res[0]['counts'])):
         if acc + b > tail_bytes:
             break
-        assert b <= tail_bucket or k == 1, (b, k)       # (a single parameter larger than the limit is a bucket of its own)
+        assert b <= 2 * tail_bucket + min_bucket or k == 1, (b, k)   # (a single parameter larger than the limit is a bucket of its own; a bucket closes where its size is nearest the limit; a group below the minimum joined its predecessor)
         acc += b
     assert acc > 0, 'no tail bucket at all'
+
+
+def test_bench_network_bucket_layout_has_no_tiny_collectives():
+    """The bench network's own parameter set (58.5 M parameters, 234 MB of fp32 gradients; shapes only: meta device) under the default
+    bucket rules, in registration order reversed (first iteration) and in an arrival-like order (decoder back to front, encoder back to
+    front, the mapping network last: what the rebuild produces): at most 14 collectives per step, none below 256 KB, the tail in
+    pieces of at most an eighth of a bucket (+ a merged remainder), every parameter in exactly one bucket (the r05
+    rehearsal issued 20 collectives, three of them of 0.0 MB)."""
+    from afcm_amd import layer_schedule as sched
+    from afcm_amd.distributed import GradientBuckets
+    from afcm_amd.networks_stylegan3 import Stylegan3Generator
+    G = Stylegan3Generator(z_dim=512, c_dim=1, w_dim=512, img_resolution=256, img_channels_in=4, img_channels_out=1,
+                           mapping_kwargs=dict(num_layers=8), synthesis_kwargs=dict(sched.DEFAULT_SYNTHESIS_KWARGS))
+    named = [(n, torch.nn.Parameter(torch.empty(p.shape, device='meta'))) for n, p in G.named_parameters()]       # shapes only
+    del G
+    assert sum(p.numel() for _, p in named) > 58e6
+    dec = [p for n, p in named if n.startswith('synthesis.L')]
+    enc = [p for n, p in named if n.startswith('synthesis.') and not n.startswith('synthesis.L')]
+    mp_ = [p for n, p in named if n.startswith('mapping.')]
+    arrival = list(reversed(dec)) + list(reversed(enc)) + list(reversed(mp_))
+    for order in (None, arrival):
+        b = GradientBuckets([p for _, p in named])
+        if order is not None:
+            b._build(order)
+        sizes = [sum(p.numel() * 4 for p in bk['params']) for bk in b._buckets]
+        assert b.num_buckets <= 14, sizes
+        assert min(sizes) >= 256 * 1024, sizes
+        assert sorted(id(p) for bk in b._buckets for p in bk['params']) == sorted(id(p) for _, p in named)
+        assert b.effective_tail_bytes <= sum(sizes) // 4
+
+
+def test_small_parameter_set_is_not_all_tail():
+    """gradients totalling <= 1.25 buckets used to be cut into ~10 eighth-of-a-bucket collectives; the tail is now a quarter
+    of the bytes at most."""
+    from afcm_amd.distributed import GradientBuckets
+    params = [torch.nn.Parameter(torch.zeros(1 << 20, device='meta')) for _ in range(6)]       # 24 MB of fp32 gradients, 25 MB buckets
+    b = GradientBuckets(params)
+    sizes = [sum(p.numel() * 4 for p in bk['params']) for bk in b._buckets]
+    assert b.num_buckets <= 3, sizes

@@ -6,7 +6,7 @@ out=gpurun_out/${tag}_bench_ab.jsonl
 : > $out
 for v in "$@"; do
   if [ $v = NEW ]; then unset AFCM_HIP_LIB; else export AFCM_HIP_LIB=$PWD/afcm_amd/csrc/variants/$v.so; fi
-  python bench.py --cpu-baseline off --steps 12 --warmup 3 2>/dev/null | tail -n 1 > /tmp/line.json || exit 1
+  python bench.py --lean --steps 12 --warmup 3 2>/dev/null | tail -n 1 > /tmp/line.json || exit 1
   python - "$v" <<'PY' | tee -a $out
 import json,sys
 d=json.load(open('/tmp/line.json'))

@@ -6,7 +6,7 @@ out=gpurun_out/${tag}_dg_ab.txt
 : > $out
 for v in "$@"; do
   if [ $v = NEW ]; then unset AFCM_HIP_LIB; else export AFCM_HIP_LIB=$PWD/afcm_amd/csrc/variants/$v.so; fi
-  timeout -k 10 300 python bench.py --cpu-baseline off --with-discriminator --steps 5 --warmup 2 2>/dev/null | tail -n 1 > /tmp/line.json || exit 1
+  timeout -k 10 300 python bench.py --lean --with-discriminator --steps 5 --warmup 2 2>/dev/null | tail -n 1 > /tmp/line.json || exit 1
   python - "$v" <<'PY' | tee -a $out
 import json,sys
 d=json.load(open('/tmp/line.json'))

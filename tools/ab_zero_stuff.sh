@@ -6,7 +6,7 @@ python - "$v" <<'PY' 2>/dev/null | tail -n 1 | python -c "import json,sys; d=jso
 import sys, runpy
 import afcm_amd.torch_utils.ops.conv2d as C
 C.ZERO_STUFF_UPFIRDN = sys.argv[1] == 'True'
-sys.argv = ['bench.py', '--cpu-baseline', 'off', '--with-discriminator', '--steps', '5', '--warmup', '2']
+sys.argv = ['bench.py', '--lean', '--with-discriminator', '--steps', '5', '--warmup', '2']
 runpy.run_path('bench.py', run_name='__main__')
 PY
 done

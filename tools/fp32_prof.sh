@@ -4,7 +4,7 @@ tag=$1
 export TMPDIR=/tmp
 d=gpurun_out/${tag}_fp32_prof
 rm -rf $d; mkdir -p $d
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $d -- python3 bench.py --dtype fp32 --steps 4 --warmup 2 --cpu-baseline off --no-kernel-timing > $d/log.txt 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $d -- python3 bench.py --dtype fp32 --steps 4 --warmup 2 --lean --no-kernel-timing > $d/log.txt 2>&1
 f=$(find $d -name "*kernel_stats.csv" | head -1)
 cp "$f" gpurun_out/${tag}_fp32_kernel_stats.csv
 rm -rf $d

@@ -8,7 +8,7 @@ err=gpurun_out/${tag}_bench_other_configs.err
 run() {   # run <label> <bench.py arguments...>
   local label=$1; shift
   echo "== $label: bench.py $*" >> $err
-  timeout -k 10 400 python bench.py --cpu-baseline off "$@" 2>> $err < /dev/null | tail -n 1 > /tmp/extra_line.json
+  timeout -k 10 400 python bench.py --lean "$@" 2>> $err < /dev/null | tail -n 1 > /tmp/extra_line.json
   local rc=${PIPESTATUS[0]}
   if [ $rc -eq 0 ] && head -c 1 /tmp/extra_line.json | grep -q '{'; then cat /tmp/extra_line.json >> $out; fi
   echo "$label: rc $rc"

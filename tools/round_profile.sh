@@ -14,9 +14,9 @@ python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/${tag}_smoke.log
 bash tools/r03_step_profile.sh ${tag} < /dev/null > /dev/null 2>&1 || true
 cp gpurun_out/${tag}_traf/trace/*/*kernel_stats.csv gpurun_out/${tag}_bench_kernel_stats.csv 2>/dev/null || true
 echo traffic done
-bash tools/pmc_wave.sh ${tag}_pmcw bench.py --steps 2 --warmup 1 --cpu-baseline off --no-kernel-timing < /dev/null > /dev/null 2>&1 || true
+bash tools/pmc_wave.sh ${tag}_pmcw bench.py --steps 2 --warmup 1 --lean --no-kernel-timing < /dev/null > /dev/null 2>&1 || true
 python tools/pmc_wave_table.py gpurun_out/${tag}_pmcw > gpurun_out/${tag}_flrelu_pmc_wave.txt 2>&1 || true
-bash tools/pmc_flrelu.sh ${tag}_pmc bench.py --steps 2 --warmup 1 --cpu-baseline off --no-kernel-timing < /dev/null > gpurun_out/${tag}_pmc.log 2>&1 || true
+bash tools/pmc_flrelu.sh ${tag}_pmc bench.py --steps 2 --warmup 1 --lean --no-kernel-timing < /dev/null > gpurun_out/${tag}_pmc.log 2>&1 || true
 python tools/pmc_table.py gpurun_out/${tag}_pmc > gpurun_out/${tag}_bench_pmc_raw.txt 2>&1 || true
 echo pmc done
 python tools/bench_conv.py --dtype bf16 > gpurun_out/${tag}_conv_layers_bf16.txt 2>&1 < /dev/null || true
