@@ -825,7 +825,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_fwd16_kernel(ConvParams p) {
 //     apart.  A B fragment is 16 consecutive pixels x 4 channel groups; ds_read_b128 serves lanes in four groups of 16 that each hold all
 //     16 pixel columns with two of the channel groups, so every group reads 16 consecutive 16-byte slots = all 64 banks once, at any
 //     pixel offset (taps shift by 1 and 2 pixels) -- no padding (the [pixel][32 channels] row form conflicts for every odd pitch);
-//     a plane holds 512 pixels = one 4-pixel group per staging thread, so lanes outside the patch need no sink and no predicate;
+//     a plane holds kPlaneX16 = 416 pixels (patch <= 412 + a 4-pixel sink for the staging threads whose group lies past the patch: no predicate);
 //   * B fragments live in a ring of four, read four 16-pixel blocks ahead of their MFMAs (one fragment feeds MO MFMAs = 64 cycles);
 //     the tap's column offset is the read's immediate, the row offset is added to the block's base register in place: 32 vector adds
 //     per chunk of 72 reads;
@@ -854,7 +854,9 @@ __global__ __launch_bounds__(256, 2) void conv2d_fwd16x_kernel(ConvParams p) {
     // staging writes every thread's four pixels).  Occupancy: two workgroups per CU for both block heights.  The 64-row kernel fits three
     // by registers (<= 168) and LDS (159,744 of 163,840 bytes) on paper; the wave counters show ~1.7 alive (SQ_WAVE_CYCLES x 4 = 58 % of
     // the dispatch), a grid of two per CU runs as fast as one of three (profiles/r05_conv_persistent.txt), and FORCING three
-    // (__launch_bounds__(256, 3), 51 KB planes) cost 17 spilled registers and 15-20 % on those layers: two it is.
+    // (__launch_bounds__(256, 3), 51 KB planes) cost 17 spilled registers and 15-20 % on those layers: the register budget stays at two
+    // (__launch_bounds__(256, 2)); the persistent 64-row launch still sizes its grid for three per CU (conv_persistent_grid(blocks, 3)) so
+    // that a CU that does fit a third workgroup gets one.
     constexpr int PLANE_B = kPlaneX16 * 16;
     constexpr int BUF_B = 4 * PLANE_B;
     static_assert(PLANE_B % 256 == 0 && kPatchMaxX16 % 4 == 0, "planes: a multiple of 256 bytes apart, patch + sink inside");

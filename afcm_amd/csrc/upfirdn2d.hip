@@ -194,7 +194,10 @@ template <int UP, int DOWN> struct UpfRows {
     static constexpr int NL = (NEED + 1 + 7) / 8;                                       // 16-byte loads per row (+ 1: the odd start)
 };
 
-template <typename T, int UP, int DOWN, bool XODD, bool YODD>
+// SMALLF: the filter has fewer than 4 x 4 taps -- slots beyond it are SKIPPED (uniform branches on fh / fw), not multiplied by a zero tap:
+// 0 * inf = NaN would poison positions the reference never touches (the one-tap zero-stuffing call of the stride-2 backward
+// turned an overflowed dy element into NaN in its three stuffed neighbours as well; a fill + strided copy writes exact zeros there)
+template <typename T, int UP, int DOWN, bool XODD, bool YODD, bool SMALLF>
 __global__ __launch_bounds__(256) void upfirdn2d_rows_kernel(UpfirdnParams p, const float* __restrict__ f, int ncg, int nstrips, long long total) {
     typedef UpfRows<UP, DOWN> G;
     constexpr int RPT = G::RPT, NIN = G::NIN, NL = G::NL;
@@ -216,7 +219,6 @@ __global__ __launch_bounds__(256) void upfirdn2d_rows_kernel(UpfirdnParams p, co
     const int strip = (int)(rest % nstrips);
     const long long plane = rest / nstrips;
     const int x0 = cg * 8, oy0 = strip * RPT;
-    const T* xp = (const T*)p.x + plane * p.xh * p.xw;
 
     // first input column / row of the group, and the even column the loads start from
     int c0, iy0;
@@ -292,11 +294,13 @@ __global__ __launch_bounds__(256) void upfirdn2d_rows_kernel(UpfirdnParams p, co
             for (int o = 0; o < RPT; o++) {
                 constexpr int dummy = 0; (void)dummy;
                 const int ky = r - o * DOWN;                                               // compile-time after unrolling
-                if (ky >= 0 && ky < 4) {
+                if (ky >= 0 && ky < 4 && (!SMALLF || ky < p.fh)) {
 #pragma unroll
-                    for (int j = 0; j < 8; j++)
+                    for (int kx = 0; kx < 4; kx++) {
+                        if (SMALLF && kx >= p.fw) continue;
 #pragma unroll
-                        for (int kx = 0; kx < 4; kx++) acc[o][j] = fmaf(t[ky][kx], v[j * DOWN + kx], acc[o][j]);
+                        for (int j = 0; j < 8; j++) acc[o][j] = fmaf(t[ky][kx], v[j * DOWN + kx], acc[o][j]);
+                    }
                 }
             }
         } else {
@@ -308,12 +312,14 @@ __global__ __launch_bounds__(256) void upfirdn2d_rows_kernel(UpfirdnParams p, co
                 for (int a = 0; a < 2; a++) {
                     if ((o + par - qy) / 2 + a != r) continue;
                     const int ky = par + 2 * a;
+                    if (SMALLF && ky >= p.fh) continue;
 #pragma unroll
                     for (int j = 0; j < 8; j++) {
                         const int qx = XODD ? 1 : 0, parx = (qx + j) & 1;
 #pragma unroll
                         for (int b = 0; b < 2; b++) {
                             const int kx = parx + 2 * b;
+                            if (SMALLF && kx >= p.fw) continue;
                             acc[o][j] = fmaf(t[ky][kx], v[(j + parx - qx) / 2 + b], acc[o][j]);
                         }
                     }
@@ -356,7 +362,9 @@ static bool launch_rows(const UpfirdnParams& p, const float* f, hipStream_t st) 
         if (nblk <= 0 || nblk >= (1ll << 31)) return false;
         dim3 grid((unsigned)nblk), block(256);
         const bool xo = (p.padx0 & 1) != 0, yo = (p.pady0 & 1) != 0;      // x0 is a multiple of 8, a strip's first row a multiple of 4
-#define AFCM_UPF_ROWS(U, D, XO, YO) hipLaunchKernelGGL((upfirdn2d_rows_kernel<T, U, D, XO, YO>), grid, block, 0, st, p, f, ncg, nstrips, total)
+        const bool smallf = p.fw < 4 || p.fh < 4;
+#define AFCM_UPF_ROWS(U, D, XO, YO) do { if (smallf) hipLaunchKernelGGL((upfirdn2d_rows_kernel<T, U, D, XO, YO, true>), grid, block, 0, st, p, f, ncg, nstrips, total); \
+        else hipLaunchKernelGGL((upfirdn2d_rows_kernel<T, U, D, XO, YO, false>), grid, block, 0, st, p, f, ncg, nstrips, total); } while (0)
         if (up == 1 && down == 1) { if (xo) AFCM_UPF_ROWS(1, 1, true, false); else AFCM_UPF_ROWS(1, 1, false, false); }
         else if (up == 1) { if (xo) AFCM_UPF_ROWS(1, 2, true, false); else AFCM_UPF_ROWS(1, 2, false, false); }
         else if (xo) { if (yo) AFCM_UPF_ROWS(2, 1, true, true); else AFCM_UPF_ROWS(2, 1, true, false); }

@@ -568,34 +568,6 @@ class _ConvWgrad(torch.autograd.Function):
         return g_dy, g_x, None, None
 
 
-# id(weight tensor) -> (weak reference to it, its version counter, activation dtype, packed image of the stride-2 kernel).  The entry
-# is only valid for the very tensor OBJECT it was made from, at the version it had (a key on data_ptr matched the temporaries
-# `weight * gain` of later iterations and of other same-shape layers whenever the allocator handed their address out again -- a stale
-# image of other weights).  A tensor that died takes its entry along (weak-reference callback), so a recycled id() cannot match either.
-_S2_PACKS = {}
-
-
-def _s2_pack_lookup(w, dtype):
-    e = _S2_PACKS.get(id(w))
-    if e is not None and e[0]() is w and e[1] == w._version and e[2] == dtype:
-        return e[3]
-    return None
-
-
-def _s2_pack_store(w, dtype, wp):
-    import weakref
-    key = id(w)
-
-    def _gone(ref, key=key):
-        e = _S2_PACKS.get(key)
-        if e is not None and e[0] is ref:
-            del _S2_PACKS[key]
-
-    if len(_S2_PACKS) >= 64:
-        _S2_PACKS.clear()
-    _S2_PACKS[key] = (weakref.ref(w, _gone), w._version, dtype, wp)
-
-
 ZERO_STUFF_UPFIRDN = True      # module switch (A/B): the stride-2 backward's zero-stuffed dy through upfirdn2d(up=2, one tap)
 _ONE_TAP = {}
 
@@ -608,8 +580,9 @@ def _one_tap(device):
 
 
 class _StridedConv2d(torch.autograd.Function):
-    """y = conv(x, w, pad) at stride 2, 16-bit 3x3 (C ABI afcm_conv2d_stride2): the even rows / columns of the stride-1 result, bit for
-    bit, at a quarter of its MFMAs.  The gradients of a strided correlation are stride-1 convolutions with the zero-stuffed dy: the
+    """y = conv(x, w, pad) at stride 2, 16-bit 3x3 (C ABI afcm_conv2d_stride2): the even rows / columns of the stride-1 result -- same
+    operands, fp32 accumulation, within 1 ulp of the stride-1 route (whose kernel sums 32-channel chunks since r05, this one 16-channel
+    ones) -- at a quarter of its MFMAs.  The gradients of a strided correlation are stride-1 convolutions with the zero-stuffed dy: the
     backward is written with the differentiable nodes above, so first- and higher-order graphs (the discriminator's R1 penalty) come
     out the same way they did when the stride was a slice of the stride-1 result."""
 
@@ -623,14 +596,12 @@ class _StridedConv2d(torch.autograd.Function):
         code = _lib._DTYPES[x.dtype]
         bk = lib.afcm_conv2d_block_k(code)
         rows_pad = (cout + 127) // 128 * 128                       # the stride-2 kernel runs 128-row blocks only
-        # the packed image is reused while the SAME weight tensor object is unchanged (a caller that passes its Parameter runs a
-        # down-conv three times per D iteration -- fake, real, R1 -- on one image); a temporary (`weight * gain`) is packed per call
-        wp = _s2_pack_lookup(w, x.dtype)
-        if wp is None:
-            w32 = w.detach().to(torch.float32).contiguous()
-            wp = torch.empty([(cin + bk - 1) // bk, 9, rows_pad, bk], dtype=x.dtype, device=x.device)
-            _lib.check(lib.afcm_conv2d_pack_weights_bk(wp.data_ptr(), w32.data_ptr(), code, cout, cin, 3, 0, rows_pad, bk, _lib.stream_ptr(x)), 'conv2d_pack_weights')
-            _s2_pack_store(w, x.dtype, wp)
+        # the image is packed per call (8 us): every caller in the package passes a temporary (`weight * weight_gain`, then `.to(dtype)`), so
+        # the per-tensor cache r04 / r05 kept here never hit -- and a cache keyed on anything but the tensor object served
+        # stale images
+        w32 = w.detach().to(torch.float32).contiguous()
+        wp = torch.empty([(cin + bk - 1) // bk, 9, rows_pad, bk], dtype=x.dtype, device=x.device)
+        _lib.check(lib.afcm_conv2d_pack_weights_bk(wp.data_ptr(), w32.data_ptr(), code, cout, cin, 3, 0, rows_pad, bk, _lib.stream_ptr(x)), 'conv2d_pack_weights')
         p, q = (h + 2 * padding - 3) // 2 + 1, (wd + 2 * padding - 3) // 2 + 1
         y = torch.empty([n, cout, p, q], dtype=x.dtype, device=x.device)
         span = profiling.span('conv2d', 2.0 * n * cout * cin * 9 * p * q)

@@ -416,8 +416,9 @@ int afcm_conv2d_split(float* y, const void* x_parts, const void* wpacked, const 
 /* ----------------------------------------------------------------------------------------
  * 3x3 convolution at stride 2 (the discriminator's down-sampling convs, CoModGAN/generator.py:613-692, after the blur): 16-bit x
  * [n][cin][h][w] (dense, w even), weights packed by afcm_conv2d_pack_weights_bk(mode 0, block_k = afcm_conv2d_block_k(dtype)) with rows_pad a multiple of 128, y
- * [n][cout][(h + 2 pad - 3) / 2 + 1][(w + 2 pad - 3) / 2 + 1] = the even rows / columns of afcm_conv2d's result, bit for bit, at a
- * quarter of its MFMAs and without the full-resolution intermediate.  Forward only (the gradients are stride-1 convolutions with the
+ * [n][cout][(h + 2 pad - 3) / 2 + 1][(w + 2 pad - 3) / 2 + 1] = the even rows / columns of afcm_conv2d's result (same 16-bit operands, fp32 accumulation; the two
+ * kernels sum their K-chunks in a different order -- 16 channels here, 32 in the stride-1 kernel since r05 -- so results agree within 1 ulp
+ * of the 16-bit output, not bit for bit: tests/test_gpu_conv.py holds both to a float64 strided conv), at a quarter of its MFMAs and without the full-resolution intermediate.  Forward only (the gradients are stride-1 convolutions with the
  * zero-stuffed dy: afcm_conv2d / afcm_conv2d_wgrad).
  * ---------------------------------------------------------------------------------------- */
 int afcm_conv2d_stride2(void* y, const void* x, const void* wpacked, int32_t dtype, int32_t n, int32_t cin, int32_t cout, int32_t h, int32_t w,

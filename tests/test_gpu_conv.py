@@ -433,7 +433,7 @@ def test_stride2_conv_repacks_after_an_optimizer_step():
     assert _close16(C.strided_conv2d(x, wt, 1), C.scaled_conv2d(x, wt.detach(), None, None, 1)[:, :, ::2, ::2])
 
 
-def test_stride2_pack_cache_never_serves_another_tensors_image():
+def test_stride2_conv_under_address_reuse_uses_current_weights():
     """every real caller hands the stride-2 conv a TEMPORARY (`self.weight * self.weight_gain`, then `.to(float32)`:
     networks_discriminator.py Conv2dLayer -> conv2d_resample), whose address the caching allocator hands out again -- to the next
     iteration's temporary after an optimizer step, or to another same-shape layer's.  A cache keyed on the address served a stale image.
@@ -465,15 +465,6 @@ def test_stride2_pack_cache_never_serves_another_tensors_image():
             wa.mul_(1.25)                                  # "optimizer step": the next iteration's temporaries reuse the addresses
             wb.add_(0.01)
     assert len(seen) < 12, 'the allocator never reused an address: the test did not exercise the hazard'
-    # the intended reuse still works for a tensor object that stays alive and unchanged
-    wt = (wa.detach() * gain).float()
-    y0 = C.strided_conv2d(x, wt, 1)
-    assert C._s2_pack_lookup(wt, x.dtype) is not None and torch.equal(y0, C.strided_conv2d(x, wt, 1))
-    wt.mul_(2.0)
-    assert C._s2_pack_lookup(wt, x.dtype) is None and _close16(C.strided_conv2d(x, wt, 1), C.scaled_conv2d(x, wt, None, None, 1)[:, :, ::2, ::2])
-    key = id(wt)
-    del wt
-    assert key not in C._S2_PACKS, 'a dead tensor must take its cache entry along'
 
 
 # ---- fp32 on the 16-bit matrix pipe: split operands (C ABI afcm_split16 / afcm_conv2d_split) -------------------------------------
