@@ -110,7 +110,6 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? 1 : 2)) void conv2d_fwd_kern
     constexpr int PPR = BK / EPV;                    // pieces per weight row (2)
     constexpr int NPIECES = KK * BM_O * PPR;
     constexpr int NWP = cdiv(NPIECES, 256);
-    constexpr int NCG = F32 ? 1 : BK / 8;            // 8-channel groups per chunk in the patch staging
     __shared__ __attribute__((aligned(16))) T lds[(KK * BM_O + kPatchMax) * PITCH];
     T* lds_w = lds;
     T* lds_p = lds + KK * BM_O * PITCH;
@@ -1753,9 +1752,12 @@ __global__ __launch_bounds__(256) void scale_planes_kernel(TO* __restrict__ y, c
 }
 
 // Magnitude bound of a tensor, for the float16 split (split16_kernel): out[0] = max(out[0], bits of max |scale[plane] * x[plane, :]|).
-// Magnitudes compare as their bit patterns (a NaN ranks above inf).  The consumers turn the bound into the power of two g with
+// Magnitudes compare as their bit patterns; r06: over the FINITE elements only (an inf / NaN element keeps its place in the split's first part
+// whatever the factor).  The consumers turn the bound into the power of two g with
 // g * bound in [2^14, 2^15) (pow2_factor): float16 parts of g * v cannot overflow (65504) and the second part of every element above
-// 2^-18 of the bound is a normal number; a non-finite bound gives g = 1, so an inf / NaN tensor goes through the split as it is.
+// 2^-18 of the bound is a normal number (below that it is a subnormal: 22 significand bits shrink to 11 at 2^-29 of the bound).  One bound
+// per TENSOR, not per plane: the contraction sums over the input planes, so a per-plane factor cannot leave the sum (a per-sample one could
+// in forward / data gradient, not in the weight gradient, which sums over samples) -- DESIGN.md section 4.4.
 // One atomic per workgroup, and only from workgroups that would raise the value (2048 unconditional atomics on one word cost 50 us).
 __global__ __launch_bounds__(256) void amax_bits_kernel(unsigned* __restrict__ out, const float* __restrict__ x, long long planes, int hw,
                                                         const float* __restrict__ scale) {
@@ -1768,8 +1770,14 @@ __global__ __launch_bounds__(256) void amax_bits_kernel(unsigned* __restrict__ o
     const long long stride = (long long)gridDim.x * blockDim.x;
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     auto fold = [&](const uint4 v, long long g) {
-        unsigned a = max(max(v.x & 0x7fffffffu, v.y & 0x7fffffffu), max(v.z & 0x7fffffffu, v.w & 0x7fffffffu));
-        if (scale) a = __float_as_uint(__uint_as_float(a) * __builtin_fabsf(scale[g / per]));      // |s| max|x| = max|s x| (NaN stays NaN)
+        // non-finite magnitudes (exponent all ones) do not count: one inf or NaN would otherwise take the power-of-two factor -- and with it
+        // 22-bit parts -- away from every finite element of the tensor; the split keeps such an element whole in its first part
+        const unsigned ax = v.x & 0x7fffffffu, ay = v.y & 0x7fffffffu, az = v.z & 0x7fffffffu, aw = v.w & 0x7fffffffu;
+        unsigned a = max(max(ax < 0x7f800000u ? ax : 0u, ay < 0x7f800000u ? ay : 0u), max(az < 0x7f800000u ? az : 0u, aw < 0x7f800000u ? aw : 0u));
+        if (scale) {
+            a = __float_as_uint(__uint_as_float(a) * __builtin_fabsf(scale[g / per]));              // |s| max|x| = max|s x|
+            if (a >= 0x7f800000u) a = 0u;                                                           // (an overflowing or non-finite factor: as above)
+        }
         m = max(m, a);
     };
     // four independent 16-byte loads in flight per lane
@@ -1780,7 +1788,8 @@ __global__ __launch_bounds__(256) void amax_bits_kernel(unsigned* __restrict__ o
     for (; i < n4; i += stride) fold(((const uint4*)x)[i], i);
     for (long long j = 4 * n4 + (long long)blockIdx.x * blockDim.x + threadIdx.x; j < numel; j += stride) {
         const float v = x[j] * (scale ? scale[j / hw] : 1.f);
-        m = max(m, __float_as_uint(v) & 0x7fffffffu);
+        const unsigned a = __float_as_uint(v) & 0x7fffffffu;
+        m = max(m, a < 0x7f800000u ? a : 0u);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
@@ -2489,7 +2498,6 @@ __global__ __launch_bounds__(512, 1) void conv2d_wgrad16_kernel(WgradParams p) {
     constexpr int NTAILP = TAIL ? (4 * XR) / 8 : 0; // tail pieces per wave
     static_assert(!TAIL || (4 * XR) % 8 == 0, "tail pieces must divide over the 8 waves");
     constexpr int NPIECE = 8 + 4 * XR + NTAILP;     // LDS-DMA instructions per wave and step
-    constexpr unsigned kOob = 0x80000000u;
     __shared__ __attribute__((aligned(256))) char lds[NBUF * BUF];
     const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) void*)lds;
 
@@ -2802,7 +2810,6 @@ __global__ __launch_bounds__(512, 1) void conv2d_wgrad16g_kernel(WgradParams p) 
     const int o0 = obk * 64, i0 = ib * 64;
 
     // 32x32x16: one 32 x 32 tile per tap, element e = MFMA register e; 16x16x32: element 4 (2 ob2 + ib2) + reg of the (ob2, ib2) 16 x 16 tile
-    typedef __attribute__((ext_vector_type(4))) float wf32x4;
     f32x16 acc[KK];
 #pragma unroll
     for (int t = 0; t < KK; t++)
