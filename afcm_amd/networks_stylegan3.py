@@ -16,7 +16,7 @@ import torch
 import torch.nn.functional as F
 
 from . import layer_schedule as sched
-from .torch_utils.ops import affine_bank, bias_act, conv2d_gradfix, filtered_lrelu, fused_layer, modulation_bank
+from .torch_utils.ops import affine_bank, bias_act, conv2d_gradfix, fc_bank, filtered_lrelu, fused_layer, modulation_bank
 from .torch_utils.ops import conv2d as _conv_ops
 from .torch_utils.ops.conv2d import modulation_coefficients_fused, scaled_conv2d
 from .torch_utils.ops.conv2d import modulated_conv2d  # noqa: F401  (re-exported: NET:25 lives in this module)
@@ -76,6 +76,9 @@ class FullyConnectedLayer(torch.nn.Module):
         self.bias_gain = lr_multiplier
 
     def forward(self, x):
+        if fc_bank.supported(x, self.weight, self.activation):
+            # GEMM + gains + bias + activation as one launch (and one backward): torch_utils/ops/fc_bank.py
+            return fc_bank.fc_act(x, self.weight, self.bias, self.weight_gain, self.bias_gain, self.activation)
         b = self.bias
         if b is not None:
             b = b.to(x.dtype)
@@ -117,12 +120,18 @@ class MappingNetwork(torch.nn.Module):
         if truncation_cutoff is None:
             truncation_cutoff = self.num_ws
         x = z.to(torch.float32)
-        x = x * (x.square().mean(1, keepdim=True) + 1e-8).rsqrt()
         if self.c_dim > 0:
             _assert_shape(c, [None, self.c_dim])
-            y = self.embed(c.to(torch.float32))
-            y = y * (y.square().mean(1, keepdim=True) + 1e-8).rsqrt()
-            x = torch.cat([x, y], dim=1)
+        cc = c.to(torch.float32) if self.c_dim > 0 else None
+        if fc_bank.mapping_input_supported(x, cc, self.embed):
+            # both normalisations, the embedding and the cat as one launch (NET:143-150)
+            x = fc_bank.mapping_input(x, cc, self.embed)
+        else:
+            x = x * (x.square().mean(1, keepdim=True) + 1e-8).rsqrt()
+            if self.c_dim > 0:
+                y = self.embed(cc)
+                y = y * (y.square().mean(1, keepdim=True) + 1e-8).rsqrt()
+                x = torch.cat([x, y], dim=1)
         for idx in range(self.num_layers):
             x = getattr(self, f'fc{idx}')(x)
         if update_emas:
@@ -441,7 +450,9 @@ class SynthesisNetwork(torch.nn.Module):
             rev_prev = self.num_layers - max(idx - 1, 0) - 1
             img_in = enc_layers[idx](img_in, _packed=enc_packs[idx])   # the reference passes no kwargs to the encoder (NET:678)
             if (self.sizes[rev_idx] != self.sizes[rev_prev]) and self.sizes[rev_prev] != self.sizes[0]:
-                E_features[self.sizes[rev_idx]] = img_in
+                # the feature map has two consumers (the next encoder layer, a decoder layer's skip input): fork it, so that its two
+                # gradients meet in one fused pass (torch_utils/ops/fused_layer.py skip_fork)
+                img_in, E_features[self.sizes[rev_idx]] = fused_layer.skip_fork(img_in)
 
         img_pool = self.e_16x16(img_in)
         img_pool = self._pool4(img_pool.to(torch.float32))

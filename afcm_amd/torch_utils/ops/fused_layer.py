@@ -21,13 +21,14 @@ fewer per fused factor).
 import torch
 
 from ... import _lib
+from . import _rows
 from . import conv2d as _conv
 from . import filtered_lrelu as _flr
 
 
 class _ConvFilteredLRelu(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, in_scale, out_scale, bias, fu, fd, skip, next_scale, conv_pad, cfg, prescaled, packed=None):
+    def forward(ctx, x, w, in_scale, out_scale, bias, fu, fd, skip, next_scale, conv_pad, cfg, prescaled, packed=None, fork=None):
         _lib.require_gpu(x, w, in_scale, out_scale, bias, fu, fd, skip, next_scale)
         cout, cin, ks, _ = w.shape
         xs = _conv.scale_planes(x, in_scale) if (in_scale is not None and not prescaled) else x
@@ -56,6 +57,12 @@ class _ConvFilteredLRelu(torch.autograd.Function):
         keep_z = (next_scale is not None and ctx.needs_input_grad[8]) or flags is not None
         ctx.save_for_backward(xs, w, in_scale, out_scale, bias, fu, fd, signs, next_scale, y if keep_y else None, z if keep_z else None,
                               flags, skip if (flags is not None and skip is not None) else None)
+        # the skip tensor is one arm of a SkipFork: its gradient leaves this node UNSCALED (g itself, no pass over it) and the fork's backward
+        # applies s_next while it adds the two arms (C ABI afcm_axpy_planes)
+        ctx.skip_by_fork = False
+        if fork is not None and skip is not None and next_scale is not None and ctx.needs_input_grad[7]:
+            fork.scale = next_scale.detach()
+            ctx.skip_by_fork = True
         ctx.meta = (conv_pad, cfg, bool(prescaled), layout, tuple(y.shape), tuple(z.shape), skip is not None)
         return z
 
@@ -100,7 +107,7 @@ class _ConvFilteredLRelu(torch.autograd.Function):
             d_next = None if dn32 is None else dn32.to(next_scale.dtype)
             d_out = None if do32 is None else do32.to(out_scale.dtype)
         if has_skip and ctx.needs_input_grad[7]:
-            d_skip = _conv.scale_planes(g, next_scale) if next_scale is not None else g
+            d_skip = _conv.scale_planes(g, next_scale) if (next_scale is not None and not ctx.skip_by_fork) else g
         if ctx.needs_input_grad[0] or (ctx.needs_input_grad[2] and not prescaled):
             wpt, rows_pad = ctx.wpt if (ctx.wpt is not None and ctx.wpt[0].dtype == g.dtype) else _conv.pack_weights(w, g.dtype, 1)
             eff_in = None if prescaled else in_scale
@@ -110,7 +117,7 @@ class _ConvFilteredLRelu(torch.autograd.Function):
                 d_in = torch.where(s2 > 0, _conv.plane_dot(xs, dx) / s2.clamp_min(1e-30), torch.zeros_like(s2)).to(in_scale.dtype)
         if ctx.needs_input_grad[1]:
             dw = _conv._wgrad_raw(dys, xs, cout, cin, ks, conv_pad).to(w.dtype)
-        return dx, dw, d_in, d_out, db, None, None, d_skip, d_next, None, None, None, None
+        return dx, dw, d_in, d_out, db, None, None, d_skip, d_next, None, None, None, None, None
 
 
 # the demodulation gradient's <dys, y> from <g, z> where no strip of a plane could reach the clamp (tests switch it off to compare)
@@ -137,4 +144,60 @@ def conv_filtered_lrelu(x, w, in_scale, out_scale, bias, fu, fd, up, down, paddi
     * next_scale.  ``prescaled``: x already carries in_scale (the producer's epilogue applied it).  ``packed``: the two weight
     images of `w` from ``conv2d.pack_weights_bank`` (the caller packed several layers in one launch), else they are made here."""
     cfg = _cfg(up, down, padding, gain, slope, clamp)
-    return _ConvFilteredLRelu.apply(x, w, in_scale, out_scale, bias, fu, fd, skip, next_scale, int(conv_pad), cfg, bool(prescaled), packed)
+    fork = getattr(skip, '_afcm_fork', None) if skip is not None else None
+    return _ConvFilteredLRelu.apply(x, w, in_scale, out_scale, bias, fu, fd, skip, next_scale, int(conv_pad), cfg, bool(prescaled), packed, fork)
+
+
+# ---- an encoder feature map that feeds the next encoder layer AND a decoder layer's skip input (NET:678-681, 371-377) ----------------------
+class _ForkState:
+    """What the decoder side tells the fork between forward and backward: the per-plane factor its epilogue applied to (F(y) + skip)."""
+    __slots__ = ('scale',)
+
+    def __init__(self):
+        self.scale = None
+
+
+class _SkipFork(torch.autograd.Function):
+    """x -> (x, x).  Its backward is the accumulation autograd would do for a tensor with two consumers -- ga + gb -- as ONE pass that also
+    applies the skip arm's pending style factor: ga + scale[n, c] * gb (C ABI afcm_axpy_planes).  Op by op that was scale_planes (a new
+    156 MB tensor at 276^2) followed by autograd's add: five passes over the planes instead of three, two roundings instead of one."""
+
+    @staticmethod
+    def forward(ctx, x, state):
+        ctx.state = state
+        return x.view_as(x), x.view_as(x)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, ga, gb):
+        scale = ctx.state.scale
+        ctx.state.scale = None
+        if gb is None:
+            return ga, None
+        if ga is None:
+            return (gb if scale is None else _conv.scale_planes(gb, scale)), None
+        out = None
+        if ga.is_cuda and ga.dtype in (torch.bfloat16, torch.float16) and ga.dtype == gb.dtype and ga.shape == gb.shape:
+            fa, fb = (_rows.whole_buffer(ga), _rows.whole_buffer(gb)) if not ga.is_contiguous() else (ga, gb if gb.is_contiguous() else None)
+            if fa is not None and fb is not None and fa.shape == fb.shape:
+                n, c, h, ld = fa.shape
+                y = torch.empty_like(fa)
+                sc = None if scale is None else scale.to(torch.float32).contiguous()
+                rc = _lib.check(_lib.load().afcm_axpy_planes(y.data_ptr(), fa.data_ptr(), fb.data_ptr(), _lib.ptr(sc), _lib.dtype_code(fa), n * c, h * ld,
+                                                            _lib.stream_ptr(fa)), 'axpy_planes')
+                if rc == 0:
+                    out = y[..., :ga.shape[3]]
+        if out is None:
+            out = ga + (gb if scale is None else _conv.scale_planes(gb, scale))
+        return out, None
+
+
+def skip_fork(x):
+    """(x for the next encoder layer, x for E_features): two views of `x` whose gradients meet in one fused pass (see _SkipFork).  The
+    second carries the fork's state as a Python attribute; `conv_filtered_lrelu(skip=...)` finds it there."""
+    if not (x.requires_grad and torch.is_grad_enabled()):
+        return x, x
+    state = _ForkState()
+    a, b = _SkipFork.apply(x, state)
+    b._afcm_fork = state
+    return a, b

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define AFCM_ABI_VERSION 13  /* 13 (r06): + afcm_noop (additions only; see the end of this header for the r06 entry points).  12 (r05): + afcm_conv2d_block_k_ks, afcm_conv2d_pack_weights_bk; the packed layout's K-chunk depends on (dtype, kernel size): 16-bit 3x3 images are [nkc][9][rows_pad][32] for the v_mfma 16x16x32 kernel (the pack / conv entry points keep their signatures).  11 (r04): + afcm_amax_bits, afcm_split16, afcm_conv2d_pack_split, afcm_conv2d_split, afcm_unscale, afcm_plane_dot_parts (additions only).  10 (r04): + afcm_filtered_lrelu_args.clamp_flags (appended), afcm_plane_dot_gated_ld; the runtime getenv switches are gone.  9 (r03): + afcm_affine_bank_*, afcm_modulation_bank_*, afcm_conv2d_pack_bank, afcm_conv2d_stride2 (additions only; every v8 entry point and struct is unchanged) */
+#define AFCM_ABI_VERSION 13  /* 13 (r06): + afcm_noop, afcm_axpy_planes, afcm_fc_act_fwd / _bwd, afcm_mapping_input_fwd / _bwd (additions only; see the end of this header for the r06 entry points).  12 (r05): + afcm_conv2d_block_k_ks, afcm_conv2d_pack_weights_bk; the packed layout's K-chunk depends on (dtype, kernel size): 16-bit 3x3 images are [nkc][9][rows_pad][32] for the v_mfma 16x16x32 kernel (the pack / conv entry points keep their signatures).  11 (r04): + afcm_amax_bits, afcm_split16, afcm_conv2d_pack_split, afcm_conv2d_split, afcm_unscale, afcm_plane_dot_parts (additions only).  10 (r04): + afcm_filtered_lrelu_args.clamp_flags (appended), afcm_plane_dot_gated_ld; the runtime getenv switches are gone.  9 (r03): + afcm_affine_bank_*, afcm_modulation_bank_*, afcm_conv2d_pack_bank, afcm_conv2d_stride2 (additions only; every v8 entry point and struct is unchanged) */
 
 enum { AFCM_F32 = 0, AFCM_F16 = 1, AFCM_BF16 = 2 };
 enum { AFCM_OK = 0, AFCM_E_NOKERNEL = -1, AFCM_E_INVALID = -2 };
@@ -423,6 +423,36 @@ int afcm_conv2d_split(float* y, const void* x_parts, const void* wpacked, const 
  * ---------------------------------------------------------------------------------------- */
 int afcm_conv2d_stride2(void* y, const void* x, const void* wpacked, int32_t dtype, int32_t n, int32_t cin, int32_t cout, int32_t h, int32_t w,
                         int32_t pad, int32_t rows_pad, void* stream);
+
+/* y[plane][:] = a[plane][:] + scale[plane] * b[plane][:] (r06), 16-bit tensors of ONE layout, hw elements per plane (hw % 8 == 0, 16-byte aligned
+ * bases; else AFCM_E_NOKERNEL), scale [planes] fp32 or NULL (1): the accumulation autograd performs for an encoder feature map that feeds the next
+ * encoder layer and a decoder layer's skip input (NET:371-377: `x = x + x_skip`), with the decoder's style factor folded in -- three passes
+ * over the planes instead of scale_planes + add's five.  Sum in fp32, one rounding. */
+int afcm_axpy_planes(void* y, const void* a, const void* b, const float* scale, int32_t dtype, int64_t planes, int32_t hw, void* stream);
+
+/* ----------------------------------------------------------------------------------------
+ * Equalised-learning-rate dense layers as one launch per layer and direction (r06): the mapping network's eight FCs and the
+ * bottleneck's `fc_in` -- NET:69-104 (`FullyConnectedLayer.forward`: x @ (w * weight_gain).T + b * bias_gain, then bias_act, which the
+ * reference runs as addmm / matmul + plugin `bias_act(x, b, xref, yref, dy, grad, dim, act, alpha, gain, clamp)`, SG3OPS/bias_act.cpp:32-90).
+ * All tensors fp32, row-major: x [n][cin], w [cout][cin], b [cout] or NULL, y [n][cout].  act: 0 = linear, 1 = lrelu (slope 0.2, gain
+ * sqrt 2: bias_act.py:21-31).  alpha = weight_gain, beta = bias_gain.  n <= 64, cin % 16 == 0 (and cout % 16 == 0 for the backward), else
+ * AFCM_E_NOKERNEL (the host keeps the GEMM + bias_act composition).  Exact fp32 arithmetic (v_mfma_f32_16x16x4_f32 = an fmaf chain).
+ *   afcm_fc_act_fwd:  y = act(alpha * x w^T + beta * b)
+ *   afcm_fc_act_bwd:  with gp = gy * act'(y) (from the saved output y, as bias_act.cu:68-73): dx = alpha * gp w, dw = alpha * gp^T x,
+ *                     db = beta * colsum(gp); any of dx / dw / db may be NULL (not wanted).
+ * afcm_mapping_input_fwd / _bwd: the mapping network's input stage (NET:143-150): x0 [n][zdim + wdim] = cat(normalize(z),
+ * normalize(embed(c))) with normalize(v) = v * rsqrt(mean(v^2) + 1e-8) and embed = the linear FC c_dim -> w_dim (weight ew [wdim][cdim],
+ * bias eb, gains alpha / beta); cdim = 0: x0 = normalize(z) only.  The backward returns the embedding layer's weight / bias gradients
+ * from gx0 = dL/dx0 (z and c carry none).
+ * ---------------------------------------------------------------------------------------- */
+int afcm_fc_act_fwd(float* y, const float* x, const float* w, const float* b, int32_t n, int32_t cin, int32_t cout, float alpha, float beta,
+                    int32_t act, void* stream);
+int afcm_fc_act_bwd(float* dx, float* dw, float* db, const float* gy, const float* y, const float* x, const float* w, int32_t n, int32_t cin,
+                    int32_t cout, float alpha, float beta, int32_t act, void* stream);
+int afcm_mapping_input_fwd(float* x0, const float* z, const float* c, const float* ew, const float* eb, int32_t n, int32_t zdim, int32_t cdim,
+                           int32_t wdim, float alpha, float beta, void* stream);
+int afcm_mapping_input_bwd(float* dew, float* deb, const float* gx0, const float* c, const float* ew, const float* eb, int32_t n, int32_t zdim,
+                           int32_t cdim, int32_t wdim, float alpha, float beta, void* stream);
 
 #ifdef __cplusplus
 }
