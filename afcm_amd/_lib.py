@@ -95,6 +95,7 @@ SIGNATURES = {
     'afcm_conv2d_wgrad_splits': (C.c_int, [_i32, _i32, _i32, _i32]),
     'afcm_conv2d_wgrad': (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     'afcm_conv2d_wgrad_ld': (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    'afcm_conv2d_wgrad_dots_ld': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     'afcm_scale_planes': (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i64, _i32, _vp]),
     'afcm_plane_dot': (C.c_int, [_vp, _vp, _vp, _i32, _i64, _i32, _vp]),
     'afcm_plane_dot_ld': (C.c_int, [_vp, _vp, _vp, _i32, _i64, _i32, _i32, _i32, _i32, _vp]),
@@ -118,13 +119,17 @@ SIGNATURES = {
     'afcm_conv2d_stride2': (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     'afcm_conv2d_pack_bank': (C.c_int, [C.POINTER(PackEntry), _i32, _i32, _i32, _vp]),
     'afcm_affine_bank_bwd': (C.c_int, [C.POINTER(AffineBank), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _vp, _vp, _vp, _vp]),
+    'afcm_l1_partials': (C.c_int, [_vp, _vp, _vp, _i64, _i32, _f32, _vp]),
+    'afcm_l1_grad': (C.c_int, [_vp, _vp, _vp, _vp, _i64, _f32, _vp]),
     'afcm_axpy_planes': (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i64, _i32, _vp]),
     'afcm_fc_act_fwd': (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _f32, _i32, _vp]),
     'afcm_fc_act_bwd': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _f32, _i32, _vp]),
     'afcm_mapping_input_fwd': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _f32, _vp]),
-    'afcm_mapping_input_bwd': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _f32, _vp]),
+    'afcm_mapping_input_bwd_workspace_bytes': (C.c_int64, [_i32, _i32]),
+    'afcm_mapping_input_bwd': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _f32, _vp, _vp]),
     'afcm_adam_chunk_elems': (C.c_int32, []),
     'afcm_adam_multi': (C.c_int, [_vp, _i32, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _i32, _f32, _f32, _i32, _vp]),
+    'afcm_adam_multi_capturable': (C.c_int, [_vp, _i32, _i64, _vp, _f32, _f32, _f32, _f32, _f32, _i32, _f32, _f32, _i32, _vp]),
 }
 
 

@@ -2196,6 +2196,9 @@ struct WgradParams {
     int fo, fi, splits_p, steps_per_split_p;
     int qchunks;                  // ceil(Q / kWgKQ)
     int rowgroups;                // ceil(P / R)
+    // conv2d_wgrad16g_kernel, r06: > 0 = splits per IMAGE (splits = N * splits_img): a split never crosses an image, so the slabs of image n are
+    // its own weight gradient dW_n -- what the per-plane dot products <x[n, i], dx[n, i]> are read from (wgrad_reduce_dots_kernel)
+    int splits_img;
 };
 
 // R = output rows per K macro-step (2 for 16-bit: halves the barriers and re-uses the overlapping input rows).
@@ -2859,8 +2862,14 @@ __global__ __launch_bounds__(512, 1) void conv2d_wgrad16g_kernel(WgradParams p) 
     unsigned c_dy32 = 0, c_x32 = 0;                                              // byte offsets of (image n, channel o0 / i0)
 
     const int steps_per_img = p.rowgroups * p.qchunks;
-    const int s0 = split * my_steps;
-    const int s1 = min(s0 + my_steps, p.N * steps_per_img);
+    int s0 = split * my_steps;
+    int s1 = min(s0 + my_steps, p.N * steps_per_img);
+    if (p.splits_img > 0) {                                                      // image-aligned shares (my_steps = ceil(steps_per_img / splits_img))
+        const int img = __builtin_amdgcn_readfirstlane(split / p.splits_img), j = split - img * p.splits_img;
+        s0 = img * steps_per_img + j * my_steps;
+        s1 = min(s0 + my_steps, (img + 1) * steps_per_img);
+        if (s1 < s0) s1 = s0;                                                    // (a share past the image's last step: zeros)
+    }
     // a quadrant wholly outside the matrix: its waves only issue their share of the loads
     const bool quad_dead = o0 + wo * 32 >= p.O || i0 + wi * 32 >= p.I;
     int ld_n = __builtin_amdgcn_readfirstlane(s0 / steps_per_img);
@@ -3283,6 +3292,69 @@ __global__ __launch_bounds__(256) void wgrad_reduce4_kernel(float* __restrict__ 
         }
     } else if (c4 < numel4) {
         ((f32x4v*)dw)[c4] = s0;
+    }
+}
+
+
+// Slab reduction of an IMAGE-ALIGNED weight gradient (WgradParams::splits_img) that also returns, per image n and input channel i,
+//     dots[n][i] = sum_{o, tap} wq[o][i][tap] * dW_n[o][i][tap]          dW_n = the sum of image n's slabs, wq = w rounded to the conv's 16-bit type
+// = <x[n, i], dx[n, i]> with dx = conv^T(wq, dy): the contraction <dy_n, conv(wq[:, i], x[n, i])> written from the weight side instead of
+// the pixel side.  For the layer below this is <g, z> -- the gradient of the styles its epilogue multiplied z by -- which r01-r05 read from
+// g and z themselves: a full pass over both tensors (312-624 MB per 276^2 layer, 50-118 us) for numbers that these slabs already hold
+// (27-38 MB, read here anyway).  Differs from the pixel-side dot product only by the 16-bit rounding of the STORED dx.
+// One workgroup per input channel i; wave q takes images q, q + 4, ...; lane = output row of a block of 64.
+template <typename T, int KK>
+__global__ __launch_bounds__(256) void wgrad_reduce_dots_kernel(float* __restrict__ dw, float* __restrict__ dots, const float* __restrict__ part,
+                                                                const float* __restrict__ w, int N, int O, int I, int splits_img) {
+    __shared__ float red[3][64][KK];
+    const int i = blockIdx.x, lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const size_t slab = (size_t)O * I * KK;
+    float dotp[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) dotp[k] = 0.f;
+    for (int ob = 0; ob < O; ob += 64) {
+        const int o = ob + lane;
+        const bool live = o < O;
+        const size_t e0 = ((size_t)(live ? o : O - 1) * I + i) * KK;
+        float wq[KK], tot[KK];
+#pragma unroll
+        for (int t = 0; t < KK; t++) { wq[t] = live ? to_f32(from_f32<T>(w[e0 + t])) : 0.f; tot[t] = 0.f; }
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const int n = q + 4 * k;
+            if (n >= N) break;                                  // (wave-uniform)
+            float acc[KK];
+#pragma unroll
+            for (int t = 0; t < KK; t++) acc[t] = 0.f;
+            for (int sp = 0; sp < splits_img; sp++) {
+                const float* src = part + (size_t)(n * splits_img + sp) * slab + e0;
+#pragma unroll
+                for (int t = 0; t < KK; t++) acc[t] += src[t];
+            }
+            float d = 0.f;
+#pragma unroll
+            for (int t = 0; t < KK; t++) { tot[t] += acc[t]; d = fmaf(wq[t], acc[t], d); }
+            dotp[k] += d;
+        }
+        if (ob > 0) __syncthreads();                            // (the previous block's partials have been read)
+        if (q > 0) {
+#pragma unroll
+            for (int t = 0; t < KK; t++) red[q - 1][lane][t] = tot[t];
+        }
+        __syncthreads();
+        if (q == 0 && live) {
+#pragma unroll
+            for (int t = 0; t < KK; t++) dw[e0 + t] = tot[t] + red[0][lane][t] + red[1][lane][t] + red[2][lane][t];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const int n = q + 4 * k;
+        if (n >= N) break;
+        float d = dotp[k];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) d += __shfl_xor(d, off);
+        if (lane == 0) dots[(size_t)n * I + i] = d;
     }
 }
 
@@ -3783,8 +3855,8 @@ extern "C" int afcm_conv2d_wgrad(float* dw, float* workspace, const void* dy, co
     return afcm_conv2d_wgrad_ld(dw, workspace, dy, x, dtype, n, cin, cout, h, w, ks, pad, 0, 0, stream);
 }
 
-extern "C" int afcm_conv2d_wgrad_ld(float* dw, float* workspace, const void* dy, const void* x, int32_t dtype, int32_t n, int32_t cin,
-                                    int32_t cout, int32_t h, int32_t w, int32_t ks, int32_t pad, int32_t dy_pitch, int32_t x_pitch, void* stream) {
+static int wgrad_impl(float* dw, float* workspace, const void* dy, const void* x, int32_t dtype, int32_t n, int32_t cin,
+                      int32_t cout, int32_t h, int32_t w, int32_t ks, int32_t pad, int32_t dy_pitch, int32_t x_pitch, float* dots, const float* wref, void* stream) {
     AFCM_REQUIRE(dw != nullptr && workspace != nullptr && dy != nullptr && x != nullptr, "conv2d_wgrad: null pointer");
     AFCM_REQUIRE(dtype == AFCM_F32 || dtype == AFCM_F16 || dtype == AFCM_BF16, "x must be float32, float16 or bfloat16");
     AFCM_REQUIRE(ks == 1 || ks == 3, "only 1x1 and 3x3 kernels are supported");
@@ -3808,6 +3880,17 @@ extern "C" int afcm_conv2d_wgrad_ld(float* dw, float* workspace, const void* dy,
     if (p.splits_p > ksteps) p.splits_p = (int)ksteps;
     p.steps_per_split = (int)((ksteps + p.splits - 1) / p.splits);
     p.steps_per_split_p = (int)((ksteps + p.splits_p - 1) / p.splits_p);
+    p.splits_img = 0;
+    if (dots != nullptr) {
+        // image-aligned shares: the same number of workgroups, each inside one image (the granule kernel, one tile class, a split count that
+        // is a multiple of the batch, at most 64 images: what wgrad_reduce_dots_kernel covers) -- else the caller takes its dot products
+        // from the tensors themselves
+        if (!(dtype != AFCM_F32 && granule) || p.splits != p.splits_p || n > 64 || p.splits % n != 0 || p.splits / n < 1) return AFCM_E_NOKERNEL;
+        AFCM_REQUIRE(wref != nullptr, "conv2d_wgrad_dots: the weight tensor the dot products are taken with is missing");
+        p.splits_img = p.splits / n;
+        const long long per_img = (long long)p.rowgroups * p.qchunks;
+        p.steps_per_split = p.steps_per_split_p = (int)((per_img + p.splits_img - 1) / p.splits_img);
+    }
     const long long n_full = (long long)p.fo * p.fi;
     const long long blocks = n_full * p.splits + ((long long)cdiv(cout, 64) * cdiv(cin, 64) - n_full) * p.splits_p;
     dim3 grid((unsigned)blocks), block(512);
@@ -3847,6 +3930,14 @@ extern "C" int afcm_conv2d_wgrad_ld(float* dw, float* workspace, const void* dy,
     int rc = hip_status(hipGetLastError());
     if (rc != AFCM_OK) return rc;
     const long long numel = (long long)cout * cin * ks * ks;
+    if (p.splits_img > 0) {
+        const dim3 rgrid((unsigned)cin), rblock(256);
+#define AFCM_RD(T) do { if (ks == 3) hipLaunchKernelGGL((wgrad_reduce_dots_kernel<T, 9>), rgrid, rblock, 0, st, dw, dots, (const float*)workspace, wref, n, cout, cin, p.splits_img); \
+                        else hipLaunchKernelGGL((wgrad_reduce_dots_kernel<T, 1>), rgrid, rblock, 0, st, dw, dots, (const float*)workspace, wref, n, cout, cin, p.splits_img); } while (0)
+        if (dtype == AFCM_F16) AFCM_RD(f16_t); else AFCM_RD(bf16_t);
+#undef AFCM_RD
+        return hip_status(hipGetLastError());
+    }
     const WgradSlabs slabs{cin, ks * ks, p.fo, p.fi, p.splits, p.splits_p};
     long long rb = (numel + 255) / 256;
     if (rb > 2048) rb = 2048;
@@ -3860,6 +3951,18 @@ extern "C" int afcm_conv2d_wgrad_ld(float* dw, float* workspace, const void* dy,
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)rb), dim3(256), 0, st, dw, (const float*)workspace, numel, slabs);
     }
     return hip_status(hipGetLastError());
+}
+
+extern "C" int afcm_conv2d_wgrad_ld(float* dw, float* workspace, const void* dy, const void* x, int32_t dtype, int32_t n, int32_t cin,
+                                    int32_t cout, int32_t h, int32_t w, int32_t ks, int32_t pad, int32_t dy_pitch, int32_t x_pitch, void* stream) {
+    return wgrad_impl(dw, workspace, dy, x, dtype, n, cin, cout, h, w, ks, pad, dy_pitch, x_pitch, nullptr, nullptr, stream);
+}
+
+extern "C" int afcm_conv2d_wgrad_dots_ld(float* dw, float* dots, float* workspace, const void* dy, const void* x, const float* wref, int32_t dtype,
+                                         int32_t n, int32_t cin, int32_t cout, int32_t h, int32_t w, int32_t ks, int32_t pad, int32_t dy_pitch,
+                                         int32_t x_pitch, void* stream) {
+    AFCM_REQUIRE(dots != nullptr, "conv2d_wgrad_dots: dots must be non-null");
+    return wgrad_impl(dw, workspace, dy, x, dtype, n, cin, cout, h, w, ks, pad, dy_pitch, x_pitch, dots, wref, stream);
 }
 
 extern "C" int afcm_scale_planes(void* y, const void* x, const float* scale, int32_t dtype_in, int32_t dtype_out, int64_t planes,

@@ -277,29 +277,46 @@ __global__ __launch_bounds__(256) void mapping_input_fwd_kernel(MapInArgs p) {
 
 // gradient of the embedding layer's weight / bias from g = dL/dx0[:, zdim:]:  with e the embedding, r = rsqrt(mean e^2 + eps), en = e r:
 // ge = r (g - en mean(g en));  dew[o][j] = alpha sum_n ge[n][o] c[n][j];  deb[o] = beta sum_n ge[n][o].   (z and c carry no gradient.)
-// ONE workgroup: the sums over n are short and the whole stage is a few KB.
-__global__ __launch_bounds__(256) void mapping_input_bwd_kernel(MapInArgs p, const float* __restrict__ gx0, float* __restrict__ dew, float* __restrict__ deb) {
+// One workgroup per SAMPLE writes ge[n][:] to a scratch row (phase 1); the last workgroup to finish (a ticket in global memory) sums the
+// rows into dew / deb in a fixed order (phase 2).  r06, first form: ONE workgroup walking the samples -- sixteen serial rounds of
+// (load, two block reductions, load again) = 42 us for a few KB.
+struct MapInBwd { const float* gx0; float* dew; float* deb; float* scratch; unsigned* ticket; };
+__global__ __launch_bounds__(256) void mapping_input_bwd_kernel(MapInArgs p, MapInBwd q) {
     __shared__ float red[4];
+    __shared__ bool last;
     const int stride = p.zdim + p.wdim;
-    for (int idx = threadIdx.x; idx < p.wdim * p.cdim; idx += 256) dew[idx] = 0.f;
-    for (int o = threadIdx.x; o < p.wdim; o += 256)
-        if (deb != nullptr) deb[o] = 0.f;
+    const int n = blockIdx.x;
+    float s = 0.f, d = 0.f;
+    for (int o = threadIdx.x; o < p.wdim; o += 256) {
+        const float e = embed_row(p, n, o);
+        s = fmaf(e, e, s);
+        d = fmaf(q.gx0[(size_t)n * stride + p.zdim + o], e, d);
+    }
+    const float ms = block_sum_256(s, red) / (float)p.wdim;
+    const float r = rsqrtf(ms + 1e-8f);
+    const float m = block_sum_256(d, red) * r / (float)p.wdim;              // mean(g en)
+    for (int o = threadIdx.x; o < p.wdim; o += 256) {
+        const float e = embed_row(p, n, o);
+        __hip_atomic_store(q.scratch + (size_t)n * p.wdim + o, r * (q.gx0[(size_t)n * stride + p.zdim + o] - e * r * m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // hand-off (MI355X_MICROARCH.md, Valid forms): sc1 stores drained by every wave, the workgroup's barrier, one agent-scope ticket
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    for (int n = 0; n < p.n; n++) {
-        float s = 0.f, d = 0.f;
-        for (int o = threadIdx.x; o < p.wdim; o += 256) {
-            const float e = embed_row(p, n, o);
-            s = fmaf(e, e, s);
-            d = fmaf(gx0[(size_t)n * stride + p.zdim + o], e, d);
+    if (threadIdx.x == 0) last = __hip_atomic_fetch_add(q.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+    __syncthreads();
+    if (!last) return;
+    if (threadIdx.x == 0) __hip_atomic_store(q.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // ready for the next launch
+    for (int o = threadIdx.x; o < p.wdim; o += 256) {
+        float db = 0.f;
+        for (int j = 0; j < p.cdim; j++) {
+            float acc = 0.f;
+            for (int k = 0; k < p.n; k++)
+                acc = fmaf(__hip_atomic_load(q.scratch + (size_t)k * p.wdim + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), p.c[(size_t)k * p.cdim + j], acc);
+            q.dew[(size_t)o * p.cdim + j] = p.alpha * acc;
         }
-        const float ms = block_sum_256(s, red) / (float)p.wdim;
-        const float r = rsqrtf(ms + 1e-8f);
-        const float m = block_sum_256(d, red) * r / (float)p.wdim;          // mean(g en)
-        for (int o = threadIdx.x; o < p.wdim; o += 256) {                    // (each thread owns its columns o across the n loop: no race)
-            const float e = embed_row(p, n, o);
-            const float ge = r * (gx0[(size_t)n * stride + p.zdim + o] - e * r * m);
-            for (int j = 0; j < p.cdim; j++) dew[(size_t)o * p.cdim + j] += p.alpha * ge * p.c[(size_t)n * p.cdim + j];
-            if (deb != nullptr) deb[o] += p.beta * ge;
+        if (q.deb != nullptr) {
+            for (int k = 0; k < p.n; k++) db += __hip_atomic_load(q.scratch + (size_t)k * p.wdim + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            q.deb[o] = p.beta * db;
         }
     }
 }
@@ -349,11 +366,16 @@ extern "C" int afcm_mapping_input_fwd(float* x0, const float* z, const float* c,
     return hip_status(hipGetLastError());
 }
 
+extern "C" int64_t afcm_mapping_input_bwd_workspace_bytes(int32_t n, int32_t wdim) { return ((int64_t)n * wdim + 64) * 4; }
+
 extern "C" int afcm_mapping_input_bwd(float* dew, float* deb, const float* gx0, const float* c, const float* ew, const float* eb, int32_t n,
-                                      int32_t zdim, int32_t cdim, int32_t wdim, float alpha, float beta, void* stream) {
+                                      int32_t zdim, int32_t cdim, int32_t wdim, float alpha, float beta, void* workspace, void* stream) {
     AFCM_REQUIRE(dew != nullptr && gx0 != nullptr && c != nullptr && ew != nullptr, "mapping_input_bwd: dew, gx0, c and ew must be non-null");
     AFCM_REQUIRE(n > 0 && zdim > 0 && cdim > 0 && wdim > 0, "mapping_input_bwd: empty problem");
+    AFCM_REQUIRE(workspace != nullptr && ((uintptr_t)workspace & 3) == 0, "mapping_input_bwd: workspace of afcm_mapping_input_bwd_workspace_bytes(), its first word zero");
     MapInArgs p{nullptr, nullptr, c, ew, eb, n, zdim, cdim, wdim, alpha, beta};
-    hipLaunchKernelGGL(mapping_input_bwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, p, gx0, dew, deb);
+    // workspace: [ticket (one word, zero between launches: the kernel resets it), 63 words of padding, n x wdim floats]
+    MapInBwd q{gx0, dew, deb, (float*)workspace + 64, (unsigned*)workspace};
+    hipLaunchKernelGGL(mapping_input_bwd_kernel, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, p, q);
     return hip_status(hipGetLastError());
 }

@@ -61,6 +61,33 @@ class _ScaledLinear(torch.autograd.Function):
         return dx, dw, db, None, None
 
 
+class _ScaleCast(torch.autograd.Function):
+    """(x * scale).to(out_dtype) as ONE pass each way (C ABI afcm_scale_planes with a constant per-plane factor) instead of a multiply and a
+    cast: the generator's last two ops (NET:703-705: `x * output_scale`, `.to(float32)`).  The product is formed in fp32 (the reference rounds
+    it to the compute dtype first; with output_scale a power of two, as shipped, the results are identical)."""
+    _planes = {}
+
+    @staticmethod
+    def _factor(n, scale, device):
+        key = (n, float(scale), device)
+        t = _ScaleCast._planes.get(key)
+        if t is None:
+            if len(_ScaleCast._planes) > 64:
+                _ScaleCast._planes.clear()
+            t = _ScaleCast._planes[key] = torch.full([n], float(scale), dtype=torch.float32, device=device)
+        return t
+
+    @staticmethod
+    def forward(ctx, x, scale, out_dtype):
+        ctx.cfg = (float(scale), x.dtype)
+        return _conv_ops.scale_planes(x, _ScaleCast._factor(x.shape[0] * x.shape[1], scale, x.device).view(x.shape[0], x.shape[1]), out_dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        scale, dt = ctx.cfg
+        return _ScaleCast.apply(g, scale, dt), None, None
+
+
 class FullyConnectedLayer(torch.nn.Module):
     """Equalised-learning-rate dense layer (NET:69-104)."""
 
@@ -225,11 +252,12 @@ class SynthesisLayer(torch.nn.Module, _ResampleGeometry):
         return fused_layer.available(x, self.weight, self.up_filter, self.down_filter, conv_pad=self.conv_kernel - 1, **self._act_args())
 
     def forward(self, x, w, global_w, E_features=None, include_skip=True, noise_mode='random', force_fp32=False, update_emas=False,
-                _mod=None, _prescaled=False, _next_scale=None, _packed=None):
+                _mod=None, _prescaled=False, _next_scale=None, _packed=None, _link_in=None, _link_out=None):
         """Reference signature (NET:336).  The underscore arguments are SynthesisNetwork's fusion hooks: `_mod` = this layer's
         precomputed modulation(), `_prescaled` = x already carries this layer's styles, `_next_scale` = the next layer's
         styles to fold into this layer's output (fused node only), `_packed` = the two MFMA images of this layer's normalised weight
-        from the network's multi-layer pack (fused node only)."""
+        from the network's multi-layer pack (fused node only), `_link_in` / `_link_out` = the fused_layer.LayerLink shared with the layer
+        before / after this one (x / the result have no other consumer)."""
         assert noise_mode in ['random', 'const', 'none']  # unused, as in the reference
         _assert_shape(x, [None, self.in_channels, int(self.in_size[1]), int(self.in_size[0])])
         _assert_shape(w, [x.shape[0], self.w_dim])
@@ -246,11 +274,11 @@ class SynthesisLayer(torch.nn.Module, _ResampleGeometry):
         if self.fusable(x):
             x = fused_layer.conv_filtered_lrelu(x, w_hat, in_scale, out_scale, self.bias, self.up_filter, self.down_filter,
                                                 conv_pad=self.conv_kernel - 1, skip=x_skip, next_scale=_next_scale,
-                                                prescaled=_prescaled, packed=_packed, **act)
+                                                prescaled=_prescaled, packed=_packed, link_in=_link_in, link_out=_link_out, **act)
         else:
             assert _next_scale is None, 'only the fused node can pre-scale its output'
             with torch.autograd.profiler.record_function('modulated_conv2d'):
-                x = scaled_conv2d(x, w_hat, in_scale, out_scale, self.conv_kernel - 1, prescaled=_prescaled)
+                x = scaled_conv2d(x, w_hat, in_scale, out_scale, self.conv_kernel - 1, prescaled=_prescaled, link_in=_link_in)
             x = filtered_lrelu.filtered_lrelu(x=x, fu=self.up_filter, fd=self.down_filter, b=self.bias.to(x.dtype), **act)
             if x_skip is not None:
                 x = x + x_skip
@@ -489,6 +517,7 @@ class SynthesisNetwork(torch.nn.Module):
                 for i, pk in zip(k3, _conv_ops.pack_weights_bank([mods[i][0] for i in k3], self.compute_dtype, need_dgrad=torch.is_grad_enabled())):
                     dec_packs[i] = pk
         prescaled = False
+        links = [fused_layer.LayerLink() for _ in layers]        # links[i]: between layer i and layer i + 1 (its only consumer)
         for idx, (layer, w) in enumerate(zip(layers, ws[1:])):
             nxt = min(idx + 1, len(self.layer_names) - 1)
             if (self.sizes[idx] != self.sizes[nxt]) and self.sizes[idx] != self.sizes[0]:
@@ -498,11 +527,14 @@ class SynthesisNetwork(torch.nn.Module):
                 include_skip = False
             next_scale = mods[idx + 1][1] if (fuse and idx + 1 < len(layers) and layer.fusable(x)) else None
             x = layer(x, w, img_global, E_features, include_skip, _mod=mods[idx], _prescaled=prescaled, _next_scale=next_scale,
-                      _packed=dec_packs[idx], **layer_kwargs)
+                      _packed=dec_packs[idx], _link_in=(links[idx - 1] if prescaled else None),
+                      _link_out=(links[idx] if next_scale is not None else None), **layer_kwargs)
             prescaled = next_scale is not None
+        _assert_shape(x, [None, self.img_channels_out, self.img_resolution, self.img_resolution])
+        if x.is_cuda and x.dtype in (torch.bfloat16, torch.float16):
+            return _ScaleCast.apply(x, self.output_scale, torch.float32)             # the multiply and the cast as one pass (and one backward)
         if self.output_scale != 1:
             x = x * self.output_scale
-        _assert_shape(x, [None, self.img_channels_out, self.img_resolution, self.img_resolution])
         return x.to(torch.float32)
 
     def extra_repr(self):

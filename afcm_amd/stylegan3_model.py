@@ -21,12 +21,12 @@ import torch
 
 from .distributed import GradientBuckets
 from .torch_utils.ops import upfirdn2d
-from .optim import FusedScrubAdam
+from .optim import FusedScrubAdam, weighted_l1
 
 
 class StyleGAN3GeneratorStep:
     def __init__(self, netG, lr_G=0.0025, lambda_L1=100.0, distributed=False, bucket_bytes=25 * 1024 * 1024, style_mixing_prob=0,
-                 force_collectives=False, blur_init_sigma=0.0, blur_fade_kimg=0.0, ema=False, comm_dtype=None, eval_dtype='auto'):
+                 force_collectives=False, blur_init_sigma=0.0, blur_fade_kimg=0.0, ema=False, comm_dtype=None, eval_dtype='auto', capturable=False):
         self.netG = netG
         # `ema`: keep the evaluation copy the reference creates unconditionally (models/comodgan_model.py:16-17); off by default
         # because the throughput path never reads it (234 MB)
@@ -50,7 +50,8 @@ class StyleGAN3GeneratorStep:
         self.G_mapping = netG.mapping
         self.G_synthesis = netG.synthesis
         # nan_to_num of every gradient + Adam(betas=(0, 0.99)) (stylegan3_model.py:132-135, comodgan_model.py:19-20) as one HIP launch
-        self.optimizer_G = FusedScrubAdam(netG.parameters(), lr=lr_G, betas=(0.0, 0.99), eps=1e-8, scrub=True, posinf=1e5, neginf=-1e5)
+        # (capturable: step count and bias corrections on the device, so that optimize_parameters() can be captured into a hipGraph: capture_step())
+        self.optimizer_G = FusedScrubAdam(netG.parameters(), lr=lr_G, betas=(0.0, 0.99), eps=1e-8, scrub=True, posinf=1e5, neginf=-1e5, capturable=capturable)
         self.criterionL1 = torch.nn.L1Loss()
         self.lambda_L1 = lambda_L1
         self.style_mixing_prob = style_mixing_prob
@@ -125,7 +126,8 @@ class StyleGAN3GeneratorStep:
         return upfirdn2d.filter2d(img, f / f.sum())
 
     def backward_G(self, extra_loss=None):
-        self.loss_G_L1 = self.criterionL1(self._blur(self.fake_B), self._blur(self.real_B)) * self.lambda_L1
+        # criterionL1(fake_B, real_B) * lambda_L1 (models/stylegan3_model.py:107), three launches instead of eight (optim.weighted_l1)
+        self.loss_G_L1 = weighted_l1(self._blur(self.fake_B), self._blur(self.real_B), self.lambda_L1)
         self.loss_G = self.loss_G_L1 if extra_loss is None else self.loss_G_L1 + extra_loss
         self.loss_G.backward()
 
@@ -147,6 +149,38 @@ class StyleGAN3GeneratorStep:
         # reduced gradients are read where the all-reduce left them
         self.optimizer_G.step(grads=grads, grad_scale=scale)
         mark('end')
+
+
+def capture_step(step, inputs, warmup=3):
+    """The whole training step -- set_input, forward, loss, backward, scrub + Adam -- as ONE hipGraph (r06; the step must have been built with
+    capturable=True and without gradient buckets).  Every launch of the step goes to the current stream (the HIP kernels through the C ABI's
+    stream argument, the framework's own), nothing in it reads the device from the host, and its allocations come from the graph's private
+    pool, so the captured graph replays the step on the SAME input tensors (refresh them in place between replays).  Returns the
+    torch.cuda.CUDAGraph; `graph.replay()` runs one step.  What a replay does not do: Python-side bookkeeping (optimizer state['step'] --
+    FusedScrubAdam.device_step() has the count --, loss tensors are those of the captured step's buffers, refreshed by every replay)."""
+    if step.buckets is not None or not step.optimizer_G.capturable:
+        raise RuntimeError('capture_step needs a single-process step built with capturable=True')
+    real_A, real_B, z, c = inputs
+
+    def one():
+        step.set_input(real_A, real_B, z, c)
+        step.optimize_parameters()
+
+    # warm-up AND capture on one side stream (allocator pools, workspace caches, pointer tables: everything lazy happens in the warm-up).  The same
+    # stream for both, and the step's FIRST use of autograd should be this warm-up: a parameter's AccumulateGrad node runs on the stream that was
+    # current when the node was made (the first time the parameter entered a graph) -- a step that has already run on the default stream would
+    # accumulate its gradients there, outside the capture
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(max(1, warmup)):
+            one()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side, capture_error_mode='thread_local'):
+        one()
+    return graph
 
 
 def _recorded_event():

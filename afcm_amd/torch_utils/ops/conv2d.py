@@ -402,8 +402,10 @@ def _frame_dy(dy, ks, pad):
     return dy, pad
 
 
-def _wgrad_raw(dy, x, cout, cin, ks, pad, work_share=1.0):
-    """``work_share``: the fraction of the algorithmic flops this launch stands for in the kernel timing (a split-operand term: 1 / terms)."""
+def _wgrad_raw(dy, x, cout, cin, ks, pad, work_share=1.0, dots_with=None):
+    """``work_share``: the fraction of the algorithmic flops this launch stands for in the kernel timing (a split-operand term: 1 / terms).
+    ``dots_with``: a weight tensor [cout, cin, ks, ks] -- return (dw, dots) with dots[n, i] = <x[n, i], conv^T(dots_with, dy)[n, i]> read from the
+    per-image weight-gradient slabs (C ABI afcm_conv2d_wgrad_dots_ld), or (dw, None) where that form is not available."""
     lib = _lib.load()
     n, _, h, w = x.shape
     work = work_share * 2.0 * n * cout * cin * ks * ks * (h + 2 * pad - ks + 1) * (w + 2 * pad - ks + 1)      # algorithmic flops (before any framing)
@@ -417,18 +419,33 @@ def _wgrad_raw(dy, x, cout, cin, ks, pad, work_share=1.0):
     dw = torch.empty([cout, cin, ks, ks], dtype=torch.float32, device=x.device)
     ws = torch.empty([splits, cout, cin, ks, ks], dtype=torch.float32, device=x.device)
     span = profiling.span('conv2d_wgrad', work)
-    _lib.check(lib.afcm_conv2d_wgrad_ld(dw.data_ptr(), ws.data_ptr(), dy.data_ptr(), x.data_ptr(), _lib.dtype_code(x), n, cin, cout,
-                                        h, w, ks, pad, 0 if lddy == dy.shape[3] else lddy, 0 if ldx == w else ldx, _lib.stream_ptr(x)), 'conv2d_wgrad')
+    dots = None
+    if dots_with is not None and WGRAD_DOTS and x.dtype in (torch.bfloat16, torch.float16):
+        wref = dots_with.detach().to(torch.float32).contiguous()
+        dots = torch.empty([n, cin], dtype=torch.float32, device=x.device)
+        rc = _lib.check(lib.afcm_conv2d_wgrad_dots_ld(dw.data_ptr(), dots.data_ptr(), ws.data_ptr(), dy.data_ptr(), x.data_ptr(), wref.data_ptr(),
+                                                      _lib.dtype_code(x), n, cin, cout, h, w, ks, pad, 0 if lddy == dy.shape[3] else lddy,
+                                                      0 if ldx == w else ldx, _lib.stream_ptr(x)), 'conv2d_wgrad_dots')
+        if rc != 0:
+            dots = None
+    if dots is None:
+        _lib.check(lib.afcm_conv2d_wgrad_ld(dw.data_ptr(), ws.data_ptr(), dy.data_ptr(), x.data_ptr(), _lib.dtype_code(x), n, cin, cout,
+                                            h, w, ks, pad, 0 if lddy == dy.shape[3] else lddy, 0 if ldx == w else ldx, _lib.stream_ptr(x)), 'conv2d_wgrad')
     if span is not None:
         span.end()
-    return dw
+    return dw if dots_with is None else (dw, dots)
+
+
+# the per-plane dot products <x, dx> from the weight gradient's per-image slabs where the split plan allows (module switch: tests compare)
+WGRAD_DOTS = True
 
 
 class _ScaledConv2d(torch.autograd.Function):
     """y = out_scale * conv(w, in_scale * x); scales are [N, C] fp32 tensors or None."""
 
     @staticmethod
-    def forward(ctx, x, w, in_scale, out_scale, padding, prescaled=False):
+    def forward(ctx, x, w, in_scale, out_scale, padding, prescaled=False, link=None):
+        ctx.link = link if (link is not None and prescaled) else None
         _lib.require_gpu(x, w, in_scale, out_scale)
         if x.ndim != 4 or w.ndim != 4 or x.shape[1] != w.shape[1]:
             raise RuntimeError(f'conv2d: incompatible shapes x{tuple(x.shape)} w{tuple(w.shape)}')
@@ -486,7 +503,7 @@ class _ScaledConv2d(torch.autograd.Function):
                 dx = _ScaledConv2d.apply(dy, w.transpose(0, 1).flip([2, 3]), None, None, ks - 1 - pad, False)
             if ctx.needs_input_grad[1]:
                 dw = _ConvWgrad.apply(dy, xs, ks, pad).to(w.dtype)
-            return dx, dw, None, None, None, None
+            return dx, dw, None, None, None, None, None
         dy = dy.detach()
         if ctx.prescaled:
             in_scale = None
@@ -521,7 +538,7 @@ class _ScaledConv2d(torch.autograd.Function):
                 dw = _wgrad_split(dparts, xparts, cout, cin, pad, tw, bounds=(gsd, gsx)).to(w.dtype)
             if ctx.needs_input_grad[3]:
                 d_out = (plane_dot(dy, y) / out_scale.to(torch.float32)).to(out_scale.dtype)
-            return dx, dw, d_in, d_out, None, None
+            return dx, dw, d_in, d_out, None, None, None
         dys = scale_planes(dy, out_scale) if out_scale is not None else dy
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[2]:
             wpt, rows_pad = ctx.wpt if (ctx.wpt is not None and ctx.wpt[0].dtype == dy.dtype) else pack_weights(w, dy.dtype, 1)
@@ -533,11 +550,16 @@ class _ScaledConv2d(torch.autograd.Function):
                 s2 = in_scale.to(torch.float32).square()
                 d_in = torch.where(s2 > 0, plane_dot(xs, dx) / s2.clamp_min(1e-30), torch.zeros_like(s2)).to(in_scale.dtype)
         if ctx.needs_input_grad[1]:
-            dw = _wgrad_raw(dys, xs, cout, cin, ks, pad).to(w.dtype)
+            if ctx.link is not None and ctx.link.want:
+                # the producer of the (prescaled) input wants <xs, dx> per plane: from this weight gradient's per-image slabs (fused_layer.LayerLink)
+                dw, ctx.link.gz = _wgrad_raw(dys, xs, cout, cin, ks, pad, dots_with=w)
+                dw = dw.to(w.dtype)
+            else:
+                dw = _wgrad_raw(dys, xs, cout, cin, ks, pad).to(w.dtype)
         if ctx.needs_input_grad[3]:
             # y = d * c  =>  d d[n,o] = <dy, c> = <dy, y> / d
             d_out = (plane_dot(dy, y) / out_scale.to(torch.float32)).to(out_scale.dtype)
-        return dx, dw, d_in, d_out, None, None
+        return dx, dw, d_in, d_out, None, None, None
 
 
 class _ConvWgrad(torch.autograd.Function):
@@ -645,10 +667,10 @@ def strided_conv2d(x, w, padding=0):
     return _StridedConv2d.apply(x.contiguous(), w.contiguous(), int(padding))
 
 
-def scaled_conv2d(x, w, in_scale=None, out_scale=None, padding=0, prescaled=False):
+def scaled_conv2d(x, w, in_scale=None, out_scale=None, padding=0, prescaled=False, link_in=None):
     # contiguity is established out here, under autograd, so that the node saves tensors that are still part of the graph
     # (a second-order backward differentiates through them)
-    return _ScaledConv2d.apply(x.contiguous(), w.contiguous(), in_scale, out_scale, int(padding), bool(prescaled))
+    return _ScaledConv2d.apply(x.contiguous(), w.contiguous(), in_scale, out_scale, int(padding), bool(prescaled), link_in)
 
 
 def modulation_coefficients(w, s, demodulate=True, input_gain=None):

@@ -18,6 +18,7 @@ from ... import _lib
 
 ENABLED = True
 _ACTS = {'linear': 0, 'lrelu': 1}
+_MAPIN_WS = {}
 
 
 def supported(x, weight, activation):
@@ -98,8 +99,13 @@ class _MappingInput(torch.autograd.Function):
         gx0 = gx0.contiguous()
         dew = torch.empty_like(ew)
         deb = torch.empty_like(eb) if (eb is not None and ctx.needs_input_grad[3]) else None
+        key = (n, wdim, gx0.device)
+        ws = _MAPIN_WS.get(key)
+        if ws is None:
+            # (zeroed once: the kernel leaves its ticket word at zero; one launch at a time per device and shape -- launches on one stream)
+            ws = _MAPIN_WS[key] = torch.zeros([lib.afcm_mapping_input_bwd_workspace_bytes(n, wdim) // 4], dtype=torch.float32, device=gx0.device)
         _lib.check(lib.afcm_mapping_input_bwd(dew.data_ptr(), _lib.ptr(deb), gx0.data_ptr(), c.data_ptr(), ew.data_ptr(), _lib.ptr(eb), n, zdim, cdim, wdim,
-                                              alpha, beta, _lib.stream_ptr(gx0)), 'mapping_input_bwd')
+                                              alpha, beta, ws.data_ptr(), _lib.stream_ptr(gx0)), 'mapping_input_bwd')
         return None, None, (dew if ctx.needs_input_grad[2] else None), deb, None, None
 
 

@@ -28,7 +28,7 @@ from . import filtered_lrelu as _flr
 
 class _ConvFilteredLRelu(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, in_scale, out_scale, bias, fu, fd, skip, next_scale, conv_pad, cfg, prescaled, packed=None, fork=None):
+    def forward(ctx, x, w, in_scale, out_scale, bias, fu, fd, skip, next_scale, conv_pad, cfg, prescaled, packed=None, fork=None, link_in=None, link_out=None):
         _lib.require_gpu(x, w, in_scale, out_scale, bias, fu, fd, skip, next_scale)
         cout, cin, ks, _ = w.shape
         xs = _conv.scale_planes(x, in_scale) if (in_scale is not None and not prescaled) else x
@@ -63,6 +63,12 @@ class _ConvFilteredLRelu(torch.autograd.Function):
         if fork is not None and skip is not None and next_scale is not None and ctx.needs_input_grad[7]:
             fork.scale = next_scale.detach()
             ctx.skip_by_fork = True
+        # <g, z> of THIS node's output (its styles' gradient, the demodulation gradient by homogeneity) can come from the consumer's weight
+        # gradient (LayerLink below): say so to the consumer; and remember the producer's request for this node's input
+        ctx.link_out = link_out if (link_out is not None and next_scale is not None) else None
+        if ctx.link_out is not None:
+            ctx.link_out.want, ctx.link_out.gz = True, None
+        ctx.link_in = link_in if (link_in is not None and prescaled) else None
         ctx.meta = (conv_pad, cfg, bool(prescaled), layout, tuple(y.shape), tuple(z.shape), skip is not None)
         return z
 
@@ -83,7 +89,13 @@ class _ConvFilteredLRelu(torch.autograd.Function):
         want_db, want_next, want_out = ctx.needs_input_grad[4], ctx.needs_input_grad[8], ctx.needs_input_grad[3]
         if want_db or want_next or want_out:
             lib = _lib.load()
-            gz = _conv.plane_dot(g, z) if (want_next or (want_out and flags is not None)) else None
+            gz = None
+            if want_next or (want_out and flags is not None):
+                # from the consumer's backward (it ran before this one) where its weight gradient could supply it, else a pass over g and z
+                if ctx.link_out is not None and ctx.link_out.gz is not None and tuple(ctx.link_out.gz.shape) == (n, o):
+                    gz, ctx.link_out.gz = ctx.link_out.gz, None
+                else:
+                    gz = _conv.plane_dot(g, z)
             osc = None if out_scale is None else out_scale.to(f32).contiguous()
             nsc = None if next_scale is None else next_scale.to(f32).contiguous()
             if want_out and flags is not None:
@@ -116,8 +128,13 @@ class _ConvFilteredLRelu(torch.autograd.Function):
                 s2 = in_scale.to(f32).square()
                 d_in = torch.where(s2 > 0, _conv.plane_dot(xs, dx) / s2.clamp_min(1e-30), torch.zeros_like(s2)).to(in_scale.dtype)
         if ctx.needs_input_grad[1]:
-            dw = _conv._wgrad_raw(dys, xs, cout, cin, ks, conv_pad).to(w.dtype)
-        return dx, dw, d_in, d_out, db, None, None, d_skip, d_next, None, None, None, None, None
+            if ctx.link_in is not None and ctx.link_in.want:
+                # ... and with it <xs, dx> per input plane = the producer's <g, z> (see LayerLink)
+                dw, ctx.link_in.gz = _conv._wgrad_raw(dys, xs, cout, cin, ks, conv_pad, dots_with=w)
+                dw = dw.to(w.dtype)
+            else:
+                dw = _conv._wgrad_raw(dys, xs, cout, cin, ks, conv_pad).to(w.dtype)
+        return dx, dw, d_in, d_out, db, None, None, d_skip, d_next, None, None, None, None, None, None, None
 
 
 # the demodulation gradient's <dys, y> from <g, z> where no strip of a plane could reach the clamp (tests switch it off to compare)
@@ -138,14 +155,29 @@ def available(x, w, fu, fd, up, down, padding, gain, slope, clamp, conv_pad):
     return _flr.matrix_core_available(yshape, x.dtype, x.device, fu, fd, _cfg(up, down, padding, gain, slope, clamp))
 
 
+class LayerLink:
+    """Between a producer layer that multiplied its output z by the consumer's styles (`next_scale`, consumer called with `prescaled`) and
+    that consumer: the producer needs <g, z> per plane in its backward (g = dL/dz); the consumer's backward -- which runs first -- has the
+    same numbers in its weight gradient's per-image slabs (<xs, dx> with xs = z, dx = g: conv2d._wgrad_raw(dots_with=...)), PROVIDED z
+    has no other consumer.  The producer sets `want` in its forward, the consumer leaves `gz` ([N, C] fp32, or None where its split plan
+    does not allow it) in its backward, the producer takes it or falls back to a pass over g and z."""
+    __slots__ = ('want', 'gz')
+
+    def __init__(self):
+        self.want, self.gz = False, None
+
+
 def conv_filtered_lrelu(x, w, in_scale, out_scale, bias, fu, fd, up, down, padding, gain, slope, clamp, conv_pad, skip=None,
-                        next_scale=None, prescaled=False, packed=None):
+                        next_scale=None, prescaled=False, packed=None, link_in=None, link_out=None):
     """z = (filtered_lrelu(out_scale * conv(w, in_scale * x) + bias; fu, fd, up, down, padding, gain, slope, clamp) + skip)
     * next_scale.  ``prescaled``: x already carries in_scale (the producer's epilogue applied it).  ``packed``: the two weight
-    images of `w` from ``conv2d.pack_weights_bank`` (the caller packed several layers in one launch), else they are made here."""
+    images of `w` from ``conv2d.pack_weights_bank`` (the caller packed several layers in one launch), else they are made here.
+    ``link_in`` / ``link_out``: the LayerLink objects shared with the producer of x / the consumer of the result (x / the result must
+    have NO other consumer)."""
     cfg = _cfg(up, down, padding, gain, slope, clamp)
     fork = getattr(skip, '_afcm_fork', None) if skip is not None else None
-    return _ConvFilteredLRelu.apply(x, w, in_scale, out_scale, bias, fu, fd, skip, next_scale, int(conv_pad), cfg, bool(prescaled), packed, fork)
+    return _ConvFilteredLRelu.apply(x, w, in_scale, out_scale, bias, fu, fd, skip, next_scale, int(conv_pad), cfg, bool(prescaled), packed, fork,
+                                    link_in, link_out)
 
 
 # ---- an encoder feature map that feeds the next encoder layer AND a decoder layer's skip input (NET:678-681, 371-377) ----------------------

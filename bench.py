@@ -38,6 +38,7 @@ def parse():
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp16', 'fp32'])
     ap.add_argument('--cpu-baseline', default='auto', choices=['auto', 'off'])
     ap.add_argument('--cpu-baseline-worker', action='store_true', help=argparse.SUPPRESS)
+    ap.add_argument('--graph-worker', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--cpu-threads', type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument('--cpu-timed', type=int, default=2, help=argparse.SUPPRESS)
     ap.add_argument('--host-threads', type=int, default=0,
@@ -223,7 +224,7 @@ def host_calibration(dev, launches=200):
     return out
 
 
-def build_step(args, dev, dtype_name, with_discriminator, use_dist, fp32_conv):
+def build_step(args, dev, dtype_name, with_discriminator, use_dist, fp32_conv, capturable=False):
     """The module(s), the step object and the synthetic batch of one workload; sets the fp32 conv route for it."""
     import torch
     from afcm_amd import layer_schedule as sched
@@ -254,7 +255,7 @@ def build_step(args, dev, dtype_name, with_discriminator, use_dist, fp32_conv):
                              force_collectives=args.force_dist, comm_dtype=comm_dtype)
     else:
         step = StyleGAN3GeneratorStep(G, lr_G=0.0025, lambda_L1=100.0, distributed=use_dist, force_collectives=args.force_dist,
-                                      comm_dtype=comm_dtype)
+                                      comm_dtype=comm_dtype, capturable=capturable)
     inputs = synthetic.generator_inputs(args.batch, size=args.res, seed=rank, device=dev)
     return step, inputs
 
@@ -401,10 +402,58 @@ def also_record(args, dev, name, dtype_name, with_discriminator, steps, warmup):
     return out
 
 
+def graph_worker(args):
+    """Child process of `graph_record`: build the bf16 generator step with a capturable optimizer, capture it into ONE hipGraph
+    (stylegan3_model.capture_step: warm-up and capture on one side stream, before the step ever ran elsewhere), time replays.  One JSON line."""
+    import torch
+    from afcm_amd.stylegan3_model import capture_step
+    torch.set_num_threads(max(1, (os.cpu_count() or 8) // 8))
+    dev = torch.device('cuda', 0)
+    torch.cuda.set_device(dev)
+    steps = args.also_steps
+    step, inputs = build_step(args, dev, 'bf16', False, False, args.fp32_conv, capturable=True)
+    graph = capture_step(step, inputs, warmup=3)
+    for _ in range(2):
+        graph.replay()
+    torch.cuda.synchronize()
+    host = 0.0
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        h0 = time.perf_counter()
+        graph.replay()
+        host += time.perf_counter() - h0
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    print(json.dumps(dict(graph_record=True, ms_per_step=el / steps * 1e3, images_per_sec=args.batch * steps / el, host_ms_per_replay=host / steps * 1e3,
+                          steps=steps, optimizer_steps_on_device=step.optimizer_G.device_step(), loss_G_L1=float(step.loss_G_L1))), flush=True)
+
+
+def graph_record(args, limit=240.0):
+    """The N = 1 bf16 step captured into ONE hipGraph and replayed (asked for when the eager step's host side takes >= 50 % of
+    the step on the driver's box): ms per replayed step and the host's wall time per replay.  The step is GPU-bound either way at N = 1;
+    what the graph removes is the host's ~20 ms of Python / autograd / launch work per step -- the margin eight ranks sharing one host live
+    on.  Measured in a CHILD process (a fresh context: the capture must be the step's first use of autograd, and a capture that fails must
+    not take the headline line with it)."""
+    try:
+        cmd = [sys.executable, os.path.abspath(__file__), '--graph-worker', '--also-steps', str(args.also_steps), '--batch', str(args.batch), '--res', str(args.res)]
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=limit, cwd=ROOT)
+        lines = [l for l in out.stdout.splitlines() if l.startswith('{"graph_record"')]
+        if not lines:
+            return dict(error=f'child exited with code {out.returncode}', stderr_tail=out.stderr[-400:])
+        d = json.loads(lines[-1])
+        d.pop('graph_record')
+        return d
+    except Exception as e:
+        return dict(error=f'{type(e).__name__}: {e}'[:400])
+
+
 def main():
     args = parse()
     if args.cpu_baseline_worker:
         cpu_baseline_worker(args.res, timed=args.cpu_timed, threads=args.cpu_threads)
+        return
+    if args.graph_worker:
+        graph_worker(args)
         return
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(self_launch(args.gpus))
@@ -496,7 +545,8 @@ def main():
             gc.collect()
             torch.cuda.empty_cache()
             also = dict(fp32=also_record(args, dev, 'fp32', 'fp32', False, args.also_steps, 2),
-                        d_plus_g=also_record(args, dev, 'd_plus_g', 'bf16', True, args.also_steps, 2))
+                        d_plus_g=also_record(args, dev, 'd_plus_g', 'bf16', True, args.also_steps, 2),
+                        graph=graph_record(args))
         cpu = run_cpu_baseline(args.res) if (world == 1 and args.cpu_baseline == 'auto') else None
         images = world * args.batch * args.steps
         out = {

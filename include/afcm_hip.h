@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define AFCM_ABI_VERSION 13  /* 13 (r06): + afcm_noop, afcm_axpy_planes, afcm_fc_act_fwd / _bwd, afcm_mapping_input_fwd / _bwd (additions only; see the end of this header for the r06 entry points).  12 (r05): + afcm_conv2d_block_k_ks, afcm_conv2d_pack_weights_bk; the packed layout's K-chunk depends on (dtype, kernel size): 16-bit 3x3 images are [nkc][9][rows_pad][32] for the v_mfma 16x16x32 kernel (the pack / conv entry points keep their signatures).  11 (r04): + afcm_amax_bits, afcm_split16, afcm_conv2d_pack_split, afcm_conv2d_split, afcm_unscale, afcm_plane_dot_parts (additions only).  10 (r04): + afcm_filtered_lrelu_args.clamp_flags (appended), afcm_plane_dot_gated_ld; the runtime getenv switches are gone.  9 (r03): + afcm_affine_bank_*, afcm_modulation_bank_*, afcm_conv2d_pack_bank, afcm_conv2d_stride2 (additions only; every v8 entry point and struct is unchanged) */
+#define AFCM_ABI_VERSION 13  /* 13 (r06): + afcm_noop, afcm_adam_multi_capturable, afcm_conv2d_wgrad_dots_ld, afcm_mapping_input_bwd_workspace_bytes, afcm_axpy_planes, afcm_l1_partials, afcm_l1_grad, afcm_fc_act_fwd / _bwd, afcm_mapping_input_fwd / _bwd (additions only; see the end of this header for the r06 entry points).  12 (r05): + afcm_conv2d_block_k_ks, afcm_conv2d_pack_weights_bk; the packed layout's K-chunk depends on (dtype, kernel size): 16-bit 3x3 images are [nkc][9][rows_pad][32] for the v_mfma 16x16x32 kernel (the pack / conv entry points keep their signatures).  11 (r04): + afcm_amax_bits, afcm_split16, afcm_conv2d_pack_split, afcm_conv2d_split, afcm_unscale, afcm_plane_dot_parts (additions only).  10 (r04): + afcm_filtered_lrelu_args.clamp_flags (appended), afcm_plane_dot_gated_ld; the runtime getenv switches are gone.  9 (r03): + afcm_affine_bank_*, afcm_modulation_bank_*, afcm_conv2d_pack_bank, afcm_conv2d_stride2 (additions only; every v8 entry point and struct is unchanged) */
 
 enum { AFCM_F32 = 0, AFCM_F16 = 1, AFCM_BF16 = 2 };
 enum { AFCM_OK = 0, AFCM_E_NOKERNEL = -1, AFCM_E_INVALID = -2 };
@@ -218,6 +218,15 @@ int afcm_conv2d_wgrad(float* dw, float* workspace, const void* dy, const void* x
  * columns, afcm_filtered_lrelu writes the whole pitch. */
 int afcm_conv2d_wgrad_ld(float* dw, float* workspace, const void* dy, const void* x, int32_t dtype, int32_t n, int32_t cin,
                          int32_t cout, int32_t h, int32_t w, int32_t ks, int32_t pad, int32_t dy_pitch, int32_t x_pitch, void* stream);
+/* afcm_conv2d_wgrad_ld that ALSO returns dots[n][cin] = sum_{o, tap} wq[o][i][tap] * dW_n[o][i][tap] (r06), dW_n = image n's share of the weight
+ * gradient, wq = wref [cout][cin][ks][ks] (fp32) rounded to the operands' 16-bit type: by bilinearity this is <x[n, i], dx[n, i]> with
+ * dx = conv^T(wq, dy) -- for a conv whose input carries a per-plane style factor s (modulated_conv2d, NET:41-63) the gradient of s times s,
+ * which the host otherwise takes from a pass over x and dx (afcm_plane_dot_ld).  The K range is split over workgroups WITHIN images; available
+ * for the 16-bit granule kernel (3x3 pad 2, 1x1 pad 0) when the split count of afcm_conv2d_wgrad_splits() is a multiple of n <= 64, else
+ * AFCM_E_NOKERNEL (nothing launched: call afcm_conv2d_wgrad_ld and afcm_plane_dot_ld).  Same workspace as afcm_conv2d_wgrad_ld. */
+int afcm_conv2d_wgrad_dots_ld(float* dw, float* dots, float* workspace, const void* dy, const void* x, const float* wref, int32_t dtype, int32_t n,
+                              int32_t cin, int32_t cout, int32_t h, int32_t w, int32_t ks, int32_t pad, int32_t dy_pitch, int32_t x_pitch,
+                              void* stream);
 
 /* y[plane, :] = x[plane, :] * scale[plane] with dtype conversion (style modulation s[n,i] of NET:46-47 and the
  * demodulation d[n,o] of NET:50-52 applied to activations instead of weights).  scale may be NULL (pure cast). */
@@ -293,6 +302,11 @@ int32_t afcm_adam_chunk_elems(void);
 int afcm_adam_multi(const afcm_adam_entry* table, int32_t n, int64_t total_chunks, float step_size, float beta1, float beta2,
                     float one_minus_beta1, float one_minus_beta2, float bias_correction2_sqrt, float eps, float grad_scale, int32_t scrub, float posinf, float neginf,
                     int32_t write_grad, void* stream);
+/* afcm_adam_multi for a step captured into a hipGraph (r06): the step count is a DEVICE float (step_dev[0], advanced by one before the update)
+ * and the bias corrections 1 - beta^t are formed on the device from it (in double), so a replayed launch applies the corrections of ITS step;
+ * `lr` is the plain learning rate.  Same update arithmetic otherwise. */
+int afcm_adam_multi_capturable(const afcm_adam_entry* table_dev, int32_t n, int64_t total_chunks, float* step_dev, float lr, float beta1, float beta2,
+                               float eps, float grad_scale, int32_t scrub, float posinf, float neginf, int32_t write_grad, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * The style affine layers of all SynthesisLayers at once (NET:349-352 `styles = self.affine(cat(w, global_w))`, FullyConnectedLayer
@@ -424,6 +438,12 @@ int afcm_conv2d_split(float* y, const void* x_parts, const void* wpacked, const 
 int afcm_conv2d_stride2(void* y, const void* x, const void* wpacked, int32_t dtype, int32_t n, int32_t cin, int32_t cout, int32_t h, int32_t w,
                         int32_t pad, int32_t rows_pad, void* stream);
 
+/* The generator's L1 term `criterionL1(fake_B, real_B) * lambda_L1` (models/stylegan3_model.py:107; torch.nn.L1Loss, mean reduction) on fp32 tensors
+ * (r06): partials[k] = weight / numel * sum over workgroup k's slice of |a - b| (blocks <= 1024; the caller adds them), and the gradient
+ * ga = gout[0] * weight / numel * sign(a - b) with gout a DEVICE scalar (the incoming gradient of the loss). */
+int afcm_l1_partials(float* partials, const float* a, const float* b, int64_t numel, int32_t blocks, float weight, void* stream);
+int afcm_l1_grad(float* ga, const float* a, const float* b, const float* gout, int64_t numel, float weight, void* stream);
+
 /* y[plane][:] = a[plane][:] + scale[plane] * b[plane][:] (r06), 16-bit tensors of ONE layout, hw elements per plane (hw % 8 == 0, 16-byte aligned
  * bases; else AFCM_E_NOKERNEL), scale [planes] fp32 or NULL (1): the accumulation autograd performs for an encoder feature map that feeds the next
  * encoder layer and a decoder layer's skip input (NET:371-377: `x = x + x_skip`), with the decoder's style factor folded in -- three passes
@@ -451,8 +471,11 @@ int afcm_fc_act_bwd(float* dx, float* dw, float* db, const float* gy, const floa
                     int32_t cout, float alpha, float beta, int32_t act, void* stream);
 int afcm_mapping_input_fwd(float* x0, const float* z, const float* c, const float* ew, const float* eb, int32_t n, int32_t zdim, int32_t cdim,
                            int32_t wdim, float alpha, float beta, void* stream);
+int64_t afcm_mapping_input_bwd_workspace_bytes(int32_t n, int32_t wdim);
+/* workspace: afcm_mapping_input_bwd_workspace_bytes() of device memory whose FIRST WORD IS ZERO before the first launch (the kernel leaves it zero):
+ * one row of the intermediate gradient per sample + the ticket by which the last workgroup to finish sums the rows (fixed order: reproducible). */
 int afcm_mapping_input_bwd(float* dew, float* deb, const float* gx0, const float* c, const float* ew, const float* eb, int32_t n, int32_t zdim,
-                           int32_t cdim, int32_t wdim, float alpha, float beta, void* stream);
+                           int32_t cdim, int32_t wdim, float alpha, float beta, void* workspace, void* stream);
 
 #ifdef __cplusplus
 }

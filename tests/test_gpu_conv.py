@@ -665,3 +665,80 @@ def test_demodulation_gradient_takes_the_real_dot_product_when_the_skip_branch_d
     _, gd_r2 = run(False, small)
     assert not torch.equal(gd_h2, gd_r2), 'comparable magnitudes stay on the homogeneous route'
     _close_rel(gd_h2, gd_r2, 4e-2 if dtype == torch.bfloat16 else 8e-3, 'homogeneity vs real dot products')
+
+
+# ---- r06: <x, dx> per plane from the weight gradient's per-image slabs (C ABI afcm_conv2d_wgrad_dots_ld, fused_layer.LayerLink) -----------
+@pytest.mark.parametrize('dtype,tol', [(torch.bfloat16, 1.5e-2), (torch.float16, 2e-3)])
+@pytest.mark.parametrize('case', [(16, 64, 64, 40, 44, 3), (2, 24, 40, 30, 36, 3), (16, 91, 64, 24, 278, 3), (4, 64, 1, 32, 256, 1), (3, 16, 16, 90, 20, 3)], ids=str)
+def test_wgrad_dots_equal_the_plane_dots_of_x_and_dx(case, dtype, tol):
+    """dots[n, i] = sum_{o, tap} wq dW_n = <x[n, i], conv^T(wq, dy)[n, i]>: the weight gradient stays what it was (bit for bit: the same K
+    order inside an image ... summed over images in a fixed order), the dots match the pixel-side dot products of x with the STORED
+    (16-bit) dx up to that rounding; a batch the split count is not a multiple of (n = 3) has no slab form (None)."""
+    from afcm_amd.torch_utils.ops import conv2d as C
+    n, cin, cout, h, w, ks = case
+    pad = ks - 1
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn([n, cin, h, w], generator=g).cuda().to(dtype)
+    dy = torch.randn([n, cout, h + 2 * pad - ks + 1, w + 2 * pad - ks + 1], generator=g).cuda().to(dtype)
+    wt = (torch.randn([cout, cin, ks, ks], generator=g) / np.sqrt(cin * ks * ks)).cuda()
+    dw_plain = C._wgrad_raw(dy, x, cout, cin, ks, pad)
+    dw, dots = C._wgrad_raw(dy, x, cout, cin, ks, pad, dots_with=wt)
+    ref_dw = torch.nn.grad.conv2d_weight(x.double().cpu(), wt.shape, dy.double().cpu(), padding=pad).float()
+    _close_rel(dw, ref_dw, 2e-4, 'dw (image-aligned shares)')
+    _close_rel(dw_plain, ref_dw, 2e-4, 'dw')
+    if n == 3:
+        assert dots is None
+        return
+    assert dots is not None and dots.shape == (n, cin) and dots.dtype == torch.float32
+    wq = wt.to(dtype).double().cpu()
+    dx = torch.nn.grad.conv2d_input(x.shape, wq, dy.double().cpu(), padding=pad)
+    want = (x.double().cpu() * dx).sum([2, 3]).float()
+    _close_rel(dots, want, 2e-4, 'dots vs float64')
+    # ... and against what the product computed before: a pass over x and the stored dx
+    wp, rows_pad = C.pack_weights(wt, dtype, 1)
+    dx16 = C._conv_raw(dy, wp, rows_pad, None, cin, ks, ks - 1 - pad)
+    _close_rel(dots, C.plane_dot(x, dx16), tol, 'dots vs plane_dot(x, stored dx)')
+
+
+@pytest.mark.parametrize('dtype,tol', [(torch.bfloat16, 4e-2), (torch.float16, 8e-3)])
+def test_linked_layers_take_the_style_gradient_from_the_consumers_weight_gradient(dtype, tol):
+    """Two fused nodes in a row, the first multiplying its output by the second's styles (next_scale / prescaled), with a LayerLink between them:
+    the first node's <g, z> comes from the second node's weight-gradient slabs.  Every gradient against the same chain without the link
+    (a pass over g and z), and the link is used (gz delivered and consumed)."""
+    from afcm_amd.torch_utils.ops import conv2d as C
+    from afcm_amd.torch_utils.ops import fused_layer
+    from oracle import generator as ogen
+    pl = ogen.plan(256, 4, 1, {})
+    L = [l for l in pl['dec'] if l['name'] == 'L12_276_64'][0]
+    torch.manual_seed(3)
+    n, c0, c1, c2, h = 16, 16, 32, 16, 36
+    act = dict(up=2, down=2, padding=L['padding'], gain=float(np.sqrt(2)), slope=0.2, clamp=256.0)
+    fu, fd = L['fu'].cuda(), L['fd'].cuda()
+    # (the layer's geometry at a small plane: up 2 / down 2 with its padding keeps the size)
+    leaves = dict(x=torch.randn(n, c0, h, h).to(dtype), w1=torch.randn(c1, c0, 3, 3) / np.sqrt(c0 * 9), s1=torch.rand(n, c0) + 0.5, d1=torch.rand(n, c1) + 0.5,
+                  b1=torch.randn(c1) * 0.1, w2=torch.randn(c2, c1, 3, 3) / np.sqrt(c1 * 9), s2=torch.rand(n, c1) + 0.5, d2=torch.rand(n, c2) + 0.5, b2=torch.randn(c2) * 0.1)
+
+    def run(linked):
+        dev = {k: v.clone().cuda().requires_grad_(True) for k, v in leaves.items()}
+        link = fused_layer.LayerLink() if linked else None
+        z1 = fused_layer.conv_filtered_lrelu(dev['x'], dev['w1'], dev['s1'], dev['d1'], dev['b1'], fu, fd, conv_pad=2, next_scale=dev['s2'], link_out=link, **act)
+        z2 = fused_layer.conv_filtered_lrelu(z1, dev['w2'], dev['s2'], dev['d2'], dev['b2'], fu, fd, conv_pad=2, prescaled=True, link_in=link, **act)
+        r = torch.randn(z2.shape, generator=torch.Generator().manual_seed(1)).cuda()
+        if linked:
+            assert link.want and link.gz is None
+        grads = torch.autograd.grad((z2.float() * r).sum(), list(dev.values()))
+        return z2, dict(zip(dev.keys(), grads)), link
+
+    z_ref, g_ref, _ = run(False)
+    used = []
+    orig = C.plane_dot
+    C.plane_dot = lambda a, b=None: (used.append(tuple(a.shape)), orig(a, b))[1]
+    try:
+        z_l, g_l, link = run(True)
+    finally:
+        C.plane_dot = orig
+    assert torch.equal(z_l, z_ref)
+    z1_shape = (n, c1, z_ref.shape[2], z_ref.shape[3])
+    assert link.gz is None and z1_shape not in used, 'the first node still passed over g and z'
+    for k in g_ref:
+        _close_rel(g_l[k], g_ref[k], tol if k in ('s2', 'd1') else 1e-5, f'd{k}')

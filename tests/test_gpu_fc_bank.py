@@ -123,7 +123,8 @@ def test_skip_fork_backward_is_the_scaled_sum_of_both_arms(shape, dtype):
         b._afcm_fork.scale = scale
         gx, = torch.autograd.grad([a, b], [x], [ga, gb])
         want = ga.float() + gb.float() * (1.0 if scale is None else scale[:, :, None, None])
-        assert gx.dtype == dtype and float((gx.float() - want).abs().max()) <= float(want.abs().max()) * 2.0 ** (-8 if dtype == torch.bfloat16 else -11)
+        # (one rounding on the fused path; two -- the scaled arm, then the sum -- where the plane size keeps the op-by-op route: 6 x 38)
+        assert gx.dtype == dtype and float((gx.float() - want).abs().max()) <= float(want.abs().max()) * 2.0 ** (-7 if dtype == torch.bfloat16 else -10)
         assert b._afcm_fork.scale is None                                   # consumed
     a, b = fused_layer.skip_fork(x)
     gx, = torch.autograd.grad([a], [x], [ga])
