@@ -425,7 +425,7 @@ def graph_worker(args):
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     print(json.dumps(dict(graph_record=True, ms_per_step=el / steps * 1e3, images_per_sec=args.batch * steps / el, host_ms_per_replay=host / steps * 1e3,
-                          steps=steps, optimizer_steps_on_device=step.optimizer_G.device_step(), loss_G_L1=float(step.loss_G_L1))), flush=True)
+                          steps=steps, optimizer_steps_on_device=step.optimizer_G.device_step(), loss_G_L1=float(step.loss_G_L1.detach()))), flush=True)
 
 
 def graph_record(args, limit=240.0):
