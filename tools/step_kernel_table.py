@@ -43,13 +43,14 @@ def family(n):
 ap = argparse.ArgumentParser()
 ap.add_argument('trace')
 ap.add_argument('--launches', action='store_true')
+ap.add_argument('--spans', type=int, default=1, help='adam-to-adam intervals that make up one step (2 for the D + G iteration: the D update, then the G update)')
 a = ap.parse_args()
 rows = []
 for f in glob.glob(os.path.join(a.trace, '**', '*kernel_trace.csv'), recursive=True):
     rows += list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 idx = [i for i, r in enumerate(rows) if 'adam_multi' in r['Kernel_Name']]
-step = rows[idx[-2] + 1: idx[-1] + 1] if len(idx) >= 2 else rows
+step = rows[idx[-1 - a.spans] + 1: idx[-1] + 1] if len(idx) > a.spans else rows
 t0, t1 = int(step[0]['Start_Timestamp']), int(step[-1]['End_Timestamp'])
 busy = sum(int(r['End_Timestamp']) - int(r['Start_Timestamp']) for r in step)
 gaps = sum(max(0, int(b['Start_Timestamp']) - int(a_['End_Timestamp'])) for a_, b in zip(step, step[1:]))
