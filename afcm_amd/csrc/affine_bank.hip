@@ -35,105 +35,128 @@ __device__ __forceinline__ int find_layer(const BankArgs& A, int blk) {
     return l;
 }
 
-// x_l[n][k] for this launch's batch rows into LDS [kNB][K] (rows beyond nb: zero)
-__device__ __forceinline__ void stage_x(float* __restrict__ sx, const BankArgs& A, int l, int K) {
-    const int kw = A.a.kw;
-    for (int idx = threadIdx.x * 4; idx < kNB * K; idx += blockDim.x * 4) {
-        const int n = idx / K, k = idx - n * K;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (n < A.nb) {
-            const float* src = (k < kw) ? A.a.w + (size_t)(A.n0 + n) * A.a.w_stride_n + (size_t)A.a.w_index[l] * A.a.w_stride_l + k
-                                        : A.a.g + (size_t)(A.n0 + n) * A.a.kg + (k - kw);
-            v = *(const float4*)src;
-        }
-        *(float4*)(sx + idx) = v;
-    }
+// r06: forward and weight gradient on the exact-fp32 matrix instruction (v_mfma_f32_16x16x4_f32, as csrc/fc_bank.hip: lane maps and the
+// "one 16-byte load = four contraction indices = four MFMAs" form are described there).  The r03 kernels staged the layer's input
+// [16][1536] into 96 KB of LDS in EVERY workgroup (one workgroup per CU, 28 MB of re-reads over the bank), gave a wave four rows in turn
+// and reduced sixteen accumulators over the lanes with 96 shuffles per row: 64 us forward, 58 us weight gradient for 29 MB of weights.
+typedef __attribute__((ext_vector_type(4))) float abx4;
+
+// x_l[n][k .. k + 3] (k a multiple of 4): the latent's slice for k < kw, the global vector behind it
+__device__ __forceinline__ abx4 bank_x4(const BankArgs& A, int l, int n, int k) {
+    const float* src = (k < A.a.kw) ? A.a.w + (size_t)(A.n0 + n) * A.a.w_stride_n + (size_t)A.a.w_index[l] * A.a.w_stride_l + k
+                                    : A.a.g + (size_t)(A.n0 + n) * A.a.kg + (k - A.a.kw);
+    return *(const abx4*)src;
 }
 
 __global__ __launch_bounds__(256) void affine_bank_fwd_kernel(BankArgs A) {
-    __shared__ __attribute__((aligned(16))) float sx[kNB * kKMax];
+    __shared__ abx4 red[3][64];
     const int l = find_layer(A, blockIdx.x);
     const int K = A.a.kw + A.a.kg;
-    stage_x(sx, A, l, K);
-    __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
     const int cout = A.a.cout[l];
-    const float* __restrict__ W = A.a.weight[l];
+    const int row0 = (blockIdx.x - A.blk0[l]) * kRowsW;
+    const float* __restrict__ wp = A.a.weight[l] + (size_t)min(row0 + l15, cout - 1) * K + 4 * g;
+    const bool live = l15 < A.nb;
+    const int nrow = live ? l15 : 0;
+    abx4 acc = {0.f, 0.f, 0.f, 0.f};
+    // 16 contraction indices per chunk; wave w takes a contiguous quarter of the chunks
+    const int chunks = K >> 4, per = (chunks + 3) >> 2;
+    const int c_end = min(chunks, (wave + 1) * per);
+    constexpr int U = 8;
+    int c = wave * per;
+    for (; c + U <= c_end; c += U) {
+        abx4 a[U], bv[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) { a[u] = *(const abx4*)(wp + 16 * (c + u)); bv[u] = bank_x4(A, l, nrow, 16 * (c + u) + 4 * g); }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const abx4 bb = live ? bv[u] : abx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][j], bb[j], acc, 0, 0, 0);
+        }
+    }
+    for (; c < c_end; c++) {
+        const abx4 a = *(const abx4*)(wp + 16 * c);
+        abx4 bb = bank_x4(A, l, nrow, 16 * c + 4 * g);
+        if (!live) bb = abx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], bb[j], acc, 0, 0, 0);
+    }
+    if (wave > 0) red[wave - 1][lane] = acc;
+    __syncthreads();
+    if (wave != 0 || !live) return;
+    acc += red[0][lane] + red[1][lane] + red[2][lane];
+    // D[i = 4 g + r][j = l15]: rows row0 + 4 g + r of sample n0 + l15
     float* __restrict__ yl = (float*)A.t0[l];
-#pragma unroll 1
-    for (int rr = 0; rr < kRowsW / 4; rr++) {
-        const int row = (blockIdx.x - A.blk0[l]) * kRowsW + wave * (kRowsW / 4) + rr;
-        if (row >= cout) break;                                   // wave-uniform
-        float acc[kNB];
 #pragma unroll
-        for (int n = 0; n < kNB; n++) acc[n] = 0.f;
-        for (int k = 4 * lane; k < K; k += 256) {
-            const float4 wv = *(const float4*)(W + (size_t)row * K + k);
-#pragma unroll
-            for (int n = 0; n < kNB; n++) {
-                const float4 xv = *(const float4*)(sx + n * K + k);
-                acc[n] += wv.x * xv.x + wv.y * xv.y + wv.z * xv.z + wv.w * xv.w;
-            }
-        }
-#pragma unroll
-        for (int n = 0; n < kNB; n++)
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) acc[n] += __shfl_xor(acc[n], off, 64);
-        if (lane < A.nb) {
-            float v = 0.f;
-#pragma unroll
-            for (int n = 0; n < kNB; n++) v = (lane == n) ? acc[n] : v;
-            const float b = A.a.bias[l] ? A.a.bias[l][row] : 0.f;
-            yl[(size_t)(A.n0 + lane) * cout + row] = A.a.alpha[l] * v + A.a.beta[l] * b;
-        }
+    for (int r = 0; r < 4; r++) {
+        const int row = row0 + 4 * g + r;
+        if (row >= cout) continue;
+        const float b = A.a.bias[l] ? A.a.bias[l][row] : 0.f;
+        yl[(size_t)(A.n0 + l15) * cout + row] = A.a.alpha[l] * acc[r] + A.a.beta[l] * b;
     }
 }
 
-// dW_l, db_l: same workgroup map as the forward; `accumulate`: add to what is there (second batch half)
+// dW_l, db_l: same workgroup map as the forward (16 rows x the whole K, the 96 column tiles of 16 over the 4 waves); `accumulate`: add to
+// what is there (second batch half).  D[i = row][j = k] = sum_n A[row][n] B[n][k], A = dy[n = 4 g + j][row0 + l15], B = x[n = 4 g + j][k0 + l15]
 __global__ __launch_bounds__(256) void affine_bank_bwd_w_kernel(BankArgs A, int accumulate) {
-    __shared__ __attribute__((aligned(16))) float sx[kNB * kKMax];
-    __shared__ float sdy[kNB][kRowsW];
     const int l = find_layer(A, blockIdx.x);
-    const int K = A.a.kw + A.a.kg;
+    const int K = A.a.kw + A.a.kg, kw = A.a.kw;
     const int cout = A.a.cout[l];
     const int row0 = (blockIdx.x - A.blk0[l]) * kRowsW;
-    stage_x(sx, A, l, K);
-    {
-        const int n = threadIdx.x / kRowsW, r = threadIdx.x % kRowsW;          // 256 threads = kNB x kRowsW
-        const float* g = A.t0[l];
-        sdy[n][r] = (g != nullptr && n < A.nb && row0 + r < cout) ? g[(size_t)(A.n0 + n) * cout + row0 + r] : 0.f;
-    }
-    __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    const float* gy = A.t0[l];
     float* __restrict__ dWl = A.t1[l];
     float* __restrict__ dbl = A.t2[l];
     const float alpha = A.a.alpha[l];
-#pragma unroll 1
-    for (int rr = 0; rr < kRowsW / 4; rr++) {
-        const int r = wave * (kRowsW / 4) + rr, row = row0 + r;
-        if (row >= cout) break;
-        float g[kNB];
+    float a[4];
+    float colsum = 0.f;
 #pragma unroll
-        for (int n = 0; n < kNB; n++) g[n] = sdy[n][r];
-        if (dWl != nullptr) {
-            for (int k = 4 * lane; k < K; k += 256) {
-                float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = 0; j < 4; j++) {
+        const int n = 4 * g + j;
+        a[j] = (gy != nullptr && n < A.nb && row0 + l15 < cout) ? gy[(size_t)(A.n0 + n) * cout + row0 + l15] : 0.f;
+        colsum += a[j];
+    }
+    if (dbl != nullptr && wave == 0) {
+        colsum += __shfl_xor(colsum, 16);
+        colsum += __shfl_xor(colsum, 32);
+        if (g == 0 && row0 + l15 < cout) dbl[row0 + l15] = A.a.beta[l] * colsum + (accumulate ? dbl[row0 + l15] : 0.f);
+    }
+    if (dWl == nullptr) return;
+    const float* xb[4];                                           // this lane's four samples: row bases of the latent slice and of the global vector
+    const float* xg[4];
 #pragma unroll
-                for (int n = 0; n < kNB; n++) {
-                    const float4 xv = *(const float4*)(sx + n * K + k);
-                    s.x += g[n] * xv.x; s.y += g[n] * xv.y; s.z += g[n] * xv.z; s.w += g[n] * xv.w;
-                }
-                float4* dst = (float4*)(dWl + (size_t)row * K + k);
-                float4 o = make_float4(alpha * s.x, alpha * s.y, alpha * s.z, alpha * s.w);
-                if (accumulate) { const float4 p = *dst; o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w; }
-                *dst = o;
-            }
+    for (int j = 0; j < 4; j++) {
+        const int n = min(4 * g + j, A.nb - 1);
+        xb[j] = A.a.w + (size_t)(A.n0 + n) * A.a.w_stride_n + (size_t)A.a.w_index[l] * A.a.w_stride_l;
+        xg[j] = A.a.g + (size_t)(A.n0 + n) * A.a.kg - kw;
+    }
+    const int ktiles = K >> 4;
+    constexpr int U = 4;
+    for (int kt = wave; kt < ktiles; kt += 4 * U) {
+        float bv[U][4];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int k = 16 * (kt + 4 * u) + l15;
+#pragma unroll
+            for (int j = 0; j < 4; j++) bv[u][j] = (kt + 4 * u < ktiles) ? ((k < kw) ? xb[j][k] : xg[j][k]) : 0.f;
         }
-        if (lane == 0 && dbl != nullptr) {
-            float s = 0.f;
 #pragma unroll
-            for (int n = 0; n < kNB; n++) s += g[n];
-            dbl[row] = A.a.beta[l] * s + (accumulate ? dbl[row] : 0.f);
+        for (int u = 0; u < U; u++) {
+            if (kt + 4 * u >= ktiles) break;                      // (wave-uniform)
+            abx4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 4; j++) d = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], bv[u][j], d, 0, 0, 0);
+            const int k = 16 * (kt + 4 * u) + l15;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int row = row0 + 4 * g + r;
+                if (row >= cout) continue;
+                float* dst = dWl + (size_t)row * K + k;
+                *dst = alpha * d[r] + (accumulate ? *dst : 0.f);
+            }
         }
     }
 }
@@ -203,7 +226,7 @@ static int check_bank(const afcm_affine_bank* a) {
 // the kernels' shapes: K a multiple of 4 up to kKMax, 16-byte aligned rows
 static bool bank_supported(const afcm_affine_bank* a) {
     const int K = a->kw + a->kg;
-    if (K > kKMax || (a->kw & 3) || (a->kg & 3) || (a->w_stride_n & 3) || (a->w_stride_l & 3)) return false;
+    if (K > kKMax || (K & 15) || (a->kw & 3) || (a->kg & 3) || (a->w_stride_n & 3) || (a->w_stride_l & 3)) return false;   // (K % 16: the matrix kernels' chunks)
     if (((uintptr_t)a->w | (uintptr_t)a->g) & 15) return false;
     for (int l = 0; l < a->layers; l++)
         if ((uintptr_t)a->weight[l] & 15) return false;

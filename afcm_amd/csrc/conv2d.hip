@@ -62,6 +62,12 @@ static int g_conv_x16 = AFCM_CONV_X16;
 #endif
 // K-chunk (channels) of the packed weight image for (dtype, kernel size)
 static inline int conv_bk(int dtype, int ks);
+// conv2d_direct.hip: 16-bit 3x3 convs with at most four input channels (the generator's first layer)
+int conv2d_direct_small_cin(const void* x, void* y, const void* wp, const float* oscale, const float* obias, int dtype, int n, int cin, int cout,
+                            int h, int w, int pad, int rows_pad, int bk, int ldx, int ldy, hipStream_t st);
+#ifndef AFCM_CONV_DIRECT4
+#define AFCM_CONV_DIRECT4 1        // 0: the implicit-GEMM kernel for every layer (A/B builds)
+#endif
 
 constexpr int kPatchMax = 416;   // LDS patch capacity in pixels
 constexpr int kPlaneX16 = 416;    // pixels per channel-group plane of conv2d_fwd16x_kernel (a multiple of 16: planes 256 bytes apart) ...
@@ -3639,6 +3645,10 @@ extern "C" int afcm_conv2d_ld(void* y, const void* x, const void* wpacked, const
         AFCM_REQUIRE((long long)cout * p.P * p.ldy < (1ll << 30), "conv2d: pitched output image is out of range");
     }
     AFCM_REQUIRE(dtype == AFCM_F32 || ks != 3 || (long long)cout * p.P * p.ldy * 2 < (1ll << 30), "conv2d: 16-bit output image of %lld bytes is out of range (< 2^30)", (long long)cout * p.P * p.ldy * 2);
+    if (AFCM_CONV_DIRECT4 && dtype != AFCM_F32 && ks == 3 && cin <= 4 && cout <= 64 && conv_bk(dtype, ks) == 32) {
+        // a handful of input channels: the contraction index is (tap column, channel), no channel padding (conv2d_direct.hip; r06)
+        return conv2d_direct_small_cin(x, y, wpacked, oscale, obias, dtype, n, cin, cout, h, w, pad, rows_pad, 32, p.ldx, p.ldy, (hipStream_t)stream);
+    }
     choose_tile(p.P, p.Q, ks, &p.TH, &p.TW, &p.PWL, (dtype != AFCM_F32 && ks == 3 && AFCM_X16_ON) ? kPatchMaxX16 : kPatchMax);
     p.tilesX = cdiv(p.Q, p.TW); p.tilesY = cdiv(p.P, p.TH);
     p.magicTW = (unsigned)((0x100000000ull + (unsigned)p.TW - 1) / (unsigned)p.TW);

@@ -1,0 +1,164 @@
+// 3x3 convolution of an image with AT MOST FOUR input channels (the generator's first layer, `encoder_0`: 4 -> 64 channels at 276^2,
+// NET:505 through conv2d_gradfix.conv2d) -- r06.
+//
+// The implicit-GEMM kernel (conv2d_fwd16x_kernel) contracts 32 channels per tap and K step: with 4 channels seven eighths of every
+// product multiply zeros (79 TFLOP/s = 0.03 of the pipe, 72 us for a layer whose output alone is 158 MB = 26 us of HBM time).  Here the
+// contraction index of one MFMA is (tap column, channel): v_mfma_f32_16x16x16 with k = 4 s + c for the taps s = 0, 1, 2 of one filter
+// row (slot s = 3 carries zero weights), one MFMA per filter row and 16 x 16 output tile, K = 36 of 48 slots live.
+//   * LDS patch [row][column][4 channels]: a pixel is 8 bytes, so the B fragment of a 16-pixel group -- lane (s, column): the four
+//     channels of pixel (column + s) -- is ONE ds_read_b64 per filter row, no im2col;
+//   * a wave takes 64 consecutive pixels of one output row as four INTERLEAVED groups (group q holds pixels 4 i + q): the four
+//     accumulator sets of a lane are then four consecutive pixels of one channel row -- an 8-byte store per lane, 128 contiguous
+//     bytes per 16 lanes, with no transposition through LDS;
+//   * the twelve weight fragments (3 filter rows x 4 blocks of 16 output channels) stay in registers for the workgroup's life.
+// Bound by its output stream: algorithmic bytes = x + y (SURVEY.md 8d prices the conv by flops; this layer's floor is HBM).
+#include "common.h"
+
+namespace afcm {
+
+struct DirectConvParams {
+    const void* x; void* y; const void* wp; const float* oscale; const float* obias;
+    int N, Cin, Cout, H, W, P, Q, pad, ldx, ldy, Opad, tilesX, tilesY, bk;
+};
+
+constexpr int kDcRows = 16, kDcCols = 64;                 // output tile of a workgroup
+constexpr int kDcPR = kDcRows + 2, kDcPC = kDcCols + 2;   // patch rows / columns that hold data
+constexpr int kDcPW = 68;                                 // patch row pitch in pixels (8 bytes each)
+
+template <typename T> struct DcMfma;
+template <> struct DcMfma<bf16_t> {
+    typedef __attribute__((ext_vector_type(4))) short frag;
+    static __device__ __forceinline__ __attribute__((ext_vector_type(4))) float mma(frag a, frag b, __attribute__((ext_vector_type(4))) float c) {
+        return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct DcMfma<f16_t> {
+    typedef __attribute__((ext_vector_type(4))) _Float16 frag;
+    static __device__ __forceinline__ __attribute__((ext_vector_type(4))) float mma(frag a, frag b, __attribute__((ext_vector_type(4))) float c) {
+        return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0);
+    }
+};
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void conv2d_direct4_kernel(DirectConvParams p) {
+    typedef DcMfma<T> M;
+    typedef typename M::frag frag;
+    typedef __attribute__((ext_vector_type(4))) float f32x4;
+    __shared__ __attribute__((aligned(16))) unsigned short patch[kDcPR * kDcPW * 4];
+    __shared__ float scs[64], obs[64];                                       // epilogue factors per output channel (LDS: 32 registers less per lane)
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, g = lane >> 4;
+    int bid = blockIdx.x;
+    const int tx = bid % p.tilesX; bid /= p.tilesX;
+    const int ty = bid % p.tilesY;
+    const int n = bid / p.tilesY;
+    const int y0 = ty * kDcRows, x0 = tx * kDcCols;
+
+    // ---- weights: A[o = 16 ot + l15][k = 4 s + c], s = g; slot 3 and channels >= Cin are zero
+    frag wa[3][4];
+    {
+        const unsigned short* wp = (const unsigned short*)p.wp;
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int ot = 0; ot < 4; ot++) {
+                union { uint2 u; frag f; unsigned short h[4]; } v;
+                v.u = make_uint2(0u, 0u);
+                const int o = ot * 16 + l15;
+                if (g < 3 && o < p.Opad) v.u = *(const uint2*)(wp + ((size_t)(r * 3 + g) * p.Opad + o) * p.bk);
+#pragma unroll
+                for (int c = 0; c < 4; c++)
+                    if (c >= p.Cin) v.h[c] = 0;
+                wa[r][ot] = v.f;
+            }
+    }
+
+    // ---- patch: rows y0 - pad .. + 17, columns x0 - pad .. + 65 of the (at most four) input planes, zero outside the image
+    {
+        const unsigned short* xn = (const unsigned short*)p.x + (size_t)n * p.Cin * p.H * p.ldx;
+        constexpr int PER = kDcPR * kDcPC;                                    // elements per channel
+        constexpr int NIT = (4 * PER + 255) / 256;
+        unsigned short v[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+            const int idx = tid + 256 * it;
+            const int c = idx / PER, rem = idx - c * PER;
+            const int pr = rem / kDcPC, pc = rem - pr * kDcPC;
+            const int iy = y0 - p.pad + pr, ix = x0 - p.pad + pc;
+            v[it] = 0;
+            if (idx < 4 * PER && c < p.Cin && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) v[it] = xn[((size_t)c * p.H + iy) * p.ldx + ix];
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+            const int idx = tid + 256 * it;
+            const int c = idx / PER, rem = idx - c * PER;
+            const int pr = rem / kDcPC, pc = rem - pr * kDcPC;
+            if (idx < 4 * PER) patch[(pr * kDcPW + pc) * 4 + c] = v[it];
+        }
+    }
+    if (tid < 64) {
+        scs[tid] = (p.oscale != nullptr && tid < p.Cout) ? p.oscale[(size_t)n * p.Cout + tid] : 1.f;
+        obs[tid] = (p.obias != nullptr && tid < p.Cout) ? p.obias[tid] : 0.f;
+    }
+    __syncthreads();
+
+    const int qlim = min(p.ldy, (p.Q + 7) & ~7);                              // columns written: up to the granule past Q (the contract of afcm_conv2d_ld)
+    unsigned short* const yn = (unsigned short*)p.y + (size_t)n * p.Cout * p.P * p.ldy;
+    const int sg = g < 3 ? g : 2;                                             // slot 3 (zero weights) re-reads slot 2's pixel: finite whenever the window is
+
+#pragma unroll 1
+    for (int i = 0; i < kDcRows / 4; i++) {
+        const int pr0 = wave * (kDcRows / 4) + i;
+        const int oy = y0 + pr0;
+        if (oy >= p.P) break;                                                 // (wave-uniform)
+        f32x4 acc[4][4];
+#pragma unroll
+        for (int ot = 0; ot < 4; ot++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) acc[ot][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                union { uint2 u; frag f; } b;
+                b.u = *(const uint2*)(patch + ((pr0 + r) * kDcPW + 4 * l15 + q + sg) * 4);
+#pragma unroll
+                for (int ot = 0; ot < 4; ot++) acc[ot][q] = M::mma(wa[r][ot], b.f, acc[ot][q]);
+            }
+        const int ox = x0 + 4 * l15;
+        if (ox + 4 <= qlim) {
+#pragma unroll
+            for (int ot = 0; ot < 4; ot++)
+#pragma unroll
+                for (int reg = 0; reg < 4; reg++) {
+                    const int o = ot * 16 + 4 * g + reg;
+                    if (o >= p.Cout) continue;
+                    union { uint2 u; T t[4]; } w;
+                    const float sc = scs[o], ob = obs[o];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) w.t[q] = from_f32<T>(acc[ot][q][reg] * sc + ob);
+                    *(uint2*)(yn + ((size_t)o * p.P + oy) * p.ldy + ox) = w.u;
+                }
+        }
+    }
+}
+
+// host side: called by afcm_conv2d_ld for 16-bit 3x3 convs with cin <= 4, cout <= 64 (declared there)
+int conv2d_direct_small_cin(const void* x, void* y, const void* wp, const float* oscale, const float* obias, int dtype, int n, int cin, int cout,
+                            int h, int w, int pad, int rows_pad, int bk, int ldx, int ldy, hipStream_t st) {
+    DirectConvParams p;
+    p.x = x; p.y = y; p.wp = wp; p.oscale = oscale; p.obias = obias;
+    p.N = n; p.Cin = cin; p.Cout = cout; p.H = h; p.W = w; p.pad = pad;
+    p.P = h + 2 * pad - 2; p.Q = w + 2 * pad - 2;
+    p.ldx = ldx; p.ldy = ldy; p.Opad = rows_pad; p.bk = bk;
+    p.tilesX = cdiv(p.Q, kDcCols); p.tilesY = cdiv(p.P, kDcRows);
+    const long long blocks = (long long)p.tilesX * p.tilesY * n;
+    if (blocks <= 0 || blocks >= (1ll << 31)) return AFCM_E_NOKERNEL;
+    if (dtype == AFCM_F16) hipLaunchKernelGGL((conv2d_direct4_kernel<f16_t>), dim3((unsigned)blocks), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((conv2d_direct4_kernel<bf16_t>), dim3((unsigned)blocks), dim3(256), 0, st, p);
+    return hip_status(hipGetLastError());
+}
+
+}  // namespace afcm

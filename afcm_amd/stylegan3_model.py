@@ -158,7 +158,7 @@ def capture_step(step, inputs, warmup=3):
     pool, so the captured graph replays the step on the SAME input tensors (refresh them in place between replays).  Returns the
     torch.cuda.CUDAGraph; `graph.replay()` runs one step.  What a replay does not do: Python-side bookkeeping (optimizer state['step'] --
     FusedScrubAdam.device_step() has the count --, loss tensors are those of the captured step's buffers, refreshed by every replay)."""
-    if step.buckets is not None or not step.optimizer_G.capturable:
+    if step.buckets is not None or not step.optimizer_G.capturable or not getattr(getattr(step, 'optimizer_D', None), 'capturable', True):
         raise RuntimeError('capture_step needs a single-process step built with capturable=True')
     real_A, real_B, z, c = inputs
 
@@ -220,7 +220,8 @@ class StyleGAN3Step(StyleGAN3GeneratorStep):
         self.model_names.insert(1, 'D')                             # ['G', 'D'(, 'G_ema')] as pix2pix_model.py:80 + comodgan_model.py:17
         self.lambda_r1 = float(lambda_r1)
         self.combine_ab = bool(combine_ab)
-        self.optimizer_D = FusedScrubAdam(netD.parameters(), lr=lr_D, betas=(0.0, 0.99), eps=1e-8, scrub=True, posinf=1e5, neginf=-1e5)
+        self.optimizer_D = FusedScrubAdam(netD.parameters(), lr=lr_D, betas=(0.0, 0.99), eps=1e-8, scrub=True, posinf=1e5, neginf=-1e5,
+                                          capturable=kw.get('capturable', False))
         self.buckets_D = None
         if self.buckets is not None:
             self.buckets_D = GradientBuckets(netD.parameters(), bucket_bytes=kw.get('bucket_bytes', 25 * 1024 * 1024),

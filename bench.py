@@ -252,7 +252,7 @@ def build_step(args, dev, dtype_name, with_discriminator, use_dist, fp32_conv, c
                                num_fp16_res=n16, conv_clamp=(256 if n16 else None), block_kwargs=dict(fp16_dtype=dtype if n16 else torch.float16),
                                epilogue_kwargs=dict(mbstd_group_size=16)).to(dev)
         step = StyleGAN3Step(G, D, lr_G=0.0025, lr_D=0.0025, lambda_L1=100.0, lambda_r1=10.0, distributed=use_dist,
-                             force_collectives=args.force_dist, comm_dtype=comm_dtype)
+                             force_collectives=args.force_dist, comm_dtype=comm_dtype, capturable=capturable)
     else:
         step = StyleGAN3GeneratorStep(G, lr_G=0.0025, lambda_L1=100.0, distributed=use_dist, force_collectives=args.force_dist,
                                       comm_dtype=comm_dtype, capturable=capturable)
@@ -411,7 +411,7 @@ def graph_worker(args):
     dev = torch.device('cuda', 0)
     torch.cuda.set_device(dev)
     steps = args.also_steps
-    step, inputs = build_step(args, dev, 'bf16', False, False, args.fp32_conv, capturable=True)
+    step, inputs = build_step(args, dev, 'bf16', args.with_discriminator, False, args.fp32_conv, capturable=True)
     graph = capture_step(step, inputs, warmup=3)
     for _ in range(2):
         graph.replay()
@@ -428,7 +428,7 @@ def graph_worker(args):
                           steps=steps, optimizer_steps_on_device=step.optimizer_G.device_step(), loss_G_L1=float(step.loss_G_L1.detach()))), flush=True)
 
 
-def graph_record(args, limit=240.0):
+def graph_record(args, limit=240.0, with_discriminator=False):
     """The N = 1 bf16 step captured into ONE hipGraph and replayed (asked for when the eager step's host side takes >= 50 % of
     the step on the driver's box): ms per replayed step and the host's wall time per replay.  The step is GPU-bound either way at N = 1;
     what the graph removes is the host's ~20 ms of Python / autograd / launch work per step -- the margin eight ranks sharing one host live
@@ -436,6 +436,8 @@ def graph_record(args, limit=240.0):
     not take the headline line with it)."""
     try:
         cmd = [sys.executable, os.path.abspath(__file__), '--graph-worker', '--also-steps', str(args.also_steps), '--batch', str(args.batch), '--res', str(args.res)]
+        if with_discriminator:
+            cmd.append('--with-discriminator')
         out = subprocess.run(cmd, capture_output=True, text=True, timeout=limit, cwd=ROOT)
         lines = [l for l in out.stdout.splitlines() if l.startswith('{"graph_record"')]
         if not lines:

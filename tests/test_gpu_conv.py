@@ -742,3 +742,39 @@ def test_linked_layers_take_the_style_gradient_from_the_consumers_weight_gradien
     assert link.gz is None and z1_shape not in used, 'the first node still passed over g and z'
     for k in g_ref:
         _close_rel(g_l[k], g_ref[k], tol if k in ('s2', 'd1') else 1e-5, f'd{k}')
+
+
+# ---- r06: the direct kernel for convs with at most four input channels (C ABI afcm_conv2d_ld -> conv2d_direct.hip) ---------------------------
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('case', [(2, 4, 64, 276, 276, 2), (1, 4, 64, 30, 34, 2), (3, 3, 20, 17, 70, 2), (2, 1, 64, 40, 130, 1), (1, 4, 33, 16, 64, 0), (2, 2, 5, 5, 6, 2)], ids=str)
+def test_direct_conv_for_few_input_channels(case, dtype):
+    """3x3 convs with cin <= 4 (the generator's encoder_0: 4 -> 64 at 276^2) run the direct kernel: every output against float64 aten on the
+    16-bit-rounded operands (one rounding of the output), with per-plane factors and a bias, dense and row-pitched outputs, the padding
+    columns of a pitched output finite up to the next multiple of 8 (the contract of afcm_conv2d_ld), NaN only where a window holds one."""
+    from afcm_amd.torch_utils.ops import _rows
+    from afcm_amd.torch_utils.ops import conv2d as C
+    n, cin, cout, h, w, pad = case
+    g = torch.Generator().manual_seed(h * w + cin)
+    x = torch.randn([n, cin, h, w], generator=g).to(dtype)
+    wt = torch.randn([cout, cin, 3, 3], generator=g) / np.sqrt(9 * cin)
+    osc = torch.rand([n, cout], generator=g) + 0.5
+    ob = torch.randn([cout], generator=g) * 0.3
+    ref = torch.nn.functional.conv2d(x.double(), wt.to(dtype).double(), padding=pad) * osc.double()[:, :, None, None] + ob.double()[None, :, None, None]
+    wp, rows_pad = C.pack_weights(wt.cuda(), dtype, 0)
+    eps = 2.0 ** (-8 if dtype == torch.bfloat16 else -11)
+    for pitched in (False, True):
+        y = C._conv_raw(x.cuda(), wp, rows_pad, osc.cuda(), cout, 3, pad, obias=ob.cuda(), pitched_out=pitched)
+        assert y.dtype == dtype and tuple(y.shape) == tuple(ref.shape)
+        err = (y.double().cpu() - ref).abs().max().item()
+        assert err <= eps * float(ref.abs().max()) * 1.01, (pitched, err)
+        full = _rows.whole_buffer(y)
+        if full is not None:
+            q = y.shape[3]
+            assert bool(torch.isfinite(full[..., q:min(full.shape[3], (q + 7) // 8 * 8)].float()).all())
+    xn = x.clone()
+    xn[0, 0, h // 2, w // 2] = float('nan')
+    yn = C._conv_raw(xn.cuda(), wp, rows_pad, None, cout, 3, pad).float().cpu()
+    bad = torch.zeros_like(yn[0, 0], dtype=torch.bool)
+    cy, cx = h // 2 + pad, w // 2 + pad                         # output pixels (cy - r, cx - s), r, s in 0..2, see the element
+    bad[max(cy - 2, 0):cy + 1, max(cx - 2, 0):cx + 1] = True
+    assert bool(yn[0, :, bad].isnan().all()) and bool(torch.isfinite(yn[0][:, ~bad]).all()) and bool(torch.isfinite(yn[1:]).all())
