@@ -3002,6 +3002,9 @@ __global__ __launch_bounds__(512, 1) void conv2d_wgrad16g_kernel(WgradParams p) 
                                          : DY_BYTES + XMAIN + (rb >> 3) * (XR * 128) + xr * 128 + (rb & 7) * 16;
     }
 
+#ifdef AFCM_WGRAD_PRIO           // A/B builds: static priority for one half of the workgroup's waves (MI355X_MICROARCH.md, two waves per SIMD, item 4): 1 = waves 4-7, 2 = waves 0-3
+    if ((AFCM_WGRAD_PRIO == 1) == (wave >= 4)) __builtin_amdgcn_s_setprio(1);
+#endif
     // ---- pipeline: NBUF-1 steps of loads in flight; a step's loads are waited for (counted vmcnt) before the barrier that
     // precedes its use.
 #pragma unroll

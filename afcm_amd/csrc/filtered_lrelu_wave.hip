@@ -47,6 +47,20 @@
 #define AFCM_WAVE_SIGNLOAD_AUX 0
 #endif
 
+#if defined(AFCM_WAVE_STAMPS) && !defined(AFCM_WAVE_F16)     // (the bf16 translation unit only: one definition of the symbols)
+#define AFCM_WAVE_STAMPS_ON 1
+// diagnostic build only (VERDICT r05 #2d): shader-clock and real-time stamps around every strip, summed per kernel variant
+// slot = (UP == 4) | (DOWN == 4) << 1 | (sign mode 0..3) << 2 | (TOH == 48) << 4; per slot: {sum of s_memtime deltas (shader cycles), sum of
+// s_memrealtime deltas (100 MHz ticks), strips}.  In-loop clock of a variant = cycles / ticks x 100 MHz (MI355X_MICROARCH.md, DVFS item 6).
+// The stamps go to a buffer of their own that nothing else reads; no output depends on them.
+__device__ unsigned long long afcm_wave_stamp_acc[32][4];
+extern "C" int afcm_debug_wave_stamps(void* dst) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(afcm_wave_stamp_acc), sizeof(unsigned long long) * 32 * 4); }
+extern "C" int afcm_debug_wave_stamps_clear() {
+    static unsigned long long zero[32][4] = {};
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(afcm_wave_stamp_acc), zero, sizeof(zero));
+}
+#endif
+
 namespace afcm {
 
 template <int UP, int DOWN, int TOW, int TOH>
@@ -845,6 +859,9 @@ __global__ __launch_bounds__(256, (wave_occupancy<UP, DOWN, TOW, TOH, SIGN, EPI>
         if (RD) return __builtin_amdgcn_ballot_w64((anyc & 0xaaaaaaaau) != 0) != 0;   // a clamped element in reach
         return __builtin_amdgcn_ballot_w64(!(amax <= cthr1)) != 0;                                        // NaN takes the exact path
     };
+#ifdef AFCM_WAVE_STAMPS_ON
+    const unsigned long long st_c0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
     // (READ never writes codes: one LASTY variant suffices)
     bool exact;
     if (SIGN == AFCM_SIGNS_WRITE && lastY) {
@@ -854,6 +871,18 @@ __global__ __launch_bounds__(256, (wave_occupancy<UP, DOWN, TOW, TOH, SIGN, EPI>
         exact = run_strip(std::false_type{}, std::false_type{});
         if (__builtin_expect(exact, 0)) run_strip(std::true_type{}, std::false_type{});
     }
+#ifdef AFCM_WAVE_STAMPS_ON
+    {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        const unsigned long long st_c1 = __builtin_amdgcn_s_memtime(), st_r1 = __builtin_amdgcn_s_memrealtime();
+        constexpr int slot = (UP == 4 ? 1 : 0) | (DOWN == 4 ? 2 : 0) | ((SIGN & 3) << 2) | (TOH == 48 ? 16 : 0);
+        if (lane == 0) {
+            atomicAdd(&afcm_wave_stamp_acc[slot][0], st_c1 - st_c0);
+            atomicAdd(&afcm_wave_stamp_acc[slot][1], st_r1 - st_r0);
+            atomicAdd(&afcm_wave_stamp_acc[slot][2], 1ull);
+        }
+    }
+#endif
     // optional per-strip flag: the strip's activations could reach the clamp (a plane with no flagged strip is positively homogeneous
     // of degree 1 in its input: the caller derives <dL/dy, y> from <g, z>, afcm_plane_dot_gated_ld).  Every slot is written.
     if (!RD && p.clamp_flags != nullptr && lane == 0) p.clamp_flags[(size_t)plane * (p.tilesX * p.tilesY) + ty * p.tilesX + tx] = exact ? 1 : 0;
