@@ -3,10 +3,14 @@
 //
 // The implicit-GEMM kernel (conv2d_fwd16x_kernel) contracts 32 channels per tap and K step: with 4 channels seven eighths of every
 // product multiply zeros (79 TFLOP/s = 0.03 of the pipe, 72 us for a layer whose output alone is 158 MB = 26 us of HBM time).  Here the
-// contraction index of one MFMA is (tap column, channel): v_mfma_f32_16x16x16 with k = 4 s + c for the taps s = 0, 1, 2 of one filter
-// row (slot s = 3 carries zero weights), one MFMA per filter row and 16 x 16 output tile, K = 36 of 48 slots live.
-//   * LDS patch [row][column][4 channels]: a pixel is 8 bytes, so the B fragment of a 16-pixel group -- lane (s, column): the four
-//     channels of pixel (column + s) -- is ONE ds_read_b64 per filter row, no im2col;
+// contraction index of one MFMA is (tap, channel): v_mfma_f32_16x16x32 with k = 8 g + 4 t + c, where lane group g holds a PAIR of
+// horizontally adjacent taps t = 0, 1 (adjacent pixels of the patch = 16 contiguous bytes):
+//     MFMA 0:  g0 = row 0 taps (0, 1)   g1 = row 0 taps (2, -)   g2 = row 1 taps (0, 1)   g3 = row 1 taps (2, -)
+//     MFMA 1:  g0 = row 2 taps (0, 1)   g1 = row 2 taps (2, -)   g2, g3 = -                       ("-": zero weights)
+// two MFMAs per 16 x 16 output tile, 36 of 64 K slots live.  (First form, r06: one 16x16x16 MFMA per filter row -- 48 instead of 32 MFMAs
+// per 64 pixels and the older instruction: 53 us.)
+//   * LDS patch [row][column][4 channels]: a pixel is 8 bytes, so the B fragment of a 16-pixel group -- lane (g, column): the four
+//     channels of the two pixels (column + 2 (g & 1)), + 1 in row (g >> 1) -- is ONE ds_read2_b64, no im2col;
 //   * a wave takes 64 consecutive pixels of one output row as four INTERLEAVED groups (group q holds pixels 4 i + q): the four
 //     accumulator sets of a lane are then four consecutive pixels of one channel row -- an 8-byte store per lane, 128 contiguous
 //     bytes per 16 lanes, with no transposition through LDS;
@@ -22,20 +26,20 @@ struct DirectConvParams {
 };
 
 constexpr int kDcRows = 16, kDcCols = 64;                 // output tile of a workgroup
-constexpr int kDcPR = kDcRows + 2, kDcPC = kDcCols + 2;   // patch rows / columns that hold data
+constexpr int kDcPR = kDcRows + 2, kDcPC = kDcCols + 4;   // patch rows / columns that hold data (columns 66, 67: read with zero weights only)
 constexpr int kDcPW = 68;                                 // patch row pitch in pixels (8 bytes each)
 
 template <typename T> struct DcMfma;
 template <> struct DcMfma<bf16_t> {
-    typedef __attribute__((ext_vector_type(4))) short frag;
+    typedef __attribute__((ext_vector_type(8))) __bf16 frag;
     static __device__ __forceinline__ __attribute__((ext_vector_type(4))) float mma(frag a, frag b, __attribute__((ext_vector_type(4))) float c) {
-        return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
     }
 };
 template <> struct DcMfma<f16_t> {
-    typedef __attribute__((ext_vector_type(4))) _Float16 frag;
+    typedef __attribute__((ext_vector_type(8))) _Float16 frag;
     static __device__ __forceinline__ __attribute__((ext_vector_type(4))) float mma(frag a, frag b, __attribute__((ext_vector_type(4))) float c) {
-        return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0);
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
     }
 };
 
@@ -56,22 +60,29 @@ __global__ __launch_bounds__(256, 2) void conv2d_direct4_kernel(DirectConvParams
     const int n = bid / p.tilesY;
     const int y0 = ty * kDcRows, x0 = tx * kDcCols;
 
-    // ---- weights: A[o = 16 ot + l15][k = 4 s + c], s = g; slot 3 and channels >= Cin are zero
-    frag wa[3][4];
+    // ---- weights: A[o = 16 ot + l15][k = 8 g + 4 t + c]: MFMA m, lane group g -> filter row 2 m + (g >> 1), taps 2 (g & 1) + t; taps beyond the
+    // filter, rows beyond it and channels >= Cin are zero
+    frag wa[2][4];
     {
         const unsigned short* wp = (const unsigned short*)p.wp;
 #pragma unroll
-        for (int r = 0; r < 3; r++)
+        for (int m = 0; m < 2; m++)
 #pragma unroll
             for (int ot = 0; ot < 4; ot++) {
-                union { uint2 u; frag f; unsigned short h[4]; } v;
-                v.u = make_uint2(0u, 0u);
-                const int o = ot * 16 + l15;
-                if (g < 3 && o < p.Opad) v.u = *(const uint2*)(wp + ((size_t)(r * 3 + g) * p.Opad + o) * p.bk);
+                union { uint4 u; frag f; unsigned short h[8]; uint2 d[2]; } v;
+                v.u = make_uint4(0u, 0u, 0u, 0u);
+                const int o = ot * 16 + l15, r = 2 * m + (g >> 1);
+                if (r < 3 && o < p.Opad) {
 #pragma unroll
-                for (int c = 0; c < 4; c++)
-                    if (c >= p.Cin) v.h[c] = 0;
-                wa[r][ot] = v.f;
+                    for (int t = 0; t < 2; t++) {
+                        const int sx = 2 * (g & 1) + t;
+                        if (sx < 3) v.d[t] = *(const uint2*)(wp + ((size_t)(r * 3 + sx) * p.Opad + o) * p.bk);
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < 8; c++)
+                    if ((c & 3) >= p.Cin) v.h[c] = 0;
+                wa[m][ot] = v.f;
             }
     }
 
@@ -106,7 +117,9 @@ __global__ __launch_bounds__(256, 2) void conv2d_direct4_kernel(DirectConvParams
 
     const int qlim = min(p.ldy, (p.Q + 7) & ~7);                              // columns written: up to the granule past Q (the contract of afcm_conv2d_ld)
     unsigned short* const yn = (unsigned short*)p.y + (size_t)n * p.Cout * p.P * p.ldy;
-    const int sg = g < 3 ? g : 2;                                             // slot 3 (zero weights) re-reads slot 2's pixel: finite whenever the window is
+    // this lane's window inside a patch row pair: row (g >> 1) of the MFMA's two filter rows, pixels + 2 (g & 1) and + 2 (g & 1) + 1 (the last one,
+    // column + 3, carries a zero weight: it lies inside the padded row (kDcPW = 68), finite whenever the window is)
+    const int lrow = g >> 1, lcol = 2 * (g & 1);
 
 #pragma unroll 1
     for (int i = 0; i < kDcRows / 4; i++) {
@@ -119,16 +132,21 @@ __global__ __launch_bounds__(256, 2) void conv2d_direct4_kernel(DirectConvParams
 #pragma unroll
             for (int q = 0; q < 4; q++) acc[ot][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int r = 0; r < 3; r++)
+        for (int m = 0; m < 2; m++)
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                union { uint2 u; frag f; } b;
-                b.u = *(const uint2*)(patch + ((pr0 + r) * kDcPW + 4 * l15 + q + sg) * 4);
+                union { uint2 d[2]; frag f; } b;
+                // (MFMA 1, lane groups 2, 3: zero weights -- they re-read the row of groups 0, 1: inside the patch)
+                const int prow = pr0 + 2 * m + (m == 1 ? 0 : lrow);
+                const unsigned short* src = patch + (prow * kDcPW + 4 * l15 + q + lcol) * 4;
+                b.d[0] = *(const uint2*)src;
+                b.d[1] = *(const uint2*)(src + 4);
 #pragma unroll
-                for (int ot = 0; ot < 4; ot++) acc[ot][q] = M::mma(wa[r][ot], b.f, acc[ot][q]);
+                for (int ot = 0; ot < 4; ot++) acc[ot][q] = M::mma(wa[m][ot], b.f, acc[ot][q]);
             }
         const int ox = x0 + 4 * l15;
-        if (ox + 4 <= qlim) {
+        const int npx = ox + 4 <= qlim ? 4 : (ox + 2 <= qlim ? 2 : 0);      // (even widths: a dense row may end on a pixel pair)
+        if (npx > 0) {
 #pragma unroll
             for (int ot = 0; ot < 4; ot++)
 #pragma unroll
@@ -139,7 +157,9 @@ __global__ __launch_bounds__(256, 2) void conv2d_direct4_kernel(DirectConvParams
                     const float sc = scs[o], ob = obs[o];
 #pragma unroll
                     for (int q = 0; q < 4; q++) w.t[q] = from_f32<T>(acc[ot][q][reg] * sc + ob);
-                    *(uint2*)(yn + ((size_t)o * p.P + oy) * p.ldy + ox) = w.u;
+                    unsigned short* dst = yn + ((size_t)o * p.P + oy) * p.ldy + ox;
+                    if (npx == 4) *(uint2*)dst = w.u;
+                    else *(unsigned*)dst = w.u.x;
                 }
         }
     }
