@@ -16,7 +16,8 @@
 //     bytes per 16 lanes, with no transposition through LDS;
 //   * the twelve weight fragments (3 filter rows x 4 blocks of 16 output channels) stay in registers for the workgroup's life.
 // Bound by its output stream: algorithmic bytes = x + y (SURVEY.md 8d prices the conv by flops; this layer's floor is HBM).
-#include "common.h"
+#include <type_traits>
+#include "flrelu_mfma_common.h"      // pack2<T>: one v_cvt_pk of exactly a pair
 
 namespace afcm {
 
@@ -26,7 +27,7 @@ struct DirectConvParams {
 };
 
 constexpr int kDcRows = 16, kDcCols = 64;                 // output tile of a workgroup
-constexpr int kDcPR = kDcRows + 2, kDcPC = kDcCols + 4;   // patch rows / columns that hold data (columns 66, 67: read with zero weights only)
+constexpr int kDcPR = kDcRows + 2, kDcPC = kDcCols + 2;   // patch rows / columns that hold data
 constexpr int kDcPW = 68;                                 // patch row pitch in pixels (8 bytes each)
 
 template <typename T> struct DcMfma;
@@ -116,10 +117,11 @@ __global__ __launch_bounds__(256, 2) void conv2d_direct4_kernel(DirectConvParams
     __syncthreads();
 
     const int qlim = min(p.ldy, (p.Q + 7) & ~7);                              // columns written: up to the granule past Q (the contract of afcm_conv2d_ld)
-    unsigned short* const yn = (unsigned short*)p.y + (size_t)n * p.Cout * p.P * p.ldy;
-    // this lane's window inside a patch row pair: row (g >> 1) of the MFMA's two filter rows, pixels + 2 (g & 1) and + 2 (g & 1) + 1 (the last one,
-    // column + 3, carries a zero weight: it lies inside the padded row (kDcPW = 68), finite whenever the window is)
-    const int lrow = g >> 1, lcol = 2 * (g & 1);
+    const int plane = p.P * p.ldy;                                            // elements per output channel (Cout planes < 2^30 bytes: host)
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void*)((unsigned short*)p.y + (size_t)n * p.Cout * plane), 0, p.Cout * plane * 2, 0x00020000);
+    // this lane's window inside a patch row pair: row (g >> 1) of the MFMA's two filter rows, pixels + 2 (g & 1) and + 2 (g & 1) + 1 -- except that
+    // the slot behind tap 2 (zero weights) re-reads tap 2's pixel: no element outside the 3 x 3 window is ever multiplied (0 x NaN)
+    const int lrow = g >> 1, lcol = 2 * (g & 1), pair2 = (g & 1) ? 0 : 4;
 
 #pragma unroll 1
     for (int i = 0; i < kDcRows / 4; i++) {
@@ -140,28 +142,32 @@ __global__ __launch_bounds__(256, 2) void conv2d_direct4_kernel(DirectConvParams
                 const int prow = pr0 + 2 * m + (m == 1 ? 0 : lrow);
                 const unsigned short* src = patch + (prow * kDcPW + 4 * l15 + q + lcol) * 4;
                 b.d[0] = *(const uint2*)src;
-                b.d[1] = *(const uint2*)(src + 4);
+                b.d[1] = *(const uint2*)(src + pair2);          // (taps (2, -): the zero-weight slot re-reads tap 2's pixel -- inside the window)
 #pragma unroll
                 for (int ot = 0; ot < 4; ot++) acc[ot][q] = M::mma(wa[m][ot], b.f, acc[ot][q]);
             }
+        // stores through a buffer descriptor over this image's output: the lane offset is made once per row, the channel rides in the scalar
+        // offset, and rows o >= Cout fall behind the descriptor's end (dropped) -- per-store 64-bit address arithmetic and a branch per channel
+        // were 595 vector instructions per 64 pixels (r06, first form)
         const int ox = x0 + 4 * l15;
         const int npx = ox + 4 <= qlim ? 4 : (ox + 2 <= qlim ? 2 : 0);      // (even widths: a dense row may end on a pixel pair)
-        if (npx > 0) {
+        const unsigned voff = (unsigned)(((4 * g) * plane + oy * p.ldy + ox) * 2);
+        const unsigned v64 = npx == 4 ? voff : 0x80000000u, v32 = npx == 2 ? voff : 0x80000000u;
+        const bool any2 = __builtin_amdgcn_ballot_w64(npx == 2) != 0;        // (wave-uniform: the row's last column tile only)
 #pragma unroll
-            for (int ot = 0; ot < 4; ot++)
+        for (int ot = 0; ot < 4; ot++)
 #pragma unroll
-                for (int reg = 0; reg < 4; reg++) {
-                    const int o = ot * 16 + 4 * g + reg;
-                    if (o >= p.Cout) continue;
-                    union { uint2 u; T t[4]; } w;
-                    const float sc = scs[o], ob = obs[o];
-#pragma unroll
-                    for (int q = 0; q < 4; q++) w.t[q] = from_f32<T>(acc[ot][q][reg] * sc + ob);
-                    unsigned short* dst = yn + ((size_t)o * p.P + oy) * p.ldy + ox;
-                    if (npx == 4) *(uint2*)dst = w.u;
-                    else *(unsigned*)dst = w.u.x;
-                }
-        }
+            for (int reg = 0; reg < 4; reg++) {
+                const int o = ot * 16 + 4 * g + reg;
+                const float sc = scs[o], ob = obs[o];
+                typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+                u32x2 wv;
+                wv.x = pack2<T>(__builtin_fmaf(acc[ot][0][reg], sc, ob), __builtin_fmaf(acc[ot][1][reg], sc, ob));
+                wv.y = pack2<T>(__builtin_fmaf(acc[ot][2][reg], sc, ob), __builtin_fmaf(acc[ot][3][reg], sc, ob));
+                const int soff = (ot * 16 + reg) * plane * 2;
+                __builtin_amdgcn_raw_buffer_store_b64(wv, yrs, v64, soff, 0);
+                if (any2) __builtin_amdgcn_raw_buffer_store_b32(wv.x, yrs, v32, soff, 0);
+            }
     }
 }
 
