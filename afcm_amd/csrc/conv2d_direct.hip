@@ -26,8 +26,8 @@ struct DirectConvParams {
     int N, Cin, Cout, H, W, P, Q, pad, ldx, ldy, Opad, tilesX, tilesY, bk;
 };
 
-constexpr int kDcRows = 16, kDcCols = 64;                 // output tile of a workgroup
-constexpr int kDcPR = kDcRows + 2, kDcPC = kDcCols + 2;   // patch rows / columns that hold data
+constexpr int kDcRows = 32, kDcCols = 64;                 // output tile of a workgroup (16 rows: the per-workgroup set-up -- weights, patch, factors -- was half of a wave's instructions)
+constexpr int kDcPR = kDcRows + 2;                        // patch rows (columns that hold data: kDcCols + 2)
 constexpr int kDcPW = 68;                                 // patch row pitch in pixels (8 bytes each)
 
 template <typename T> struct DcMfma;
@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_direct4_kernel(DirectConvParams
     typedef typename M::frag frag;
     typedef __attribute__((ext_vector_type(4))) float f32x4;
     __shared__ __attribute__((aligned(16))) unsigned short patch[kDcPR * kDcPW * 4];
-    __shared__ float scs[64], obs[64];                                       // epilogue factors per output channel (LDS: 32 registers less per lane)
+    __shared__ __attribute__((aligned(16))) float scs[64], obs[64];                                       // epilogue factors per output channel, staged once per workgroup
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -87,27 +87,27 @@ __global__ __launch_bounds__(256, 2) void conv2d_direct4_kernel(DirectConvParams
             }
     }
 
-    // ---- patch: rows y0 - pad .. + 17, columns x0 - pad .. + 65 of the (at most four) input planes, zero outside the image
+    // ---- patch: rows y0 - pad .. + 17, columns x0 - pad .. + 65 of the (at most four) input planes, zero outside the image.  Wave c stages
+    // channel c: lane = column (64 of them; lanes 0, 1 also take columns 64, 65), one row per step -- the addresses advance by the row pitch
+    // (as a flat index over (channel, row, column) every element paid two divisions by constants: 270 instructions per wave)
     {
-        const unsigned short* xn = (const unsigned short*)p.x + (size_t)n * p.Cin * p.H * p.ldx;
-        constexpr int PER = kDcPR * kDcPC;                                    // elements per channel
-        constexpr int NIT = (4 * PER + 255) / 256;
-        unsigned short v[NIT];
+        const int c = wave;
+        const unsigned short* xc = (const unsigned short*)p.x + ((size_t)n * p.Cin + min(c, p.Cin - 1)) * p.H * p.ldx;
+        const int ix = x0 - p.pad + lane, ix2 = x0 - p.pad + 64 + lane;
+        const bool cok = c < p.Cin && (unsigned)ix < (unsigned)p.W, cok2 = c < p.Cin && lane < 2 && (unsigned)ix2 < (unsigned)p.W;
+        unsigned short v[kDcPR], v2[kDcPR];
 #pragma unroll
-        for (int it = 0; it < NIT; it++) {
-            const int idx = tid + 256 * it;
-            const int c = idx / PER, rem = idx - c * PER;
-            const int pr = rem / kDcPC, pc = rem - pr * kDcPC;
-            const int iy = y0 - p.pad + pr, ix = x0 - p.pad + pc;
-            v[it] = 0;
-            if (idx < 4 * PER && c < p.Cin && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) v[it] = xn[((size_t)c * p.H + iy) * p.ldx + ix];
+        for (int pr = 0; pr < kDcPR; pr++) {
+            const int iy = y0 - p.pad + pr;
+            const bool rok = (unsigned)iy < (unsigned)p.H;
+            const unsigned short* row = xc + (size_t)(rok ? iy : 0) * p.ldx;
+            v[pr] = (rok && cok) ? row[ix] : (unsigned short)0;
+            v2[pr] = (rok && cok2) ? row[ix2] : (unsigned short)0;
         }
 #pragma unroll
-        for (int it = 0; it < NIT; it++) {
-            const int idx = tid + 256 * it;
-            const int c = idx / PER, rem = idx - c * PER;
-            const int pr = rem / kDcPC, pc = rem - pr * kDcPC;
-            if (idx < 4 * PER) patch[(pr * kDcPW + pc) * 4 + c] = v[it];
+        for (int pr = 0; pr < kDcPR; pr++) {
+            patch[(pr * kDcPW + lane) * 4 + c] = v[pr];
+            if (lane < 2) patch[(pr * kDcPW + 64 + lane) * 4 + c] = v2[pr];
         }
     }
     if (tid < 64) {
@@ -120,9 +120,11 @@ __global__ __launch_bounds__(256, 2) void conv2d_direct4_kernel(DirectConvParams
     const int plane = p.P * p.ldy;                                            // elements per output channel (Cout planes < 2^30 bytes: host)
     const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void*)((unsigned short*)p.y + (size_t)n * p.Cout * plane), 0, p.Cout * plane * 2, 0x00020000);
     // this lane's window inside a patch row pair: row (g >> 1) of the MFMA's two filter rows, pixels + 2 (g & 1) and + 2 (g & 1) + 1 -- except that
-    // the slot behind tap 2 (zero weights) re-reads tap 2's pixel: no element outside the 3 x 3 window is ever multiplied (0 x NaN)
-    const int lrow = g >> 1, lcol = 2 * (g & 1), pair2 = (g & 1) ? 0 : 4;
-
+    // the slot behind tap 2 (zero weights) re-reads tap 2's pixel: no element outside the 3 x 3 window is ever multiplied (0 x NaN).  Two lane
+    // offsets made once (opaque: as `base + select` the compiler read 16 bytes and chose per lane -- 120 vector instructions per 64 pixels)
+    const int lrow = g >> 1, lcol = 2 * (g & 1);
+    int off_a = (4 * l15 + lcol) * 4, off_b = off_a + ((g & 1) ? 0 : 4);    // elements
+    asm volatile("" : "+v"(off_a), "+v"(off_b));
 #pragma unroll 1
     for (int i = 0; i < kDcRows / 4; i++) {
         const int pr0 = wave * (kDcRows / 4) + i;
@@ -130,21 +132,18 @@ __global__ __launch_bounds__(256, 2) void conv2d_direct4_kernel(DirectConvParams
         if (oy >= p.P) break;                                                 // (wave-uniform)
         f32x4 acc[4][4];
 #pragma unroll
-        for (int ot = 0; ot < 4; ot++)
-#pragma unroll
-            for (int q = 0; q < 4; q++) acc[ot][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
         for (int m = 0; m < 2; m++)
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 union { uint2 d[2]; frag f; } b;
                 // (MFMA 1, lane groups 2, 3: zero weights -- they re-read the row of groups 0, 1: inside the patch)
                 const int prow = pr0 + 2 * m + (m == 1 ? 0 : lrow);
-                const unsigned short* src = patch + (prow * kDcPW + 4 * l15 + q + lcol) * 4;
-                b.d[0] = *(const uint2*)src;
-                b.d[1] = *(const uint2*)(src + pair2);          // (taps (2, -): the zero-weight slot re-reads tap 2's pixel -- inside the window)
+                const unsigned short* src = patch + (prow * kDcPW + q) * 4;
+                b.d[0] = *(const uint2*)(src + off_a);
+                b.d[1] = *(const uint2*)(src + off_b);
 #pragma unroll
-                for (int ot = 0; ot < 4; ot++) acc[ot][q] = M::mma(wa[m][ot], b.f, acc[ot][q]);
+                for (int ot = 0; ot < 4; ot++)                                // (the first product starts from a literal zero: no accumulator clearing)
+                    acc[ot][q] = M::mma(wa[m][ot], b.f, m == 0 ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[ot][q]);
             }
         // stores through a buffer descriptor over this image's output: the lane offset is made once per row, the channel rides in the scalar
         // offset, and rows o >= Cout fall behind the descriptor's end (dropped) -- per-store 64-bit address arithmetic and a branch per channel
@@ -155,19 +154,21 @@ __global__ __launch_bounds__(256, 2) void conv2d_direct4_kernel(DirectConvParams
         const unsigned v64 = npx == 4 ? voff : 0x80000000u, v32 = npx == 2 ? voff : 0x80000000u;
         const bool any2 = __builtin_amdgcn_ballot_w64(npx == 2) != 0;        // (wave-uniform: the row's last column tile only)
 #pragma unroll
-        for (int ot = 0; ot < 4; ot++)
+        for (int ot = 0; ot < 4; ot++) {
+            // this lane's rows o = 16 ot + 4 g + reg: their factors as two 16-byte LDS reads (in registers for the kernel's life they cost the
+            // third wave per SIMD)
+            const f32x4 sc4 = *(const f32x4*)(scs + ot * 16 + 4 * g), ob4 = *(const f32x4*)(obs + ot * 16 + 4 * g);
 #pragma unroll
             for (int reg = 0; reg < 4; reg++) {
-                const int o = ot * 16 + 4 * g + reg;
-                const float sc = scs[o], ob = obs[o];
                 typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
                 u32x2 wv;
-                wv.x = pack2<T>(__builtin_fmaf(acc[ot][0][reg], sc, ob), __builtin_fmaf(acc[ot][1][reg], sc, ob));
-                wv.y = pack2<T>(__builtin_fmaf(acc[ot][2][reg], sc, ob), __builtin_fmaf(acc[ot][3][reg], sc, ob));
+                wv.x = pack2<T>(__builtin_fmaf(acc[ot][0][reg], sc4[reg], ob4[reg]), __builtin_fmaf(acc[ot][1][reg], sc4[reg], ob4[reg]));
+                wv.y = pack2<T>(__builtin_fmaf(acc[ot][2][reg], sc4[reg], ob4[reg]), __builtin_fmaf(acc[ot][3][reg], sc4[reg], ob4[reg]));
                 const int soff = (ot * 16 + reg) * plane * 2;
                 __builtin_amdgcn_raw_buffer_store_b64(wv, yrs, v64, soff, 0);
                 if (any2) __builtin_amdgcn_raw_buffer_store_b32(wv.x, yrs, v32, soff, 0);
             }
+        }
     }
 }
 

@@ -552,7 +552,8 @@ def main():
             torch.cuda.empty_cache()
             also = dict(fp32=also_record(args, dev, 'fp32', 'fp32', False, args.also_steps, 2),
                         d_plus_g=also_record(args, dev, 'd_plus_g', 'bf16', True, args.also_steps, 2),
-                        graph=graph_record(args))
+                        graph=graph_record(args),
+                        d_plus_g_graph=graph_record(args, with_discriminator=True))
         cpu = run_cpu_baseline(args.res) if (world == 1 and args.cpu_baseline == 'auto') else None
         images = world * args.batch * args.steps
         out = {
