@@ -132,16 +132,6 @@ class _ConvFilteredLRelu(torch.autograd.Function):
                 # ... and with it <xs, dx> per input plane = the producer's <g, z> (see LayerLink)
                 dw, ctx.link_in.gz = _conv._wgrad_raw(dys, xs, cout, cin, ks, conv_pad, dots_with=w)
                 dw = dw.to(w.dtype)
-            elif WGRAD_STREAM and g.is_cuda:
-                # experiment (module switch, off): nothing in the rest of the backward pass reads a weight gradient, so it runs on a side
-                # stream beside the next layer's kernels (joined at the end of the pass: _join_side)
-                main, side = torch.cuda.current_stream(g.device), _side_stream(g.device)
-                side.wait_stream(main)
-                with torch.cuda.stream(side):
-                    dw = _conv._wgrad_raw(dys, xs, cout, cin, ks, conv_pad).to(w.dtype)
-                dys.record_stream(side)
-                xs.record_stream(side)
-                _queue_join(g.device, main)
             else:
                 dw = _conv._wgrad_raw(dys, xs, cout, cin, ks, conv_pad).to(w.dtype)
         return dx, dw, d_in, d_out, db, None, None, d_skip, d_next, None, None, None, None, None, None, None
@@ -150,29 +140,6 @@ class _ConvFilteredLRelu(torch.autograd.Function):
 # the demodulation gradient's <dys, y> from <g, z> where no strip of a plane could reach the clamp (tests switch it off to compare)
 HOMOGENEOUS_DOT = True
 
-# experiment (r06, profiles/r06_wgrad_stream_ab.txt): weight gradients on a side stream.  Off.
-WGRAD_STREAM = False
-_SIDE, _JOIN_QUEUED = {}, set()
-
-
-def _side_stream(device):
-    s = _SIDE.get(device)
-    if s is None:
-        s = _SIDE[device] = torch.cuda.Stream(device=device)
-    return s
-
-
-def _queue_join(device, main):
-    """Once per backward pass: when the pass ends, the stream it ran on waits for the side stream (whoever reads .grad next does so behind it)."""
-    if device in _JOIN_QUEUED:
-        return
-    _JOIN_QUEUED.add(device)
-
-    def _join():
-        _JOIN_QUEUED.discard(device)
-        main.wait_stream(_side_stream(device))
-
-    torch.autograd.Variable._execution_engine.queue_callback(_join)
 
 
 def _cfg(up, down, padding, gain, slope, clamp):

@@ -65,7 +65,6 @@ def parse():
     ap.add_argument('--no-launch-census', action='store_true',
                     help='skip the extra untimed step under the framework\'s kernel tracer (tools/pmc*.sh pass it: no second tracer beside rocprofv3, '
                          'no extra step in the kernel statistics)')
-    ap.add_argument('--wgrad-stream', action='store_true', help='experiment: the fused layers\' weight gradients on a side stream (fused_layer.WGRAD_STREAM)')
     ap.add_argument('--with-discriminator', action='store_true',
                     help='time the FULL iteration (D update with R1, then G update with the GAN term; SURVEY.md row f1) instead of the '
                          'generator step that BASELINE.json\'s metric names')
@@ -495,9 +494,6 @@ def main():
     if args.no_homogeneous_dot:
         from afcm_amd.torch_utils.ops import fused_layer
         fused_layer.HOMOGENEOUS_DOT = False
-    if args.wgrad_stream:
-        from afcm_amd.torch_utils.ops import fused_layer
-        fused_layer.WGRAD_STREAM = True
     step, inputs = build_step(args, dev, args.dtype, args.with_discriminator, use_dist, args.fp32_conv)
     r = timed_steps(step, inputs, args.steps, args.warmup, world, use_dist, not args.no_kernel_timing, args.kernel_timing_every, dev)
     elapsed, host_wall, host_cpu, timed_with_events = r['elapsed'], r['host_wall'], r['host_cpu'], r['timed_with_events']
