@@ -12,7 +12,7 @@ def load(d, name):
         for row in csv.DictReader(open(f)):
             if row['Counter_Name'] == name:
                 k = row['Kernel_Name']
-                fam = ('filtered_lrelu' if 'flrelu_mfma_kernel' in k or 'flrelu_sep' in k or 'flrelu_wave_kernel' in k else 'conv2d_wgrad' if ('wgrad' in k and 'reduce' not in k) else 'conv2d' if 'conv2d_fwd' in k else None)
+                fam = ('filtered_lrelu' if 'flrelu_mfma_kernel' in k or 'flrelu_sep' in k or 'flrelu_wave_kernel' in k else 'conv2d_wgrad' if ('wgrad' in k and 'reduce' not in k) else 'conv2d' if ('conv2d_fwd' in k or 'conv2d_direct' in k) else None)
                 if fam:
                     acc[fam][0] += float(row['Counter_Value']); acc[fam][1] += 1
     return acc
