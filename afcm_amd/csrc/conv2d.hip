@@ -3313,16 +3313,19 @@ __global__ __launch_bounds__(256) void wgrad_reduce4_kernel(float* __restrict__ 
 // the pixel side.  For the layer below this is <g, z> -- the gradient of the styles its epilogue multiplied z by -- which r01-r05 read from
 // g and z themselves: a full pass over both tensors (312-624 MB per 276^2 layer, 50-118 us) for numbers that these slabs already hold
 // (27-38 MB, read here anyway).  Differs from the pixel-side dot product only by the 16-bit rounding of the STORED dx.
-// One workgroup per input channel i; wave q takes images q, q + 4, ...; lane = output row of a block of 64.
+// One workgroup (16 waves) per input channel i; wave q takes images q, q + 16, ...; lane = output row of a block of 64.
 template <typename T, int KK>
-__global__ __launch_bounds__(256) void wgrad_reduce_dots_kernel(float* __restrict__ dw, float* __restrict__ dots, const float* __restrict__ part,
-                                                                const float* __restrict__ w, int N, int O, int I, int splits_img) {
-    __shared__ float red[3][64][KK];
+__global__ __launch_bounds__(1024) void wgrad_reduce_dots_kernel(float* __restrict__ dw, float* __restrict__ dots, const float* __restrict__ part,
+                                                                 const float* __restrict__ w, int N, int O, int I, int splits_img) {
+    // 16 waves: wave q takes images q, q + 16, ... (one each at batch 16); lane = output row of a block of 64.  (r06, first form: 4 waves, four
+    // images each in turn -- 58 us for the 64 -> 64 layer's 38 MB of slabs where the plain reduction took 7.)
+    constexpr int NW = 16;
+    __shared__ float red[NW - 1][64][KK];
     const int i = blockIdx.x, lane = threadIdx.x & 63, q = threadIdx.x >> 6;
     const size_t slab = (size_t)O * I * KK;
-    float dotp[16];
+    float dotp[4];
 #pragma unroll
-    for (int k = 0; k < 16; k++) dotp[k] = 0.f;
+    for (int k = 0; k < 4; k++) dotp[k] = 0.f;
     for (int ob = 0; ob < O; ob += 64) {
         const int o = ob + lane;
         const bool live = o < O;
@@ -3331,8 +3334,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_dots_kernel(float* __restric
 #pragma unroll
         for (int t = 0; t < KK; t++) { wq[t] = live ? to_f32(from_f32<T>(w[e0 + t])) : 0.f; tot[t] = 0.f; }
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const int n = q + 4 * k;
+        for (int k = 0; k < 4; k++) {
+            const int n = q + NW * k;
             if (n >= N) break;                                  // (wave-uniform)
             float acc[KK];
 #pragma unroll
@@ -3355,12 +3358,17 @@ __global__ __launch_bounds__(256) void wgrad_reduce_dots_kernel(float* __restric
         __syncthreads();
         if (q == 0 && live) {
 #pragma unroll
-            for (int t = 0; t < KK; t++) dw[e0 + t] = tot[t] + red[0][lane][t] + red[1][lane][t] + red[2][lane][t];
+            for (int t = 0; t < KK; t++) {
+                float s = tot[t];
+#pragma unroll
+                for (int k = 0; k < NW - 1; k++) s += red[k][lane][t];
+                dw[e0 + t] = s;
+            }
         }
     }
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-        const int n = q + 4 * k;
+    for (int k = 0; k < 4; k++) {
+        const int n = q + NW * k;
         if (n >= N) break;
         float d = dotp[k];
 #pragma unroll
@@ -3964,7 +3972,7 @@ static int wgrad_impl(float* dw, float* workspace, const void* dy, const void* x
     if (rc != AFCM_OK) return rc;
     const long long numel = (long long)cout * cin * ks * ks;
     if (p.splits_img > 0) {
-        const dim3 rgrid((unsigned)cin), rblock(256);
+        const dim3 rgrid((unsigned)cin), rblock(1024);
 #define AFCM_RD(T) do { if (ks == 3) hipLaunchKernelGGL((wgrad_reduce_dots_kernel<T, 9>), rgrid, rblock, 0, st, dw, dots, (const float*)workspace, wref, n, cout, cin, p.splits_img); \
                         else hipLaunchKernelGGL((wgrad_reduce_dots_kernel<T, 1>), rgrid, rblock, 0, st, dw, dots, (const float*)workspace, wref, n, cout, cin, p.splits_img); } while (0)
         if (dtype == AFCM_F16) AFCM_RD(f16_t); else AFCM_RD(bf16_t);
