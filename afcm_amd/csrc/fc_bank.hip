@@ -30,9 +30,11 @@ struct FcArgs {
     float alpha, beta;
 };
 
-template <int NT>
-__global__ __launch_bounds__(256) void fc_act_fwd_kernel(FcArgs p) {
-    __shared__ fcx4 red[3][NT][64];
+// NW waves per workgroup split K (4; 16 for long rows: `fc_in`'s 4608-float rows on 64 workgroups x 4 waves kept 2 MB in flight -- 47 us for
+// its 18.9 MB)
+template <int NT, int NW>
+__global__ __launch_bounds__(64 * NW) void fc_act_fwd_kernel(FcArgs p) {
+    __shared__ fcx4 red[NW - 1][NT][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l15 = lane & 15, g = lane >> 4;
     const int o0 = blockIdx.x * 16;
@@ -53,7 +55,7 @@ __global__ __launch_bounds__(256) void fc_act_fwd_kernel(FcArgs p) {
     // 16 contraction indices per chunk; wave w takes a CONTIGUOUS quarter of the chunks (r06: interleaved by wave, a row's requests were 64
     // bytes every 256 -- fc_in's 18.9 MB weight matrix streamed at 0.34 TB/s; a wave now walks 512 contiguous bytes of each row per pass)
     const int chunks = K >> 4;
-    const int per = (chunks + 3) >> 2;
+    const int per = (chunks + NW - 1) / NW;
     const int c_end = min(chunks, (wave + 1) * per);
     constexpr int U = 8;                                        // chunks in flight per wave
     int c = wave * per;
@@ -102,7 +104,7 @@ __global__ __launch_bounds__(256) void fc_act_fwd_kernel(FcArgs p) {
         const int n = t * 16 + l15;
         fcx4 v = acc[t];
 #pragma unroll
-        for (int k = 0; k < 3; k++) v += red[k][t][lane];
+        for (int k = 0; k < NW - 1; k++) v += red[k][t][lane];
         fcx4 out;
 #pragma unroll
         for (int r = 0; r < 4; r++) {
@@ -333,11 +335,15 @@ extern "C" int afcm_fc_act_fwd(float* y, const float* x, const float* w, const f
     if (n > 64 || (cin & 15) != 0) return AFCM_E_NOKERNEL;
     AFCM_REQUIRE((((uintptr_t)x | (uintptr_t)w | (uintptr_t)y) & 15) == 0, "fc_act_fwd: pointers must be 16-byte aligned");
     FcArgs p{y, x, w, b, n, cin, cout, act, alpha, beta};
-    const dim3 grid((unsigned)cdiv(cout, 16)), block(256);
+    const dim3 grid((unsigned)cdiv(cout, 16));
     hipStream_t st = (hipStream_t)stream;
-    if (n <= 16) hipLaunchKernelGGL((fc_act_fwd_kernel<1>), grid, block, 0, st, p);
-    else if (n <= 32) hipLaunchKernelGGL((fc_act_fwd_kernel<2>), grid, block, 0, st, p);
-    else hipLaunchKernelGGL((fc_act_fwd_kernel<4>), grid, block, 0, st, p);
+    const bool wide = cin >= 2048 && n <= 32;                   // long rows: 16 waves share a row block's K range (64 rows: over the 128-register cap)
+#define AFCM_FC(NT) do { if (wide) hipLaunchKernelGGL((fc_act_fwd_kernel<NT, 16>), grid, dim3(1024), 0, st, p); \
+                         else hipLaunchKernelGGL((fc_act_fwd_kernel<NT, 4>), grid, dim3(256), 0, st, p); } while (0)
+    if (n <= 16) AFCM_FC(1);
+    else if (n <= 32) AFCM_FC(2);
+    else hipLaunchKernelGGL((fc_act_fwd_kernel<4, 4>), grid, dim3(256), 0, st, p);
+#undef AFCM_FC
     return hip_status(hipGetLastError());
 }
 
