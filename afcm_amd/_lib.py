@@ -119,6 +119,8 @@ SIGNATURES = {
     'afcm_conv2d_stride2': (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     'afcm_conv2d_pack_bank': (C.c_int, [C.POINTER(PackEntry), _i32, _i32, _i32, _vp]),
     'afcm_affine_bank_bwd': (C.c_int, [C.POINTER(AffineBank), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _vp, _vp, _vp, _vp]),
+    'afcm_pool_blocks_fwd': (C.c_int, [_vp, _vp, _i32, _i64, _i32, _i32, _vp]),
+    'afcm_pool_blocks_bwd': (C.c_int, [_vp, _vp, _i32, _i64, _i32, _i32, _vp]),
     'afcm_l1_partials': (C.c_int, [_vp, _vp, _vp, _i64, _i32, _f32, _vp]),
     'afcm_l1_grad': (C.c_int, [_vp, _vp, _vp, _vp, _i64, _f32, _vp]),
     'afcm_axpy_planes': (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i64, _i32, _vp]),

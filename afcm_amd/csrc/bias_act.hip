@@ -200,3 +200,66 @@ extern "C" int afcm_bias_act(void* y, const void* x, const void* b, const void* 
         default: return launch_bias_act<bf16_t>(p, act, st);
     }
 }
+
+
+// ---- block mean of a plane (r06): AdaptiveAvgPool2d((4, 4)) of the bottleneck (NET:636,683) when the plane divides evenly --------------------------
+// y[plane][by][bx] = mean of the (h / 4) x (w / 4) block, fp32, from a 16-bit or fp32 x; backward dx = gy[block] / (block size) in x's type.
+// The op-by-op form was a cast to fp32, a reshape + mean (46 us for 8192 planes of 36^2) and their three backward launches.
+namespace afcm {
+template <typename T>
+__global__ __launch_bounds__(256) void pool_blocks_fwd_kernel(float* __restrict__ y, const T* __restrict__ x, long long planes, int h, int w) {
+    // one wave per plane; lane = (block b = lane & 15, quarter = lane >> 4): a quarter of the block's elements each, then two shuffles
+    const long long plane = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (plane >= planes) return;
+    const int lane = threadIdx.x & 63, b = lane & 15, sub = lane >> 4;
+    const int bh = h >> 2, bw = w >> 2, by = b >> 2, bx = b & 3;
+    const T* xp = x + plane * h * w + (size_t)(by * bh) * w + bx * bw;
+    float s = 0.f;
+    for (int e = sub; e < bh * bw; e += 4) {
+        const int r = e / bw, c = e - r * bw;
+        s += to_f32(xp[r * w + c]);
+    }
+    s += __shfl_xor(s, 16);
+    s += __shfl_xor(s, 32);
+    if (sub == 0) y[plane * 16 + b] = s / (float)(bh * bw);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void pool_blocks_bwd_kernel(T* __restrict__ dx, const float* __restrict__ gy, long long planes, int h, int w) {
+    const int bh = h >> 2, bw = w >> 2;
+    const float inv = 1.f / (float)(bh * bw);
+    const long long total = planes * h * w;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const long long plane = idx / (h * w);
+        const int rem = (int)(idx - plane * (h * w)), r = rem / w, c = rem - r * w;
+        dx[idx] = from_f32<T>(gy[plane * 16 + (r / bh) * 4 + c / bw] * inv);
+    }
+}
+}  // namespace afcm
+
+extern "C" int afcm_pool_blocks_fwd(float* y, const void* x, int32_t dtype, int64_t planes, int32_t h, int32_t w, void* stream) {
+    using namespace afcm;
+    AFCM_REQUIRE(y != nullptr && x != nullptr && planes > 0 && h >= 4 && w >= 4, "pool_blocks: empty input");
+    AFCM_REQUIRE(dtype == AFCM_F32 || dtype == AFCM_F16 || dtype == AFCM_BF16, "x must be float32, float16 or bfloat16");
+    if ((h & 3) || (w & 3)) return AFCM_E_NOKERNEL;
+    const dim3 grid((unsigned)((planes + 3) / 4)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == AFCM_F32) hipLaunchKernelGGL((pool_blocks_fwd_kernel<float>), grid, block, 0, st, y, (const float*)x, (long long)planes, h, w);
+    else if (dtype == AFCM_F16) hipLaunchKernelGGL((pool_blocks_fwd_kernel<f16_t>), grid, block, 0, st, y, (const f16_t*)x, (long long)planes, h, w);
+    else hipLaunchKernelGGL((pool_blocks_fwd_kernel<bf16_t>), grid, block, 0, st, y, (const bf16_t*)x, (long long)planes, h, w);
+    return hip_status(hipGetLastError());
+}
+
+extern "C" int afcm_pool_blocks_bwd(void* dx, const float* gy, int32_t dtype, int64_t planes, int32_t h, int32_t w, void* stream) {
+    using namespace afcm;
+    AFCM_REQUIRE(dx != nullptr && gy != nullptr && planes > 0 && h >= 4 && w >= 4, "pool_blocks: empty input");
+    AFCM_REQUIRE(dtype == AFCM_F32 || dtype == AFCM_F16 || dtype == AFCM_BF16, "dx must be float32, float16 or bfloat16");
+    if ((h & 3) || (w & 3)) return AFCM_E_NOKERNEL;
+    long long blocks = (planes * h * w + 1023) / 1024;
+    if (blocks > 4096) blocks = 4096;
+    const dim3 grid((unsigned)blocks), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == AFCM_F32) hipLaunchKernelGGL((pool_blocks_bwd_kernel<float>), grid, block, 0, st, (float*)dx, gy, (long long)planes, h, w);
+    else if (dtype == AFCM_F16) hipLaunchKernelGGL((pool_blocks_bwd_kernel<f16_t>), grid, block, 0, st, (f16_t*)dx, gy, (long long)planes, h, w);
+    else hipLaunchKernelGGL((pool_blocks_bwd_kernel<bf16_t>), grid, block, 0, st, (bf16_t*)dx, gy, (long long)planes, h, w);
+    return hip_status(hipGetLastError());
+}

@@ -88,6 +88,32 @@ class _ScaleCast(torch.autograd.Function):
         return _ScaleCast.apply(g, scale, dt), None, None
 
 
+class _PoolBlocks(torch.autograd.Function):
+    """[N, C, H, W] (16-bit or fp32 device tensor, H % 4 == W % 4 == 0) -> [N, C, 4, 4] fp32 block means (C ABI afcm_pool_blocks_fwd / _bwd): the
+    evenly dividing case of AdaptiveAvgPool2d((4, 4)) (NET:636,683) in one launch each way, straight from the 16-bit activations."""
+
+    @staticmethod
+    def forward(ctx, x):
+        from . import _lib
+        x = x.contiguous()
+        n, c, h, w = x.shape
+        y = torch.empty([n, c, 4, 4], dtype=torch.float32, device=x.device)
+        _lib.check(_lib.load().afcm_pool_blocks_fwd(y.data_ptr(), x.data_ptr(), _lib.dtype_code(x), n * c, h, w, _lib.stream_ptr(x)), 'pool_blocks_fwd')
+        ctx.cfg = (tuple(x.shape), x.dtype)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gy):
+        from . import _lib
+        shape, dtype = ctx.cfg
+        n, c, h, w = shape
+        dx = torch.empty(shape, dtype=dtype, device=gy.device)
+        gy = gy.to(torch.float32).contiguous()
+        _lib.check(_lib.load().afcm_pool_blocks_bwd(dx.data_ptr(), gy.data_ptr(), _lib._DTYPES[dtype], n * c, h, w, _lib.stream_ptr(gy)), 'pool_blocks_bwd')
+        return dx
+
+
 class FullyConnectedLayer(torch.nn.Module):
     """Equalised-learning-rate dense layer (NET:69-104)."""
 
@@ -454,8 +480,11 @@ class SynthesisNetwork(torch.nn.Module):
         atomic scatter kernel of adaptive_avg_pool2d_backward (0.38 ms per step at batch 16)."""
         h, w = x.shape[-2:]
         if h % 4 == 0 and w % 4 == 0:
+            if x.is_cuda and x.dtype in (torch.bfloat16, torch.float16, torch.float32):
+                return _PoolBlocks.apply(x)                      # fp32 block means straight from the activations: one launch each way
+            x = x.to(torch.float32)
             return x.reshape(x.shape[0], x.shape[1], 4, h // 4, 4, w // 4).mean(dim=(3, 5))
-        return self.pool(x)
+        return self.pool(x.to(torch.float32))
 
     def forward(self, ws, img_in, **layer_kwargs):
         _assert_shape(ws, [None, self.num_ws, self.w_dim])
@@ -483,7 +512,7 @@ class SynthesisNetwork(torch.nn.Module):
                 img_in, E_features[self.sizes[rev_idx]] = fused_layer.skip_fork(img_in)
 
         img_pool = self.e_16x16(img_in)
-        img_pool = self._pool4(img_pool.to(torch.float32))
+        img_pool = self._pool4(img_pool)                         # (fp32 out)
         img_pool = self.fc_in(img_pool.flatten(1))
         img_global = self.dropout(img_pool)
 

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define AFCM_ABI_VERSION 13  /* 13 (r06): + afcm_noop, afcm_adam_multi_capturable, afcm_conv2d_wgrad_dots_ld, afcm_mapping_input_bwd_workspace_bytes, afcm_axpy_planes, afcm_l1_partials, afcm_l1_grad, afcm_fc_act_fwd / _bwd, afcm_mapping_input_fwd / _bwd (additions only; see the end of this header for the r06 entry points).  12 (r05): + afcm_conv2d_block_k_ks, afcm_conv2d_pack_weights_bk; the packed layout's K-chunk depends on (dtype, kernel size): 16-bit 3x3 images are [nkc][9][rows_pad][32] for the v_mfma 16x16x32 kernel (the pack / conv entry points keep their signatures).  11 (r04): + afcm_amax_bits, afcm_split16, afcm_conv2d_pack_split, afcm_conv2d_split, afcm_unscale, afcm_plane_dot_parts (additions only).  10 (r04): + afcm_filtered_lrelu_args.clamp_flags (appended), afcm_plane_dot_gated_ld; the runtime getenv switches are gone.  9 (r03): + afcm_affine_bank_*, afcm_modulation_bank_*, afcm_conv2d_pack_bank, afcm_conv2d_stride2 (additions only; every v8 entry point and struct is unchanged) */
+#define AFCM_ABI_VERSION 13  /* 13 (r06): + afcm_noop, afcm_pool_blocks_fwd / _bwd, afcm_adam_multi_capturable, afcm_conv2d_wgrad_dots_ld, afcm_mapping_input_bwd_workspace_bytes, afcm_axpy_planes, afcm_l1_partials, afcm_l1_grad, afcm_fc_act_fwd / _bwd, afcm_mapping_input_fwd / _bwd (additions only; see the end of this header for the r06 entry points).  12 (r05): + afcm_conv2d_block_k_ks, afcm_conv2d_pack_weights_bk; the packed layout's K-chunk depends on (dtype, kernel size): 16-bit 3x3 images are [nkc][9][rows_pad][32] for the v_mfma 16x16x32 kernel (the pack / conv entry points keep their signatures).  11 (r04): + afcm_amax_bits, afcm_split16, afcm_conv2d_pack_split, afcm_conv2d_split, afcm_unscale, afcm_plane_dot_parts (additions only).  10 (r04): + afcm_filtered_lrelu_args.clamp_flags (appended), afcm_plane_dot_gated_ld; the runtime getenv switches are gone.  9 (r03): + afcm_affine_bank_*, afcm_modulation_bank_*, afcm_conv2d_pack_bank, afcm_conv2d_stride2 (additions only; every v8 entry point and struct is unchanged) */
 
 enum { AFCM_F32 = 0, AFCM_F16 = 1, AFCM_BF16 = 2 };
 enum { AFCM_OK = 0, AFCM_E_NOKERNEL = -1, AFCM_E_INVALID = -2 };
@@ -437,6 +437,11 @@ int afcm_conv2d_split(float* y, const void* x_parts, const void* wpacked, const 
  * ---------------------------------------------------------------------------------------- */
 int afcm_conv2d_stride2(void* y, const void* x, const void* wpacked, int32_t dtype, int32_t n, int32_t cin, int32_t cout, int32_t h, int32_t w,
                         int32_t pad, int32_t rows_pad, void* stream);
+
+/* AdaptiveAvgPool2d((4, 4)) of the bottleneck (NET:636,683) for planes that divide evenly (r06): y [planes][4][4] fp32 = block means of x
+ * [planes][h][w] (16-bit or fp32; h % 4 == w % 4 == 0, else AFCM_E_NOKERNEL), and its backward dx = gy[block] / block size in x's type. */
+int afcm_pool_blocks_fwd(float* y, const void* x, int32_t dtype, int64_t planes, int32_t h, int32_t w, void* stream);
+int afcm_pool_blocks_bwd(void* dx, const float* gy, int32_t dtype, int64_t planes, int32_t h, int32_t w, void* stream);
 
 /* The generator's L1 term `criterionL1(fake_B, real_B) * lambda_L1` (models/stylegan3_model.py:107; torch.nn.L1Loss, mean reduction) on fp32 tensors
  * (r06): partials[k] = weight / numel * sum over workgroup k's slice of |a - b| (blocks <= 1024; the caller adds them), and the gradient

@@ -134,7 +134,11 @@ def test_generator_gradients_with_the_kernels_branch_decisions_imposed(name, res
         d = a.cpu().double() - b.double()
         scale = max(1e-6, float(b.abs().max()))
         assert float(d.abs().max()) <= 1e-4 * scale, f'{name} grad {k}: max-abs {float(d.abs().max()):.3e} of scale {scale:.3g}'
-        assert float(d.norm() / b.double().norm().clamp_min(1e-30)) <= 1e-4, f'{name} grad {k}: relative L2'
+        # (relative L2 against the reference's norm, floored at the same 1e-6 per element as the max-abs scale: a gradient that is
+        # analytically zero -- the styles of the demodulated one-input-channel layer of the tiny generators: y ~ s / |s| -- is exactly 0 in
+        # the oracle and O(1e-14) rounding noise on the device, which no relative measure can grade)
+        floor = 1e-6 * float(np.sqrt(b.numel()))
+        assert float(d.norm()) <= 1e-4 * max(float(b.double().norm()), floor), f'{name} grad {k}: relative L2'
 
 
 def test_state_dict_keys_match_reference_full_width():

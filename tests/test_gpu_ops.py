@@ -757,3 +757,24 @@ def test_fp32_strip_kernel_hands_a_nan_on(layer):
     assert not (gn & ~near).any(), f'{layer}: {int(gn.sum())} NaN outputs, the oracle has {int(rn.sum())}'
     both = ~gn & ~rn
     _close(torch.where(both, got, torch.zeros_like(got)), torch.where(both, ref, torch.zeros_like(ref)), what=f'{layer} y beside the NaN')
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize('shape', [(16, 512, 36, 36), (2, 3, 8, 12), (1, 5, 4, 4)], ids=str)
+def test_pool_blocks_matches_adaptive_avg_pool(shape, dtype):
+    """networks_stylegan3._PoolBlocks (C ABI afcm_pool_blocks_fwd / _bwd): AdaptiveAvgPool2d((4, 4)) of planes that divide evenly (NET:636,683),
+    fp32 block means straight from the 16-bit activations, and its gradient, against aten on the same (rounded) values."""
+    from afcm_amd.networks_stylegan3 import _PoolBlocks
+    g = torch.Generator().manual_seed(shape[1])
+    x = torch.randn(shape, generator=g).to(dtype)
+    r = torch.randn([shape[0], shape[1], 4, 4], generator=g)
+    xr = x.float().requires_grad_(True)
+    ref = torch.nn.functional.adaptive_avg_pool2d(xr, (4, 4))
+    gref, = torch.autograd.grad((ref * r).sum(), [xr])
+    xg = x.cuda().requires_grad_(True)
+    got = _PoolBlocks.apply(xg)
+    ggot, = torch.autograd.grad((got * r.cuda()).sum(), [xg])
+    assert got.dtype == torch.float32 and ggot.dtype == dtype
+    assert float((got.cpu() - ref).abs().max()) <= 1e-6 * max(1.0, float(ref.abs().max()))
+    tol = {torch.bfloat16: 2.0 ** -8, torch.float16: 2.0 ** -11, torch.float32: 1e-6}[dtype]
+    assert float((ggot.float().cpu() - gref).abs().max()) <= tol * float(gref.abs().max())
