@@ -91,8 +91,11 @@ __global__ __launch_bounds__(256, 2) void conv2d_direct4_kernel(DirectConvParams
     // channel c: lane = column (64 of them; lanes 0, 1 also take columns 64, 65), one row per step -- the addresses advance by the row pitch
     // (as a flat index over (channel, row, column) every element paid two divisions by constants: 270 instructions per wave)
     {
+        // (buffer loads: an element outside the image -- a row above / below it, a column left / right of it, a channel >= Cin -- gets the
+        // out-of-range offset and reads as zero: no branch around a load.  As `cond ? row[ix] : 0` every row was a divergent branch.)
         const int c = wave;
-        const unsigned short* xc = (const unsigned short*)p.x + ((size_t)n * p.Cin + min(c, p.Cin - 1)) * p.H * p.ldx;
+        const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)((const unsigned short*)p.x + (size_t)n * p.Cin * p.H * p.ldx), 0,
+                                                                              p.Cin * p.H * p.ldx * 2, 0x00020000);
         const int ix = x0 - p.pad + lane, ix2 = x0 - p.pad + 64 + lane;
         const bool cok = c < p.Cin && (unsigned)ix < (unsigned)p.W, cok2 = c < p.Cin && lane < 2 && (unsigned)ix2 < (unsigned)p.W;
         unsigned short v[kDcPR], v2[kDcPR];
@@ -100,9 +103,9 @@ __global__ __launch_bounds__(256, 2) void conv2d_direct4_kernel(DirectConvParams
         for (int pr = 0; pr < kDcPR; pr++) {
             const int iy = y0 - p.pad + pr;
             const bool rok = (unsigned)iy < (unsigned)p.H;
-            const unsigned short* row = xc + (size_t)(rok ? iy : 0) * p.ldx;
-            v[pr] = (rok && cok) ? row[ix] : (unsigned short)0;
-            v2[pr] = (rok && cok2) ? row[ix2] : (unsigned short)0;
+            const unsigned base = (unsigned)((c * p.H + iy) * p.ldx) * 2u;
+            v[pr] = __builtin_amdgcn_raw_buffer_load_b16(xrs, (rok && cok) ? base + (unsigned)ix * 2u : 0x80000000u, 0, 0);
+            v2[pr] = __builtin_amdgcn_raw_buffer_load_b16(xrs, (rok && cok2) ? base + (unsigned)ix2 * 2u : 0x80000000u, 0, 0);
         }
 #pragma unroll
         for (int pr = 0; pr < kDcPR; pr++) {
@@ -241,7 +244,8 @@ __global__ __launch_bounds__(256, 2) void conv2d_wgrad_direct4_kernel(DirectWgra
         {
             // wave c stages channel c: lane j loads x[.., x0 - pad + j] (lanes 0, 1 also + 64) row by row and writes it into the three copies
             const int c = wave;
-            const unsigned short* xc = (const unsigned short*)p.x + ((size_t)n * p.Cin + min(c, p.Cin - 1)) * p.H * p.ldx;
+            const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)((const unsigned short*)p.x + (size_t)n * p.Cin * p.H * p.ldx), 0,
+                                                                                  p.Cin * p.H * p.ldx * 2, 0x00020000);
             const int ix = x0 - p.pad + lane, ix2 = ix + 64;
             const bool cok = c < p.Cin && (unsigned)ix < (unsigned)p.W, cok2 = c < p.Cin && lane < 2 && (unsigned)ix2 < (unsigned)p.W;
             unsigned short v[kDwPR], v2[kDwPR];
@@ -249,9 +253,9 @@ __global__ __launch_bounds__(256, 2) void conv2d_wgrad_direct4_kernel(DirectWgra
             for (int pr = 0; pr < kDwPR; pr++) {
                 const int iy = y0 - p.pad + pr;
                 const bool rok = (unsigned)iy < (unsigned)p.H;
-                const unsigned short* row = xc + (size_t)(rok ? iy : 0) * p.ldx;
-                v[pr] = (rok && cok) ? row[ix] : (unsigned short)0;
-                v2[pr] = (rok && cok2) ? row[ix2] : (unsigned short)0;
+                const unsigned base = (unsigned)((c * p.H + iy) * p.ldx) * 2u;
+                v[pr] = __builtin_amdgcn_raw_buffer_load_b16(xrs, (rok && cok) ? base + (unsigned)ix * 2u : 0x80000000u, 0, 0);
+                v2[pr] = __builtin_amdgcn_raw_buffer_load_b16(xrs, (rok && cok2) ? base + (unsigned)ix2 * 2u : 0x80000000u, 0, 0);
             }
 #pragma unroll
             for (int pr = 0; pr < kDwPR; pr++)
@@ -262,7 +266,13 @@ __global__ __launch_bounds__(256, 2) void conv2d_wgrad_direct4_kernel(DirectWgra
                 }
         }
         __syncthreads();
-        const unsigned short* dyn = (const unsigned short*)p.dy + (size_t)n * p.Cout * p.P * p.lddy;
+        // dy through a buffer descriptor over this image: rows o >= Cout lie behind its end and read as zero; a lane whose 8 columns start at or
+        // past Q gets the out-of-range offset; the tail of the row's last granule (columns >= Q: the next row's head or a pitched row's
+        // padding) is masked pair by pair -- no branch around a load (the first form's conditional loads were 877 scalar instructions of
+        // exec-mask bookkeeping per row)
+        const int dplane = p.P * p.lddy;
+        const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc((void*)((const unsigned short*)p.dy + (size_t)n * p.Cout * dplane), 0,
+                                                                              p.Cout * dplane * 2, 0x00020000);
 #pragma unroll 1
         for (int i = 0; i < kDwRows / 4; i++) {
             const int pr0 = wave + 4 * i, oy = y0 + pr0;
@@ -271,26 +281,19 @@ __global__ __launch_bounds__(256, 2) void conv2d_wgrad_direct4_kernel(DirectWgra
             for (int half = 0; half < 2; half++) {
                 const int q = x0 + 32 * half + 8 * g;          // this lane's 8 output columns q .. q + 7
                 if (x0 + 32 * half >= p.Q) break;              // (wave-uniform)
-                // B = dy[o = 16 ot + l15][oy][q ..]: 16 bytes; columns >= Q (the next row's head or a pitched row's padding) are zeroed
+                const int nlive = p.Q - q;                     // (>= 8: all; <= 0: none; even)
+                const unsigned voff = nlive > 0 ? (unsigned)((l15 * dplane + oy * p.lddy + q) * 2) : 0x80000000u;
+                unsigned dm[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) dm[k] = nlive >= 2 * k + 2 ? 0xffffffffu : 0u;
                 frag b[4];
-                const int nlive = min(8, p.Q - q);             // (<= 0: nothing)
 #pragma unroll
                 for (int ot = 0; ot < 4; ot++) {
-                    const int o = ot * 16 + l15;
-                    union { uint4 u; frag f; unsigned d[4]; } w;
-                    w.u = make_uint4(0u, 0u, 0u, 0u);
-                    if (o < p.Cout && nlive > 0) {
-                        const unsigned short* src = dyn + ((size_t)o * p.P + oy) * p.lddy + q;
-                        if (nlive == 8 && (((uintptr_t)src) & 3) == 0) {
-                            typedef unsigned u32x4a4 __attribute__((ext_vector_type(4), aligned(4)));
-                            const u32x4a4 ld = *(const u32x4a4*)src;
-                            w.d[0] = ld.x; w.d[1] = ld.y; w.d[2] = ld.z; w.d[3] = ld.w;
-                        } else {
+                    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+                    union { u32x4 u; frag f; } w;
+                    w.u = __builtin_amdgcn_raw_buffer_load_b128(drs, voff, ot * 16 * dplane * 2, 0);
 #pragma unroll
-                            for (int k = 0; k < 4; k++)
-                                if (2 * k + 2 <= nlive) w.d[k] = *(const unsigned*)(src + 2 * k);       // (even widths: whole pairs)
-                        }
-                    }
+                    for (int k = 0; k < 4; k++) w.u[k] &= dm[k];
                     b[ot] = w.f;
                 }
 #pragma unroll
