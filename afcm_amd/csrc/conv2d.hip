@@ -65,8 +65,6 @@ static inline int conv_bk(int dtype, int ks);
 // conv2d_direct.hip: 16-bit 3x3 convs with at most four input channels (the generator's first layer)
 int conv2d_direct_small_cin(const void* x, void* y, const void* wp, const float* oscale, const float* obias, int dtype, int n, int cin, int cout,
                             int h, int w, int pad, int rows_pad, int bk, int ldx, int ldy, hipStream_t st);
-int conv2d_wgrad_direct_small_cin(float* workspace, const void* dy, const void* x, int dtype, int n, int cin, int cout, int h, int w, int pad,
-                                  int lddy, int ldx, int max_slabs, int* slabs, hipStream_t st);
 #ifndef AFCM_CONV_DIRECT4
 #define AFCM_CONV_DIRECT4 1        // 0: the implicit-GEMM kernels for every layer (A/B builds)
 #endif
@@ -3893,24 +3891,6 @@ static int wgrad_impl(float* dw, float* workspace, const void* dy, const void* x
     p.lddy = dy_pitch ? dy_pitch : p.Q; p.ldx = x_pitch ? x_pitch : w;
     const bool pitched = p.lddy != p.Q || p.ldx != w;
     AFCM_REQUIRE(!pitched || (p.lddy >= p.Q && p.ldx >= w && ((p.lddy | p.ldx) & 1) == 0), "conv2d_wgrad: row pitches %d / %d must be even and cover the widths %d / %d", p.lddy, p.ldx, p.Q, w);
-    if (AFCM_CONV_DIRECT4 && dots == nullptr && dtype != AFCM_F32 && ks == 3 && pad == 2 && cin <= 4 && cout <= 64) {
-        // a handful of input channels: pixels as the contraction index, (channel, tap) as rows (conv2d_direct.hip); <= 256 partial slabs
-        // (what afcm_conv2d_wgrad_splits sizes the workspace for on a one-tile layer), the general slab reduction
-        int nslabs = 0;
-        const int cap = afcm_conv2d_wgrad_splits(n, cout, cin, p.P);
-        int rc = conv2d_wgrad_direct_small_cin(workspace, dy, x, dtype, n, cin, cout, h, w, pad, p.lddy, p.ldx, cap < 256 ? cap : 256, &nslabs, (hipStream_t)stream);
-        if (rc != AFCM_OK) return rc;
-        const long long numel = (long long)cout * cin * 9;
-        const WgradSlabs slabs{cin, 9, 1, 1, nslabs, nslabs};
-        if ((numel & 3) == 0 && (((uintptr_t)dw | (uintptr_t)workspace) & 15) == 0 && nslabs >= 64) {
-            hipLaunchKernelGGL(wgrad_reduce4_kernel<16>, dim3((unsigned)cdiv(numel / 4, 16)), dim3(256), 0, (hipStream_t)stream, dw, (const float*)workspace, numel / 4, slabs);
-        } else {
-            long long rb = (numel + 255) / 256;
-            if (rb > 2048) rb = 2048;
-            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)rb), dim3(256), 0, (hipStream_t)stream, dw, (const float*)workspace, numel, slabs);
-        }
-        return hip_status(hipGetLastError());
-    }
     const int R = wgrad_rows_per_step(dtype);
     p.qchunks = cdiv(p.Q, kWgKQ);
     p.rowgroups = cdiv(p.P, R);

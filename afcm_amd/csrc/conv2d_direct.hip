@@ -15,6 +15,7 @@
 //     accumulator sets of a lane are then four consecutive pixels of one channel row -- an 8-byte store per lane, 128 contiguous
 //     bytes per 16 lanes, with no transposition through LDS;
 //   * the twelve weight fragments (3 filter rows x 4 blocks of 16 output channels) stay in registers for the workgroup's life.
+// (A weight-gradient kernel in the same spirit was built and measured -- no faster than the general one: docs/experiments/r06_wgrad_direct4.hip.txt.)
 // Bound by its output stream: algorithmic bytes = x + y (SURVEY.md 8d prices the conv by flops; this layer's floor is HBM).
 #include <type_traits>
 #include "flrelu_mfma_common.h"      // pack2<T>: one v_cvt_pk of exactly a pair
@@ -191,172 +192,5 @@ int conv2d_direct_small_cin(const void* x, void* y, const void* wp, const float*
     return hip_status(hipGetLastError());
 }
 
-
-// ---- weight gradient of the same layer (r06) -----------------------------------------------------------------------------------------------
-// dW[o][c][r][s] = sum_{n, p, q} dy[n][o][p][q] x[n][c][p + r - pad][q + s - pad], cin <= 4, cout <= 64: 5.7 GFLOP over a 158 MB dy.  The general
-// kernel pads the 4 channels to a 64-column tile (16 x the products, 61 us).  Here the pixels are the contraction index of a
-// v_mfma_f32_16x16x32: D[(c, tap)][o] += A[(c, tap)][32 pixels] B[32 pixels][o] with
-//   * B = dy straight from global memory (a lane's 8 consecutive pixels of one channel row: one 16-byte load, every byte of dy read once);
-//   * A = x from LDS: the patch is staged as THREE copies per channel, shifted by the tap column s = 0, 1, 2, so that the 8 pixels a lane
-//     needs for tap (r, s) start on a 16-byte boundary in copy s (one ds_read_b128; from a single copy they would start at 2-byte offsets);
-//   * the 36 (c, tap) rows as three 16-row tiles x four 16-channel tiles = 12 MFMAs per 32 pixels, 48 accumulator registers.
-// Persistent workgroups (<= 256: the slab count of afcm_conv2d_wgrad_splits for a one-tile layer) walk the image tiles and write one partial
-// dW each -- [workgroup][o][c][tap], the layout of the general kernel's split-K slabs, summed by the same reduction kernel.
-struct DirectWgradParams {
-    const void* dy; const void* x; float* part;
-    int N, Cin, Cout, H, W, P, Q, pad, lddy, ldx, tilesX, tilesY, tiles;
-};
-
-constexpr int kDwRows = 16, kDwCols = 64, kDwPR = kDwRows + 2;
-
-template <typename T>
-__global__ __launch_bounds__(256, 2) void conv2d_wgrad_direct4_kernel(DirectWgradParams p) {
-    typedef DcMfma<T> M;
-    typedef typename M::frag frag;
-    typedef __attribute__((ext_vector_type(4))) float f32x4;
-    // [copy s][channel][patch row][64 columns]: copy s holds x[.., x0 - pad + s + j] at column j
-    __shared__ __attribute__((aligned(16))) unsigned short xs[3][4][kDwPR][kDwCols];
-    __shared__ f32x4 red[12][64];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l15 = lane & 15, g = lane >> 4;
-
-    // this lane's three (channel, tap) rows: idx = 16 ct + l15 = 9 c + 3 r + s (< 9 Cin), else a zero row
-    int aoff[3];                                               // element offset of (copy s, channel c, patch row r, column 8 g) or -1
-#pragma unroll
-    for (int ct = 0; ct < 3; ct++) {
-        const int idx = 16 * ct + l15, c = idx / 9, tap = idx - 9 * c, r = tap / 3, s = tap - 3 * r;
-        aoff[ct] = (idx < 9 * p.Cin) ? ((s * 4 + c) * kDwPR + r) * kDwCols + 8 * g : -1;
-    }
-    f32x4 acc[3][4];
-#pragma unroll
-    for (int ct = 0; ct < 3; ct++)
-#pragma unroll
-        for (int ot = 0; ot < 4; ot++) acc[ct][ot] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    for (int t = blockIdx.x; t < p.tiles; t += gridDim.x) {
-        int bid = t;
-        const int tx = bid % p.tilesX; bid /= p.tilesX;
-        const int ty = bid % p.tilesY;
-        const int n = bid / p.tilesY;
-        const int y0 = ty * kDwRows, x0 = tx * kDwCols;
-        __syncthreads();                                       // (the previous tile's reads of the patch are done)
-        {
-            // wave c stages channel c: lane j loads x[.., x0 - pad + j] (lanes 0, 1 also + 64) row by row and writes it into the three copies
-            const int c = wave;
-            const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)((const unsigned short*)p.x + (size_t)n * p.Cin * p.H * p.ldx), 0,
-                                                                                  p.Cin * p.H * p.ldx * 2, 0x00020000);
-            const int ix = x0 - p.pad + lane, ix2 = ix + 64;
-            const bool cok = c < p.Cin && (unsigned)ix < (unsigned)p.W, cok2 = c < p.Cin && lane < 2 && (unsigned)ix2 < (unsigned)p.W;
-            unsigned short v[kDwPR], v2[kDwPR];
-#pragma unroll
-            for (int pr = 0; pr < kDwPR; pr++) {
-                const int iy = y0 - p.pad + pr;
-                const bool rok = (unsigned)iy < (unsigned)p.H;
-                const unsigned base = (unsigned)((c * p.H + iy) * p.ldx) * 2u;
-                v[pr] = __builtin_amdgcn_raw_buffer_load_b16(xrs, (rok && cok) ? base + (unsigned)ix * 2u : 0x80000000u, 0, 0);
-                v2[pr] = __builtin_amdgcn_raw_buffer_load_b16(xrs, (rok && cok2) ? base + (unsigned)ix2 * 2u : 0x80000000u, 0, 0);
-            }
-#pragma unroll
-            for (int pr = 0; pr < kDwPR; pr++)
-#pragma unroll
-                for (int s = 0; s < 3; s++) {
-                    if (lane >= s) xs[s][c][pr][lane - s] = v[pr];
-                    if (lane < 2 && 64 + lane - s < kDwCols) xs[s][c][pr][64 + lane - s] = v2[pr];      // (s = 1: column 63 from lane 0; s = 2: 62, 63)
-                }
-        }
-        __syncthreads();
-        // dy through a buffer descriptor over this image: rows o >= Cout lie behind its end and read as zero; a lane whose 8 columns start at or
-        // past Q gets the out-of-range offset; the tail of the row's last granule (columns >= Q: the next row's head or a pitched row's
-        // padding) is masked pair by pair -- no branch around a load (the first form's conditional loads were 877 scalar instructions of
-        // exec-mask bookkeeping per row)
-        const int dplane = p.P * p.lddy;
-        const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc((void*)((const unsigned short*)p.dy + (size_t)n * p.Cout * dplane), 0,
-                                                                              p.Cout * dplane * 2, 0x00020000);
-#pragma unroll 1
-        for (int i = 0; i < kDwRows / 4; i++) {
-            const int pr0 = wave + 4 * i, oy = y0 + pr0;
-            if (oy >= p.P) break;                              // (wave-uniform)
-#pragma unroll
-            for (int half = 0; half < 2; half++) {
-                const int q = x0 + 32 * half + 8 * g;          // this lane's 8 output columns q .. q + 7
-                if (x0 + 32 * half >= p.Q) break;              // (wave-uniform)
-                const int nlive = p.Q - q;                     // (>= 8: all; <= 0: none; even)
-                const unsigned voff = nlive > 0 ? (unsigned)((l15 * dplane + oy * p.lddy + q) * 2) : 0x80000000u;
-                unsigned dm[4];
-#pragma unroll
-                for (int k = 0; k < 4; k++) dm[k] = nlive >= 2 * k + 2 ? 0xffffffffu : 0u;
-                frag b[4];
-#pragma unroll
-                for (int ot = 0; ot < 4; ot++) {
-                    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-                    union { u32x4 u; frag f; } w;
-                    w.u = __builtin_amdgcn_raw_buffer_load_b128(drs, voff, ot * 16 * dplane * 2, 0);
-#pragma unroll
-                    for (int k = 0; k < 4; k++) w.u[k] &= dm[k];
-                    b[ot] = w.f;
-                }
-#pragma unroll
-                for (int ct = 0; ct < 3; ct++) {
-                    union { uint4 u; frag f; } a;
-                    a.u = make_uint4(0u, 0u, 0u, 0u);
-                    if (aoff[ct] >= 0) a.u = *(const uint4*)(&xs[0][0][0][0] + aoff[ct] + pr0 * kDwCols + 32 * half);
-#pragma unroll
-                    for (int ot = 0; ot < 4; ot++) acc[ct][ot] = M::mma(a.f, b[ot], acc[ct][ot]);
-                }
-            }
-        }
-    }
-    // ---- the four waves' partial tiles meet in LDS (one wave at a time: 12 KB), wave 0 writes the workgroup's slab [o][c][tap]
-    for (int k = 1; k < 4; k++) {
-        __syncthreads();
-        if (wave == k) {
-#pragma unroll
-            for (int ct = 0; ct < 3; ct++)
-#pragma unroll
-                for (int ot = 0; ot < 4; ot++) red[ct * 4 + ot][lane] = acc[ct][ot];
-        }
-        __syncthreads();
-        if (wave == 0) {
-#pragma unroll
-            for (int ct = 0; ct < 3; ct++)
-#pragma unroll
-                for (int ot = 0; ot < 4; ot++) acc[ct][ot] += red[ct * 4 + ot][lane];
-        }
-    }
-    if (wave != 0) return;
-    float* out = p.part + (size_t)blockIdx.x * p.Cout * p.Cin * 9;
-#pragma unroll
-    for (int ct = 0; ct < 3; ct++)
-#pragma unroll
-        for (int ot = 0; ot < 4; ot++) {
-            const int o = ot * 16 + l15;                       // D[i = 4 g + reg][j = l15]: row = (c, tap) index 16 ct + 4 g + reg, column = o
-#pragma unroll
-            for (int reg = 0; reg < 4; reg++) {
-                const int idx = 16 * ct + 4 * g + reg;
-                if (o < p.Cout && idx < 9 * p.Cin) out[(size_t)o * p.Cin * 9 + idx] = acc[ct][ot][reg];
-            }
-        }
-}
-
-// host side: called by the weight-gradient entry points for 16-bit 3x3 pad-2 layers with cin <= 4, cout <= 64; returns the number of slabs
-// written to `workspace` (<= max_slabs) through *slabs, the caller runs the slab reduction
-int conv2d_wgrad_direct_small_cin(float* workspace, const void* dy, const void* x, int dtype, int n, int cin, int cout, int h, int w, int pad,
-                                  int lddy, int ldx, int max_slabs, int* slabs, hipStream_t st) {
-    DirectWgradParams p;
-    p.dy = dy; p.x = x; p.part = workspace;
-    p.N = n; p.Cin = cin; p.Cout = cout; p.H = h; p.W = w; p.pad = pad;
-    p.P = h + 2 * pad - 2; p.Q = w + 2 * pad - 2;
-    p.lddy = lddy; p.ldx = ldx;
-    p.tilesX = cdiv(p.Q, kDwCols); p.tilesY = cdiv(p.P, kDwRows);
-    const long long tiles = (long long)p.tilesX * p.tilesY * n;
-    if (tiles <= 0 || tiles >= (1ll << 31) || max_slabs < 1) return AFCM_E_NOKERNEL;
-    p.tiles = (int)tiles;
-    const int grid = (int)(tiles < max_slabs ? tiles : max_slabs);
-    *slabs = grid;
-    if (dtype == AFCM_F16) hipLaunchKernelGGL((conv2d_wgrad_direct4_kernel<f16_t>), dim3((unsigned)grid), dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((conv2d_wgrad_direct4_kernel<bf16_t>), dim3((unsigned)grid), dim3(256), 0, st, p);
-    return hip_status(hipGetLastError());
-}
 
 }  // namespace afcm

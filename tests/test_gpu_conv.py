@@ -778,31 +778,3 @@ def test_direct_conv_for_few_input_channels(case, dtype):
     cy, cx = h // 2 + pad, w // 2 + pad                         # output pixels (cy - r, cx - s), r, s in 0..2, see the element
     bad[max(cy - 2, 0):cy + 1, max(cx - 2, 0):cx + 1] = True
     assert bool(yn[0, :, bad].isnan().all()) and bool(torch.isfinite(yn[0][:, ~bad]).all()) and bool(torch.isfinite(yn[1:]).all())
-
-
-@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize('case', [(2, 4, 64, 276, 276), (1, 4, 64, 30, 34), (3, 3, 20, 17, 70), (16, 1, 64, 40, 130), (2, 2, 5, 5, 6)], ids=str)
-def test_direct_weight_gradient_for_few_input_channels(case, dtype):
-    """The weight gradient of a 3x3 pad-2 conv with cin <= 4 (encoder_0) on the direct kernel (pixels as the MFMA's contraction index, three
-    shifted copies of the patch in LDS, <= 256 partial slabs + the slab reduction) against float64 aten on the 16-bit operands; dense and
-    row-pitched dy (whose padding columns hold NaN: they must not be read into the sums)."""
-    from afcm_amd.torch_utils.ops import _rows
-    from afcm_amd.torch_utils.ops import conv2d as C
-    n, cin, cout, h, w = case
-    g = torch.Generator().manual_seed(h + w + cin)
-    x = torch.randn([n, cin, h, w], generator=g).to(dtype)
-    dy = torch.randn([n, cout, h + 2, w + 2], generator=g).to(dtype)
-    ref = torch.nn.grad.conv2d_weight(x.double(), (cout, cin, 3, 3), dy.double(), padding=2).float()
-    got = C._wgrad_raw(dy.cuda(), x.cuda(), cout, cin, 3, 2)
-    _close_rel(got, ref, 2e-5, 'dw (dense)')
-    dyp = _rows.empty(dy.shape, dtype, 'cuda')
-    full = _rows.whole_buffer(dyp)
-    if full is not None:
-        full.fill_(float('nan'))
-    dyp.copy_(dy)
-    xp = _rows.empty(x.shape, dtype, 'cuda')
-    fullx = _rows.whole_buffer(xp)
-    if fullx is not None:
-        fullx.fill_(float('nan'))
-    xp.copy_(x)
-    _close_rel(C._wgrad_raw(dyp, xp, cout, cin, 3, 2), ref, 2e-5, 'dw (row-pitched operands, NaN padding)')
