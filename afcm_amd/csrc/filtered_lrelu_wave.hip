@@ -264,6 +264,12 @@ __global__ __launch_bounds__(256, (wave_occupancy<UP, DOWN, TOW, TOH, SIGN, EPI>
     // column groups: the last output column block, cdiv(yw, 16) - 1, ends on X3 pair (DOWN / 2) cb + NDVK - 1
     const int ncb = (p.yw + 15) >> 4;
     const int ng = (DOWN / 2) * (ncb - 1) + G::NDVK;
+    // ... of which only the first ngc have to be COMPUTED (r06): the X3 pair of group gi covers upsampled columns [32 gi, 32 gi + 32), the
+    // plane's last output column reads up to column (yw - 1) DOWN + FD - 1, and a WRITE call owes the codes of every column block of
+    // the sign tensor.  The K windows of the last output column block reach NDVK pairs whatever the number of columns the plane has
+    // in it: with yw = 16 m + 4 (every plane of the 256^2 generator: 36, 52, 84, 148, 276) the last group -- of 4, 5, 7, 11, 19 --
+    // produced a pair that only padding columns read.  Those groups now run tail_group(): the down-x pass alone, on a zero pair.
+    const int ngc = min(ng, max(((p.yw - 1) * DOWN + G::FD - 1) / 32 + 1, SIGN == AFCM_SIGNS_WRITE ? ((p.swq >> 4) + G::NBG - 1) / G::NBG : 0));
     const int I0x = -floor_div(p.px0 - U0x, UP), I0y = -floor_div(p.py0 - U0y, UP);
     const int S0x = I0x - (I0x & 1);                                      // first input column touched (even: aligned dword pairs)
     const bool lastY = (ty == p.tilesY - 1);
@@ -796,6 +802,38 @@ __global__ __launch_bounds__(256, (wave_occupancy<UP, DOWN, TOW, TOH, SIGN, EPI>
         }
     };
 
+    // A group past the last computed one (gi >= ngc): its X3 pair lies wholly beyond the last upsampled column an output of the plane
+    // reads (and beyond the sign tensor): the pair is zero, what remains is the bookkeeping of group() around the down-x pass.
+    auto tail_group = [&](int gi, u32x4 (&hist)[G::NOB][G::NHIST], u32x4 (&cur)[G::NOB], u32x4 (&skw)[G::NOB]) __attribute__((always_inline)) {
+        const bool has_b = gi >= G::NDVK - 1 && (gi - (G::NDVK - 1)) % (DOWN / 2) == 0;
+        const int cb_b = (gi - (G::NDVK - 1)) / (DOWN / 2);
+        {
+            const int gp = gi - 1;
+            const bool prv_b = gp >= G::NDVK - 1 && (gp - (G::NDVK - 1)) % (DOWN / 2) == 0;
+            const int cb_p = (gp - (G::NDVK - 1)) / (DOWN / 2);
+            if (prv_b && ((cb_p & 3) == 3 || cb_p == ncb - 1)) flush(cb_p);
+        }
+        if (EPI & 2) {
+            if (has_b && (cb_b & 1) == 0) park_skip(skw);
+            const int gn = gi + 1;
+            const bool nxt_b = gn >= G::NDVK - 1 && (gn - (G::NDVK - 1)) % (DOWN / 2) == 0;
+            const int cb_n = (gn - (G::NDVK - 1)) / (DOWN / 2);
+            if (nxt_b && (cb_n & 1) == 0 && cb_n < ncb) load_skip(cb_n, skw);
+        }
+#pragma unroll
+        for (int ob = 0; ob < G::NOB; ob++) cur[ob] = (u32x4){0u, 0u, 0u, 0u};
+        if (has_b) {
+            u32x4 xw[G::NOB][G::NDVK];
+#pragma unroll
+            for (int ob = 0; ob < G::NOB; ob++) {
+#pragma unroll
+                for (int h = 0; h < G::NHIST; h++) xw[ob][h] = hist[ob][h];
+                xw[ob][G::NDVK - 1] = cur[ob];
+            }
+            phase_b(cb_b, xw);
+        }
+    };
+
     auto run_strip = [&](auto exact_c, auto lasty_c) __attribute__((always_inline)) -> bool {
         float amax = 0.f;
         unsigned anyc = 0;
@@ -838,15 +876,22 @@ __global__ __launch_bounds__(256, (wave_occupancy<UP, DOWN, TOW, TOH, SIGN, EPI>
 #pragma unroll
             for (int ob = 0; ob < G::NOB; ob++) alt[ob] = hist[ob][0];
 #pragma unroll 1
-            for (int gi = 0; gi < ng; gi += 2) {
+            for (int gi = 0; gi < ngc; gi += 2) {
                 group(gi, exact_c, lasty_c, raw, sg, reinterpret_cast<as_hist>(alt), cur, skw, amax, anyc);
-                if (gi + 1 >= ng) break;
+                if (gi + 1 >= ngc) break;
                 group(gi + 1, exact_c, lasty_c, raw, sg, reinterpret_cast<as_hist>(cur), alt, skw, amax, anyc);
+            }
+            // (the register sets keep trading places by the parity of the group)
+#pragma unroll 1
+            for (int gi = ngc; gi < ng; gi++) {
+                if ((gi & 1) == 0) tail_group(gi, reinterpret_cast<as_hist>(alt), cur, skw);
+                else tail_group(gi, reinterpret_cast<as_hist>(cur), alt, skw);
             }
         } else {
 #pragma unroll 1
             for (int gi = 0; gi < ng; gi++) {
-                group(gi, exact_c, lasty_c, raw, sg, hist, cur, skw, amax, anyc);
+                if (gi < ngc) group(gi, exact_c, lasty_c, raw, sg, hist, cur, skw, amax, anyc);
+                else tail_group(gi, hist, cur, skw);
 #pragma unroll
                 for (int ob = 0; ob < G::NOB; ob++) {
 #pragma unroll
