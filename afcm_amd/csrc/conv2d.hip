@@ -3115,7 +3115,11 @@ __global__ __launch_bounds__(512, 1) void conv2d_wgrad16g_kernel(WgradParams p) 
                         union { unsigned u[4]; frag_t f; } bw;
 #pragma unroll
                         for (int w = 0; w < 4; w++)
+#ifdef AFCM_WGRAD_EXPERIMENT_NOSHIFT    // timing experiment only (wrong results): 1 = no funnel shifts for the middle tap column, 2 = no register copies for the first either
+                            bw.u[w] = (sft == 0 && AFCM_WGRAD_EXPERIMENT_NOSHIFT < 2) ? d[w] : d[w + 1];
+#else
                             bw.u[w] = (sft == 0) ? d[w] : (sft == 1) ? __builtin_amdgcn_alignbyte(d[w + 1], d[w], 2) : d[w + 1];
+#endif
 #pragma unroll
                         for (int rr = 0; rr < R; rr++) {
                             const int r = xr - rr;
