@@ -117,6 +117,48 @@ def test_wave_kernels_clamp(lname, dtype, tol):
     assert rel <= 3 * tol, f'{lname} {dtype} clamp dx: relative L2 {rel:.3e}'
 
 
+# r06: column groups whose X3 pair no output of the plane reads run the down-x pass only (tail_group, csrc/filtered_lrelu_wave.hip).  Their number
+# depends on the plane's width modulo 16 (the generator's planes are all 16 m + 4 wide: one such group per strip): every residue class, incl. the
+# widths with NO such group (residues 12 .. 16) and the down-4 widths with TWO (residues <= 3), forward (codes written) and transposed (codes read).
+@pytest.mark.parametrize('lname,h', [('encoder_1', 20), ('encoder_1', 24), ('encoder_1', 28), ('encoder_1', 30), ('encoder_1', 32), ('encoder_1', 34),
+                                     ('encoder_1', 46), ('encoder_1', 66),
+                                     ('encoder_4', 18), ('encoder_4', 22), ('encoder_4', 38), ('encoder_4', 50), ('encoder_4', 54),
+                                     ('L3_52_512', 18), ('L3_52_512', 20), ('L3_52_512', 22), ('L3_52_512', 26), ('L3_52_512', 30)])
+def test_wave_kernels_plane_width_sweep(lname, h):
+    from afcm_amd.torch_utils.ops import filtered_lrelu as flr
+    from oracle import aten_ops as ops
+    from oracle import direct_np as dnp
+    L = _layer(lname)
+    dtype, tol = torch.float16, 6e-3
+    torch.manual_seed(h)
+    x = torch.randn(2, 3, h, h).to(dtype)
+    kw = dict(up=L['up'], down=L['down'], padding=L['padding'], gain=float(np.sqrt(2)), slope=0.2, clamp=256.0)
+    xr = x.float().requires_grad_(True)
+    ref = ops.filtered_lrelu(xr, fu=L['fu'], fd=L['fd'], b=None, **kw)
+    assert ref.shape[3] % 2 == 0, 'even plane widths only (matrix-core kernels)'
+    r = torch.randn_like(ref).to(dtype)
+    gref, = torch.autograd.grad((ref * r.float()).sum(), xr)
+    xg = x.cuda().requires_grad_(True)
+    got = flr.filtered_lrelu(xg, fu=L['fu'].cuda(), fd=L['fd'].cuda(), b=None, **kw)
+    assert got.shape == ref.shape and got.grad_fn.sign_layout == 2, 'expected the wave-autonomous kernels'
+    err = (got.float().cpu() - ref).abs().max().item()
+    assert err <= tol * max(1.0, ref.abs().max().item()), f'{lname} {h} (width {ref.shape[3]}) y: {err:.3e}'
+    s = got.grad_fn.saved_tensors[2].cpu().numpy()                      # (before the backward pass frees it)
+    ggot, = torch.autograd.grad((got.float() * r.cuda().float()).sum(), xg)
+    rel = ((ggot.float().cpu() - gref).norm() / gref.norm()).item()
+    assert rel <= 2 * tol, f'{lname} {h} (width {ref.shape[3]}) dx: relative L2 {rel:.3e}'
+    # every code of the sign tensor, also in the column blocks beyond the last column an output reads
+    u = dnp.upfirdn2d(x.float().numpy().astype(np.float64), L['fu'].numpy(), up=L['up'], padding=L['padding'], gain=float(L['up'] ** 2), flip_filter=False)
+    _, want = dnp.lrelu_codes(u, kw['gain'], kw['slope'], kw['clamp'])
+    sh = min(want.shape[2], 4 * s.shape[2])
+    codes = _decode_layout2(s, sh)
+    w = min(want.shape[3], codes.shape[3])
+    uu = u[:, :, :sh, :w]
+    safe = (np.abs(uu) > 4e-3 * max(1.0, np.abs(u).max())) | (uu == 0)
+    assert safe.mean() > 0.9
+    assert np.array_equal(codes[:, :, :, :w][safe], want[:, :, :sh, :w][safe])
+
+
 def test_wave_and_lds_tile_kernels_agree(monkeypatch):
     """Same call through both matrix-core families (the LDS-tile family is reached through its bias operand: b = 0): outputs and input gradients agree to 16-bit rounding; epilogue operands (skip, per-plane
     factors, per-tile output sums) behave identically."""
