@@ -842,9 +842,16 @@ __global__ __launch_bounds__(256, 2) void conv2d_fwd16_kernel(ConvParams p) {
 //   * the issue order is the source order: the loop is written as 72 steps (MO MFMAs, the read four steps ahead, a slice of the
 //     staging work) with a scheduling barrier after each.  Left to the scheduler (sched_group_barrier pipelines as in
 //     conv2d_fwd16_kernel) the MFMAs of different taps were reordered around the reads and every read was waited for at once.
-template <typename T, int BM_O, bool SPLIT = false>
+// FASTEPI (r06): tiles whose width is a multiple of 16 pixels on rows whose pitch is a multiple of 8 elements (the 276^2 / 278^2 and 256^2
+// planes of the generator: 8 x 32 and 4 x 64 tiles on 288- and 256-element rows).  A 16-pixel block of the tile then lies in ONE tile row,
+// so the row and column base of its two 8-pixel granules are wave-uniform: they are computed on the scalar unit and ride in the store's
+// scalar offset (the general form computes eight granule coordinates, validity and straddle flags per lane and tile: ~170 of the ~270
+// vector instructions of a 64-row epilogue), a granule never straddles a tile row or the pitched image row (no pair path), and the B
+// fragment bases of a tile are one vector add each (set_bbyte: 8 instead of ~64).  Same stores, same bytes.
+template <typename T, int BM_O, bool SPLIT = false, bool FASTEPI = false>
 __global__ __launch_bounds__(256, 2) void conv2d_fwd16x_kernel(ConvParams p) {
     static_assert(sizeof(T) == 2, "16-bit types only");
+    static_assert(!(SPLIT && FASTEPI), "the fp32-output epilogue has no fast form");
     typedef typename std::conditional<SPLIT, float, T>::type TO;      // output element
     // B fragments: a ring read BRING 16-pixel blocks ahead of their MFMAs.  MO = 4: four (a block = 64 MFMA cycles); MO = 2: three -- a block
     // is 32 cycles, but the three waves of a SIMD take turns, and the fourth slot is the register that decides between 168 (three waves
@@ -1002,6 +1009,18 @@ __global__ __launch_bounds__(256, 2) void conv2d_fwd16x_kernel(ConvParams p) {
         int lane_o = tid;                                    // (opaque: see stage_tile; from tid: one register less across the loop than tid AND lane)
         asm volatile("" : "+v"(lane_o));
         lane_o &= 63;
+        if constexpr (FASTEPI) {
+            // a 16-pixel block lies in one tile row: its row and first column are scalar
+            const unsigned lanepart = (unsigned)((lane_o & 15) * 16 + (lane_o >> 4) * PLANE_B);
+#pragma unroll
+            for (int ti = 0; ti < NT; ti++) {
+                const int b16 = wpx * 128 + ti * 16;
+                int py = (int)__umulhi((unsigned)b16, p.magicTW), px = b16 - py * p.TW;
+                if (b16 >= p.TH * p.TW) { py = 0; px = 0; }
+                bbyte[ti] = lanepart + (unsigned)((py * PWL + px + xoff) * 16 + buf * BUF_B);
+            }
+            return;
+        }
 #pragma unroll
         for (int ti = 0; ti < NT; ti++) {
             const int j = wpx * 128 + ti * 16 + (lane_o & 15);
@@ -1161,7 +1180,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_fwd16x_kernel(ConvParams p) {
             // -- ~3k issue cycles per wave and tile, a third of what a tile of a 64-channel layer has to issue at all.
             unsigned gbyte[8], gfullm = 0, slow_any = 0;
 #pragma unroll
-            for (int it = 0; it < 8; it++) {
+            for (int it = 0; it < (FASTEPI ? 0 : 8); it++) {
                 const int j0 = wpx * 128 + (2 * it + hh) * 8;
                 const int gpy = (int)__umulhi((unsigned)j0, p.magicTW), gpx = j0 - gpy * p.TW;
                 const int gy = y0 + gpy, gx = x0 + gpx;
@@ -1202,6 +1221,18 @@ __global__ __launch_bounds__(256, 2) void conv2d_fwd16x_kernel(ConvParams p) {
 #pragma unroll
                         for (int r = 0; r < 2; r++)
                             u.v[r] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ebuf + i4 * (16 * EROW) + rd_off[r]));
+                        if constexpr (FASTEPI) {
+                            // the block's row and first column on the scalar unit; lane half hh takes the second granule (+ 16 bytes)
+                            const int b16 = wpx * 128 + 16 * it;
+                            const int gpy = (int)__umulhi((unsigned)b16, p.magicTW), gpxs = b16 - gpy * p.TW;
+                            const int gy = y0 + gpy, gxs = x0 + gpxs;
+                            if (b16 < p.TH * p.TW && gy < p.P && gxs < p.Q) {          // wave-uniform
+                                unsigned vo = obyte + 16u * (unsigned)hh;
+                                if (gxs + 8 >= p.Q && hh) vo = kGOut;                    // (uniform test first: the image's last granule pair only)
+                                __builtin_amdgcn_raw_buffer_store_b128(u.q, yrs, vo, (gy * p.ldy + gxs) * 2, 0);
+                            }
+                            continue;
+                        }
                         const bool full = (gfullm >> it) & 1;
                         // (no branch around the common store: a lane on the pair path sends its 16 bytes out of range)
                         __builtin_amdgcn_raw_buffer_store_b128(u.q, yrs, full ? obyte + gbyte[it] : kGOut, 0, 0);
@@ -3438,6 +3469,14 @@ static int conv_persistent_grid(long long items, int per_cu) {
     return (int)(items < slots ? items : slots);
 }
 
+// conv2d_fwd16x_kernel<.., FASTEPI>: tile widths that are multiples of 16 on output rows whose pitch is a multiple of 8 elements
+#ifndef AFCM_CONV_FASTEPI
+#define AFCM_CONV_FASTEPI 1          // (0: the general epilogue everywhere; A/B builds)
+#endif
+static bool conv_fast_epilogue(const ConvParams& p) {
+    return AFCM_CONV_FASTEPI && (p.TW & 15) == 0 && (p.ldy & 7) == 0 && (p.Q & 1) == 0;
+}
+
 // o_base / row_blocks: the launch covers output rows [o_base, o_base + row_blocks * BM_O) (16-bit 3x3 16x16x32 kernel only; 0: all rows)
 template <typename T, int BM_O>
 static int launch_conv(ConvParams p, int ks, hipStream_t st, int o_base = 0, int row_blocks = 0) {
@@ -3451,7 +3490,9 @@ static int launch_conv(ConvParams p, int ks, hipStream_t st, int o_base = 0, int
 #if defined(AFCM_CONV_AB) || AFCM_CONV_X16
             if (AFCM_X16_ON) {
                 // (the 64-row kernel is persistent: one round of three workgroups per CU; the 128-row kernel takes one item per workgroup)
-                hipLaunchKernelGGL((conv2d_fwd16x_kernel<T, BM_O>), BM_O == 64 ? dim3((unsigned)conv_persistent_grid(blocks, 3)) : grid, block, 0, st, p);
+                const dim3 g16 = BM_O == 64 ? dim3((unsigned)conv_persistent_grid(blocks, 3)) : grid;
+                if (conv_fast_epilogue(p)) hipLaunchKernelGGL((conv2d_fwd16x_kernel<T, BM_O, false, true>), g16, block, 0, st, p);
+                else hipLaunchKernelGGL((conv2d_fwd16x_kernel<T, BM_O>), g16, block, 0, st, p);
                 return hip_status(hipGetLastError());
             }
 #endif
@@ -3683,7 +3724,10 @@ extern "C" int afcm_conv2d_ld(void* y, const void* x, const void* wpacked, const
         AFCM_REQUIRE(blocks > 0 && blocks < (1ll << 31), "conv2d: grid of %lld blocks is out of range", blocks);
         p.total_blocks = (int)blocks; p.o_base = 0;
         const dim3 g96((unsigned)(AFCM_CONV_BM96_PERSIST ? conv_persistent_grid(blocks, 2) : blocks));
-        if (dtype == AFCM_F16) hipLaunchKernelGGL((conv2d_fwd16x_kernel<f16_t, 96>), g96, dim3(256), 0, st, p);
+        if (conv_fast_epilogue(p)) {
+            if (dtype == AFCM_F16) hipLaunchKernelGGL((conv2d_fwd16x_kernel<f16_t, 96, false, true>), g96, dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((conv2d_fwd16x_kernel<bf16_t, 96, false, true>), g96, dim3(256), 0, st, p);
+        } else if (dtype == AFCM_F16) hipLaunchKernelGGL((conv2d_fwd16x_kernel<f16_t, 96>), g96, dim3(256), 0, st, p);
         else hipLaunchKernelGGL((conv2d_fwd16x_kernel<bf16_t, 96>), g96, dim3(256), 0, st, p);
         return hip_status(hipGetLastError());
     }

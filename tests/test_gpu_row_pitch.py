@@ -66,7 +66,9 @@ def test_filtered_lrelu_pitched_equals_dense(layer, h, ch, dtype, monkeypatch):
 
 
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize('cin,cout,h', [(20, 70, 150), (64, 64, 38), (33, 130, 86)])
+# (276 -> 278-wide outputs on 288-element rows: the tile width of conv2d_fwd16x_kernel's scalar-granule epilogue, r06;
+#  70 / 64 / 130 / 91 output channels: the 128-, 64-, 128 + 64- and 96-row blocks)
+@pytest.mark.parametrize('cin,cout,h', [(20, 70, 150), (64, 64, 38), (33, 130, 86), (8, 64, 276), (16, 91, 276), (12, 130, 276)])
 def test_conv_and_wgrad_pitched_equal_dense(cin, cout, h, dtype, monkeypatch):
     """3x3 pad-2 conv (forward kernel = data-gradient kernel) and the weight gradient on pitched operands with NaN padding vs dense."""
     from afcm_amd.torch_utils.ops import _rows
@@ -89,7 +91,7 @@ def test_conv_and_wgrad_pitched_equal_dense(cin, cout, h, dtype, monkeypatch):
     # dy's padding: finite up to the next multiple of 8 columns (what the producing kernels guarantee), NaN beyond
     dyp = _pitched(dy)
     q = dy.shape[3]
-    _rows.whole_buffer(dyp)[..., q:(q + 7) // 8 * 8] = 1e30
+    _rows.whole_buffer(dyp)[..., q:(q + 7) // 8 * 8] = 3e4           # (finite in float16 too)
     dw0 = conv._wgrad_raw(dy, x, cout, cin, 3, 2)
     dw1 = conv._wgrad_raw(dyp, _pitched(x), cout, cin, 3, 2)
     assert torch.isfinite(dw1).all()

@@ -8,6 +8,7 @@ from afcm_amd.torch_utils.ops import conv2d as C
 ap = argparse.ArgumentParser()
 ap.add_argument('--batch', type=int, default=16); ap.add_argument('--dtype', default='bf16'); ap.add_argument('--iters', type=int, default=5)
 ap.add_argument('--zeros', action='store_true', help='all-zero operands: same cycles, higher clock where the chip is power-managed')
+ap.add_argument('--pitched', action='store_true', help='row-pitched operands and results, as the fused layer node drives the kernels (afcm_amd/torch_utils/ops/_rows.py)')
 a = ap.parse_args()
 dt = {'fp32': torch.float32, 'bf16': torch.bfloat16}[a.dtype]
 pl = sched.plan(256, 4, 1, {})
@@ -28,10 +29,13 @@ for L in pl['enc'] + pl['dec']:
     if a.zeros:
         x.zero_(); w.zero_()
     wp, rp = C.pack_weights(w, dt, 0); wpt, rpt = C.pack_weights(w, dt, 1)
-    y = C._conv_raw(x, wp, rp, None, co, k, pad)
+    if a.pitched:
+        from afcm_amd.torch_utils.ops import _rows
+        xp = _rows.empty(list(x.shape), x.dtype, x.device); xp.copy_(x); x = xp
+    y = C._conv_raw(x, wp, rp, None, co, k, pad, pitched_out=a.pitched)
     fl = 2.0 * n * co * ci * k * k * y.shape[2] * y.shape[3]
-    tf = timeit(lambda: C._conv_raw(x, wp, rp, None, co, k, pad))
-    td = timeit(lambda: C._conv_raw(y, wpt, rpt, None, ci, k, k - 1 - pad))
+    tf = timeit(lambda: C._conv_raw(x, wp, rp, None, co, k, pad, pitched_out=a.pitched))
+    td = timeit(lambda: C._conv_raw(y, wpt, rpt, None, ci, k, k - 1 - pad, pitched_out=a.pitched))
     tw = timeit(lambda: C._wgrad_raw(y, x, co, ci, k, pad))
     tot[0] += tf; tot[1] += td; tot[2] += tw; tot[3] += fl
     if key not in seen:
