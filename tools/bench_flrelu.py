@@ -27,20 +27,29 @@ def raw_layer(L, x, fu, fd, kw, args):
     g = _rows.empty(list(y.shape), y.dtype, y.device, pitched=pitched)
     g.copy_(torch.randn(y.shape, device=y.device, dtype=y.dtype))
     bcfg = flr._backward_cfg(cfg, fu, fd, x.shape, y.shape, layout)
+    # --rotate K: K copies of every operand, taken in turn (and the results kept alive in a ring of K), so that no launch finds its operands
+    # in the 256 MB Infinity Cache or in L2 because the previous launch of the same layer left them there
+    K = max(1, args.rotate)
+    def copy_of(t):
+        c = _rows.empty(list(t.shape), t.dtype, t.device, pitched=not t.is_contiguous())
+        c.copy_(t)
+        return c
+    xs, gs, ss = [x] + [copy_of(x) for _ in range(K - 1)], [g] + [copy_of(g) for _ in range(K - 1)], [signs] + [signs.clone() for _ in range(K - 1)]
+    keep = [None] * K
     tf = tb = float('inf')
     for _rep in range(args.repeats):
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-        for _ in range(2):
-            flr._run(x, fu, fd, None, None, cfg, True, pitched_out=pitched)
+        for i in range(2):
+            keep[i % K] = flr._run(xs[i % K], fu, fd, None, None, cfg, True, pitched_out=pitched)
         ev[0].record()
-        for _ in range(args.iters):
-            flr._run(x, fu, fd, None, None, cfg, True, pitched_out=pitched)
+        for i in range(args.iters):
+            keep[i % K] = flr._run(xs[i % K], fu, fd, None, None, cfg, True, pitched_out=pitched)
         ev[1].record()
-        for _ in range(2):
-            flr._run(g, fd, fu, None, signs, bcfg, False, pitched_out=pitched)
+        for i in range(2):
+            keep[i % K] = flr._run(gs[i % K], fd, fu, None, ss[i % K], bcfg, False, pitched_out=pitched)
         ev[2].record()
-        for _ in range(args.iters):
-            flr._run(g, fd, fu, None, signs, bcfg, False, pitched_out=pitched)
+        for i in range(args.iters):
+            keep[i % K] = flr._run(gs[i % K], fd, fu, None, ss[i % K], bcfg, False, pitched_out=pitched)
         ev[3].record()
         torch.cuda.synchronize()
         tf = min(tf, ev[0].elapsed_time(ev[1]) / args.iters)
@@ -57,6 +66,7 @@ def main():
     ap.add_argument('--iters', type=int, default=20)
     ap.add_argument('--repeats', type=int, default=3, help='timed repeats per layer; the fastest is reported (box noise is +-10 %)')
     ap.add_argument('--layers', default='', help='comma-separated layer names (default: all)')
+    ap.add_argument('--rotate', type=int, default=1, help='raw mode: cycle through this many copies of the operands (cold caches)')
     ap.add_argument('--no-bias', action='store_true', help='b=None: the generator path (the convs add the bias)')
     ap.add_argument('--raw', choices=['dense', 'pitched'], default=None,
                     help='drive the launches as the fused layer node does (filtered_lrelu._run, no autograd), on dense or row-pitched tensors')
