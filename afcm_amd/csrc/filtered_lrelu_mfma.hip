@@ -688,6 +688,7 @@ static int fill_params(const afcm_filtered_lrelu_args* a, FlreluMfmaParams& p, i
     p.x = a->x; p.y = a->y; p.b = a->b; p.s = a->signs; p.ws = a->workspace; p.plane_sum = a->plane_sum;
     p.oscale = a->oscale; p.oscale2 = a->oscale2; p.skip = a->skip;
     p.clamp_flags = nullptr;                    // (wave kernels only: launch_wave sets it)
+    p.st_plain = 0;
     p.xw = a->xw; p.xh = a->xh; p.yw = a->yw; p.yh = a->yh; p.C = a->c;
     p.xld = a->x_pitch ? a->x_pitch : a->xw; p.yld = a->y_pitch ? a->y_pitch : a->yw; p.kld = a->skip_pitch ? a->skip_pitch : a->yw;
     p.px0 = a->px0; p.py0 = a->py0;
@@ -740,6 +741,8 @@ static int launch_wave(const afcm_filtered_lrelu_args* a, hipStream_t st) {
     p.py0 += dshift;                 // the fragments were prepared for this origin (prepare_mfma)
     p.sy -= dshift;
     p.clamp_flags = a->sign_mode == AFCM_SIGNS_READ ? nullptr : a->clamp_flags;
+    // (r06) dense output rows with a partial second 64-column group, not line-aligned: see flush() in filtered_lrelu_wave.hip
+    p.st_plain = (p.yld == p.yw && p.yw > 64 && ((p.yw * 2) & 127) != 0) ? 1 : 0;
     if constexpr (UP == 2 && DOWN == 2) {
         if (toh == kTallTOH) return launch_wave_tile<T, 2, 2, 64, kTallTOH>(a, p, st);
     }

@@ -517,7 +517,18 @@ __global__ __launch_bounds__(256, (wave_occupancy<UP, DOWN, TOW, TOH, SIGN, EPI>
 #ifdef AFCM_WAVE_EXPERIMENT_STORE_ALIAS  // timing experiment only: all output stores land in one 64 KB window (no HBM write traffic)
                 off &= 0xfff0u;
 #endif
-                if (full) {
+                if (p.st_plain) {
+                    // dense rows wider than one 64-column group (the 84- / 86-wide planes: 168- / 172-byte rows): a row leaves as a 128-byte
+                    // piece plus a 40-byte tail of pair stores, neither on a line boundary -- as write-back stores L2 merges them into whole
+                    // lines, as non-temporal ones every piece went to memory by itself (encoder_8 forward 140 -> 112 us, backward 171 -> 129)
+                    if (full) {
+                        __builtin_amdgcn_raw_buffer_store_b128(v, rsy, off, 0, 0);
+                    } else {
+#pragma unroll
+                        for (int w2 = 0; w2 < 4; w2++)
+                            __builtin_amdgcn_raw_buffer_store_b32(v[w2], rsy, (c0 + 2 * w2 + 2 <= p.yw && 8 * fl_chk + 2 * w2 < 16 * (slot + 1)) ? off + 4u * w2 : kOut, 0, 0);
+                    }
+                } else if (full) {
                     __builtin_amdgcn_raw_buffer_store_b128(v, rsy, off, 0, AFCM_WAVE_STORE_AUX);
                 } else if (p.yld != p.yw) {
                     // pitched rows end on a 16-byte boundary: the lanes whose 8 columns lie inside the pitch store, the others fall

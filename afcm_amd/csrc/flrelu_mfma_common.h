@@ -35,6 +35,7 @@ struct FlreluMfmaParams {
     int total_tiles;       // wave kernels: tilesX * tilesY * planes (one wave per tile)
     int oy0, read_aligned; // wave kernels, READ: strips start at output row ty * TOH + oy0 (oy0 <= 0) so that they fall on 16-row blocks of the sign tensor
     int* clamp_flags;      // wave kernels, WRITE / NONE: optional [planes][tilesX * tilesY]: 1 if the strip took the exact (clamp-capable) path
+    int st_plain;          // wave kernels: output rows leave as write-back stores instead of non-temporal ones (dense rows wider than 64 columns: launch_wave)
 };
 
 constexpr int kFUT = 6;            // taps per polyphase branch of the up filter (filter_size of the model)
