@@ -53,6 +53,9 @@ def parse():
     ap.add_argument('--comm-dtype', default='fp32', choices=['fp32', 'bf16'], help='dtype of the gradient buckets on the wire')
     ap.add_argument('--no-homogeneous-dot', action='store_true', help='ablation: the demodulation gradient from real plane dot products everywhere '
                                                                       '(torch_utils/ops/fused_layer.py HOMOGENEOUS_DOT)')
+    ap.add_argument('--watchdog', type=int, default=int(os.environ.get('AFCM_BENCH_WATCHDOG', 0)),
+                    help='seconds after which a rank that is still running dumps every thread\'s stack to stderr and exits (0: off); a rank stuck in a '
+                         'collective otherwise burns the launcher\'s whole time limit without a word')
     ap.add_argument('--fp32-conv', default='f16x3', choices=['f16x3', 'bf16x6', 'bf16x663', 'bf16x633', 'bf16x3', 'native'],
                     help='--dtype fp32 only: the 3x3 convs on the 16-bit matrix pipe from split operands (f16x3: scaled float16 parts, 3 terms, '
                          'fp32-grade; bf16x6: 6 terms, fp32-grade; bf16x663 / 633: 3 terms in the weight / both gradients; bf16x3: ~16 bits) '
@@ -469,6 +472,9 @@ def main():
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    if args.watchdog > 0:
+        import faulthandler
+        faulthandler.dump_traceback_later(args.watchdog, exit=True)
     if args.gpus != world:
         raise SystemExit(f'--gpus {args.gpus} does not match WORLD_SIZE {world}')
     # rehearsal aid for a one-GPU box: AFCM_BENCH_REHEARSE=1 puts every rank on device 0 and exchanges through gloo (RCCL refuses
